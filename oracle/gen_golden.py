@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Golden-vector generator — TEST INFRASTRUCTURE, runs only in the build container.
+
+Imports the reference's own ``graph_kernel.py`` / ``dataset.py`` from ``/root/reference``
+*unchanged* (third-party packages it needs that are absent from the image come from
+``oracle/_stubs``, see its README), runs the reference code on seeded synthetic inputs on the
+CPU and writes inputs + expected outputs as small ``.npz`` fixtures under ``tests/golden/``.
+
+Two things are patched at run time, nothing in the reference is edited:
+  * ``graph_kernel.args`` — the module-global the reference's ``KernelNN.forward`` reads
+    (graph_kernel.py:279-281) only exists under ``__main__``; we set it to a Namespace.
+  * ``torch.Tensor.cuda`` — ``forward`` hard-codes ``.cuda()`` for the LSTM state
+    (graph_kernel.py:281-282); on this GPU-less container it is made a no-op.
+
+The reference itself never travels: only the data written here is committed.
+
+Usage:  python oracle/gen_golden.py [--out tests/golden] [--skip-large]
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import tempfile
+from argparse import Namespace
+from pathlib import Path
+
+import numpy as np
+import torch
+
+REPO = Path(__file__).resolve().parents[1]
+REFERENCE = Path(os.environ.get("MDNO_REFERENCE", "/root/reference"))
+
+
+def _import_reference():
+    if not (REFERENCE / "graph_kernel.py").exists():
+        raise SystemExit(f"reference not found at {REFERENCE} (this script only runs in the build container)")
+    sys.path.insert(0, str(Path(__file__).resolve().parent / "_stubs"))
+    sys.path.insert(0, str(REFERENCE))
+    sys.path.insert(0, str(REPO))
+    import matplotlib
+    matplotlib.use("Agg")
+    import graph_kernel as ref_gk  # noqa: the reference, unchanged
+    import dataset as ref_ds       # noqa
+    torch.Tensor.cuda = lambda self, *a, **k: self  # CPU container: neutralise the hard-coded .cuda()
+    return ref_gk, ref_ds
+
+
+def _sd_np(sd, prefix="p."):
+    return {prefix + k: v.detach().cpu().numpy() for k, v in sd.items()}
+
+
+def _checksums(sd):
+    names = sorted(sd.keys())
+    sums = np.array([float(sd[k].double().sum()) for k in names], dtype=np.float64)
+    asums = np.array([float(sd[k].double().abs().sum()) for k in names], dtype=np.float64)
+    return np.array(names), sums, asums
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", type=Path, default=REPO / "tests" / "golden")
+    ap.add_argument("--skip-large", action="store_true", help="skip the N=504 full-size forward (~1-2 min CPU)")
+    a = ap.parse_args()
+    a.out.mkdir(parents=True, exist_ok=True)
+    torch.set_num_threads(8)
+
+    gk, ds = _import_reference()
+    from molecular_dynamics_neural_operator_amd import synthetic as syn
+
+    THR = 8.0
+    N, W = 28, 10
+    base = syn.chain_frame(N, seed=0)
+    window = syn.jitter_window(base, W, seed=0)           # [W,N,3]
+    aa = torch.from_numpy(syn.amino_acids(N, seed=0))
+    gap = syn.min_threshold_gap(window[-1], THR)
+    assert gap > 1e-4, f"fixture frame has a pair within {gap} A of the threshold"
+
+    # ---- (4) pairdata_graph: positions -> edge_index / edge_attr  (graph_kernel.py:362-393)
+    gk.args = Namespace(window_size=W, num_residues=N, batch_size=1)
+    pd_ref = gk.construct_pairdata(window, aa, threshold=THR)
+    box = syn.box_frame(120, seed=11)[None]               # a denser, unordered cloud as a second case
+    assert syn.min_threshold_gap(box[-1], THR) > 1e-5
+    pd_box = gk.construct_pairdata(box, torch.zeros(120, dtype=torch.long), threshold=THR)
+    np.savez_compressed(
+        a.out / "pairdata_graph.npz",
+        threshold=THR,
+        x_position=window, edge_index=pd_ref.edge_index.numpy(), edge_attr=pd_ref.edge_attr.numpy(),
+        box_position=box, box_edge_index=pd_box.edge_index.numpy(), box_edge_attr=pd_box.edge_attr.numpy(),
+        min_gap=gap,
+    )
+    print("pairdata_graph: E =", pd_ref.edge_index.shape[1], " box E =", pd_box.edge_index.shape[1])
+
+    # ---- (1) nnconv_small: one NNConv_old application, Cin=Cout=8, k=16  (graph_kernel.py:125-214)
+    torch.manual_seed(1234)
+    cin = cout = 8
+    kw = 16
+    for aggr in ("mean", "add"):
+        net = gk.DenseNet([6, kw, kw, cin * cout], torch.nn.ReLU)
+        conv = gk.NNConv_old(cin, cout, net, aggr=aggr)
+        x = torch.randn(N, cin)
+        with torch.no_grad():
+            y = conv(x, pd_ref.edge_index, pd_ref.edge_attr)
+            w_e = net(pd_ref.edge_attr)
+        np.savez_compressed(
+            a.out / f"nnconv_small_{aggr}.npz",
+            x=x.numpy(), edge_index=pd_ref.edge_index.numpy(), edge_attr=pd_ref.edge_attr.numpy(),
+            y=y.numpy(), w_e=w_e.numpy(), aggr=aggr, **_sd_np(conv.state_dict()),
+        )
+    print("nnconv_small: ok")
+
+    # ---- (2) kernelnn_small: whole forward at width 8, ker_width 16, depth 2  (graph_kernel.py:245-309)
+    torch.manual_seed(4321)
+    model_s = gk.KernelNN(8, 16, 2, 6, 7, 3, 20, 4)
+    model_s.eval()
+    with torch.no_grad():
+        out_s, lat_s = model_s(pd_ref, return_latent=True)
+    np.savez_compressed(
+        a.out / "kernelnn_small.npz",
+        ctor=np.array([8, 16, 2, 6, 7, 3, 20, 4]),
+        x_position=window, x_aminoacid=aa.numpy(),
+        edge_index=pd_ref.edge_index.numpy(), edge_attr=pd_ref.edge_attr.numpy(),
+        out=out_s.numpy(), latent=lat_s.numpy(), **_sd_np(model_s.state_dict()),
+    )
+    print("kernelnn_small: ok", out_s.shape, lat_s.shape)
+
+    # ---- (5) rollout_20: free-running + teacher-forced steps at small dims (graph_kernel.py:396-413)
+    # dataset in the reference's on-disk layout (dataset.py:112-127, 159, 189), npz twin of the HDF5 file
+    T = 40
+    traj = syn.ou_trajectory(base, T, sigma=0.15, theta=0.2, seed=2)          # [T,N,3]
+    cms = np.empty(T, dtype=object)
+    for t in range(T):
+        pd_t = gk.construct_pairdata(traj[t:t + 1], aa, threshold=THR)
+        cms[t] = np.concatenate([pd_t.edge_index[0].numpy(), pd_t.edge_index[1].numpy()]).astype(np.int64)
+    with tempfile.TemporaryDirectory() as td:
+        h5 = Path(td) / "synthetic.h5"          # npz bytes under the name the reference's loader dispatches on
+        with open(h5, "wb") as fh:
+            np.savez(fh, contact_map=cms, point_cloud=np.transpose(traj, (0, 2, 1)).copy(),
+                     rmsd=np.linspace(0, 1, T).astype(np.float32), amino_acids=aa.numpy())
+        dset = ds.ContactMapDataset(str(h5), window_size=W, horizon=1, node_feature_dset_path=str(h5))
+        assert len(dset) == T - W - 1 + 1
+        samp = dset[3]
+        # untrained weights collapse every atom onto one point (E = N^2 after one step), which would pin
+        # only the trivial graph: the free run uses the repo's near-identity weight set (weights.py),
+        # loaded into the reference's own KernelNN, so the graph changes gradually over the 20 steps.
+        from molecular_dynamics_neural_operator_amd.weights import near_identity_state_dict
+        model_r = gk.KernelNN(8, 16, 2, 6, 7, 3, 20, 4)
+        print("load near-identity:", model_r.load_state_dict(
+            near_identity_state_dict(8, 16, seed=3, kernel_gain=1e-2, feature_gain=1e-1)))
+        model_r.eval()
+        holder = Namespace(module=model_r, eval=lambda: None)
+        fc = gk.recursive_propagation(holder, dset, "cpu", num_steps=20, starting_points=[0], threshold=THR)
+        free = np.stack([f.x_position[-1].numpy() for f in fc])               # [20,N,3]
+        free_E = np.array([f.edge_index.shape[1] for f in fc])
+        free_gap = np.array([syn.min_threshold_gap(f.x_position[-1].numpy(), THR) for f in fc])
+        free_ei_last = fc[-1].edge_index.numpy()
+        # teacher-forced: forward on dataset[i] for i in 0..19
+        tf = []
+        with torch.no_grad():
+            for i in range(20):
+                tf.append(model_s(dset[i]).numpy())
+        tf = np.stack(tf)
+        tf_y = np.stack([dset[i].y.numpy() for i in range(20)])
+    np.savez_compressed(
+        a.out / "rollout_20.npz",
+        threshold=THR, window=W, horizon=1,
+        point_cloud=np.transpose(traj, (0, 2, 1)).copy(), contact_map=cms, amino_acids=aa.numpy(),
+        rmsd=np.linspace(0, 1, T).astype(np.float32),
+        sample3_x_position=samp.x_position.numpy(), sample3_y=samp.y.numpy(),
+        sample3_edge_index=samp.edge_index.numpy(), sample3_edge_attr=samp.edge_attr.numpy(),
+        dataset_len=len(dset),
+        free_frames=free, free_num_edges=free_E, free_min_gap=free_gap, free_edge_index_last=free_ei_last,
+        teacher_forced_out=tf, teacher_forced_y=tf_y,
+        **_sd_np(model_s.state_dict(), "tf."), **_sd_np(model_r.state_dict(), "free."),
+    )
+    print("rollout_20: ok; free-run E per step:", free_E, " min gap", free_gap.min())
+
+    # ---- LpLoss (graph_kernel.py:75-122)
+    torch.manual_seed(5)
+    lx, ly = torch.randn(4, 84), torch.randn(4, 84)
+    np.savez_compressed(
+        a.out / "lploss.npz", x=lx.numpy(), y=ly.numpy(),
+        rel_sum=gk.LpLoss(size_average=False)(lx, ly).numpy(),
+        rel_mean=gk.LpLoss(size_average=True)(lx, ly).numpy(),
+        rel_none=gk.LpLoss(reduction=False)(lx, ly).numpy(),
+        abs_mean=gk.LpLoss().abs(lx, ly).numpy(),
+    )
+
+    # ---- (3) kernelnn_full_seeded: CLI defaults (w=64, k=1024, depth 6), torch.manual_seed(0) init
+    torch.manual_seed(0)
+    model_f = gk.KernelNN(64, 1024, 6, 6, 7, 3, 20, 4)
+    model_f.eval()
+    names, sums, asums = _checksums(model_f.state_dict())
+    with torch.no_grad():
+        out_f, lat_f = model_f(pd_ref, return_latent=True)
+        we_f = model_f.conv1.net(pd_ref.edge_attr)
+    np.savez_compressed(
+        a.out / "kernelnn_full_seeded.npz",
+        ctor=np.array([64, 1024, 6, 6, 7, 3, 20, 4]), seed=0,
+        x_position=window, x_aminoacid=aa.numpy(),
+        edge_index=pd_ref.edge_index.numpy(), edge_attr=pd_ref.edge_attr.numpy(),
+        out=out_f.numpy(), latent=lat_f.numpy(),
+        w_e_checksum=np.array([float(we_f.double().sum()), float(we_f.double().abs().sum())]),
+        w_e_first_edge=we_f[0].numpy(),
+        param_names=names, param_sum=sums, param_abs_sum=asums,
+    )
+    print("kernelnn_full_seeded: ok; |out| max", float(out_f.abs().max()))
+
+    # ---- shape B: N=504 all-atom stand-in, full-size model, reference CPU forward (slow: 7.5 TFLOP)
+    if not a.skip_large:
+        NB = 504
+        base_b = syn.box_frame(NB, seed=1)
+        win_b = syn.jitter_window(base_b, W, seed=1)
+        aa_b = torch.from_numpy(syn.amino_acids(NB, seed=1))
+        gk.args = Namespace(window_size=W, num_residues=NB, batch_size=1)
+        pd_b = gk.construct_pairdata(win_b, aa_b, threshold=THR)
+        print("shapeB: E =", pd_b.edge_index.shape[1], "gap", syn.min_threshold_gap(win_b[-1], THR))
+        with torch.no_grad():
+            out_b, lat_b = model_f(pd_b, return_latent=True)
+        np.savez_compressed(
+            a.out / "kernelnn_shapeB_seeded.npz",
+            ctor=np.array([64, 1024, 6, 6, 7, 3, 20, 4]), seed=0, threshold=THR,
+            x_position=win_b, x_aminoacid=aa_b.numpy(), num_edges=pd_b.edge_index.shape[1],
+            min_gap=syn.min_threshold_gap(win_b[-1], THR),
+            out=out_b.numpy(), latent=lat_b.numpy(),
+            param_names=names, param_sum=sums, param_abs_sum=asums,
+        )
+        print("kernelnn_shapeB_seeded: ok; |out| max", float(out_b.abs().max()))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,43 @@
+"""pytest config: `gpu` marker + shared fixtures.
+
+`-m "not gpu"` : oracle vs golden vectors, host logic, C-ABI symbol check, gloo world_size-2 tests.
+`-m gpu`       : parity tests proper — every one calls the HIP kernels through the C-ABI
+                 (libmdno.so) on cuda:0 and compares with the oracle / the golden vectors.
+"""
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+REPO = Path(__file__).resolve().parents[1]
+GOLDEN = REPO / "tests" / "golden"
+if str(REPO) not in sys.path:
+    sys.path.insert(0, str(REPO))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this process")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+def load_golden(name):
+    return np.load(GOLDEN / name, allow_pickle=True)
+
+
+def golden_state_dict(z, prefix="p."):
+    return {k[len(prefix):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(prefix)}
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return load_golden

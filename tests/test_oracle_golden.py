@@ -1,0 +1,104 @@
+"""Pins the oracle (oracle/graph_kernel_oracle.py) against golden vectors emitted by the reference's
+own code (oracle/gen_golden.py, run in the build container).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_state_dict, load_golden
+from oracle import graph_kernel_oracle as O
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.mark.parametrize("aggr", ["mean", "add"])
+def test_nnconv_small(aggr):
+    z = load_golden(f"nnconv_small_{aggr}.npz")
+    sd = golden_state_dict(z)
+    w_e = O.edge_mlp(t(z["edge_attr"]), sd, "net.")
+    assert torch.equal(w_e, t(z["w_e"]))  # same torch CPU ops on the same machine image: bitwise
+    y = O.nnconv_forward(t(z["x"]), t(z["edge_index"]), t(z["edge_attr"]), sd, "", aggr)
+    torch.testing.assert_close(y, t(z["y"]), rtol=1e-6, atol=1e-6)
+
+
+def test_kernelnn_small():
+    z = load_golden("kernelnn_small.npz")
+    sd = golden_state_dict(z)
+    depth = int(z["ctor"][2])
+    for hoist in (False, True):
+        out, lat = O.kernelnn_forward(sd, t(z["x_position"]), t(z["x_aminoacid"]), t(z["edge_index"]),
+                                      t(z["edge_attr"]), depth, return_latent=True, hoist=hoist)
+        torch.testing.assert_close(out, t(z["out"]), rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(lat, t(z["latent"]), rtol=1e-6, atol=1e-6)
+
+
+def test_pairdata_graph():
+    z = load_golden("pairdata_graph.npz")
+    thr = float(z["threshold"])
+    pd = O.construct_pairdata(z["x_position"], None, thr)
+    assert np.array_equal(pd["edge_index"].numpy(), z["edge_index"])
+    assert np.array_equal(pd["edge_attr"].numpy(), z["edge_attr"])
+    pd = O.construct_pairdata(z["box_position"], None, thr)
+    assert np.array_equal(pd["edge_index"].numpy(), z["box_edge_index"])
+    assert np.array_equal(pd["edge_attr"].numpy(), z["box_edge_attr"])
+    # self-loops are kept and the COO is row-major
+    ei = z["edge_index"]
+    assert (ei[0] == ei[1]).sum() == z["x_position"].shape[1]
+    assert np.all(np.diff(ei[0] * 10_000 + ei[1]) > 0)
+
+
+def test_dataset_sample_and_len():
+    z = load_golden("rollout_20.npz")
+    W, h = int(z["window"]), int(z["horizon"])
+    assert O.dataset_len(z["point_cloud"].shape[0], W, h) == int(z["dataset_len"])
+    s = O.dataset_sample(z["point_cloud"], z["contact_map"], z["amino_acids"], 3, W, h)
+    assert np.array_equal(s["x_position"].numpy(), z["sample3_x_position"])
+    assert np.array_equal(s["y"].numpy(), z["sample3_y"])
+    assert np.array_equal(s["edge_index"].numpy(), z["sample3_edge_index"])
+    assert np.array_equal(s["edge_attr"].numpy(), z["sample3_edge_attr"])
+
+
+def test_rollout_teacher_forced_and_free():
+    z = load_golden("rollout_20.npz")
+    W, h, thr = int(z["window"]), int(z["horizon"]), float(z["threshold"])
+    sd_tf = golden_state_dict(z, "tf.")
+    for i in range(20):
+        s = O.dataset_sample(z["point_cloud"], z["contact_map"], z["amino_acids"], i, W, h)
+        out = O.kernelnn_forward(sd_tf, s["x_position"], s["x_aminoacid"], s["edge_index"], s["edge_attr"], 2)
+        torch.testing.assert_close(out, t(z["teacher_forced_out"][i]), rtol=1e-6, atol=1e-6)
+        assert np.array_equal(s["y"].numpy(), z["teacher_forced_y"][i])
+    sd_fr = golden_state_dict(z, "free.")
+    s0 = O.dataset_sample(z["point_cloud"], z["contact_map"], z["amino_acids"], 0, W, h)
+    fc = O.recursive_propagation(sd_fr, 2, s0, 20, thr)
+    assert [f["edge_index"].shape[1] for f in fc] == list(z["free_num_edges"])
+    free = np.stack([f["x_position"][-1].numpy() for f in fc])
+    np.testing.assert_allclose(free, z["free_frames"], rtol=1e-5, atol=1e-5)
+    assert np.array_equal(fc[-1]["edge_index"].numpy(), z["free_edge_index_last"])
+
+
+def test_lploss():
+    z = load_golden("lploss.npz")
+    x, y = t(z["x"]), t(z["y"])
+    torch.testing.assert_close(O.lp_loss_rel(x, y, size_average=False), t(z["rel_sum"]))
+    torch.testing.assert_close(O.lp_loss_rel(x, y, size_average=True), t(z["rel_mean"]))
+    torch.testing.assert_close(O.lp_loss_rel(x, y, reduction=False), t(z["rel_none"]))
+    torch.testing.assert_close(O.lp_loss_abs(x, y), t(z["abs_mean"]))
+
+
+def test_reference_init_order_and_full_forward():
+    """Same seed -> same parameters as the reference's KernelNN.__init__ (checksums), and the
+    full-size (w=64, k=1024, depth 6) forward on the N=28 chain matches the reference output."""
+    z = load_golden("kernelnn_full_seeded.npz")
+    c = [int(v) for v in z["ctor"]]
+    sd = O.reference_init_state_dict(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], seed=int(z["seed"]))
+    names = [str(n) for n in z["param_names"]]
+    assert sorted(sd.keys()) == names
+    for n, s, a in zip(names, z["param_sum"], z["param_abs_sum"]):
+        assert float(sd[n].double().sum()) == pytest.approx(float(s), rel=1e-12, abs=1e-12), n
+        assert float(sd[n].double().abs().sum()) == pytest.approx(float(a), rel=1e-12), n
+    out, lat = O.kernelnn_forward(sd, t(z["x_position"]), t(z["x_aminoacid"]), t(z["edge_index"]),
+                                  t(z["edge_attr"]), c[2], return_latent=True, hoist=True)
+    scale = float(np.abs(z["out"]).max())
+    torch.testing.assert_close(out, t(z["out"]), rtol=1e-5, atol=1e-5 * scale)
+    torch.testing.assert_close(lat, t(z["latent"]), rtol=1e-5, atol=1e-5 * float(np.abs(z["latent"]).max()))

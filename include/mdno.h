@@ -1,0 +1,198 @@
+/*
+ * mdno.h — C ABI of libmdno.so: the MI355X (gfx950) implementation of the graph-kernel
+ * neural-operator hot path of ramanathanlab/molecular_dynamics_neural_operator.
+ *
+ * The reference has NO native/FFI boundary for this path: it is a Python torch.nn.Module API
+ * (graph_kernel.py) over implicit PyTorch / torch_geometric device ops.  This header is therefore
+ * the boundary a maintainer binds with ctypes; every entry point names the
+ * reference code it replaces as file:line under the reference root.
+ *
+ * Conventions (all entry points)
+ *   - return 0 on success, a negative MDNO_E* code on failure; mdno_last_error() gives the message
+ *     of the calling thread's most recent failure.
+ *   - every pointer is a DEVICE pointer owned by the caller unless marked [host]; nothing is
+ *     allocated or freed on the caller's behalf; sizes are explicit.
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued asynchronously and not
+ *     synchronised (one exception: mdno_rollout with use_graph != 0 waits for `stream` before it
+ *     returns, to release the captured graph).  Entry points are re-entrant; there is no global
+ *     state besides the per-thread error string.
+ *   - graphs are CSR over DESTINATION rows: row r (= member*N + atom) lists, in ascending order,
+ *     the SOURCE nodes j of its in-edges (j -> r), self-loop included.  "Edge p" is position p of
+ *     that list; per-edge tensors (W_e) are stored in this order, so every row's edges are one
+ *     contiguous run and aggregation needs no atomics (run-to-run bitwise reproducible).
+ *   - float = IEEE fp32; positions are Angstrom, frames are float32 [n_atoms,3] (dataset.py:159).
+ */
+#ifndef MDNO_H
+#define MDNO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDNO_ABI_VERSION 1
+
+#define MDNO_OK            0
+#define MDNO_EINVAL       -1   /* bad argument (null pointer, non-positive size, unsupported dim) */
+#define MDNO_ELAUNCH      -2   /* HIP runtime error while enqueuing */
+#define MDNO_EWORKSPACE   -3   /* workspace too small */
+#define MDNO_EUNSUPPORTED -4   /* shape outside what the kernels implement */
+
+#define MDNO_AGGR_ADD  0
+#define MDNO_AGGR_MEAN 1
+
+/* status word bits written by device code (read back by the caller after synchronising) */
+#define MDNO_STATUS_EDGE_OVERFLOW 1   /* radius graph found more than edge_cap edges; list truncated */
+#define MDNO_STATUS_BAD_AMINOACID 2   /* x_aminoacid outside [0, num_embeddings) */
+
+int         mdno_abi_version(void);
+const char* mdno_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Parameters of KernelNN under the reference's state_dict key names (graph_kernel.py:246-275).
+ * All weights fp32, torch layouts: Linear.weight [out,in]; LSTM weight_ih_l0/weight_hh_l0 [4H,H]
+ * gate order i,f,g,o; NNConv_old.root [Cin,Cout].  conv1.net and conv2.net are ONE module in the
+ * reference (graph_kernel.py:271-273): set k2_* = NULL to share k_* (edge weights then evaluated
+ * once per forward instead of 2*depth times — same values, the inputs never change, :278-302).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct mdno_kernelnn_params {
+    int32_t width, ker_width, depth, ker_in, in_width, out_width;
+    int32_t num_embeddings, embedding_dim, x_position_dim, reserved0;
+    const float *lstm_w_ih, *lstm_w_hh, *lstm_b_ih, *lstm_b_hh;     /* lstm.*_l0            */
+    const float *lstm_fc_w, *lstm_fc_b;                             /* lstm_fc.{weight,bias} */
+    const float *emb_w;                                             /* emb.weight [20,4]     */
+    const float *fc1_w, *fc1_b;                                     /* fc1 [width,in_width]  */
+    const float *k_w0, *k_b0, *k_w1, *k_b1, *k_w2, *k_b2;           /* conv1.net.layers.{0,2,4} */
+    const float *k2_w0, *k2_b0, *k2_w1, *k2_b1, *k2_w2, *k2_b2;     /* conv2.net.* or NULL = shared */
+    const float *conv1_root, *conv1_bias, *conv2_root, *conv2_bias; /* [width,width], [width] */
+    const float *fc2_w, *fc2_b;                                     /* fc2 [out_width,width] */
+} mdno_kernelnn_params;
+
+/* ------------------------------------------------------------------------------------------
+ * K0/K1  radius graph  — replaces construct_pairdata's scipy distance_matrix + coo_matrix +
+ * per-edge Python loop (graph_kernel.py:362-379; notebook variant bba_analysis.ipynb:302-320).
+ *   pos       f32 [M*N,3]  one frame per member (M independent members, no cross-member edges)
+ *   cutoff    f64; pair kept iff sqrt(dx^2+dy^2+dz^2) < cutoff with the sum and sqrt in f64 on the
+ *             f32 coordinates (scipy promotes to f64), strict <, self-loops kept
+ *   row_ptr   i32 [M*N+1] out   src i32 [edge_cap] out   dst i32 [edge_cap] out (may be NULL)
+ *   num_edges i32 [1] out (device)   status i32 [1] in/out (device, OR-ed; may be NULL)
+ * Row-major COO of the reference == (dst, src) pairs of this CSR read in order (the contact map is
+ * symmetric), i.e. reference edge_index = [expand(row_ptr); src].
+ * ---------------------------------------------------------------------------------------- */
+int mdno_radius_graph_csr(const float* pos, int M, int N, double cutoff,
+                          int32_t* row_ptr, int32_t* src, int32_t* dst, int64_t edge_cap,
+                          int32_t* num_edges, int32_t* status, void* stream);
+
+/* General graphs: stable sort of a COO edge list by destination — what torch_geometric's
+ * scatter over edge_index[1] implies (graph_kernel.py:198 -> MessagePassing.propagate).
+ *   edge_index i64 [2,E] (row 0 = source, row 1 = target)
+ *   row_ptr i32 [num_nodes+1], src i32 [E], dst i32 [E] (may be NULL), perm i32 [E]: CSR position
+ *   p holds input edge perm[p].  Workspace size from mdno_coo_to_csr_workspace_bytes. */
+size_t mdno_coo_to_csr_workspace_bytes(int64_t E, int num_nodes);
+int mdno_coo_to_csr(const int64_t* edge_index, int64_t E, int num_nodes,
+                    int32_t* row_ptr, int32_t* src, int32_t* dst, int32_t* perm,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K2  edge-MLP — replaces DenseNet.forward (graph_kernel.py:239-242) as called from
+ * NNConv_old.message (:201): W_e = L3(relu(L2(relu(L1(edge_attr))))) -> f32 [E, out_dim],
+ * written in CSR edge order; row e viewed [Cin,Cout] row-major (:201 .view(-1,Cin,Cout)).
+ * Edge attributes come from ONE of
+ *   (a) edge_pos f32 [R,3] + CSR (src,dst): attr[p] = [pos[src[p]], pos[dst[p]]]   (:372-379)
+ *   (b) edge_attr f32 [E,ker_in] (+ perm i32 [E] or NULL): attr[p] = edge_attr[perm[p]]
+ *   num_edges  i32 [1] device (rows >= *num_edges are not computed); edge_cap bounds it.
+ *   workspace: mdno_edge_mlp_workspace_bytes(ker_width, edge_cap) for the two hidden activations.
+ * ---------------------------------------------------------------------------------------- */
+size_t mdno_edge_mlp_workspace_bytes(int ker_width, int64_t edge_cap);
+int mdno_edge_mlp_fwd(const float* edge_pos, const int32_t* src, const int32_t* dst,
+                      const float* edge_attr, const int32_t* perm,
+                      const int32_t* num_edges, int64_t edge_cap, int ker_in, int ker_width, int out_dim,
+                      const float* w0, const float* b0, const float* w1, const float* b1,
+                      const float* w2, const float* b2,
+                      float* w_e, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K3-K6  conv application — replaces NNConv_old.forward/message/update (graph_kernel.py:194-209)
+ * and torch_geometric's gather + scatter-mean:
+ *   y[r] = act( aggr_{p in row r} ( x[src[p]] . W_e[p] )  +  x[r] . root  +  bias )
+ *   aggr = sum (MDNO_AGGR_ADD) or sum / max(deg,1) (MDNO_AGGR_MEAN); act = ReLU if relu != 0
+ *   (the ReLU of graph_kernel.py:300/302 fused).  root / bias may be NULL.
+ *   x f32 [R,Cin]  W_e f32 [E,Cin,Cout]  y f32 [R,Cout]; y must not alias x.
+ * ---------------------------------------------------------------------------------------- */
+int mdno_nnconv_fwd(const float* x, const int32_t* row_ptr, const int32_t* src, int num_rows,
+                    const float* w_e, const float* root, const float* bias,
+                    int Cin, int Cout, int aggr, int relu, float* y, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Frame buffers are TIME-MAJOR: frames f32 [T, M, N, 3]; frame t of all M members is one contiguous
+ * [M*N, 3] block (for M = 1 this is exactly PairData.x_position [W,N,3], dataset.py:185/207).
+ *
+ * K7/K8  node prologue — replaces graph_kernel.py:279-298: W sequential LSTM(3,3) cells over the
+ * window (batch = atoms, zero initial state), lstm_fc, Embedding lookup, concat, fc1, ReLU.
+ *   frames f32 [W, M, N, 3]
+ *   x_aminoacid i64 [N] (aa_per_member = 0: shared by all members) or [M*N] (aa_per_member = 1)
+ *   x0 f32 [M*N, width] out
+ * ---------------------------------------------------------------------------------------- */
+int mdno_node_prologue_fwd(const mdno_kernelnn_params* p, const float* frames, int M, int W, int N,
+                           const int64_t* x_aminoacid, int aa_per_member,
+                           float* x0, int32_t* status, void* stream);
+
+/* K9  output projection — replaces fc2 (graph_kernel.py:305): out[r,:] = x[r] . W^T + b,
+ * x f32 [rows,width], w f32 [out_width,width], out f32 [rows,out_width]. */
+int mdno_fc_out_fwd(const float* x, const float* w, const float* b, int rows, int width, int out_width,
+                    float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Whole forward — replaces KernelNN.forward (graph_kernel.py:277-309) for M independent samples
+ * (B=1 semantics each).  frames f32 [W,M,N,3].  Graph given as CSR over the M*N rows; edge
+ * attributes by (a) edge_pos f32 [M*N,3] (the frame the graph was built on) or (b) edge_attr
+ * (+perm), as in mdno_edge_mlp_fwd.  out f32 [M*N,out_width]; latent f32 [M*N,width] (the
+ * return_latent=True output, :303) may be NULL.
+ * Workspace: mdno_kernelnn_workspace_bytes(p, M, N, edge_cap).
+ * ---------------------------------------------------------------------------------------- */
+size_t mdno_kernelnn_workspace_bytes(const mdno_kernelnn_params* p, int M, int N, int64_t edge_cap);
+int mdno_kernelnn_fwd(const mdno_kernelnn_params* p, const float* frames, int M, int W, int N,
+                      const int64_t* x_aminoacid, int aa_per_member,
+                      const int32_t* row_ptr, const int32_t* src, const int32_t* dst,
+                      const int32_t* num_edges, int64_t edge_cap,
+                      const float* edge_pos, const float* edge_attr, const int32_t* perm,
+                      float* out, float* latent, void* workspace, size_t workspace_bytes,
+                      int32_t* status, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Autoregressive rollout — replaces recursive_propagation (graph_kernel.py:396-413) and the
+ * notebook's propogate (bba_analysis.ipynb:336-358) with the whole loop on the device:
+ *   for s in 0..steps-1:  graph + edge attrs of frame s+W-1 (the last window frame, :363,:375)
+ *                         -> forward on frames s..s+W-1 -> frame s+W       (no host crossing)
+ *   traj f32 [W+steps, M, N, 3] in/out (time-major): caller fills frames 0..W-1 (the start window,
+ *   :401); frames W.. are produced.  Members are independent (block-diagonal graph).
+ *   edges_per_step i32 [steps] out (device, may be NULL): E of each step's graph.
+ *   use_graph != 0 and stream != NULL: one step is stream-captured into a hipGraph and replayed
+ *   `steps` times (a device-side step counter advances the window); otherwise plain launches.
+ * ---------------------------------------------------------------------------------------- */
+size_t mdno_rollout_workspace_bytes(const mdno_kernelnn_params* p, int M, int N, int64_t edge_cap);
+int mdno_rollout(const mdno_kernelnn_params* p, float* traj, int M, int W, int N, int steps,
+                 const int64_t* x_aminoacid, int aa_per_member, double threshold, int64_t edge_cap,
+                 void* workspace, size_t workspace_bytes, int32_t* edges_per_step,
+                 int32_t* status, int use_graph, void* stream);
+
+/* The same loop as a reusable plan: the step is captured once at creation (on `stream`, nothing
+ * executes), then any range of steps is replayed without re-capturing and without synchronising.
+ *   traj f32 [W+max_steps, M, N, 3]; run(start_step, steps) produces frames W+start_step ..
+ *   W+start_step+steps-1 from the frames before them.  The plan keeps a copy of *p (the weight
+ *   pointers must stay valid) and must be destroyed only after its enqueued work has completed. */
+typedef struct mdno_rollout_plan mdno_rollout_plan;
+int mdno_rollout_plan_create(mdno_rollout_plan** plan, const mdno_kernelnn_params* p, float* traj,
+                             int M, int W, int N, int max_steps,
+                             const int64_t* x_aminoacid, int aa_per_member, double threshold,
+                             int64_t edge_cap, void* workspace, size_t workspace_bytes,
+                             int32_t* edges_per_step, int32_t* status, int use_graph, void* stream);
+int mdno_rollout_plan_run(mdno_rollout_plan* plan, int start_step, int steps, void* stream);
+int mdno_rollout_plan_destroy(mdno_rollout_plan* plan);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDNO_H */

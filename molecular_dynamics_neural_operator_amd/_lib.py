@@ -1,0 +1,118 @@
+"""ctypes binding of libmdno.so (include/mdno.h).  No CPU fallback exists: if the library is
+missing, or a tensor is not on the GPU, the call raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import torch
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("MDNO_LIB", _HERE / "libmdno.so"))
+
+OK, EINVAL, ELAUNCH, EWORKSPACE, EUNSUPPORTED = 0, -1, -2, -3, -4
+AGGR = {"add": 0, "mean": 1}
+STATUS_EDGE_OVERFLOW, STATUS_BAD_AMINOACID = 1, 2
+ABI_VERSION = 1
+
+
+class MdnoError(RuntimeError):
+    pass
+
+
+class KernelNNParams(C.Structure):
+    """struct mdno_kernelnn_params"""
+    _INTS = ["width", "ker_width", "depth", "ker_in", "in_width", "out_width",
+             "num_embeddings", "embedding_dim", "x_position_dim", "reserved0"]
+    _PTRS = ["lstm_w_ih", "lstm_w_hh", "lstm_b_ih", "lstm_b_hh", "lstm_fc_w", "lstm_fc_b", "emb_w",
+             "fc1_w", "fc1_b", "k_w0", "k_b0", "k_w1", "k_b1", "k_w2", "k_b2",
+             "k2_w0", "k2_b0", "k2_w1", "k2_b1", "k2_w2", "k2_b2",
+             "conv1_root", "conv1_bias", "conv2_root", "conv2_bias", "fc2_w", "fc2_b"]
+    _fields_ = [(n, C.c_int32) for n in _INTS] + [(n, C.c_void_p) for n in _PTRS]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_L = C.c_int64
+_SZ = C.c_size_t
+_D = C.c_double
+
+# name -> (restype, argtypes); kept in step with include/mdno.h (tests/test_cabi.py checks both ways)
+SIGNATURES = {
+    "mdno_abi_version": (_I, []),
+    "mdno_last_error": (C.c_char_p, []),
+    "mdno_radius_graph_csr": (_I, [_P, _I, _I, _D, _P, _P, _P, _L, _P, _P, _P]),
+    "mdno_coo_to_csr_workspace_bytes": (_SZ, [_L, _I]),
+    "mdno_coo_to_csr": (_I, [_P, _L, _I, _P, _P, _P, _P, _P, _SZ, _P]),
+    "mdno_edge_mlp_workspace_bytes": (_SZ, [_I, _L]),
+    "mdno_edge_mlp_fwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "mdno_nnconv_fwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "mdno_node_prologue_fwd": (_I, [C.POINTER(KernelNNParams), _P, _I, _I, _I, _P, _I, _P, _P, _P]),
+    "mdno_fc_out_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
+    "mdno_kernelnn_workspace_bytes": (_SZ, [C.POINTER(KernelNNParams), _I, _I, _L]),
+    "mdno_kernelnn_fwd": (_I, [C.POINTER(KernelNNParams), _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _L,
+                               _P, _P, _P, _P, _P, _P, _SZ, _P, _P]),
+    "mdno_rollout_workspace_bytes": (_SZ, [C.POINTER(KernelNNParams), _I, _I, _L]),
+    "mdno_rollout": (_I, [C.POINTER(KernelNNParams), _P, _I, _I, _I, _I, _P, _I, _D, _L, _P, _SZ, _P, _P, _I, _P]),
+    "mdno_rollout_plan_create": (_I, [C.POINTER(_P), C.POINTER(KernelNNParams), _P, _I, _I, _I, _I, _P, _I, _D, _L,
+                                      _P, _SZ, _P, _P, _I, _P]),
+    "mdno_rollout_plan_run": (_I, [_P, _I, _I, _P]),
+    "mdno_rollout_plan_destroy": (_I, [_P]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libmdno.so once; raise (never fall back) if it is absent or has the wrong ABI."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise MdnoError(
+            f"{LIB_PATH} not found: the HIP library is not built. Run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` (or molecular_dynamics_neural_operator_amd/csrc/build.sh). There is no CPU fallback.")
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    ver = lib.mdno_abi_version()
+    if ver != ABI_VERSION:
+        raise MdnoError(f"libmdno ABI {ver} != binding {ABI_VERSION}; rebuild the library")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != OK:
+        msg = load().mdno_last_error().decode(errors="replace")
+        raise MdnoError(f"{what or 'libmdno'} failed (code {rc}): {msg}")
+
+
+def ptr(t) -> int | None:
+    """Device pointer of a CUDA(HIP) tensor, None for None."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise MdnoError("libmdno kernels run on the GPU only: got a CPU tensor (no CPU fallback exists)")
+    if not t.is_contiguous():
+        raise MdnoError("libmdno needs contiguous tensors")
+    return t.data_ptr()
+
+
+def f32(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        t = t.to(torch.float32)
+    return t.contiguous()
+
+
+def stream_ptr(device=None) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_gpu(device=None) -> torch.device:
+    if not torch.cuda.is_available():
+        raise MdnoError("no HIP device visible: this package only runs on an MI355X-class GPU (no CPU fallback)")
+    return torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)

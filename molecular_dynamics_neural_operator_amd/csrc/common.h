@@ -1,0 +1,65 @@
+// Internal helpers shared by the libmdno translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/mdno.h"
+
+namespace mdno {
+
+void set_error(const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return MDNO_ELAUNCH;
+    }
+    return MDNO_OK;
+}
+
+#define MDNO_REQUIRE(cond, code, ...)          \
+    do {                                       \
+        if (!(cond)) {                         \
+            ::mdno::set_error(__VA_ARGS__);    \
+            return (code);                     \
+        }                                      \
+    } while (0)
+
+#define MDNO_HIP(call)                                                           \
+    do {                                                                         \
+        hipError_t e_ = (call);                                                  \
+        if (e_ != hipSuccess) {                                                  \
+            ::mdno::set_error("%s: %s", #call, hipGetErrorString(e_));           \
+            return MDNO_ELAUNCH;                                                 \
+        }                                                                        \
+    } while (0)
+
+#define MDNO_TRY(call)                 \
+    do {                               \
+        int rc_ = (call);              \
+        if (rc_ != MDNO_OK) return rc_; \
+    } while (0)
+
+constexpr int kWave = 64;  // CDNA4 wavefront
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Bump allocator over the caller's workspace (256-B aligned carves).
+struct Carver {
+    char* base;
+    size_t off = 0;
+    explicit Carver(void* p) : base(static_cast<char*>(p)) {}
+    template <class T>
+    T* take(size_t count) {
+        off = align_up(off, 256);
+        T* r = reinterpret_cast<T*>(base ? base + off : nullptr);
+        off += count * sizeof(T);
+        return r;
+    }
+    size_t used() const { return align_up(off, 256); }
+};
+
+}  // namespace mdno

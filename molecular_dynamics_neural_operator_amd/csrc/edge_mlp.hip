@@ -1,0 +1,298 @@
+// K1+K2: edge attributes -> edge-MLP -> W_e, written in CSR edge order.
+//
+// Replaces DenseNet.forward (graph_kernel.py:239-242) as called per conv application from
+// NNConv_old.message (:201), and the per-edge Python loop that builds edge_attr (:372-379).
+//   layer 0  [E,ker_in] x [ker_in,k]   + bias, ReLU   (VALU; K = 6, fused with the attr gather)
+//   layer 1  [E,k]      x [k,k]        + bias, ReLU   (fp32 MFMA GEMM)
+//   layer 2  [E,k]      x [k,Cin*Cout] + bias         (fp32 MFMA GEMM; 80 % of the model's flops)
+//
+// Roofline: MFMA (v_mfma_f32_32x32x2_f32, exact fp32, 157 TF peak).  Flops per edge =
+// 2*(ker_in*k + k*k + k*Cin*Cout) = 10,498,048 at k=1024, 64x64.
+//
+// GEMM shape: C[M,N] = act(A[M,K] . Bt[N,K]^T + bias[N]) with BOTH operands K-contiguous (torch
+// Linear keeps weight as [out,in]), which is the natural operand order for MFMA: lane l feeds
+// A[row l&31][k] and Bt[col l&31][k].  Block tile 128x128x32, 4 waves as 2x2, each wave 64x64 =
+// 2x2 MFMA tiles (4 independent accumulators keep the matrix pipe issuing back-to-back).  Tiles go
+// global -> registers -> LDS (rows padded to 36 floats so ds_read_b128 is bank-conflict-free),
+// double-buffered, one barrier per K-tile.  Each lane reads its fragment as one 16-B LDS load that
+// covers FOUR k-steps: lane half h reads k = 8t+4h..8t+4h+3; MFMA step c of that group contracts
+// k = 8t+4h+c in both operands, which is a permutation of the k order and leaves the sum's value
+// set unchanged (fp32 rounding order differs from a left-to-right dot product, as any blocked GEMM).
+//
+// The number of valid rows (edges) lives in device memory (the graph is rebuilt on the device every
+// rollout step), so grids are sized by capacity and whole tiles beyond *num_edges exit at once.
+#include "kernels.h"
+
+namespace mdno {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 32, LDS_LD = BK + 4;  // 36 floats = 144 B rows
+
+// ---------------------------------------------------------------- layer 0 (+ attr gather)
+// Block = 256 threads handles EB consecutive edges; thread c-strided over the k hidden units.
+constexpr int EB = 16;
+constexpr int MAX_F = 8;
+
+__global__ __launch_bounds__(256) void edge_l0_kernel(
+    const float* __restrict__ frames, int frame, const int* __restrict__ t_dev, int rows_per_frame,
+    const int* __restrict__ src, const int* __restrict__ dst,
+    const float* __restrict__ edge_attr, const int* __restrict__ perm, const int* __restrict__ num_edges,
+    long long e_begin, int e_count, int F, int k, const float* __restrict__ w0, const float* __restrict__ b0,
+    float* __restrict__ h) {
+    __shared__ float attr[EB][MAX_F];
+    const long long E = *num_edges;
+    const long long e0 = e_begin + (long long)blockIdx.x * EB;
+    if (e0 >= E || (long long)blockIdx.x * EB >= e_count) return;
+    const int tid = threadIdx.x;
+    if (tid < EB * MAX_F) {
+        const int le = tid / MAX_F, f = tid % MAX_F;
+        const long long e = e0 + le;
+        float v = 0.f;
+        if (e < E && f < F) {
+            if (frames != nullptr) {  // attr = [pos[src], pos[dst]]   (graph_kernel.py:372-379)
+                const float* edge_pos = frames + (size_t)(frame + (t_dev ? *t_dev : 0)) * rows_per_frame * 3;
+                const int node = (f < 3) ? src[e] : dst[e];
+                v = edge_pos[(size_t)node * 3 + (f % 3)];
+            } else {
+                const long long pe = perm ? (long long)perm[e] : e;
+                v = edge_attr[pe * F + f];
+            }
+        }
+        attr[le][f] = v;
+    }
+    __syncthreads();
+    for (int c = tid; c < k; c += 256) {
+        float w[MAX_F];
+#pragma unroll
+        for (int f = 0; f < MAX_F; ++f) w[f] = (f < F) ? w0[(size_t)c * F + f] : 0.f;
+        const float bc = b0[c];
+#pragma unroll 4
+        for (int le = 0; le < EB; ++le) {
+            const long long e = e0 + le;
+            if (e >= E || e - e_begin >= e_count) break;
+            float s = 0.f;
+#pragma unroll
+            for (int f = 0; f < MAX_F; ++f) s = fmaf(attr[le][f], w[f], s);
+            s += bc;
+            h[(size_t)(e - e_begin) * k + c] = fmaxf(s, 0.f);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- fp32 MFMA GEMM (TN)
+struct GemmArgs {
+    const float* A;      // [rows, K] rows local to the chunk
+    const float* Bt;     // [N, K]
+    const float* bias;   // [N]
+    float* C;            // [rows, N] rows local to the chunk
+    const int* num_edges;
+    long long row_begin;  // global edge index of local row 0
+    int rows;             // chunk rows (capacity)
+    int N, K;
+};
+
+template <bool RELU>
+__global__ __launch_bounds__(256, 2) void gemm_tn_mfma_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                       // [2][BM][LDS_LD]
+    float* Bs = smem + 2 * BM * LDS_LD;     // [2][BN][LDS_LD]
+
+    long long valid = (long long)(*g.num_edges) - g.row_begin;
+    if (valid > g.rows) valid = g.rows;
+    const int bm = blockIdx.y * BM;
+    if (bm >= valid) return;
+    const int bn = blockIdx.x * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+
+    // global -> register staging: thread covers rows (tid>>3) + 32*i, 16-B column chunk (tid&7)
+    const int srow = tid >> 3, scol = (tid & 7) * 4;
+    const float* Ag = g.A + (size_t)(bm + srow) * g.K + scol;
+    const float* Bg = g.Bt + (size_t)(bn + srow) * g.K + scol;
+    float4 ra[4], rb[4];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = *reinterpret_cast<const float4*>(Ag + (size_t)(32 * i) * g.K + kt * BK);
+            rb[i] = *reinterpret_cast<const float4*>(Bg + (size_t)(32 * i) * g.K + kt * BK);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float* a = As + buf * BM * LDS_LD + srow * LDS_LD + scol;
+        float* b = Bs + buf * BN * LDS_LD + srow * LDS_LD + scol;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<float4*>(a + 32 * i * LDS_LD) = ra[i];
+            *reinterpret_cast<float4*>(b + 32 * i * LDS_LD) = rb[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = g.K / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const float* a_base = As + buf * BM * LDS_LD + (wm * 64 + l31) * LDS_LD + 4 * h;
+        const float* b_base = Bs + buf * BN * LDS_LD + (wn * 64 + l31) * LDS_LD + 4 * h;
+#pragma unroll
+        for (int t = 0; t < BK / 8; ++t) {
+            float4 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = *reinterpret_cast<const float4*>(a_base + i * 32 * LDS_LD + 8 * t);
+                b[i] = *reinterpret_cast<const float4*>(b_base + i * 32 * LDS_LD + 8 * t);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = bn + wn * 64 + j * 32 + l31;
+        const float bv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = bm + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m < valid) {
+                    float v = acc[i][j][r] + bv;
+                    if (RELU) v = fmaxf(v, 0.f);
+                    g.C[(size_t)m * g.N + n] = v;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- any-shape fallback (fixtures)
+template <bool RELU>
+__global__ __launch_bounds__(256) void gemm_tn_generic_kernel(GemmArgs g) {
+    __shared__ float As[16][17], Bs[16][17];
+    long long valid = (long long)(*g.num_edges) - g.row_begin;
+    if (valid > g.rows) valid = g.rows;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int m = blockIdx.y * 16 + ty, n = blockIdx.x * 16 + tx;
+    if ((long long)blockIdx.y * 16 >= valid) return;
+    float s = 0.f;
+    for (int k0 = 0; k0 < g.K; k0 += 16) {
+        const int am = blockIdx.y * 16 + ty, bn_ = blockIdx.x * 16 + ty;
+        As[ty][tx] = (am < valid && k0 + tx < g.K) ? g.A[(size_t)am * g.K + k0 + tx] : 0.f;
+        Bs[ty][tx] = (bn_ < g.N && k0 + tx < g.K) ? g.Bt[(size_t)bn_ * g.K + k0 + tx] : 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) s = fmaf(As[ty][kk], Bs[tx][kk], s);
+        __syncthreads();
+    }
+    if (m < valid && n < g.N) {
+        float v = s + (g.bias ? g.bias[n] : 0.f);
+        if (RELU) v = fmaxf(v, 0.f);
+        g.C[(size_t)m * g.N + n] = v;
+    }
+}
+
+template <bool RELU>
+int launch_gemm(const GemmArgs& g, hipStream_t s) {
+    const bool mfma_ok = (g.K % BK == 0) && (g.N % BN == 0) && (g.rows % BM == 0) &&
+                         ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.Bt)) & 15) == 0;
+    if (mfma_ok) {
+        const size_t lds = sizeof(float) * 2 * (BM + BN) * LDS_LD;  // 73,728 B
+        static bool attr_set[2] = {false, false};
+        if (!attr_set[RELU]) {
+            MDNO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_mfma_kernel<RELU>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set[RELU] = true;
+        }
+        dim3 grid(g.N / BN, g.rows / BM);
+        hipLaunchKernelGGL(gemm_tn_mfma_kernel<RELU>, grid, dim3(256), lds, s, g);
+    } else {
+        dim3 grid((g.N + 15) / 16, (g.rows + 15) / 16);
+        hipLaunchKernelGGL(gemm_tn_generic_kernel<RELU>, grid, dim3(256), 0, s, g);
+    }
+    return check_launch("edge-MLP GEMM");
+}
+
+constexpr long long kMaxChunkRows = 262144;
+
+long long chunk_rows_for(long long edge_cap) {
+    long long r = (edge_cap + BM - 1) / BM * BM;
+    return r < kMaxChunkRows ? r : kMaxChunkRows;
+}
+
+}  // namespace
+}  // namespace mdno
+
+using namespace mdno;
+
+extern "C" size_t mdno_edge_mlp_workspace_bytes(int ker_width, int64_t edge_cap) {
+    if (ker_width <= 0 || edge_cap <= 0) return 0;
+    return align_up(2 * (size_t)chunk_rows_for(edge_cap) * (size_t)ker_width * sizeof(float) + 512, 256);
+}
+
+int mdno::edge_mlp(const float* frames, int frame, const int* t_dev, int rows_per_frame, const int* src,
+                   const int* dst, const float* edge_attr, const int* perm, const int* num_edges,
+                   long long edge_cap, int ker_in, int ker_width, int out_dim, const EdgeMlpWeights& w, float* w_e,
+                   void* workspace, size_t workspace_bytes, hipStream_t s) {
+    MDNO_REQUIRE(num_edges && w.w0 && w.b0 && w.w1 && w.b1 && w.w2 && w.b2 && w_e && workspace, MDNO_EINVAL,
+                 "edge_mlp: null pointer");
+    MDNO_REQUIRE((frames && src && dst) || edge_attr, MDNO_EINVAL, "edge_mlp: need (edge_pos, src, dst) or edge_attr");
+    MDNO_REQUIRE(edge_cap > 0 && ker_width > 0 && out_dim > 0, MDNO_EINVAL, "edge_mlp: bad sizes");
+    MDNO_REQUIRE(ker_in > 0 && ker_in <= MAX_F, MDNO_EUNSUPPORTED, "edge_mlp: ker_in=%d (1..%d)", ker_in, MAX_F);
+    MDNO_REQUIRE(edge_attr || ker_in == 6, MDNO_EINVAL, "edge_mlp: position-derived attributes need ker_in == 6");
+    MDNO_REQUIRE(workspace_bytes >= mdno_edge_mlp_workspace_bytes(ker_width, edge_cap), MDNO_EWORKSPACE,
+                 "edge_mlp: workspace %zu < %zu", workspace_bytes, mdno_edge_mlp_workspace_bytes(ker_width, edge_cap));
+    const long long chunk = chunk_rows_for(edge_cap);
+    Carver cv(workspace);
+    float* h1 = cv.take<float>((size_t)chunk * ker_width);
+    float* h2 = cv.take<float>((size_t)chunk * ker_width);
+    const float* pos_mode = edge_attr ? nullptr : frames;
+    for (long long e0 = 0; e0 < edge_cap; e0 += chunk) {
+        const int cnt = (int)((edge_cap - e0) < chunk ? (edge_cap - e0) : chunk);
+        hipLaunchKernelGGL(edge_l0_kernel, dim3((cnt + EB - 1) / EB), dim3(256), 0, s, pos_mode, frame, t_dev,
+                           rows_per_frame, src, dst, edge_attr, perm, num_edges, e0, cnt, ker_in, ker_width, w.w0,
+                           w.b0, h1);
+        MDNO_TRY(check_launch("edge_l0_kernel"));
+        GemmArgs g1{h1, w.w1, w.b1, h2, num_edges, e0, (int)chunk, ker_width, ker_width};
+        MDNO_TRY(launch_gemm<true>(g1, s));
+        // the last layer writes straight into W_e; rows past *num_edges are masked by `valid`
+        GemmArgs g2{h2, w.w2, w.b2, w_e + (size_t)e0 * out_dim, num_edges, e0, (int)chunk, out_dim, ker_width};
+        MDNO_TRY(launch_gemm<false>(g2, s));
+    }
+    return MDNO_OK;
+}
+
+extern "C" int mdno_edge_mlp_fwd(const float* edge_pos, const int32_t* src, const int32_t* dst,
+                                 const float* edge_attr, const int32_t* perm, const int32_t* num_edges,
+                                 int64_t edge_cap, int ker_in, int ker_width, int out_dim, const float* w0,
+                                 const float* b0, const float* w1, const float* b1, const float* w2,
+                                 const float* b2, float* w_e, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+    EdgeMlpWeights w{w0, b0, w1, b1, w2, b2};
+    return mdno::edge_mlp(edge_pos, 0, nullptr, 0, src, dst, edge_attr, perm, num_edges, (long long)edge_cap, ker_in,
+                          ker_width, out_dim, w, w_e, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}

@@ -1,0 +1,300 @@
+// Whole forward and the on-device autoregressive rollout.
+//
+// forward  replaces KernelNN.forward            (graph_kernel.py:277-309)
+// rollout  replaces recursive_propagation       (graph_kernel.py:396-413) and the notebook's
+//          propogate (bba_analysis.ipynb:336-358): the reference crosses PCIe twice per step and
+//          rebuilds the graph with scipy on the host; here a step is a fixed sequence of launches
+//          on one stream, captured once into a hipGraph and replayed.
+//
+// One algorithmic change relative to the reference, value-preserving: conv1 and conv2 share ONE
+// edge-MLP (graph_kernel.py:271-273) and edge_attr never changes inside a forward (:278-302), so
+// all 2*depth conv applications use the same W_e = net(edge_attr).  It is evaluated once per
+// forward instead of 2*depth times.
+#include "kernels.h"
+
+#include <string>
+
+namespace mdno {
+
+namespace {
+thread_local std::string g_last_error;
+}
+
+void set_error(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+namespace {
+
+int validate_params(const mdno_kernelnn_params* p) {
+    MDNO_REQUIRE(p != nullptr, MDNO_EINVAL, "params: null");
+    MDNO_REQUIRE(p->width > 0 && p->ker_width > 0 && p->depth >= 0 && p->ker_in > 0 && p->out_width > 0, MDNO_EINVAL,
+                 "params: width=%d ker_width=%d depth=%d ker_in=%d out_width=%d", p->width, p->ker_width, p->depth,
+                 p->ker_in, p->out_width);
+    MDNO_REQUIRE(p->k_w0 && p->k_b0 && p->k_w1 && p->k_b1 && p->k_w2 && p->k_b2 && p->conv1_root && p->conv1_bias &&
+                     p->conv2_root && p->conv2_bias && p->fc2_w && p->fc2_b,
+                 MDNO_EINVAL, "params: null weight pointer");
+    return MDNO_OK;
+}
+
+bool separate_conv2_kernel(const mdno_kernelnn_params* p) {
+    return p->k2_w0 && (p->k2_w0 != p->k_w0 || p->k2_w1 != p->k_w1 || p->k2_w2 != p->k_w2 || p->k2_b0 != p->k_b0 ||
+                        p->k2_b1 != p->k_b1 || p->k2_b2 != p->k_b2);
+}
+
+struct FwdWs {
+    float *xa, *xb, *w_e;
+    void* mlp;
+    size_t mlp_bytes, total;
+};
+
+FwdWs carve_fwd(void* ws, const mdno_kernelnn_params* p, int M, int N, long long edge_cap) {
+    FwdWs f{};
+    Carver cv(ws);
+    const size_t R = (size_t)M * N;
+    f.xa = cv.take<float>(R * p->width);
+    f.xb = cv.take<float>(R * p->width);
+    f.w_e = cv.take<float>((size_t)edge_cap * p->width * p->width);
+    f.mlp_bytes = mdno_edge_mlp_workspace_bytes(p->ker_width, edge_cap);
+    f.mlp = cv.take<char>(f.mlp_bytes);
+    f.total = cv.used();
+    return f;
+}
+
+// frames/t0/t_dev address the window; edge_frames/edge_frame the frame the graph was built on.
+int forward_impl(const mdno_kernelnn_params* p, const float* frames, int t0, const int* t_dev, int M, int W, int N,
+                 const long long* aa, int aa_per_member, const int* row_ptr, const int* src, const int* dst,
+                 const int* num_edges, long long edge_cap, const float* edge_frames, int edge_frame,
+                 const float* edge_attr, const int* perm, float* out_frames, int t_out, float* latent,
+                 const FwdWs& ws, int* status, hipStream_t s) {
+    const int R = M * N, C = p->width;
+    MDNO_TRY(node_prologue(p, frames, t0, t_dev, M, W, N, aa, aa_per_member, ws.xa, status, s));
+    float* cur = ws.xa;
+    float* nxt = ws.xb;
+    for (int block = 0; block < 2; ++block) {
+        if (block == 0 || separate_conv2_kernel(p)) {
+            EdgeMlpWeights w = (block == 0) ? EdgeMlpWeights{p->k_w0, p->k_b0, p->k_w1, p->k_b1, p->k_w2, p->k_b2}
+                                            : EdgeMlpWeights{p->k2_w0, p->k2_b0, p->k2_w1, p->k2_b1, p->k2_w2, p->k2_b2};
+            MDNO_TRY(edge_mlp(edge_frames, edge_frame, t_dev, R, src, dst, edge_attr, perm, num_edges, edge_cap,
+                              p->ker_in, p->ker_width, C * C, w, ws.w_e, ws.mlp, ws.mlp_bytes, s));
+        }
+        const float* root = block == 0 ? p->conv1_root : p->conv2_root;
+        const float* bias = block == 0 ? p->conv1_bias : p->conv2_bias;
+        for (int d = 0; d < p->depth; ++d) {
+            MDNO_TRY(nnconv(cur, row_ptr, src, R, ws.w_e, root, bias, C, C, MDNO_AGGR_MEAN, /*relu=*/1, nxt, s));
+            float* t = cur; cur = nxt; nxt = t;
+        }
+    }
+    if (latent) MDNO_HIP(hipMemcpyAsync(latent, cur, sizeof(float) * (size_t)R * C, hipMemcpyDeviceToDevice, s));
+    MDNO_TRY(fc_out(cur, p->fc2_w, p->fc2_b, R, C, p->out_width, out_frames, t_out, t_dev, s));
+    return MDNO_OK;
+}
+
+__global__ void advance_step_kernel(int* t_dev, const int* num_edges, int* edges_per_step) {
+    const int t = *t_dev;
+    if (edges_per_step) edges_per_step[t] = *num_edges;
+    *t_dev = t + 1;
+}
+
+struct RolloutWs {
+    int *row_ptr, *src, *dst, *num_edges, *t_dev;
+    void* fwd;
+    size_t fwd_bytes, total;
+};
+
+RolloutWs carve_rollout(void* ws, const mdno_kernelnn_params* p, int M, int N, long long edge_cap) {
+    RolloutWs r{};
+    Carver cv(ws);
+    const size_t R = (size_t)M * N;
+    r.row_ptr = cv.take<int>(R + 1);
+    r.src = cv.take<int>((size_t)edge_cap);
+    r.dst = cv.take<int>((size_t)edge_cap);
+    r.num_edges = cv.take<int>(64);   // counters on their own 256-B line
+    r.t_dev = r.num_edges + 1;
+    r.fwd_bytes = carve_fwd(nullptr, p, M, N, edge_cap).total;
+    r.fwd = cv.take<char>(r.fwd_bytes);
+    r.total = cv.used();
+    return r;
+}
+
+}  // namespace
+}  // namespace mdno
+
+using namespace mdno;
+
+extern "C" int mdno_abi_version(void) { return MDNO_ABI_VERSION; }
+
+extern "C" const char* mdno_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" size_t mdno_kernelnn_workspace_bytes(const mdno_kernelnn_params* p, int M, int N, int64_t edge_cap) {
+    if (!p || M <= 0 || N <= 0 || edge_cap <= 0) return 0;
+    return carve_fwd(nullptr, p, M, N, (long long)edge_cap).total;
+}
+
+extern "C" int mdno_kernelnn_fwd(const mdno_kernelnn_params* p, const float* frames, int M, int W, int N,
+                                 const int64_t* x_aminoacid, int aa_per_member, const int32_t* row_ptr,
+                                 const int32_t* src, const int32_t* dst, const int32_t* num_edges,
+                                 int64_t edge_cap, const float* edge_pos, const float* edge_attr,
+                                 const int32_t* perm, float* out, float* latent, void* workspace,
+                                 size_t workspace_bytes, int32_t* status, void* stream) {
+    MDNO_TRY(validate_params(p));
+    MDNO_REQUIRE(frames && x_aminoacid && row_ptr && src && num_edges && out && workspace, MDNO_EINVAL,
+                 "mdno_kernelnn_fwd: null pointer");
+    MDNO_REQUIRE(M > 0 && W > 0 && N > 0 && edge_cap > 0, MDNO_EINVAL, "mdno_kernelnn_fwd: M=%d W=%d N=%d", M, W, N);
+    FwdWs ws = carve_fwd(workspace, p, M, N, (long long)edge_cap);
+    MDNO_REQUIRE(workspace_bytes >= ws.total, MDNO_EWORKSPACE, "mdno_kernelnn_fwd: workspace %zu < %zu",
+                 workspace_bytes, ws.total);
+    return forward_impl(p, frames, 0, nullptr, M, W, N, (const long long*)x_aminoacid, aa_per_member, row_ptr, src,
+                        dst, num_edges, (long long)edge_cap, edge_pos, 0, edge_attr, perm, out, 0, latent, ws, status,
+                        static_cast<hipStream_t>(stream));
+}
+
+extern "C" size_t mdno_rollout_workspace_bytes(const mdno_kernelnn_params* p, int M, int N, int64_t edge_cap) {
+    if (!p || M <= 0 || N <= 0 || edge_cap <= 0) return 0;
+    return carve_rollout(nullptr, p, M, N, (long long)edge_cap).total;
+}
+
+namespace mdno {
+namespace {
+__global__ void set_step_kernel(int* t_dev, int v) { *t_dev = v; }
+}  // namespace
+}  // namespace mdno
+
+struct mdno_rollout_plan {
+    mdno_kernelnn_params p;
+    float* traj;
+    int M, W, N, max_steps;
+    const long long* aa;
+    int aa_per_member;
+    double threshold;
+    long long edge_cap;
+    RolloutWs r;
+    FwdWs fw;
+    int* edges_per_step;
+    int* status;
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+};
+
+static int plan_enqueue_step(mdno_rollout_plan* pl, hipStream_t s) {
+    const int W = pl->W;
+    // graph + edge attributes of the LAST window frame (graph_kernel.py:363, :375): frame W-1+t
+    MDNO_TRY(radius_graph(pl->traj, W - 1, pl->r.t_dev, pl->M, pl->N, pl->threshold, pl->r.row_ptr, pl->r.src,
+                          pl->r.dst, pl->edge_cap, pl->r.num_edges, pl->status, s));
+    MDNO_TRY(forward_impl(&pl->p, pl->traj, 0, pl->r.t_dev, pl->M, W, pl->N, pl->aa, pl->aa_per_member, pl->r.row_ptr,
+                          pl->r.src, pl->r.dst, pl->r.num_edges, pl->edge_cap, pl->traj, W - 1, nullptr, nullptr,
+                          pl->traj, W, nullptr, pl->fw, pl->status, s));
+    hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(1), 0, s, pl->r.t_dev, (const int*)pl->r.num_edges,
+                       pl->edges_per_step);
+    return check_launch("advance_step");
+}
+
+extern "C" int mdno_rollout_plan_create(mdno_rollout_plan** plan, const mdno_kernelnn_params* p, float* traj, int M,
+                                        int W, int N, int max_steps, const int64_t* x_aminoacid, int aa_per_member,
+                                        double threshold, int64_t edge_cap, void* workspace, size_t workspace_bytes,
+                                        int32_t* edges_per_step, int32_t* status, int use_graph, void* stream) {
+    MDNO_REQUIRE(plan != nullptr, MDNO_EINVAL, "mdno_rollout_plan_create: null plan pointer");
+    *plan = nullptr;
+    MDNO_TRY(validate_params(p));
+    MDNO_REQUIRE(traj && x_aminoacid && workspace, MDNO_EINVAL, "mdno_rollout_plan_create: null pointer");
+    MDNO_REQUIRE(M > 0 && W > 0 && N > 0 && max_steps > 0 && edge_cap > 0, MDNO_EINVAL,
+                 "mdno_rollout_plan_create: M=%d W=%d N=%d max_steps=%d", M, W, N, max_steps);
+    MDNO_REQUIRE(p->out_width == 3, MDNO_EINVAL,
+                 "rollout: out_width=%d, the model output must be a frame [N,3] (graph_kernel.py:407-410)",
+                 p->out_width);
+    RolloutWs r = carve_rollout(workspace, p, M, N, (long long)edge_cap);
+    MDNO_REQUIRE(workspace_bytes >= r.total, MDNO_EWORKSPACE, "rollout: workspace %zu < %zu", workspace_bytes, r.total);
+    mdno_rollout_plan* pl = new mdno_rollout_plan{};
+    pl->p = *p;
+    pl->traj = traj;
+    pl->M = M; pl->W = W; pl->N = N; pl->max_steps = max_steps;
+    pl->aa = (const long long*)x_aminoacid;
+    pl->aa_per_member = aa_per_member;
+    pl->threshold = threshold;
+    pl->edge_cap = (long long)edge_cap;
+    pl->r = r;
+    pl->fw = carve_fwd(r.fwd, p, M, N, (long long)edge_cap);
+    pl->edges_per_step = edges_per_step;
+    pl->status = status;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (use_graph && s != nullptr) {
+        hipError_t eb = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+        if (eb != hipSuccess) {
+            set_error("hipStreamBeginCapture: %s", hipGetErrorString(eb));
+            delete pl;
+            return MDNO_ELAUNCH;
+        }
+        const int rc = plan_enqueue_step(pl, s);
+        hipError_t ec = hipStreamEndCapture(s, &pl->graph);
+        if (rc != MDNO_OK || ec != hipSuccess || !pl->graph) {
+            if (rc == MDNO_OK) set_error("hipStreamEndCapture: %s", hipGetErrorString(ec));
+            if (pl->graph) (void)hipGraphDestroy(pl->graph);
+            delete pl;
+            return rc != MDNO_OK ? rc : MDNO_ELAUNCH;
+        }
+        hipError_t ei = hipGraphInstantiate(&pl->exec, pl->graph, nullptr, nullptr, 0);
+        if (ei != hipSuccess) {
+            set_error("hipGraphInstantiate: %s", hipGetErrorString(ei));
+            (void)hipGraphDestroy(pl->graph);
+            delete pl;
+            return MDNO_ELAUNCH;
+        }
+    }
+    *plan = pl;
+    return MDNO_OK;
+}
+
+extern "C" int mdno_rollout_plan_run(mdno_rollout_plan* pl, int start_step, int steps, void* stream) {
+    MDNO_REQUIRE(pl != nullptr, MDNO_EINVAL, "mdno_rollout_plan_run: null plan");
+    MDNO_REQUIRE(start_step >= 0 && steps >= 0 && start_step + steps <= pl->max_steps, MDNO_EINVAL,
+                 "mdno_rollout_plan_run: start_step=%d steps=%d exceed max_steps=%d", start_step, steps, pl->max_steps);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (steps == 0) return MDNO_OK;
+    hipLaunchKernelGGL(set_step_kernel, dim3(1), dim3(1), 0, s, pl->r.t_dev, start_step);
+    MDNO_TRY(check_launch("set_step"));
+    for (int t = 0; t < steps; ++t) {
+        if (pl->exec) {
+            hipError_t el = hipGraphLaunch(pl->exec, s);
+            MDNO_REQUIRE(el == hipSuccess, MDNO_ELAUNCH, "hipGraphLaunch(step %d): %s", t, hipGetErrorString(el));
+        } else {
+            MDNO_TRY(plan_enqueue_step(pl, s));
+        }
+    }
+    return MDNO_OK;
+}
+
+extern "C" int mdno_rollout_plan_destroy(mdno_rollout_plan* pl) {
+    if (!pl) return MDNO_OK;
+    if (pl->exec) (void)hipGraphExecDestroy(pl->exec);
+    if (pl->graph) (void)hipGraphDestroy(pl->graph);
+    delete pl;
+    return MDNO_OK;
+}
+
+extern "C" int mdno_rollout(const mdno_kernelnn_params* p, float* traj, int M, int W, int N, int steps,
+                            const int64_t* x_aminoacid, int aa_per_member, double threshold, int64_t edge_cap,
+                            void* workspace, size_t workspace_bytes, int32_t* edges_per_step, int32_t* status,
+                            int use_graph, void* stream) {
+    MDNO_REQUIRE(steps >= 0, MDNO_EINVAL, "mdno_rollout: steps=%d", steps);
+    if (steps == 0) return MDNO_OK;
+    mdno_rollout_plan* pl = nullptr;
+    MDNO_TRY(mdno_rollout_plan_create(&pl, p, traj, M, W, N, steps, x_aminoacid, aa_per_member, threshold, edge_cap,
+                                      workspace, workspace_bytes, edges_per_step, status, use_graph, stream));
+    int rc = mdno_rollout_plan_run(pl, 0, steps, stream);
+    if (pl->exec) {
+        // The executable graph must outlive its enqueued launches; this convenience call has no
+        // object to park it in, so it waits for the stream before releasing it (see mdno.h).
+        hipError_t es = hipStreamSynchronize(static_cast<hipStream_t>(stream));
+        if (es != hipSuccess && rc == MDNO_OK) {
+            set_error("hipStreamSynchronize after rollout: %s", hipGetErrorString(es));
+            rc = MDNO_ELAUNCH;
+        }
+    }
+    mdno_rollout_plan_destroy(pl);
+    return rc;
+}

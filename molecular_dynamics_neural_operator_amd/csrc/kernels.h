@@ -1,0 +1,32 @@
+// Internal launch functions behind the C ABI.  They take one extra pair of arguments the public
+// entry points do not expose: a frame index plus an optional DEVICE-side step counter, so that a
+// captured rollout step (hipGraph) can be replayed unchanged while the window advances.
+//   frames : f32 [T, R, 3] time-major, R = M*N rows per frame; frame f starts at frames + f*R*3
+//   frame  : host index; effective frame = frame + (t_dev ? *t_dev : 0)
+#pragma once
+#include "common.h"
+
+namespace mdno {
+
+int radius_graph(const float* frames, int frame, const int* t_dev, int M, int N, double cutoff, int* row_ptr,
+                 int* src, int* dst, long long edge_cap, int* num_edges, int* status, hipStream_t s);
+
+struct EdgeMlpWeights {
+    const float *w0, *b0, *w1, *b1, *w2, *b2;
+};
+
+int edge_mlp(const float* frames, int frame, const int* t_dev, int rows_per_frame, const int* src, const int* dst,
+             const float* edge_attr, const int* perm, const int* num_edges, long long edge_cap, int ker_in,
+             int ker_width, int out_dim, const EdgeMlpWeights& w, float* w_e, void* workspace,
+             size_t workspace_bytes, hipStream_t s);
+
+int nnconv(const float* x, const int* row_ptr, const int* src, int num_rows, const float* w_e, const float* root,
+           const float* bias, int Cin, int Cout, int aggr, int relu, float* y, hipStream_t s);
+
+int node_prologue(const mdno_kernelnn_params* p, const float* frames, int t0, const int* t_dev, int M, int W, int N,
+                  const long long* aa, int aa_per_member, float* x0, int* status, hipStream_t s);
+
+int fc_out(const float* x, const float* w, const float* b, int rows, int width, int out_width, float* out_frames,
+           int t_out, const int* t_dev, hipStream_t s);
+
+}  // namespace mdno

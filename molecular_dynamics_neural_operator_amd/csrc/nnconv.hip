@@ -1,0 +1,160 @@
+// K3-K6: gather -> per-edge matvec -> segmented aggregation -> root/bias/ReLU, one launch.
+//
+// Replaces NNConv_old.forward/message/update (graph_kernel.py:194-209) plus torch_geometric's
+// index_select gather and scatter-mean, i.e. per conv application
+//     y[r] = act( aggr_{p in row r} x[src[p]] . W_e[p]  +  x[r] . root + bias ).
+//
+// Roofline: HBM.  W_e is read exactly once (Cin*Cout*4 B per edge, 16 KiB at 64x64) at
+// 2*Cin*Cout flop per edge = 0.5 flop/B; x (R*Cin*4 B) is L2-resident and re-gathered from cache.
+// Algorithmic bytes per launch: E*(Cin*Cout*4 + 4) + (R+1)*4 + 2*R*C*4.
+//
+// Layout / mapping (64x64 specialisation): edges are sorted by destination, so a row's W_e block
+// is ONE contiguous run of deg*16 KiB.  One 256-thread workgroup owns one destination row; its 4
+// waves take the row's edges round-robin.  Inside a wave, lane l = (g, q) with g = l>>4, q = l&15
+// accumulates output columns 4q..4q+3 over input rows 16g..16g+15: every wave-instruction is a
+// 16 B/lane load covering four whole 256-B rows of W_e[p] (fully coalesced), 16 such loads per
+// edge, 64 FMAs per lane.  Partial sums stay in registers across ALL edges of the row; the
+// reduction over g (2 shuffles) and over the 4 waves (LDS) happens once per row, in a fixed order,
+// so results are bitwise reproducible (no atomics).  The root term x[r].root is folded in as one
+// more "edge" (weight matrix = root) with its own accumulator.
+#include "kernels.h"
+
+namespace mdno {
+namespace {
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+__device__ __forceinline__ void fma4(float4& a, float s, const float4& w) {
+    a.x = fmaf(s, w.x, a.x);
+    a.y = fmaf(s, w.y, a.y);
+    a.z = fmaf(s, w.z, a.z);
+    a.w = fmaf(s, w.w, a.w);
+}
+
+// acc += x[16g..16g+15] . Wblk[16g..16g+15][4q..4q+3]
+__device__ __forceinline__ void edge_accumulate64(float4& acc, const float* __restrict__ xrow,
+                                                  const float* __restrict__ wmat, int g, int q) {
+    const float* xp = xrow + 16 * g;
+    const float4 x0 = ld4(xp), x1 = ld4(xp + 4), x2 = ld4(xp + 8), x3 = ld4(xp + 12);
+    const float* wp = wmat + (16 * g) * 64 + 4 * q;
+    float4 w[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) w[r] = ld4(wp + r * 64);
+    fma4(acc, x0.x, w[0]);  fma4(acc, x0.y, w[1]);  fma4(acc, x0.z, w[2]);  fma4(acc, x0.w, w[3]);
+    fma4(acc, x1.x, w[4]);  fma4(acc, x1.y, w[5]);  fma4(acc, x1.z, w[6]);  fma4(acc, x1.w, w[7]);
+    fma4(acc, x2.x, w[8]);  fma4(acc, x2.y, w[9]);  fma4(acc, x2.z, w[10]); fma4(acc, x2.w, w[11]);
+    fma4(acc, x3.x, w[12]); fma4(acc, x3.y, w[13]); fma4(acc, x3.z, w[14]); fma4(acc, x3.w, w[15]);
+}
+
+__device__ __forceinline__ float4 reduce_over_g(float4 a) {
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+        a.x += __shfl_xor(a.x, o);
+        a.y += __shfl_xor(a.y, o);
+        a.z += __shfl_xor(a.z, o);
+        a.w += __shfl_xor(a.w, o);
+    }
+    return a;
+}
+
+__global__ __launch_bounds__(256) void nnconv64_row_kernel(
+    const float* __restrict__ x, const int* __restrict__ row_ptr, const int* __restrict__ src,
+    const float* __restrict__ w_e, const float* __restrict__ root, const float* __restrict__ bias,
+    float* __restrict__ y, int num_rows, int aggr, int relu) {
+    __shared__ float red[4][2][64];
+    const int row = blockIdx.x;
+    if (row >= num_rows) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int g = lane >> 4, q = lane & 15;
+    const int beg = row_ptr[row], end = row_ptr[row + 1];
+    const int deg = end - beg;
+
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = beg + wave; p < end; p += 4) {
+        const int j = src[p];
+        edge_accumulate64(acc, x + (size_t)j * 64, w_e + (size_t)p * 4096, g, q);
+    }
+    float4 racc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (root != nullptr && wave == (deg & 3)) edge_accumulate64(racc, x + (size_t)row * 64, root, g, q);
+
+    acc = reduce_over_g(acc);
+    racc = reduce_over_g(racc);
+    if (lane < 16) {
+        *reinterpret_cast<float4*>(&red[wave][0][4 * lane]) = acc;
+        *reinterpret_cast<float4*>(&red[wave][1][4 * lane]) = racc;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        float s = (red[0][0][tid] + red[1][0][tid]) + (red[2][0][tid] + red[3][0][tid]);
+        const float rs = (red[0][1][tid] + red[1][1][tid]) + (red[2][1][tid] + red[3][1][tid]);
+        if (aggr == MDNO_AGGR_MEAN) s = s / (float)(deg > 1 ? deg : 1);
+        s += rs;
+        if (bias != nullptr) s += bias[tid];
+        if (relu) s = fmaxf(s, 0.f);
+        y[(size_t)row * 64 + tid] = s;
+    }
+}
+
+// Any (Cin, Cout): one wave per destination row, lane = output column (strided), sequential edges.
+// Used for the small-dimension fixtures; not a performance path.
+__global__ __launch_bounds__(256) void nnconv_generic_kernel(
+    const float* __restrict__ x, const int* __restrict__ row_ptr, const int* __restrict__ src,
+    const float* __restrict__ w_e, const float* __restrict__ root, const float* __restrict__ bias,
+    float* __restrict__ y, int num_rows, int Cin, int Cout, int aggr, int relu) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= num_rows) return;
+    const int beg = row_ptr[row], end = row_ptr[row + 1];
+    const int deg = end - beg;
+    for (int o = lane; o < Cout; o += 64) {
+        float s = 0.f;
+        for (int p = beg; p < end; ++p) {
+            const float* xj = x + (size_t)src[p] * Cin;
+            const float* w = w_e + (size_t)p * Cin * Cout + o;
+            float m = 0.f;
+            for (int i = 0; i < Cin; ++i) m = fmaf(xj[i], w[(size_t)i * Cout], m);
+            s += m;
+        }
+        if (aggr == MDNO_AGGR_MEAN) s = s / (float)(deg > 1 ? deg : 1);
+        if (root != nullptr) {
+            const float* xr = x + (size_t)row * Cin;
+            float m = 0.f;
+            for (int i = 0; i < Cin; ++i) m = fmaf(xr[i], root[(size_t)i * Cout + o], m);
+            s += m;
+        }
+        if (bias != nullptr) s += bias[o];
+        if (relu) s = fmaxf(s, 0.f);
+        y[(size_t)row * Cout + o] = s;
+    }
+}
+
+}  // namespace
+}  // namespace mdno
+
+int mdno::nnconv(const float* x, const int* row_ptr, const int* src, int num_rows, const float* w_e,
+                 const float* root, const float* bias, int Cin, int Cout, int aggr, int relu, float* y,
+                 hipStream_t s) {
+    MDNO_REQUIRE(x && row_ptr && src && w_e && y, MDNO_EINVAL, "nnconv: null pointer");
+    MDNO_REQUIRE(num_rows > 0 && Cin > 0 && Cout > 0, MDNO_EINVAL, "nnconv: rows=%d Cin=%d Cout=%d", num_rows, Cin,
+                 Cout);
+    MDNO_REQUIRE(aggr == MDNO_AGGR_ADD || aggr == MDNO_AGGR_MEAN, MDNO_EUNSUPPORTED,
+                 "nnconv: aggr %d not implemented (add, mean)", aggr);
+    MDNO_REQUIRE(x != y, MDNO_EINVAL, "nnconv: y aliases x");
+    const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_e) |
+                           reinterpret_cast<uintptr_t>(root)) & 15) == 0;
+    if (Cin == 64 && Cout == 64 && aligned) {
+        hipLaunchKernelGGL(nnconv64_row_kernel, dim3(num_rows), dim3(256), 0, s, x, row_ptr, src, w_e, root, bias,
+                           y, num_rows, aggr, relu);
+    } else {
+        hipLaunchKernelGGL(nnconv_generic_kernel, dim3((num_rows + 3) / 4), dim3(256), 0, s, x, row_ptr, src, w_e,
+                           root, bias, y, num_rows, Cin, Cout, aggr, relu);
+    }
+    return check_launch("nnconv");
+}
+
+extern "C" int mdno_nnconv_fwd(const float* x, const int32_t* row_ptr, const int32_t* src, int num_rows,
+                               const float* w_e, const float* root, const float* bias, int Cin, int Cout,
+                               int aggr, int relu, float* y, void* stream) {
+    return mdno::nnconv(x, row_ptr, src, num_rows, w_e, root, bias, Cin, Cout, aggr, relu, y,
+                        static_cast<hipStream_t>(stream));
+}

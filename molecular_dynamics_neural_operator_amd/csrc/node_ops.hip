@@ -1,0 +1,163 @@
+// K7/K8 node prologue and K9 output projection: the per-atom ends of KernelNN.forward.
+//
+// Prologue replaces graph_kernel.py:279-298 — W sequential nn.LSTM(3,3) single-step calls over the
+// window with the atoms as the LSTM batch and zero initial (h, c), lstm_fc, nn.Embedding lookup,
+// concat [emb, x], fc1, ReLU — in one launch.  B=1 semantics per member (members
+// are independent; the reference's batched mode threads one LSTM state through the batch axis and
+// is not reproduced).  Output projection replaces fc2 (:305) and writes the new frame straight
+// into the trajectory buffer.  Both are negligible in time (R*~1e3 flop); they exist so that a
+// rollout step never leaves the device.
+#include "kernels.h"
+
+namespace mdno {
+namespace {
+
+constexpr int H = 3;            // x_position_dim == LSTM hidden size (graph_kernel.py:264)
+constexpr int MAX_EMB = 16;
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+struct PrologueArgs {
+    const float* frames;
+    int t0;
+    const int* t0_dev;
+    int M, W, N;
+    const long long* aa;
+    int aa_per_member;
+    const float *w_ih, *w_hh, *b_ih, *b_hh, *fc_w, *fc_b, *emb_w, *fc1_w, *fc1_b;
+    int num_emb, emb_dim, width;
+    float* x0;
+    int* status;
+};
+
+__global__ __launch_bounds__(256) void node_prologue_kernel(PrologueArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int R = a.M * a.N;
+    if (r >= R) return;
+    const int m = r / a.N, n = r - m * a.N;
+    const int t0 = a.t0 + (a.t0_dev ? *a.t0_dev : 0);
+    const float* f0 = a.frames + ((size_t)t0 * R + r) * 3;  // frames are time-major [T, M*N, 3]
+
+    // LSTM weights are 2*36 + 24 floats: every lane keeps them in registers (wave-uniform loads)
+    float wih[4 * H][H], whh[4 * H][H], bsum[4 * H];
+#pragma unroll
+    for (int g = 0; g < 4 * H; ++g) {
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+            wih[g][k] = a.w_ih[g * H + k];
+            whh[g][k] = a.w_hh[g * H + k];
+        }
+        bsum[g] = a.b_ih[g] + a.b_hh[g];
+    }
+    float h[H] = {0.f, 0.f, 0.f}, c[H] = {0.f, 0.f, 0.f};
+    for (int t = 0; t < a.W; ++t) {
+        const float* p = f0 + (size_t)t * R * 3;
+        const float x[H] = {p[0], p[1], p[2]};
+        float gate[4 * H];
+#pragma unroll
+        for (int g = 0; g < 4 * H; ++g) {
+            float s = bsum[g];
+#pragma unroll
+            for (int k = 0; k < H; ++k) s = fmaf(wih[g][k], x[k], s);
+#pragma unroll
+            for (int k = 0; k < H; ++k) s = fmaf(whh[g][k], h[k], s);
+            gate[g] = s;
+        }
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+            const float ig = sigmoidf_(gate[k]), fg = sigmoidf_(gate[H + k]);
+            const float gg = tanhf(gate[2 * H + k]), og = sigmoidf_(gate[3 * H + k]);
+            c[k] = fg * c[k] + ig * gg;
+            h[k] = og * tanhf(c[k]);
+        }
+    }
+    float feat[MAX_EMB + H];
+    long long id = a.aa[a.aa_per_member ? r : n];
+    if (id < 0 || id >= a.num_emb) {
+        if (lane == 0 && a.status) atomicOr(a.status, MDNO_STATUS_BAD_AMINOACID);
+        id = id < 0 ? 0 : a.num_emb - 1;
+    }
+#pragma unroll
+    for (int e = 0; e < MAX_EMB; ++e) feat[e] = (e < a.emb_dim) ? a.emb_w[id * a.emb_dim + e] : 0.f;
+#pragma unroll
+    for (int k = 0; k < H; ++k) {
+        float s = a.fc_b[k];
+#pragma unroll
+        for (int j = 0; j < H; ++j) s = fmaf(a.fc_w[k * H + j], h[j], s);
+        feat[MAX_EMB + k] = s;
+    }
+    const int in_w = a.emb_dim + H;
+    for (int o = lane; o < a.width; o += 64) {
+        const float* w = a.fc1_w + (size_t)o * in_w;
+        float s = a.fc1_b[o];
+        for (int e = 0; e < a.emb_dim; ++e) s = fmaf(w[e], feat[e], s);
+#pragma unroll
+        for (int k = 0; k < H; ++k) s = fmaf(w[a.emb_dim + k], feat[MAX_EMB + k], s);
+        a.x0[(size_t)r * a.width + o] = fmaxf(s, 0.f);
+    }
+}
+
+__global__ __launch_bounds__(256) void fc_out_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ b, int R, int width,
+                                                     int out_width, float* __restrict__ out, int t_out,
+                                                     const int* __restrict__ t_dev) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int t = t_out + (t_dev ? *t_dev : 0);
+    float* o_ptr = out + ((size_t)t * R + r) * out_width;
+    const float* xr = x + (size_t)r * width;
+    for (int o = 0; o < out_width; ++o) {
+        float s = 0.f;
+        for (int c = lane; c < width; c += 64) s = fmaf(xr[c], w[(size_t)o * width + c], s);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if (lane == 0) o_ptr[o] = s + (b ? b[o] : 0.f);
+    }
+}
+
+}  // namespace
+}  // namespace mdno
+
+int mdno::node_prologue(const mdno_kernelnn_params* p, const float* frames, int t0, const int* t_dev, int M, int W,
+                        int N, const long long* aa, int aa_per_member, float* x0, int* status, hipStream_t s) {
+    MDNO_REQUIRE(p && frames && aa && x0, MDNO_EINVAL, "node_prologue: null pointer");
+    MDNO_REQUIRE(p->lstm_w_ih && p->lstm_w_hh && p->lstm_b_ih && p->lstm_b_hh && p->lstm_fc_w && p->lstm_fc_b &&
+                     p->emb_w && p->fc1_w && p->fc1_b,
+                 MDNO_EINVAL, "node_prologue: null weight pointer");
+    MDNO_REQUIRE(M > 0 && W > 0 && N > 0 && t0 >= 0, MDNO_EINVAL, "node_prologue: M=%d W=%d N=%d", M, W, N);
+    MDNO_REQUIRE(p->x_position_dim == H, MDNO_EUNSUPPORTED, "x_position_dim=%d (only 3)", p->x_position_dim);
+    MDNO_REQUIRE(p->embedding_dim >= 0 && p->embedding_dim <= MAX_EMB, MDNO_EUNSUPPORTED, "embedding_dim=%d (0..%d)",
+                 p->embedding_dim, MAX_EMB);
+    MDNO_REQUIRE(p->in_width == p->embedding_dim + H, MDNO_EINVAL,
+                 "in_width=%d must equal embedding_dim + 3 = %d (graph_kernel.py:296)", p->in_width,
+                 p->embedding_dim + H);
+    PrologueArgs a{frames, t0, t_dev, M, W, N, aa, aa_per_member, p->lstm_w_ih, p->lstm_w_hh, p->lstm_b_ih,
+                   p->lstm_b_hh, p->lstm_fc_w, p->lstm_fc_b, p->emb_w, p->fc1_w, p->fc1_b, p->num_embeddings,
+                   p->embedding_dim, p->width, x0, status};
+    const int R = M * N;
+    hipLaunchKernelGGL(node_prologue_kernel, dim3((R + 3) / 4), dim3(256), 0, s, a);
+    return check_launch("node_prologue");
+}
+
+int mdno::fc_out(const float* x, const float* w, const float* b, int rows, int width, int out_width,
+                 float* out_frames, int t_out, const int* t_dev, hipStream_t s) {
+    MDNO_REQUIRE(x && w && out_frames, MDNO_EINVAL, "fc_out: null pointer");
+    MDNO_REQUIRE(rows > 0 && width > 0 && out_width > 0 && t_out >= 0, MDNO_EINVAL, "fc_out: bad sizes");
+    hipLaunchKernelGGL(fc_out_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, b, rows, width, out_width,
+                       out_frames, t_out, t_dev);
+    return check_launch("fc_out");
+}
+
+extern "C" int mdno_node_prologue_fwd(const mdno_kernelnn_params* p, const float* frames, int M, int W, int N,
+                                      const int64_t* x_aminoacid, int aa_per_member, float* x0, int32_t* status,
+                                      void* stream) {
+    return mdno::node_prologue(p, frames, 0, nullptr, M, W, N, (const long long*)x_aminoacid, aa_per_member, x0,
+                               status, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int mdno_fc_out_fwd(const float* x, const float* w, const float* b, int rows, int width, int out_width,
+                               float* out, void* stream) {
+    return mdno::fc_out(x, w, b, rows, width, out_width, out, 0, nullptr, static_cast<hipStream_t>(stream));
+}

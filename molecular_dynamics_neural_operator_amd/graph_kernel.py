@@ -1,0 +1,284 @@
+"""Drop-in for the hot path of the reference's ``graph_kernel.py`` — same names, constructor and
+``forward`` signatures, state_dict keys and RNG-draw order, with the arithmetic done by the HIP
+kernels of libmdno.so (include/mdno.h) on an MI355X.  There is no CPU fallback: calling any
+``forward`` with CPU tensors, or without the built library, raises.
+
+  LpLoss                 graph_kernel.py:75-122
+  NNConv_old             graph_kernel.py:125-214   (+ torch_geometric MessagePassing.propagate)
+  DenseNet               graph_kernel.py:217-242
+  KernelNN               graph_kernel.py:245-309
+  construct_pairdata     graph_kernel.py:362-393   (notebook variant bba_analysis.ipynb:302-334)
+  recursive_propagation  graph_kernel.py:396-413
+  propogate              bba_analysis.ipynb:336-358
+
+Differences from the reference, all explicit:
+  * ``KernelNN.forward`` reads the window length and atom count from ``data.x_position``'s shape
+    ([W,N,3]) instead of a module-global ``args`` (graph_kernel.py:279) and never calls ``.cuda()``.
+  * one sample per ``forward`` (B=1 semantics); several independent samples go
+    through ``rollout.RolloutEngine`` / ``ops.kernelnn_forward`` as a block-diagonal batch.
+  * inference only this round: ``forward`` in training mode with autograd enabled raises rather
+    than returning tensors without a graph.
+"""
+from __future__ import annotations
+
+import math
+from collections import defaultdict
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import MdnoError, require_gpu
+from .dataset import ContactMapDataset, PairData  # noqa: F401  (re-exported like the reference)
+
+EPS = 1e-15
+
+
+# --------------------------------------------------------------------------- init helpers
+def uniform(size: int, tensor: Optional[torch.Tensor]) -> None:
+    """U(-1/sqrt(size), 1/sqrt(size)) in place (torch_geometric.nn.inits.uniform semantics)."""
+    if tensor is not None:
+        bound = 1.0 / math.sqrt(size)
+        tensor.data.uniform_(-bound, bound)
+
+
+def reset(value) -> None:
+    """Recursively call ``reset_parameters`` (torch_geometric.nn.inits.reset semantics)."""
+    if hasattr(value, "reset_parameters"):
+        value.reset_parameters()
+    else:
+        for child in value.children() if hasattr(value, "children") else []:
+            reset(child)
+
+
+def _no_training(module: nn.Module) -> None:
+    if module.training and torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
+        raise NotImplementedError(
+            "the HIP path is forward-only this round (SURVEY.md §8f row 2): call model.eval() or run "
+            "under torch.no_grad()")
+
+
+# --------------------------------------------------------------------------- loss
+class LpLoss(object):
+    """Relative / absolute Lp loss (graph_kernel.py:75-122); host-side torch, not a kernel."""
+
+    def __init__(self, d=2, p=2, size_average=True, reduction=True):
+        assert d > 0 and p > 0
+        self.d, self.p, self.reduction, self.size_average = d, p, reduction, size_average
+
+    def _reduce(self, v):
+        if not self.reduction:
+            return v
+        return torch.mean(v) if self.size_average else torch.sum(v)
+
+    def abs(self, x, y):
+        n = x.size()[0]
+        h = 1.0 / (x.size()[1] - 1.0)
+        norms = (h ** (self.d / self.p)) * torch.norm(x.reshape(n, -1) - y.reshape(n, -1), self.p, 1)
+        return self._reduce(norms)
+
+    def rel(self, x, y):
+        n = x.size()[0]
+        diff = torch.norm(x.reshape(n, -1) - y.reshape(n, -1), self.p, 1)
+        ynorm = torch.norm(y.reshape(n, -1), self.p, 1)
+        return self._reduce(diff / ynorm)
+
+    def __call__(self, x, y):
+        return self.rel(x, y)
+
+
+# --------------------------------------------------------------------------- edge-MLP
+class DenseNet(nn.Module):
+    """``DenseNet(layers, nonlinearity, out_nonlinearity=None, normalize=False)``; the HIP path
+    implements the configuration the model uses — three Linear layers with ReLU between them
+    (graph_kernel.py:271) — and raises for anything else."""
+
+    def __init__(self, layers, nonlinearity, out_nonlinearity=None, normalize=False):
+        super().__init__()
+        self.n_layers = len(layers) - 1
+        assert self.n_layers >= 1
+        self.layers = nn.ModuleList()
+        for j in range(self.n_layers):
+            self.layers.append(nn.Linear(layers[j], layers[j + 1]))
+            if j != self.n_layers - 1:
+                if normalize:
+                    self.layers.append(nn.BatchNorm1d(layers[j + 1]))
+                self.layers.append(nonlinearity())
+        if out_nonlinearity is not None:
+            self.layers.append(out_nonlinearity())
+        self._hip_ok = (self.n_layers == 3 and not normalize and out_nonlinearity is None
+                        and nonlinearity is nn.ReLU)
+        self._dims = list(layers)
+
+    def hip_weights(self):
+        if not self._hip_ok:
+            raise NotImplementedError(
+                "libmdno implements the edge-MLP as Linear-ReLU-Linear-ReLU-Linear (graph_kernel.py:271); "
+                f"got layers={self._dims}")
+        l0, l2, l4 = self.layers[0], self.layers[2], self.layers[4]
+        return (l0.weight, l0.bias, l2.weight, l2.bias, l4.weight, l4.bias)
+
+    def forward(self, x):
+        _no_training(self)
+        w = self.hip_weights()
+        x = ops.f32(x)
+        E = x.shape[0]
+        ne = torch.full((1,), E, dtype=torch.int32, device=x.device)
+        g = ops.CSRGraph(None, None, None, ne, max(E, 1), None, None)
+        with torch.no_grad():
+            return ops.edge_mlp(w, self._dims[0], self._dims[1], self._dims[3], g, edge_attr=x)[:E]
+
+
+# --------------------------------------------------------------------------- conv
+class NNConv_old(nn.Module):
+    """Edge-conditioned convolution, ``out_i = aggr_j(x_j . net(e_ji)) + x_i . root + bias``."""
+
+    def __init__(self, in_channels, out_channels, net, aggr="add", root_weight=True, bias=True, **kwargs):
+        super().__init__()
+        if kwargs.get("flow", "source_to_target") != "source_to_target" or kwargs.get("node_dim", -2) != -2:
+            raise NotImplementedError("only flow='source_to_target', node_dim=-2 (the reference's defaults)")
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.net = net
+        self.aggr = aggr
+        if root_weight:
+            self.root = nn.Parameter(torch.Tensor(in_channels, out_channels))
+        else:
+            self.register_parameter("root", None)
+        if bias:
+            self.bias = nn.Parameter(torch.Tensor(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        reset(self.net)
+        size = self.in_channels
+        uniform(size, self.root)
+        uniform(size, self.bias)
+
+    def forward(self, x, edge_index, edge_attr):
+        _no_training(self)
+        x = x.unsqueeze(-1) if x.dim() == 1 else x
+        pseudo = edge_attr.unsqueeze(-1) if edge_attr.dim() == 1 else edge_attr
+        if self.aggr not in ("add", "mean"):
+            raise NotImplementedError(f"aggr={self.aggr!r}: the HIP path implements 'add' and 'mean'")
+        with torch.no_grad():
+            graph = ops.coo_to_csr(edge_index, x.shape[0])
+            dims = self.net._dims
+            w_e = ops.edge_mlp(self.net.hip_weights(), dims[0], dims[1], dims[3], graph, edge_attr=pseudo)
+            return ops.nnconv(x, graph, w_e, self.root, self.bias, self.aggr, relu=False)
+
+    def __repr__(self):
+        return "{}({}, {})".format(self.__class__.__name__, self.in_channels, self.out_channels)
+
+
+# --------------------------------------------------------------------------- model
+class KernelNN(nn.Module):
+    def __init__(self, width: int, ker_width: int, depth: int, ker_in: int, in_width: int = 1,
+                 out_width: int = 1, num_embeddings: int = 20, embedding_dim: int = 4,
+                 x_position_dim: int = 3) -> None:
+        super().__init__()
+        self.depth = depth
+        self.num_embeddings = num_embeddings
+        self.embedding_dim = embedding_dim
+        self.x_position_dim = x_position_dim
+        # module order == RNG draw order of the reference (graph_kernel.py:264-275)
+        self.lstm = nn.LSTM(x_position_dim, x_position_dim)
+        self.lstm_fc = nn.Linear(x_position_dim, x_position_dim)
+        self.emb = nn.Embedding(num_embeddings, embedding_dim)
+        self.fc1 = nn.Linear(in_width, width)
+        kernel = DenseNet([ker_in, ker_width, ker_width, width ** 2], nn.ReLU)
+        self.conv1 = NNConv_old(width, width, kernel, aggr="mean")
+        self.conv2 = NNConv_old(width, width, kernel, aggr="mean")
+        self.fc2 = nn.Linear(width, out_width)
+        self._pack = None
+        self._pack_key = None
+
+    # -- parameter pack (device pointers) cached until a parameter changes
+    def param_pack(self, device=None) -> ops.ParamPack:
+        device = require_gpu(device)
+        params = list(self.parameters())
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in params)
+        if self._pack is None or self._pack_key != key:
+            self._pack = ops.ParamPack(self.state_dict(), self.depth, device)
+            self._pack_key = key
+        return self._pack
+
+    def forward(self, data: PairData, return_latent: bool = False, single_example: bool = False):
+        _no_training(self)
+        x_position = data.x_position
+        if x_position.dim() == 2:  # notebook-era single-frame sample [N,3]
+            x_position = x_position.unsqueeze(0)
+        if not x_position.is_cuda:
+            raise MdnoError("KernelNN.forward needs the sample on the GPU (data.to('cuda')); no CPU fallback")
+        n_nodes = data.x_aminoacid.shape[0]
+        if x_position.shape[1] != n_nodes:
+            raise MdnoError(
+                f"x_position {tuple(x_position.shape)} vs {n_nodes} nodes: batched samples go through "
+                "rollout.RolloutEngine / ops.kernelnn_forward (one PairData per forward here)")
+        with torch.no_grad():
+            pack = self.param_pack(x_position.device)
+            graph = ops.coo_to_csr(data.edge_index, n_nodes)
+            out, latent = ops.kernelnn_forward(pack, x_position.unsqueeze(1), data.x_aminoacid, graph,
+                                               edge_attr=data.edge_attr, return_latent=return_latent)
+        return [out, latent] if return_latent else out
+
+
+# --------------------------------------------------------------------------- graph construction
+def construct_pairdata(x_position, x_aminoacid, threshold: float = 8.0) -> PairData:
+    """Radius graph + edge attributes of the LAST frame of ``x_position`` ([W,N,3]; a single frame
+    [N,3] is accepted as in the notebook).  Returns tensors on the GPU."""
+    dev = require_gpu()
+    xp = torch.as_tensor(np.asarray(x_position) if not torch.is_tensor(x_position) else x_position)
+    xp = xp.to(device=dev, dtype=torch.float32)
+    single = xp.dim() == 2
+    last = (xp if single else xp[-1]).contiguous()
+    n = last.shape[0]
+    g = ops.radius_graph(last, n, threshold)
+    edge_index = g.to_edge_index()
+    edge_attr = torch.cat([last[edge_index[0]], last[edge_index[1]]], dim=1)
+    if torch.is_tensor(x_aminoacid):
+        x_aminoacid = x_aminoacid.to(dev)
+    return PairData(x_aminoacid=x_aminoacid, x_position=xp, edge_attr=edge_attr, edge_index=edge_index)
+
+
+# --------------------------------------------------------------------------- rollout
+def _unwrap(model):
+    return model.module if hasattr(model, "module") else model
+
+
+def recursive_propagation(model, dataset, device, num_steps: int, starting_points: list,
+                          threshold: float = 8.0) -> List[PairData]:
+    """Autoregressive rollout from each starting sample; returns the per-step ``PairData`` (on the
+    CPU, like the reference).  The loop itself runs on the device (rollout.RolloutEngine)."""
+    from .rollout import RolloutEngine
+    net = _unwrap(model)
+    net.eval()
+    forecasts: List[PairData] = []
+    for start in starting_points:
+        sample = dataset[start]
+        win = sample.x_position if sample.x_position.dim() == 3 else sample.x_position.unsqueeze(0)
+        W, N, _ = win.shape
+        eng = RolloutEngine(net, members=1, n_atoms=N, window=W, threshold=threshold, max_steps=num_steps,
+                            device=device)
+        traj = eng.run(win.unsqueeze(1), sample.x_aminoacid, num_steps)        # [steps,1,N,3]
+        frames = torch.cat([win.to(traj.device), traj[:, 0]], dim=0)             # [W+steps,N,3]
+        for i in range(num_steps):
+            pd = construct_pairdata(frames[i + 1:i + 1 + W], sample.x_aminoacid, threshold=threshold)
+            forecasts.append(pd.to("cpu"))
+    return forecasts
+
+
+def propogate(model, dataset, device, num_steps: int, threshold: float = 8.0):
+    """Notebook rollout: starts at ``dataset[0]`` and also records the per-step MSE against
+    ``dataset[i+1].x_position`` (bba_analysis.ipynb:351)."""
+    forecasts = recursive_propagation(model, dataset, device, num_steps, [0], threshold)
+    metrics = defaultdict(list)
+    for i, f in enumerate(forecasts):
+        truth = dataset[i + 1].x_position
+        truth = (truth if truth.dim() == 2 else truth[-1]).cpu().numpy()
+        metrics["mse"].append(float(((f.x_position[-1].numpy() - truth) ** 2).mean()))
+    return forecasts, dict(metrics)

@@ -1,0 +1,206 @@
+"""Tensor-level wrappers over the C ABI (include/mdno.h).  PyTorch is used for device memory and
+streams only; every computation below is a libmdno HIP kernel.  All tensors must be CUDA(HIP)
+tensors — there is no CPU path."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import AGGR, KernelNNParams, MdnoError, check, f32, ptr, stream_ptr
+
+
+@dataclass
+class CSRGraph:
+    """Destination-sorted CSR (see mdno.h): row r lists the sources of its in-edges."""
+    row_ptr: torch.Tensor            # i32 [R+1]
+    src: torch.Tensor                # i32 [cap]
+    dst: torch.Tensor                # i32 [cap]
+    num_edges: torch.Tensor          # i32 [1] (device)
+    edge_cap: int
+    perm: Optional[torch.Tensor] = None   # i32 [E]: CSR position p holds input edge perm[p]
+    status: Optional[torch.Tensor] = None
+
+    def edge_count(self) -> int:
+        return int(self.num_edges.item())
+
+    def to_edge_index(self) -> torch.Tensor:
+        """Reference-order COO `[rows; cols]` (graph_kernel.py:368) — valid for radius graphs, whose
+        contact map is symmetric, so (dst, src) read in CSR order IS the row-major COO."""
+        e = self.edge_count()
+        return torch.stack([self.dst[:e], self.src[:e]]).to(torch.long)
+
+
+def radius_graph(pos: torch.Tensor, n_atoms: int, cutoff: float = 8.0, edge_cap: Optional[int] = None) -> CSRGraph:
+    """pos f32 [M*N,3] (or [M,N,3]) -> CSRGraph.  Replaces graph_kernel.py:363-368."""
+    lib = _lib.load()
+    pos = f32(pos).reshape(-1, 3)
+    R = pos.shape[0]
+    if R % n_atoms:
+        raise MdnoError(f"{R} rows is not a multiple of n_atoms={n_atoms}")
+    M = R // n_atoms
+    cap = int(edge_cap) if edge_cap is not None else M * n_atoms * n_atoms
+    cap = max(cap, R)
+    dev = pos.device
+    row_ptr = torch.empty(R + 1, dtype=torch.int32, device=dev)
+    src = torch.empty(cap, dtype=torch.int32, device=dev)
+    dst = torch.empty(cap, dtype=torch.int32, device=dev)
+    ne = torch.zeros(1, dtype=torch.int32, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    check(lib.mdno_radius_graph_csr(ptr(pos), M, n_atoms, float(cutoff), ptr(row_ptr), ptr(src), ptr(dst), cap,
+                                    ptr(ne), ptr(status), stream_ptr(dev)), "mdno_radius_graph_csr")
+    return CSRGraph(row_ptr, src, dst, ne, cap, None, status)
+
+
+def coo_to_csr(edge_index: torch.Tensor, num_nodes: int) -> CSRGraph:
+    """edge_index i64 [2,E] (row 0 = source, row 1 = target) -> CSRGraph with `perm`."""
+    lib = _lib.load()
+    if edge_index.dim() != 2 or edge_index.shape[0] != 2:
+        raise MdnoError(f"edge_index must be [2,E], got {tuple(edge_index.shape)}")
+    ei = edge_index.to(torch.long).contiguous()
+    E = ei.shape[1]
+    dev = ei.device
+    row_ptr = torch.empty(num_nodes + 1, dtype=torch.int32, device=dev)
+    cap = max(E, 1)
+    src = torch.empty(cap, dtype=torch.int32, device=dev)
+    dst = torch.empty(cap, dtype=torch.int32, device=dev)
+    perm = torch.empty(cap, dtype=torch.int32, device=dev)
+    nbytes = lib.mdno_coo_to_csr_workspace_bytes(E, num_nodes)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    check(lib.mdno_coo_to_csr(ptr(ei), E, num_nodes, ptr(row_ptr), ptr(src), ptr(dst), ptr(perm), ptr(ws), nbytes,
+                              stream_ptr(dev)), "mdno_coo_to_csr")
+    ne = torch.full((1,), E, dtype=torch.int32, device=dev)
+    return CSRGraph(row_ptr, src, dst, ne, cap, perm, None)
+
+
+def edge_mlp(weights, ker_in: int, ker_width: int, out_dim: int, graph: CSRGraph,
+             edge_pos: Optional[torch.Tensor] = None, edge_attr: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """W_e f32 [cap, out_dim] in CSR edge order.  `weights` = (w0,b0,w1,b1,w2,b2) torch Linear
+    layout.  Attributes from `edge_pos` [R,3] + CSR, or `edge_attr` [E,ker_in] (+ graph.perm)."""
+    lib = _lib.load()
+    w = [f32(t) for t in weights]
+    dev = w[0].device
+    cap = graph.edge_cap
+    w_e = torch.empty((cap, out_dim), dtype=torch.float32, device=dev)
+    nbytes = lib.mdno_edge_mlp_workspace_bytes(ker_width, cap)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    ea = f32(edge_attr) if edge_attr is not None else None
+    ep = f32(edge_pos).reshape(-1, 3) if edge_pos is not None else None
+    check(lib.mdno_edge_mlp_fwd(ptr(ep), ptr(graph.src), ptr(graph.dst), ptr(ea),
+                                ptr(graph.perm) if ea is not None else None, ptr(graph.num_edges), cap,
+                                ker_in, ker_width, out_dim, *[ptr(t) for t in w], ptr(w_e), ptr(ws), nbytes,
+                                stream_ptr(dev)), "mdno_edge_mlp_fwd")
+    return w_e
+
+
+def nnconv(x: torch.Tensor, graph: CSRGraph, w_e: torch.Tensor, root: Optional[torch.Tensor],
+           bias: Optional[torch.Tensor], aggr: str = "mean", relu: bool = False) -> torch.Tensor:
+    lib = _lib.load()
+    if aggr not in AGGR:
+        raise MdnoError(f"aggr={aggr!r} is not implemented by the HIP path (add, mean)")
+    x = f32(x)
+    R, cin = x.shape
+    cout = w_e.shape[1] // cin
+    y = torch.empty((R, cout), dtype=torch.float32, device=x.device)
+    root_c = f32(root) if root is not None else None
+    bias_c = f32(bias) if bias is not None else None
+    check(lib.mdno_nnconv_fwd(ptr(x), ptr(graph.row_ptr), ptr(graph.src), R, ptr(w_e), ptr(root_c), ptr(bias_c),
+                              cin, cout, AGGR[aggr], int(relu), ptr(y), stream_ptr(x.device)), "mdno_nnconv_fwd")
+    return y
+
+
+class ParamPack:
+    """Owns contiguous fp32 device copies (or views) of a KernelNN state_dict and the C struct
+    pointing at them.  Keep it alive while kernels that use it are in flight."""
+
+    KEYS = {
+        "lstm_w_ih": "lstm.weight_ih_l0", "lstm_w_hh": "lstm.weight_hh_l0",
+        "lstm_b_ih": "lstm.bias_ih_l0", "lstm_b_hh": "lstm.bias_hh_l0",
+        "lstm_fc_w": "lstm_fc.weight", "lstm_fc_b": "lstm_fc.bias", "emb_w": "emb.weight",
+        "fc1_w": "fc1.weight", "fc1_b": "fc1.bias",
+        "k_w0": "conv1.net.layers.0.weight", "k_b0": "conv1.net.layers.0.bias",
+        "k_w1": "conv1.net.layers.2.weight", "k_b1": "conv1.net.layers.2.bias",
+        "k_w2": "conv1.net.layers.4.weight", "k_b2": "conv1.net.layers.4.bias",
+        "k2_w0": "conv2.net.layers.0.weight", "k2_b0": "conv2.net.layers.0.bias",
+        "k2_w1": "conv2.net.layers.2.weight", "k2_b1": "conv2.net.layers.2.bias",
+        "k2_w2": "conv2.net.layers.4.weight", "k2_b2": "conv2.net.layers.4.bias",
+        "conv1_root": "conv1.root", "conv1_bias": "conv1.bias",
+        "conv2_root": "conv2.root", "conv2_bias": "conv2.bias",
+        "fc2_w": "fc2.weight", "fc2_b": "fc2.bias",
+    }
+
+    def __init__(self, state_dict, depth: int, device):
+        sd = {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
+        self.tensors = {}
+        p = KernelNNParams()
+        for field, key in self.KEYS.items():
+            if key not in sd:
+                if field.startswith("k2_"):
+                    setattr(p, field, None)
+                    continue
+                raise MdnoError(f"state_dict lacks {key!r}")
+            t = sd[key].detach().to(device=device, dtype=torch.float32).contiguous()
+            self.tensors[field] = t
+            setattr(p, field, t.data_ptr())
+        # the reference shares ONE edge-MLP between conv1 and conv2 (graph_kernel.py:271-273):
+        # tied storage or equal values -> evaluate once
+        shared = all(
+            ("k2_" + n) not in self.tensors
+            or self.tensors["k2_" + n].data_ptr() == self.tensors["k_" + n].data_ptr()
+            or torch.equal(self.tensors["k2_" + n], self.tensors["k_" + n])
+            for n in ("w0", "b0", "w1", "b1", "w2", "b2"))
+        if shared:
+            for n in ("w0", "b0", "w1", "b1", "w2", "b2"):
+                setattr(p, "k2_" + n, None)
+        self.shared_kernel = shared
+        width = self.tensors["fc1_w"].shape[0]
+        p.width = width
+        p.ker_width = self.tensors["k_w0"].shape[0]
+        p.depth = int(depth)
+        p.ker_in = self.tensors["k_w0"].shape[1]
+        p.in_width = self.tensors["fc1_w"].shape[1]
+        p.out_width = self.tensors["fc2_w"].shape[0]
+        p.num_embeddings, p.embedding_dim = self.tensors["emb_w"].shape
+        p.x_position_dim = self.tensors["lstm_w_ih"].shape[1]
+        if self.tensors["k_w2"].shape[0] != width * width:
+            raise MdnoError("edge-MLP output size != width**2")
+        self.struct = p
+        self.device = torch.device(device)
+
+    @property
+    def ref(self):
+        return C.byref(self.struct)
+
+
+def kernelnn_forward(pack: ParamPack, frames: torch.Tensor, x_aminoacid: torch.Tensor, graph: CSRGraph,
+                     edge_pos: Optional[torch.Tensor] = None, edge_attr: Optional[torch.Tensor] = None,
+                     return_latent: bool = False, workspace: Optional[torch.Tensor] = None
+                     ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """frames f32 [W,M,N,3] (time-major) -> out [M*N,out_width] (+ latent [M*N,width])."""
+    lib = _lib.load()
+    frames = f32(frames)
+    if frames.dim() == 3:
+        frames = frames.unsqueeze(1)
+    W, M, N, _ = frames.shape
+    dev = frames.device
+    aa = x_aminoacid.to(device=dev, dtype=torch.long).contiguous()
+    if aa.numel() not in (N, M * N):
+        raise MdnoError(f"x_aminoacid has {aa.numel()} entries, expected {N} or {M * N}")
+    aa_pm = int(aa.numel() == M * N and M > 1)
+    p = pack.struct
+    out = torch.empty((M * N, p.out_width), dtype=torch.float32, device=dev)
+    latent = torch.empty((M * N, p.width), dtype=torch.float32, device=dev) if return_latent else None
+    nbytes = lib.mdno_kernelnn_workspace_bytes(pack.ref, M, N, graph.edge_cap)
+    if workspace is None or workspace.numel() < nbytes:
+        workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    status = graph.status if graph.status is not None else torch.zeros(1, dtype=torch.int32, device=dev)
+    ea = f32(edge_attr) if edge_attr is not None else None
+    ep = f32(edge_pos).reshape(-1, 3) if edge_pos is not None else None
+    check(lib.mdno_kernelnn_fwd(pack.ref, ptr(frames), M, W, N, ptr(aa), aa_pm, ptr(graph.row_ptr), ptr(graph.src),
+                                ptr(graph.dst), ptr(graph.num_edges), graph.edge_cap, ptr(ep), ptr(ea),
+                                ptr(graph.perm) if ea is not None else None, ptr(out), ptr(latent), ptr(workspace),
+                                workspace.numel(), ptr(status), stream_ptr(dev)), "mdno_kernelnn_fwd")
+    return out, latent

@@ -1,0 +1,175 @@
+"""On-device autoregressive rollout and ensemble sharding.
+
+`RolloutEngine` drives `mdno_rollout_plan_*` (include/mdno.h): the whole loop of
+recursive_propagation (graph_kernel.py:396-413) — graph rebuild on the newest frame, forward,
+window slide — stays in HBM; one step is captured into a hipGraph and replayed.
+
+Ensemble members are independent trajectories (block-diagonal graph, no cross-member edges; the
+reference's own batching never creates them either, dataset.py:41-45).  Across GPUs they are
+sharded by member with NO collective during stepping; `gather_trajectories` is the single
+RCCL all-gather (over xGMI on an MI355X node) that collects the finished trajectories.  It
+replaces torch_geometric.nn.DataParallel (graph_kernel.py:528), which broadcasts parameters and
+gathers outputs every step inside one process.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Tuple
+
+import torch
+
+from . import _lib, ops
+from ._lib import MdnoError, STATUS_BAD_AMINOACID, STATUS_EDGE_OVERFLOW, check, f32, ptr, require_gpu
+
+
+def default_edge_cap(members: int, n_atoms: int, threshold: float, density: float = 0.1, slack: float = 1.6) -> int:
+    """Edge capacity for W_e: expected in-degree of a uniform cloud at `density` atoms/A^3 within
+    `threshold`, times `slack`, bounded by the complete graph."""
+    import math
+    deg = 4.0 / 3.0 * math.pi * threshold ** 3 * density + 1.0
+    per_member = min(n_atoms * n_atoms, int(n_atoms * deg * slack) + n_atoms)
+    return max(members * per_member, members * n_atoms)
+
+
+class RolloutEngine:
+    """Owns the trajectory buffer [W+max_steps, M, N, 3], the workspace and the captured step."""
+
+    def __init__(self, model, members: int, n_atoms: int, window: int, threshold: float = 8.0,
+                 max_steps: int = 1000, edge_cap: Optional[int] = None, device=None, use_graph: bool = True):
+        self.lib = _lib.load()
+        self.device = require_gpu(device if device not in (None, "cuda") else None)
+        self.model = model
+        self.M, self.N, self.W = int(members), int(n_atoms), int(window)
+        self.threshold = float(threshold)
+        self.max_steps = int(max_steps)
+        self.edge_cap = int(edge_cap) if edge_cap is not None else self.M * self.N * self.N
+        self.edge_cap = max(self.edge_cap, self.M * self.N)
+        self.pack = model.param_pack(self.device) if hasattr(model, "param_pack") else model
+        if not isinstance(self.pack, ops.ParamPack):
+            raise MdnoError("model must be a KernelNN (or an ops.ParamPack)")
+        dev = self.device
+        self.traj = torch.zeros((self.W + self.max_steps, self.M, self.N, 3), dtype=torch.float32, device=dev)
+        nbytes = self.lib.mdno_rollout_workspace_bytes(self.pack.ref, self.M, self.N, self.edge_cap)
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self.edges_per_step = torch.zeros(self.max_steps, dtype=torch.int32, device=dev)
+        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.aa = None
+        self.plan = C.c_void_p()
+        # capture needs a real (non-default) stream
+        self.stream = torch.cuda.Stream(device=dev)
+        self.use_graph = bool(use_graph)
+        self.steps_done = 0
+
+    def _create_plan(self):
+        if self.plan:
+            check(self.lib.mdno_rollout_plan_destroy(self.plan), "mdno_rollout_plan_destroy")
+            self.plan = C.c_void_p()
+        aa_pm = int(self.aa.numel() == self.M * self.N and self.M > 1)
+        check(self.lib.mdno_rollout_plan_create(
+            C.byref(self.plan), self.pack.ref, ptr(self.traj), self.M, self.W, self.N, self.max_steps,
+            ptr(self.aa), aa_pm, self.threshold, self.edge_cap, ptr(self.workspace), self.workspace.numel(),
+            ptr(self.edges_per_step), ptr(self.status), int(self.use_graph), self.stream.cuda_stream),
+            "mdno_rollout_plan_create")
+
+    def reset(self, window: torch.Tensor, x_aminoacid: torch.Tensor) -> None:
+        """window: f32 [W,M,N,3] (time-major), [W,N,3] for M=1; x_aminoacid i64 [N] or [M*N]."""
+        w = f32(window.to(self.device))
+        if w.dim() == 3:
+            w = w.unsqueeze(1)
+        if tuple(w.shape) != (self.W, self.M, self.N, 3):
+            raise MdnoError(f"window shape {tuple(w.shape)} != {(self.W, self.M, self.N, 3)}")
+        aa = x_aminoacid.to(device=self.device, dtype=torch.long).contiguous()
+        if aa.numel() not in (self.N, self.M * self.N):
+            raise MdnoError(f"x_aminoacid has {aa.numel()} entries, expected {self.N} or {self.M * self.N}")
+        torch.cuda.current_stream(self.device).synchronize()
+        self.stream.synchronize()
+        self.traj[:self.W].copy_(w)
+        self.status.zero_()
+        new_aa = self.aa is None or self.aa.shape != aa.shape
+        if new_aa:
+            self.aa = aa
+        else:
+            self.aa.copy_(aa)
+        torch.cuda.current_stream(self.device).synchronize()
+        if new_aa or not self.plan:
+            self._create_plan()
+        self.steps_done = 0
+
+    def step(self, steps: int) -> None:
+        """Enqueue `steps` more frames on the engine's stream (asynchronous)."""
+        if not self.plan:
+            raise MdnoError("RolloutEngine.reset(window, x_aminoacid) must be called first")
+        check(self.lib.mdno_rollout_plan_run(self.plan, self.steps_done, int(steps), self.stream.cuda_stream),
+              "mdno_rollout_plan_run")
+        self.steps_done += int(steps)
+
+    def synchronize(self) -> None:
+        self.stream.synchronize()
+        st = int(self.status.item())
+        if st & STATUS_EDGE_OVERFLOW:
+            raise MdnoError(f"radius graph exceeded edge_cap={self.edge_cap}; construct the engine with a larger cap")
+        if st & STATUS_BAD_AMINOACID:
+            raise MdnoError("x_aminoacid outside [0, num_embeddings)")
+
+    def run(self, window: torch.Tensor, x_aminoacid: torch.Tensor, steps: int) -> torch.Tensor:
+        """reset + step + synchronize; returns the produced frames f32 [steps, M, N, 3] (a view)."""
+        self.reset(window, x_aminoacid)
+        self.step(steps)
+        self.synchronize()
+        return self.frames()
+
+    def frames(self) -> torch.Tensor:
+        return self.traj[self.W:self.W + self.steps_done]
+
+    def close(self) -> None:
+        if self.plan:
+            self.stream.synchronize()
+            self.lib.mdno_rollout_plan_destroy(self.plan)
+            self.plan = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# --------------------------------------------------------------------------- ensemble sharding
+def shard_members(total_members: int, rank: int, world_size: int) -> List[int]:
+    """Member m runs on rank m mod world_size."""
+    if not (0 <= rank < world_size):
+        raise ValueError(f"rank {rank} outside world of {world_size}")
+    return list(range(rank, total_members, world_size))
+
+
+def gather_trajectories(local: torch.Tensor, total_members: int, group=None) -> torch.Tensor:
+    """All-gather member trajectories: local f32 [T, M_local, N, 3] -> [T, total_members, N, 3] on
+    every rank, members in global order.  One collective (RCCL on GPUs; gloo for CPU tests).
+    Ranks may hold unequal member counts (total not divisible by world): shards are padded to the
+    largest count for the collective and trimmed afterwards."""
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        if local.shape[1] != total_members:
+            raise ValueError("not distributed: local shard must hold every member")
+        return local
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    counts = [len(shard_members(total_members, r, world)) for r in range(world)]
+    if local.shape[1] != counts[rank]:
+        raise ValueError(f"rank {rank} holds {local.shape[1]} members, expected {counts[rank]}")
+    m_max = max(counts)
+    T, _, N, D = local.shape
+    send = local
+    if counts[rank] < m_max:
+        pad = torch.zeros((T, m_max - counts[rank], N, D), dtype=local.dtype, device=local.device)
+        send = torch.cat([local, pad], dim=1)
+    send = send.contiguous()
+    recv = torch.empty((world * T, m_max, N, D), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(recv, send, group=group)   # rank r's shard = rows [r*T, (r+1)*T)
+    recv = recv.view(world, T, m_max, N, D)
+    out = torch.empty((T, total_members, N, D), dtype=local.dtype, device=local.device)
+    for r in range(world):
+        ids = shard_members(total_members, r, world)
+        if ids:
+            out[:, ids] = recv[r][:, :len(ids)]
+    return out

@@ -1,0 +1,418 @@
+"""GPU parity tests: every case runs the HIP kernels through the C ABI (libmdno.so) on cuda:0 and
+compares with the oracle (oracle/graph_kernel_oracle.py) and the committed golden vectors that the
+reference's own code produced (tests/golden, oracle/gen_golden.py).
+
+Tolerance for floating point: rtol 1e-4, atol 1e-4 * max|y| per forward, fp32.
+Integer / index results (graphs, CSR, edge counts) are compared bit-exactly.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_state_dict, load_golden
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+def close(a, b, rtol=RTOL, scale=None):
+    a = a.detach().cpu().double() if torch.is_tensor(a) else torch.as_tensor(np.asarray(a)).double()
+    b = b.detach().cpu().double() if torch.is_tensor(b) else torch.as_tensor(np.asarray(b)).double()
+    s = float(b.abs().max()) if scale is None else scale
+    torch.testing.assert_close(a, b, rtol=rtol, atol=rtol * max(s, 1e-30))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from molecular_dynamics_neural_operator_amd import _lib
+    _lib.load()  # fail loudly if the HIP library is missing
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import graph_kernel_oracle
+    return graph_kernel_oracle
+
+
+def t(a, dev=None):
+    x = torch.from_numpy(np.ascontiguousarray(a))
+    return x.to(dev) if dev is not None else x
+
+
+# ------------------------------------------------------------------------------- K0 radius graph
+def test_radius_graph_matches_reference_golden(dev):
+    from molecular_dynamics_neural_operator_amd.graph_kernel import construct_pairdata
+    z = load_golden("pairdata_graph.npz")
+    thr = float(z["threshold"])
+    for pos, ei, ea in ((z["x_position"], z["edge_index"], z["edge_attr"]),
+                        (z["box_position"], z["box_edge_index"], z["box_edge_attr"])):
+        pd = construct_pairdata(pos, torch.zeros(pos.shape[1], dtype=torch.long), thr)
+        assert np.array_equal(pd.edge_index.cpu().numpy(), ei)
+        assert np.array_equal(pd.edge_attr.cpu().numpy(), ea)
+        assert pd.x_position.shape == pos.shape
+    # single-frame (notebook) call
+    pd = construct_pairdata(z["x_position"][-1], None, thr)
+    assert np.array_equal(pd.edge_index.cpu().numpy(), z["edge_index"])
+
+
+def test_radius_graph_members_threshold_edge_and_overflow(dev, O):
+    from molecular_dynamics_neural_operator_amd import ops, synthetic as syn
+    # three independent members -> block-diagonal CSR == per-member oracle graphs, offset by m*N
+    N, M, thr = 97, 3, 8.0
+    frames = np.stack([syn.box_frame(N, seed=20 + m) for m in range(M)])
+    g = ops.radius_graph(t(frames, dev), N, thr)
+    ei = g.to_edge_index().cpu().numpy()
+    want = np.concatenate([O.radius_graph_coo(frames[m], thr) + m * N for m in range(M)], axis=1)
+    assert np.array_equal(ei, want)
+    rp = g.row_ptr.cpu().numpy()
+    assert rp[0] == 0 and rp[-1] == want.shape[1] and np.all(np.diff(rp) >= 1)  # self-loops: deg >= 1
+    # strict '<' on exactly representable distances: d == 8 is NOT an edge, nextafter below IS
+    below = np.nextafter(np.float32(8.0), np.float32(0.0))
+    pts = np.array([[0, 0, 0], [8.0, 0, 0], [0, below, 0], [0, 0, 100.0]], dtype=np.float32)
+    g = ops.radius_graph(t(pts, dev), 4, 8.0)
+    assert np.array_equal(g.to_edge_index().cpu().numpy(), O.radius_graph_coo(pts, 8.0))
+    assert g.edge_count() == 4 + 2
+    # capacity overflow: truncated, in-bounds, flagged
+    from molecular_dynamics_neural_operator_amd._lib import STATUS_EDGE_OVERFLOW
+    g = ops.radius_graph(t(frames[0], dev), N, thr, edge_cap=N + 5)
+    assert g.edge_count() == N + 5 and int(g.status.item()) & STATUS_EDGE_OVERFLOW
+    assert int(g.row_ptr.max().item()) == N + 5
+
+
+def test_radius_graph_random_threshold_sweep(dev, O):
+    from molecular_dynamics_neural_operator_amd import ops, synthetic as syn
+    frame = syn.box_frame(300, seed=5)
+    for thr in (0.5, 3.3, 6.0, 10.0, 1e3):
+        g = ops.radius_graph(t(frame, dev), 300, thr)
+        assert np.array_equal(g.to_edge_index().cpu().numpy(), O.radius_graph_coo(frame, thr)), thr
+
+
+# ------------------------------------------------------------------------------- COO -> CSR
+def test_coo_to_csr_stable_sort(dev):
+    from molecular_dynamics_neural_operator_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    n, E = 57, 1000
+    ei = torch.randint(0, n, (2, E), generator=gen)
+    ei[1, ei[1] == 13] = 14          # node 13 has no in-edges
+    g = ops.coo_to_csr(ei.to(dev), n)
+    order = torch.sort(ei[1], stable=True).indices
+    assert torch.equal(g.perm[:E].cpu().long(), order)
+    assert torch.equal(g.src[:E].cpu().long(), ei[0][order])
+    assert torch.equal(g.dst[:E].cpu().long(), ei[1][order])
+    counts = torch.bincount(ei[1], minlength=n)
+    assert torch.equal(g.row_ptr.cpu().long(), torch.cat([torch.zeros(1, dtype=torch.long), counts.cumsum(0)]))
+    # empty edge list
+    g = ops.coo_to_csr(torch.zeros((2, 0), dtype=torch.long, device=dev), 5)
+    assert g.row_ptr.cpu().tolist() == [0] * 6
+
+
+# ------------------------------------------------------------------------------- K2 edge-MLP
+def test_edge_mlp_small_golden(dev):
+    from molecular_dynamics_neural_operator_amd.graph_kernel import DenseNet
+    z = load_golden("nnconv_small_mean.npz")
+    sd = golden_state_dict(z)
+    net = DenseNet([6, 16, 16, 64], torch.nn.ReLU)
+    net.load_state_dict({k[4:]: v for k, v in sd.items() if k.startswith("net.")})
+    net.eval().to(dev)
+    with torch.no_grad():
+        w_e = net(t(z["edge_attr"], dev))
+    close(w_e, z["w_e"])
+
+
+@pytest.mark.parametrize("k", [128, 1024])
+def test_edge_mlp_mfma_vs_oracle(dev, O, k):
+    """64x64 output (4096 columns) exercises the fp32 MFMA GEMM; E not a multiple of the tile."""
+    from molecular_dynamics_neural_operator_amd import ops
+    torch.manual_seed(7)
+    E = 342 + 129
+    ea = torch.randn(E, 6) * 5
+    lins = [torch.nn.Linear(6, k), torch.nn.Linear(k, k), torch.nn.Linear(k, 4096)]
+    sd = {}
+    for j, lin in zip((0, 2, 4), lins):
+        sd[f"layers.{j}.weight"], sd[f"layers.{j}.bias"] = lin.weight.data, lin.bias.data
+    want = O.edge_mlp(ea, sd, "")
+    ne = torch.full((1,), E, dtype=torch.int32, device=dev)
+    g = ops.CSRGraph(None, None, None, ne, E, None, None)
+    w = [sd[f"layers.{j}.{n}"].to(dev) for j in (0, 2, 4) for n in ("weight", "bias")]
+    got = ops.edge_mlp(w, 6, k, 4096, g, edge_attr=ea.to(dev))
+    close(got[:E], want)
+    # permuted attributes: row p must come from edge_attr[perm[p]]
+    perm = torch.randperm(E)
+    g2 = ops.CSRGraph(None, None, None, ne, E, perm.to(torch.int32).to(dev), None)
+    got2 = ops.edge_mlp(w, 6, k, 4096, g2, edge_attr=ea.to(dev))
+    assert torch.equal(got2[:E].cpu(), got[:E].cpu()[perm])
+
+
+def test_edge_mlp_attrs_from_positions(dev, O):
+    """CSR mode: attr[p] = [pos[src[p]], pos[dst[p]]] must equal the explicit edge_attr path bitwise."""
+    from molecular_dynamics_neural_operator_amd import ops, synthetic as syn
+    frame = syn.box_frame(120, seed=11)
+    g = ops.radius_graph(t(frame, dev), 120, 8.0)
+    E = g.edge_count()
+    torch.manual_seed(1)
+    k = 128
+    w = [p.to(dev) for lin in (torch.nn.Linear(6, k), torch.nn.Linear(k, k), torch.nn.Linear(k, 4096))
+         for p in (lin.weight.data, lin.bias.data)]
+    a = ops.edge_mlp(w, 6, k, 4096, g, edge_pos=t(frame, dev))
+    pos = t(frame, dev)
+    ea = torch.cat([pos[g.src[:E].long()], pos[g.dst[:E].long()]], dim=1)
+    g_explicit = ops.CSRGraph(g.row_ptr, g.src, g.dst, g.num_edges, g.edge_cap, None, None)
+    b = ops.edge_mlp(w, 6, k, 4096, g_explicit, edge_attr=ea)
+    assert torch.equal(a[:E], b[:E])
+
+
+# ------------------------------------------------------------------------------- K3-K6 conv
+@pytest.mark.parametrize("aggr", ["mean", "add"])
+def test_nnconv_small_golden(dev, aggr):
+    from molecular_dynamics_neural_operator_amd.graph_kernel import DenseNet, NNConv_old
+    z = load_golden(f"nnconv_small_{aggr}.npz")
+    conv = NNConv_old(8, 8, DenseNet([6, 16, 16, 64], torch.nn.ReLU), aggr=aggr)
+    conv.load_state_dict(golden_state_dict(z))
+    conv.eval().to(dev)
+    with torch.no_grad():
+        y = conv(t(z["x"], dev), t(z["edge_index"], dev), t(z["edge_attr"], dev))
+    close(y, z["y"])
+
+
+@pytest.mark.parametrize("aggr,use_root,use_bias,relu", [("mean", True, True, True), ("add", True, False, False),
+                                                         ("mean", False, True, False)])
+def test_nnconv64_vs_oracle(dev, O, aggr, use_root, use_bias, relu):
+    """64x64 fast path on an irregular graph: isolated nodes, a hub, unsorted duplicated edges."""
+    from molecular_dynamics_neural_operator_amd import ops
+    gen = torch.Generator().manual_seed(11)
+    n, E = 75, 900
+    ei = torch.randint(0, n, (2, E), generator=gen)
+    ei[1, :200] = 7                      # hub: 200+ in-edges
+    ei[1, ei[1] == 20] = 21              # node 20 isolated (no in-edge): mean -> 0 + root + bias
+    x = torch.randn(n, 64, generator=gen)
+    w_e = torch.randn(E, 4096, generator=gen) * 0.1
+    root = torch.randn(64, 64, generator=gen) * 0.1 if use_root else None
+    bias = torch.randn(64, generator=gen) if use_bias else None
+    want = O.nnconv_apply(x, ei, w_e, root, bias, aggr)
+    if relu:
+        want = torch.relu(want)
+    g = ops.coo_to_csr(ei.to(dev), n)
+    w_csr = w_e.to(dev)[g.perm[:E].long()].contiguous()
+    got = ops.nnconv(x.to(dev), g, w_csr, None if root is None else root.to(dev),
+                     None if bias is None else bias.to(dev), aggr, relu)
+    close(got, want)
+    # run-to-run bitwise reproducible (no atomics)
+    again = ops.nnconv(x.to(dev), g, w_csr, None if root is None else root.to(dev),
+                       None if bias is None else bias.to(dev), aggr, relu)
+    assert torch.equal(got, again)
+
+
+def test_nnconv64_linearity_at_bba_size(dev):
+    """Size-independent property at the benchmark shape (N=504, E~60k): without bias/ReLU the
+    operator is linear in x, and equals the sum over a split of the edge weights."""
+    from molecular_dynamics_neural_operator_amd import ops, synthetic as syn
+    frame = syn.box_frame(504, seed=1)
+    g = ops.radius_graph(t(frame, dev), 504, 8.0)
+    E = g.edge_count()
+    assert 55_000 < E < 66_000
+    gen = torch.Generator(device="cpu").manual_seed(2)
+    x1 = torch.randn(504, 64, generator=gen).to(dev)
+    x2 = torch.randn(504, 64, generator=gen).to(dev)
+    w_e = (torch.randn(E, 4096, generator=gen) * 0.05).to(dev)
+    root = (torch.randn(64, 64, generator=gen) * 0.1).to(dev)
+    g.edge_cap = E
+    f = lambda x, w=w_e: ops.nnconv(x, g, w, root, None, "mean", False)
+    y = f(2.0 * x1 - 0.5 * x2)
+    close(y, 2.0 * f(x1) - 0.5 * f(x2), rtol=1e-4)
+    wa = w_e * 0.25
+    close(f(x1, wa) + ops.nnconv(x1, g, w_e - wa, None, None, "mean", False), f(x1), rtol=1e-4)
+    # the degree-normalised mean of all-ones messages is exactly 1: x = e_0, W[0,:] = 1
+    ones = torch.zeros(E, 4096, device=dev)
+    ones[:, :64] = 1.0
+    x = torch.zeros(504, 64, device=dev)
+    x[:, 0] = 1.0
+    assert torch.equal(ops.nnconv(x, g, ones, None, None, "mean", False), torch.ones(504, 64, device=dev))
+
+
+# ------------------------------------------------------------------------------- whole forward
+def test_kernelnn_small_golden(dev):
+    from molecular_dynamics_neural_operator_amd.dataset import PairData
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN
+    z = load_golden("kernelnn_small.npz")
+    model = KernelNN(*[int(v) for v in z["ctor"]])
+    print(model.load_state_dict(golden_state_dict(z)))
+    model.eval().to(dev)
+    pd = PairData(t(z["x_aminoacid"]), t(z["x_position"]), None, t(z["edge_attr"]), t(z["edge_index"])).to(dev)
+    with torch.no_grad():
+        out, lat = model(pd, return_latent=True)
+        out_only = model(pd, single_example=True)
+    close(out, z["out"])
+    close(lat, z["latent"])
+    assert torch.equal(out, out_only)
+    # DataParallel-style "module." prefix loads too (graph_kernel.py:528/635)
+    from molecular_dynamics_neural_operator_amd import ops
+    pack = ops.ParamPack({"module." + k: v for k, v in golden_state_dict(z).items()}, model.depth, dev)
+    assert pack.shared_kernel
+
+
+def test_kernelnn_full_seeded_init_and_forward(dev):
+    """torch.manual_seed(0) + the reference's constructor call -> the same parameters as the
+    reference (checksums) and the same full-size forward output (w=64, k=1024, depth 6)."""
+    from molecular_dynamics_neural_operator_amd.dataset import PairData
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN
+    z = load_golden("kernelnn_full_seeded.npz")
+    torch.manual_seed(int(z["seed"]))
+    model = KernelNN(*[int(v) for v in z["ctor"]])
+    sd = model.state_dict()
+    for n, s, a in zip([str(x) for x in z["param_names"]], z["param_sum"], z["param_abs_sum"]):
+        assert float(sd[n].double().sum()) == pytest.approx(float(s), rel=1e-12, abs=1e-12), n
+        assert float(sd[n].double().abs().sum()) == pytest.approx(float(a), rel=1e-12), n
+    model.eval().to(dev)
+    pd = PairData(t(z["x_aminoacid"]), t(z["x_position"]), None, t(z["edge_attr"]), t(z["edge_index"])).to(dev)
+    with torch.no_grad():
+        out, lat = model(pd, return_latent=True)
+        w0 = model.conv1.net(pd.edge_attr)[0]
+    close(w0, z["w_e_first_edge"])
+    close(lat, z["latent"])
+    close(out, z["out"])
+
+
+def test_kernelnn_shapeB_reference_golden(dev):
+    """BBA all-atom stand-in (N=504, E=60,592) at full model size against the REFERENCE's own CPU
+    forward (golden), graph built on the device from the last window frame."""
+    from molecular_dynamics_neural_operator_amd import ops
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN, construct_pairdata
+    z = load_golden("kernelnn_shapeB_seeded.npz")
+    torch.manual_seed(int(z["seed"]))
+    model = KernelNN(*[int(v) for v in z["ctor"]]).eval().to(dev)
+    pd = construct_pairdata(z["x_position"], t(z["x_aminoacid"]), float(z["threshold"]))
+    assert pd.edge_index.shape[1] == int(z["num_edges"])
+    with torch.no_grad():
+        out, lat = model(pd, return_latent=True)
+    close(lat, z["latent"])
+    close(out, z["out"])
+    # position-derived attributes (the rollout path) give the same result as explicit edge_attr
+    g = ops.radius_graph(pd.x_position[-1], 504, float(z["threshold"]))
+    o2, _ = ops.kernelnn_forward(model.param_pack(dev), pd.x_position.unsqueeze(1), pd.x_aminoacid, g,
+                                 edge_pos=pd.x_position[-1])
+    close(o2, z["out"])
+
+
+# ------------------------------------------------------------------------------- rollout
+def _small_model(sd, dev):
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN
+    m = KernelNN(8, 16, 2, 6, 7, 3, 20, 4)
+    m.load_state_dict(sd)
+    return m.eval().to(dev)
+
+
+def test_rollout_teacher_forced_and_free_golden(dev, tmp_path):
+    from molecular_dynamics_neural_operator_amd.dataset import ContactMapDataset
+    from molecular_dynamics_neural_operator_amd.graph_kernel import recursive_propagation
+    z = load_golden("rollout_20.npz")
+    W, thr = int(z["window"]), float(z["threshold"])
+    path = tmp_path / "traj.npz"
+    np.savez(path, contact_map=z["contact_map"], point_cloud=z["point_cloud"], rmsd=z["rmsd"],
+             amino_acids=z["amino_acids"])
+    dset = ContactMapDataset(str(path), window_size=W, horizon=int(z["horizon"]))
+    assert len(dset) == int(z["dataset_len"])
+    # teacher forced: dataset samples carry the FIRST window frame's graph (dataset.py:189-201)
+    model = _small_model(golden_state_dict(z, "tf."), dev)
+    with torch.no_grad():
+        for i in range(20):
+            close(model(dset[i].to(dev)), z["teacher_forced_out"][i])
+    # free running through the reference-shaped API (on-device loop underneath)
+    model = _small_model(golden_state_dict(z, "free."), dev)
+    fc = recursive_propagation(model, dset, dev, num_steps=20, starting_points=[0], threshold=thr)
+    assert [f.edge_index.shape[1] for f in fc] == list(z["free_num_edges"])
+    free = np.stack([f.x_position[-1].numpy() for f in fc])
+    np.testing.assert_allclose(free, z["free_frames"], rtol=1e-4, atol=1e-4 * np.abs(z["free_frames"]).max())
+    assert np.array_equal(fc[-1].edge_index.numpy(), z["free_edge_index_last"])
+    assert fc[0].x_position.shape == (W, 28, 3) and not fc[0].x_position.is_cuda
+
+
+def test_rollout_graph_replay_equals_eager_and_members_are_independent(dev):
+    from molecular_dynamics_neural_operator_amd import synthetic as syn
+    from molecular_dynamics_neural_operator_amd.rollout import RolloutEngine
+    from molecular_dynamics_neural_operator_amd.weights import near_identity_state_dict
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN
+    N, W, M, steps = 60, 10, 3, 12
+    model = KernelNN(64, 128, 2, 6, 7, 3, 20, 4)
+    model.load_state_dict(near_identity_state_dict(64, 128, seed=5, kernel_gain=3e-2, feature_gain=0.3))
+    model.eval().to(dev)
+    base = syn.jitter_window(syn.box_frame(N, seed=3), W, seed=3)
+    wins = syn.ensemble_windows(base, M, sigma=0.3)                  # [M,W,N,3]
+    tm = torch.from_numpy(np.ascontiguousarray(wins.transpose(1, 0, 2, 3)))   # [W,M,N,3]
+    aa = torch.from_numpy(syn.amino_acids(N, seed=3))
+    eg = RolloutEngine(model, M, N, W, 8.0, max_steps=steps, device=dev, use_graph=True)
+    ee = RolloutEngine(model, M, N, W, 8.0, max_steps=steps, device=dev, use_graph=False)
+    a = eg.run(tm, aa, steps).clone()
+    b = ee.run(tm, aa, steps).clone()
+    assert torch.equal(a, b)
+    assert torch.equal(eg.edges_per_step, ee.edges_per_step) and int(eg.edges_per_step.min()) > 0
+    # stepping in two calls == one call
+    eg.reset(tm, aa); eg.step(5); eg.step(steps - 5); eg.synchronize()
+    assert torch.equal(eg.frames(), a)
+    # each member alone gives bitwise the same trajectory as inside the batch
+    e1 = RolloutEngine(model, 1, N, W, 8.0, max_steps=steps, device=dev)
+    for m in range(M):
+        solo = e1.run(tm[:, m:m + 1].contiguous(), aa, steps)
+        assert torch.equal(solo[:, 0], a[:, m]), m
+    # per-member amino acids [M*N]
+    aam = torch.stack([torch.from_numpy(syn.amino_acids(N, seed=30 + m)) for m in range(M)]).reshape(-1)
+    c = eg.run(tm, aam, steps).clone()
+    solo = e1.run(tm[:, 1:2].contiguous(), aam[N:2 * N], steps)
+    assert torch.equal(solo[:, 0], c[:, 1])
+
+
+def test_rollout_vs_oracle_full_width(dev, O):
+    """width 64 (HIP fast paths) free run, 6 steps, against the oracle's host loop."""
+    from molecular_dynamics_neural_operator_amd import synthetic as syn
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN
+    from molecular_dynamics_neural_operator_amd.rollout import RolloutEngine
+    from molecular_dynamics_neural_operator_amd.weights import near_identity_state_dict
+    N, W, steps = 28, 10, 6
+    sd = near_identity_state_dict(64, 128, seed=9, kernel_gain=1e-2, feature_gain=0.1)
+    model = KernelNN(64, 128, 3, 6, 7, 3, 20, 4)
+    model.load_state_dict(sd)
+    model.eval().to(dev)
+    win = syn.jitter_window(syn.chain_frame(N, seed=4), W, seed=4)
+    aa = torch.from_numpy(syn.amino_acids(N, seed=4))
+    eng = RolloutEngine(model, 1, N, W, 8.0, max_steps=steps, device=dev)
+    traj = eng.run(torch.from_numpy(win), aa, steps).cpu().numpy()[:, 0]
+    s0 = O.construct_pairdata(win, aa, 8.0)
+    fc = O.recursive_propagation(sd, 3, s0, steps, 8.0, hoist=True)
+    ref = np.stack([f["x_position"][-1].numpy() for f in fc])
+    np.testing.assert_allclose(traj, ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+    assert eng.edges_per_step.cpu().tolist() == [s0["edge_index"].shape[1]] + [f["edge_index"].shape[1] for f in fc[:-1]]
+
+
+# ------------------------------------------------------------------------------- error behaviour
+def test_errors_are_loud(dev):
+    from molecular_dynamics_neural_operator_amd import MdnoError, ops
+    from molecular_dynamics_neural_operator_amd.dataset import PairData
+    from molecular_dynamics_neural_operator_amd.graph_kernel import DenseNet, KernelNN, NNConv_old
+    z = load_golden("kernelnn_small.npz")
+    model = KernelNN(*[int(v) for v in z["ctor"]]).to(dev)
+    pd = PairData(t(z["x_aminoacid"]), t(z["x_position"]), None, t(z["edge_attr"]), t(z["edge_index"]))
+    with pytest.raises(NotImplementedError):       # training mode + autograd: no silent graph-less output
+        model(pd.to(dev))
+    model.eval()
+    with pytest.raises(MdnoError):                 # CPU sample: no CPU fallback
+        model(PairData(t(z["x_aminoacid"]), t(z["x_position"]), None, t(z["edge_attr"]), t(z["edge_index"])))
+    with pytest.raises(NotImplementedError):
+        NNConv_old(8, 8, DenseNet([6, 16, 16, 64], torch.nn.ReLU), aggr="max").eval().to(dev)(
+            torch.zeros(3, 8, device=dev), torch.zeros((2, 1), dtype=torch.long, device=dev),
+            torch.zeros(1, 6, device=dev))
+    with pytest.raises(NotImplementedError):
+        DenseNet([6, 16, 64], torch.nn.ReLU).eval().to(dev)(torch.zeros(2, 6, device=dev))
+    with pytest.raises(MdnoError):                 # y aliases x
+        g = ops.coo_to_csr(torch.zeros((2, 1), dtype=torch.long, device=dev), 2)
+        x = torch.zeros(2, 64, device=dev)
+        from molecular_dynamics_neural_operator_amd import _lib
+        lib = _lib.load()
+        _lib.check(lib.mdno_nnconv_fwd(x.data_ptr(), g.row_ptr.data_ptr(), g.src.data_ptr(), 2, x.data_ptr(), None,
+                                       None, 64, 64, 1, 0, x.data_ptr(), None))
+    # bad amino-acid id is flagged by the device status word
+    from molecular_dynamics_neural_operator_amd.rollout import RolloutEngine
+    model8 = KernelNN(8, 16, 1, 6, 7, 3, 20, 4).eval().to(dev)
+    eng = RolloutEngine(model8, 1, 28, 10, 8.0, max_steps=1, device=dev)
+    with pytest.raises(MdnoError):
+        eng.run(t(z["x_position"]), torch.full((28,), 25, dtype=torch.long), 1)

@@ -1,0 +1,133 @@
+"""Host-side logic that needs no GPU: dataset layout, PairData batching rule, sharding, synthetic
+data and weight sets, loss, and loud failure when no GPU is present."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_state_dict, load_golden
+from molecular_dynamics_neural_operator_amd import synthetic as syn
+from molecular_dynamics_neural_operator_amd.dataset import ContactMapDataset, PairData, write_trajectory_npz
+from molecular_dynamics_neural_operator_amd.graph_kernel import DenseNet, KernelNN, LpLoss, NNConv_old
+from molecular_dynamics_neural_operator_amd.rollout import default_edge_cap, shard_members
+from molecular_dynamics_neural_operator_amd.weights import near_identity_state_dict
+from oracle import graph_kernel_oracle as O
+
+
+def test_dataset_matches_reference_sample(tmp_path):
+    z = load_golden("rollout_20.npz")
+    W, h = int(z["window"]), int(z["horizon"])
+    p = tmp_path / "t.npz"
+    np.savez(p, contact_map=z["contact_map"], point_cloud=z["point_cloud"], rmsd=z["rmsd"], amino_acids=z["amino_acids"])
+    d = ContactMapDataset(str(p), window_size=W, horizon=h)
+    assert len(d) == int(z["dataset_len"])
+    s = d[3]
+    assert np.array_equal(s.x_position.numpy(), z["sample3_x_position"])
+    assert np.array_equal(s.y.numpy(), z["sample3_y"])
+    assert np.array_equal(s.edge_index.numpy(), z["sample3_edge_index"])
+    assert np.array_equal(s.edge_attr.numpy(), z["sample3_edge_attr"])
+    assert s.x_aminoacid.dtype == torch.long and s.num_nodes == 28
+    with pytest.raises(ValueError):
+        ContactMapDataset(str(p), window_size=40, horizon=5)
+
+
+def test_dataset_directory_mode_and_writer(tmp_path):
+    base = syn.chain_frame(12, seed=3)
+    aa = syn.amino_acids(12, seed=3)
+    for i in range(2):
+        fr = syn.ou_trajectory(base, 6, seed=i)
+        cms = [O.radius_graph_coo(f, 8.0).reshape(-1) for f in fr]
+        write_trajectory_npz(tmp_path / f"part{i}.npz", fr, cms, aa)
+    d = ContactMapDataset(str(tmp_path), window_size=2, horizon=1)
+    assert len(d) == 12 - 2 - 1 + 1
+    s = d[5]   # window straddles the two files
+    assert s.x_position.shape == (2, 12, 3) and s.edge_attr.shape[1] == 6
+    assert torch.equal(s.edge_attr[:, :3], s.x_position[0][s.edge_index[0]])
+
+
+def test_pairdata_collate_offsets_edge_index():
+    a = PairData(torch.zeros(3, dtype=torch.long), torch.zeros(2, 3, 3), torch.zeros(3, 3), torch.zeros(4, 6),
+                 torch.tensor([[0, 1, 2, 2], [1, 0, 2, 0]]))
+    b = PairData(torch.ones(3, dtype=torch.long), torch.ones(2, 3, 3), torch.ones(3, 3), torch.ones(2, 6),
+                 torch.tensor([[0, 1], [1, 0]]))
+    c = PairData.collate([a, b])
+    assert c.edge_index.tolist() == [[0, 1, 2, 2, 3, 4], [1, 0, 2, 0, 4, 3]]
+    assert c.num_nodes == 6 and c.x_position.shape == (4, 3, 3) and c.edge_attr.shape == (6, 6)
+    assert a.__inc__("edge_index") == 3 and a.__inc__("x_position") == 0
+    assert "x_aminoacid=[3]" in repr(a)
+
+
+def test_shard_members_and_edge_cap():
+    assert shard_members(64, 3, 8) == list(range(3, 64, 8)) and len(shard_members(64, 3, 8)) == 8
+    allm = sorted(m for r in range(3) for m in shard_members(10, r, 3))
+    assert allm == list(range(10))
+    with pytest.raises(ValueError):
+        shard_members(4, 4, 4)
+    assert default_edge_cap(1, 28, 8.0) == 28 * 28            # bounded by the complete graph
+    assert 60_000 * 1.3 < default_edge_cap(1, 504, 8.0) < 504 * 504
+
+
+def test_model_structure_matches_reference_state_dict_keys():
+    z = load_golden("kernelnn_full_seeded.npz")
+    m = KernelNN(8, 16, 2, 6, 7, 3, 20, 4)
+    assert sorted(m.state_dict().keys()) == sorted(str(n) for n in z["param_names"])
+    assert m.conv1.net is m.conv2.net                      # ONE shared edge-MLP (graph_kernel.py:271-273)
+    assert repr(m.conv1) == "NNConv_old(8, 8)"
+    # same RNG draw order as the reference restated in the oracle
+    torch.manual_seed(123)
+    a = KernelNN(8, 16, 2, 6, 7, 3, 20, 4).state_dict()
+    b = O.reference_init_state_dict(8, 16, 2, 6, 7, 3, 20, 4, seed=123)
+    for k in b:
+        assert torch.equal(a[k], b[k]), k
+    d = DenseNet([6, 16, 16, 64], torch.nn.ReLU)
+    assert [type(l).__name__ for l in d.layers] == ["Linear", "ReLU", "Linear", "ReLU", "Linear"]
+    c = NNConv_old(4, 5, d, root_weight=False, bias=False)
+    assert c.root is None and c.bias is None
+
+
+def test_no_gpu_means_loud_failure_not_cpu_fallback():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from molecular_dynamics_neural_operator_amd import MdnoError
+    from molecular_dynamics_neural_operator_amd.graph_kernel import construct_pairdata
+    z = load_golden("kernelnn_small.npz")
+    m = KernelNN(*[int(v) for v in z["ctor"]]).eval()
+    pd = PairData(torch.from_numpy(z["x_aminoacid"]), torch.from_numpy(z["x_position"]), None,
+                  torch.from_numpy(z["edge_attr"]), torch.from_numpy(z["edge_index"]))
+    with pytest.raises(MdnoError):
+        m(pd)
+    with pytest.raises(MdnoError):
+        construct_pairdata(z["x_position"], None)
+    with pytest.raises(MdnoError):
+        m.conv1(torch.zeros(28, 8), pd.edge_index, pd.edge_attr)
+
+
+def test_near_identity_weights_keep_the_cloud(tmp_path):
+    sd = near_identity_state_dict(8, 16, seed=3, kernel_gain=1e-3, feature_gain=1e-2)
+    m = KernelNN(8, 16, 2, 6, 7, 3, 20, 4)
+    m.load_state_dict(sd)                                  # reference key names
+    N, W = 28, 10
+    win = syn.jitter_window(syn.chain_frame(N, seed=0), W, seed=0)
+    aa = torch.from_numpy(syn.amino_acids(N, seed=0))
+    s = O.construct_pairdata(win, aa, 8.0)
+    out = O.kernelnn_forward(sd, s["x_position"], aa, s["edge_index"], s["edge_attr"], 2)
+    assert float((out - s["x_position"][-1]).abs().max()) < 0.1
+    with pytest.raises(ValueError):
+        near_identity_state_dict(6, 16)
+
+
+def test_lploss_matches_reference_golden():
+    z = load_golden("lploss.npz")
+    x, y = torch.from_numpy(z["x"]), torch.from_numpy(z["y"])
+    torch.testing.assert_close(LpLoss(size_average=False)(x, y), torch.from_numpy(z["rel_sum"]))
+    torch.testing.assert_close(LpLoss(size_average=True)(x, y), torch.from_numpy(z["rel_mean"]))
+    torch.testing.assert_close(LpLoss(reduction=False)(x, y), torch.from_numpy(z["rel_none"]))
+    torch.testing.assert_close(LpLoss().abs(x, y), torch.from_numpy(z["abs_mean"]))
+
+
+def test_synthetic_shapes():
+    b = syn.box_frame(504, seed=1)
+    assert b.dtype == np.float32 and b.shape == (504, 3) and abs(np.ptp(b[:, 0]) - 17.1) < 0.5
+    e = O.radius_graph_coo(b, 8.0).shape[1]
+    assert 55_000 < e < 66_000                              # SURVEY.md §8 shape B: E ~ 59.7k
+    w = syn.ensemble_windows(syn.jitter_window(b, 10), 4)
+    assert w.shape == (4, 10, 504, 3) and not np.array_equal(w[0], w[1])

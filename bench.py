@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""Headline benchmark: rolled-out MD frames/sec (BASELINE.json), one process per GPU.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], SURVEY.md §8d shape B): BBA all-atom stand-in, N=504 atoms
+uniform at 0.1 atoms/A^3, 8 A cutoff (E ~ 60k directed edges incl. self-loops), window 10, the
+reference's CLI-default model (width 64, kernel_width 1024, depth 6 -> 12 conv applications), fp32,
+free-running autoregressive rollout entirely on the device.  One "step" = one new frame for every
+member on every rank (graph rebuild + forward + window slide).  Weak scaling: every rank runs
+`--members-per-gpu` independent trajectories (ensemble members, different perturbations of the
+start window); no collective while stepping, one RCCL all-gather of the produced frames at the end,
+inside the timed region.  value = frames produced by all ranks / max-over-ranks wall time.
+
+Weights: synthetic near-identity set (weights.py) — no trained checkpoint exists offline and
+random-init weights collapse the cloud to one point, which would change E (the cost driver) after
+one step.  The architecture, arithmetic and update rule (next frame = model output) are unchanged.
+
+Extra objects on the JSON line:
+  roofline      the conv (gather -> per-edge matvec -> scatter-mean) kernel against HBM: algorithmic
+                bytes per launch (16,388*E + 516*R + 4) / average launch duration,
+                measured with HIP events on the launching stream over K more steps of the same
+                rollout issued as plain launches (events cannot sit inside a hipGraph replay).
+  roofline_mfma the edge-MLP last-layer GEMM against the fp32 MFMA peak, same measurement.
+  cpu_baseline  the oracle (CPU restatement of the reference: edge-MLP re-evaluated in all 12 conv
+                applications + scipy graph rebuild per step) timed on this box's host cores on a
+                bounded sample; rank 0, N=1 only.  A reported baseline, not the target.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_COPY_GBS = 6290.0
+MFMA_F32_PEAK_TFLOPS = 157.3  # fp32-input MFMA = vector fp32 peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--members-per-gpu", type=int, default=1)
+    ap.add_argument("--atoms", type=int, default=504)
+    ap.add_argument("--width", type=int, default=64)
+    ap.add_argument("--kernel-width", type=int, default=1024)
+    ap.add_argument("--depth", type=int, default=6)
+    ap.add_argument("--window", type=int, default=10)
+    ap.add_argument("--threshold", type=float, default=8.0)
+    ap.add_argument("--no-graph", action="store_true", help="plain launches instead of hipGraph replay")
+    ap.add_argument("--skip-cpu-baseline", action="store_true")
+    ap.add_argument("--skip-roofline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=45.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(sd, depth, window, aa, threshold, budget_s):
+    """Reference-faithful CPU step on this host: forward with the edge-MLP evaluated in every conv
+    application (hoist=False) + scipy graph rebuild (graph_kernel.py:396-413)."""
+    from oracle import graph_kernel_oracle as O
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    sd_cpu = {k: v.detach().cpu() for k, v in sd.items()}
+    aa = aa.cpu()
+    t0 = time.perf_counter()
+    s = O.construct_pairdata(window, aa, threshold)
+    t_graph = time.perf_counter() - t0
+    E = int(s["edge_index"].shape[1])
+    # one conv application (edge-MLP + gather/matvec/scatter) to size the sample
+    x = torch.randn(window.shape[1], sd_cpu["fc1.weight"].shape[0])
+    O.edge_mlp(s["edge_attr"][:2048], sd_cpu, "conv1.net.")  # warm the thread pool
+    t0 = time.perf_counter()
+    w_e = O.edge_mlp(s["edge_attr"], sd_cpu, "conv1.net.")
+    O.nnconv_apply(x, s["edge_index"], w_e, sd_cpu["conv1.root"], sd_cpu["conv1.bias"], "mean")
+    t_conv = time.perf_counter() - t0
+    del w_e
+    est = 2 * depth * t_conv + t_graph
+    if est <= budget_s:
+        t0 = time.perf_counter()
+        O.recursive_propagation(sd_cpu, depth, s, 1, threshold, hoist=False)
+        t_step = time.perf_counter() - t0
+        sample = (f"1 full rollout step: forward with the edge-MLP evaluated {2 * depth}x as the reference does + "
+                  f"scipy graph rebuild, N={window.shape[1]}, E={E}")
+    else:
+        t_step = est
+        sample = (f"1 of the {2 * depth} conv applications (edge-MLP + conv, {t_conv:.2f}s) x {2 * depth} + measured "
+                  f"scipy graph rebuild ({t_graph:.3f}s); full step estimated, N={window.shape[1]}, E={E}")
+    return {"value": 1.0 / t_step, "unit": "frames/s", "cores": cores, "kind": "port", "sample": sample,
+            "seconds_per_frame": t_step}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from molecular_dynamics_neural_operator_amd import synthetic as syn
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN
+    from molecular_dynamics_neural_operator_amd.rollout import RolloutEngine, default_edge_cap, gather_trajectories
+    from molecular_dynamics_neural_operator_amd.weights import near_identity_state_dict
+
+    N, W, M = a.atoms, a.window, a.members_per_gpu
+    total_members = M * world
+    sd = near_identity_state_dict(a.width, a.kernel_width, seed=0, kernel_gain=2e-4, feature_gain=2e-3)
+    model = KernelNN(a.width, a.kernel_width, a.depth, 6, 7, 3, 20, 4)
+    model.load_state_dict(sd)
+    model.eval().to(dev)
+
+    base = syn.jitter_window(syn.box_frame(N, seed=1), W, seed=1)                  # [W,N,3]
+    wins = np.stack([base if (total_members == 1) else
+                     syn.ensemble_windows(base, 1, sigma=0.1, seed0=100 + rank + world * m)[0]
+                     for m in range(M)], axis=1)                                   # [W,M,N,3] member = rank + world*m
+    aa = torch.from_numpy(syn.amino_acids(N, seed=1))
+    max_steps = a.warmup + a.steps + (0 if a.skip_roofline else a.steps)
+    cap = default_edge_cap(M, N, a.threshold)
+    eng = RolloutEngine(model, M, N, W, a.threshold, max_steps=max_steps, edge_cap=cap, device=dev,
+                        use_graph=not a.no_graph)
+    eng.reset(torch.from_numpy(wins), aa)
+
+    # ---- warm-up (untimed): also captures nothing new — the step graph was captured in reset()
+    eng.step(a.warmup)
+    eng.synchronize()
+
+    # ---- timed region: exactly K steps + trajectory collection
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.step(a.steps)
+    eng.stream.synchronize()
+    produced = eng.traj[W + a.warmup:W + a.warmup + a.steps]                       # [K,M,N,3]
+    if world > 1:
+        full = gather_trajectories(produced, total_members)
+    else:
+        full = produced
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    eng.synchronize()   # raises on edge overflow / bad input
+    assert full.shape == (a.steps, total_members, N, 3) and bool(torch.isfinite(full).all())
+    eps = eng.edges_per_step[a.warmup:a.warmup + a.steps].double()
+    e_mean = float(eps.mean().item())
+    frames = a.steps * total_members
+    value = frames / elapsed
+
+    # ---- roofline leg: K more steps, plain launches bracketed by HIP events on the launch stream
+    roof = roof_mfma = None
+    kernels = {}
+    if not a.skip_roofline:
+        launches_per_step = 2 * a.depth + 8
+        eng.attach_timer(a.steps * (launches_per_step + 4))
+        eng.step(a.steps)
+        tm = eng.read_timer()
+        eng.detach_timer()
+        eng.synchronize()
+        eps2 = eng.edges_per_step[a.warmup + a.steps:a.warmup + 2 * a.steps].double()
+        e2 = float(eps2.mean().item())
+        R = M * N
+        C = a.width
+        for k, (ms, n) in tm.items():
+            if n:
+                kernels[k] = {"avg_ms": ms / n, "launches": int(n)}
+        if "nnconv" in kernels:
+            avg_s = kernels["nnconv"]["avg_ms"] * 1e-3
+            alg_bytes = e2 * (C * C * 4 + 4) + (R + 1) * 4 + 2 * R * C * 4
+            ach = alg_bytes / avg_s / 1e9
+            roof = {"bound": "hbm", "kernel": "nnconv64_row_kernel", "achieved": ach, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "frac_of_measured_copy_peak": ach / HBM_COPY_GBS,
+                    "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_s * 1e3,
+                    "edges_per_launch": e2, "rows_per_launch": R}
+            tf = REPO / "profiles" / "roofline_traffic.json"
+            if tf.exists():
+                try:
+                    roof["traffic"] = json.loads(tf.read_text()).get("nnconv_hbm_bytes_per_launch")
+                except Exception:
+                    pass
+        if "edge_mlp_gemm2" in kernels:
+            avg_s = kernels["edge_mlp_gemm2"]["avg_ms"] * 1e-3
+            flops = 2.0 * e2 * a.kernel_width * C * C
+            roof_mfma = {"bound": "mfma", "kernel": "gemm_tn_mfma_kernel<false>", "achieved": flops / avg_s / 1e12,
+                         "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": flops / avg_s / 1e12 / MFMA_F32_PEAK_TFLOPS, "avg_launch_ms": avg_s * 1e3}
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.skip_cpu_baseline:
+        cpu = cpu_baseline(sd, a.depth, base, aa, a.threshold, a.cpu_budget_s)
+
+    if rank == 0:
+        line = {
+            "metric": "rolled-out MD frames/sec", "value": value, "unit": "frames/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (uniform-box frames, seeded; near-identity synthetic weights, see weights.py)",
+            "config": {"workload": f"BBA all-atom stand-in N={N} r={a.threshold}A free-running autoregressive rollout "
+                                   f"(BASELINE configs[1]), {M} member(s) per GPU",
+                       "atoms": N, "window": W, "width": a.width, "kernel_width": a.kernel_width, "depth": a.depth,
+                       "members_per_gpu": M, "total_members": total_members, "mean_edges_per_member": e_mean / M,
+                       "edges_first_last": [int(eps[0].item()), int(eps[-1].item())], "edge_cap": cap,
+                       "parallelism": f"ensemble-sharded x{world}, one all-gather of trajectories",
+                       "launch": "plain" if a.no_graph else "hipGraph replay"},
+            "roofline": roof, "roofline_mfma": roof_mfma, "cpu_baseline": cpu, "kernels": kernels,
+        }
+        print(json.dumps(line))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

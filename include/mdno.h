@@ -192,6 +192,14 @@ int mdno_rollout_plan_create(mdno_rollout_plan** plan, const mdno_kernelnn_param
 int mdno_rollout_plan_run(mdno_rollout_plan* plan, int start_step, int steps, void* stream);
 int mdno_rollout_plan_destroy(mdno_rollout_plan* plan);
 
+/* Measurement aid (bench.py roofline leg): with a timer attached, plan_run issues plain launches
+ * (never the captured graph) and brackets every kernel with two HIP events on `stream`.
+ * kernel_id: 0 conv (K3-K6), 1 edge-MLP GEMM layer 1, 2 edge-MLP GEMM layer 2, 3 edge-MLP layer 0,
+ * 4 radius graph (3 kernels), 5 node prologue, 6 fc2.  Read after synchronising the stream. */
+int mdno_rollout_plan_timer_attach(mdno_rollout_plan* plan, int max_records);
+int mdno_rollout_plan_timer_read(mdno_rollout_plan* plan, int kernel_id, double* total_ms, int64_t* count);
+int mdno_rollout_plan_timer_detach(mdno_rollout_plan* plan);
+
 #ifdef __cplusplus
 }
 #endif

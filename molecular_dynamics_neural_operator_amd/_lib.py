@@ -59,6 +59,9 @@ SIGNATURES = {
                                       _P, _SZ, _P, _P, _I, _P]),
     "mdno_rollout_plan_run": (_I, [_P, _I, _I, _P]),
     "mdno_rollout_plan_destroy": (_I, [_P]),
+    "mdno_rollout_plan_timer_attach": (_I, [_P, _I]),
+    "mdno_rollout_plan_timer_read": (_I, [_P, _I, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "mdno_rollout_plan_timer_detach": (_I, [_P]),
 }
 
 _lib = None

@@ -218,6 +218,7 @@ __global__ __launch_bounds__(256) void gemm_tn_generic_kernel(GemmArgs g) {
 
 template <bool RELU>
 int launch_gemm(const GemmArgs& g, hipStream_t s) {
+    TimedSection ts(RELU ? KID_GEMM_L1 : KID_GEMM_L2, s);
     const bool mfma_ok = (g.K % BK == 0) && (g.N % BN == 0) && (g.rows % BM == 0) &&
                          ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.Bt)) & 15) == 0;
     if (mfma_ok) {
@@ -273,9 +274,12 @@ int mdno::edge_mlp(const float* frames, int frame, const int* t_dev, int rows_pe
     const float* pos_mode = edge_attr ? nullptr : frames;
     for (long long e0 = 0; e0 < edge_cap; e0 += chunk) {
         const int cnt = (int)((edge_cap - e0) < chunk ? (edge_cap - e0) : chunk);
-        hipLaunchKernelGGL(edge_l0_kernel, dim3((cnt + EB - 1) / EB), dim3(256), 0, s, pos_mode, frame, t_dev,
-                           rows_per_frame, src, dst, edge_attr, perm, num_edges, e0, cnt, ker_in, ker_width, w.w0,
-                           w.b0, h1);
+        {
+            TimedSection ts(KID_EDGE_L0, s);
+            hipLaunchKernelGGL(edge_l0_kernel, dim3((cnt + EB - 1) / EB), dim3(256), 0, s, pos_mode, frame, t_dev,
+                               rows_per_frame, src, dst, edge_attr, perm, num_edges, e0, cnt, ker_in, ker_width,
+                               w.w0, w.b0, h1);
+        }
         MDNO_TRY(check_launch("edge_l0_kernel"));
         GemmArgs g1{h1, w.w1, w.b1, h2, num_edges, e0, (int)chunk, ker_width, ker_width};
         MDNO_TRY(launch_gemm<true>(g1, s));

@@ -13,8 +13,31 @@
 #include "kernels.h"
 
 #include <string>
+#include <vector>
 
 namespace mdno {
+
+struct Timer {
+    struct Rec { hipEvent_t a, b; int kid; };
+    std::vector<Rec> recs;
+    size_t used = 0;
+    size_t open_idx[KID_COUNT] = {};
+};
+thread_local Timer* g_active_timer = nullptr;
+
+void timer_mark(int kid, bool start, hipStream_t s) {
+    Timer* t = g_active_timer;
+    if (!t) return;
+    if (start) {
+        if (t->used >= t->recs.size()) { t->open_idx[kid] = (size_t)-1; return; }
+        const size_t i = t->used++;
+        t->recs[i].kid = kid;
+        t->open_idx[kid] = i;
+        (void)hipEventRecord(t->recs[i].a, s);
+    } else if (t->open_idx[kid] != (size_t)-1) {
+        (void)hipEventRecord(t->recs[t->open_idx[kid]].b, s);
+    }
+}
 
 namespace {
 thread_local std::string g_last_error;
@@ -179,6 +202,7 @@ struct mdno_rollout_plan {
     int* status;
     hipGraph_t graph;
     hipGraphExec_t exec;
+    Timer* timer;
 };
 
 static int plan_enqueue_step(mdno_rollout_plan* pl, hipStream_t s) {
@@ -258,18 +282,69 @@ extern "C" int mdno_rollout_plan_run(mdno_rollout_plan* pl, int start_step, int 
     hipLaunchKernelGGL(set_step_kernel, dim3(1), dim3(1), 0, s, pl->r.t_dev, start_step);
     MDNO_TRY(check_launch("set_step"));
     for (int t = 0; t < steps; ++t) {
-        if (pl->exec) {
+        if (pl->exec && !pl->timer) {
             hipError_t el = hipGraphLaunch(pl->exec, s);
             MDNO_REQUIRE(el == hipSuccess, MDNO_ELAUNCH, "hipGraphLaunch(step %d): %s", t, hipGetErrorString(el));
-        } else {
-            MDNO_TRY(plan_enqueue_step(pl, s));
+        } else {  // plain launches (always when a timer is attached: events cannot sit inside a replay)
+            g_active_timer = pl->timer;
+            const int rc = plan_enqueue_step(pl, s);
+            g_active_timer = nullptr;
+            MDNO_TRY(rc);
         }
     }
     return MDNO_OK;
 }
 
+extern "C" int mdno_rollout_plan_timer_attach(mdno_rollout_plan* pl, int max_records) {
+    MDNO_REQUIRE(pl != nullptr && max_records > 0, MDNO_EINVAL, "mdno_rollout_plan_timer_attach: bad arguments");
+    if (pl->timer) return MDNO_OK;
+    Timer* t = new Timer();
+    t->recs.resize((size_t)max_records);
+    for (auto& r : t->recs) {
+        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) {
+            set_error("hipEventCreate failed");
+            delete t;
+            return MDNO_ELAUNCH;
+        }
+    }
+    pl->timer = t;
+    return MDNO_OK;
+}
+
+extern "C" int mdno_rollout_plan_timer_read(mdno_rollout_plan* pl, int kernel_id, double* total_ms, int64_t* count) {
+    MDNO_REQUIRE(pl && pl->timer && total_ms && count && kernel_id >= 0 && kernel_id < KID_COUNT, MDNO_EINVAL,
+                 "mdno_rollout_plan_timer_read: bad arguments");
+    double tot = 0.0;
+    int64_t n = 0;
+    for (size_t i = 0; i < pl->timer->used; ++i) {
+        const auto& r = pl->timer->recs[i];
+        if (r.kid != kernel_id) continue;
+        float ms = 0.f;
+        hipError_t e = hipEventElapsedTime(&ms, r.a, r.b);
+        MDNO_REQUIRE(e == hipSuccess, MDNO_ELAUNCH, "hipEventElapsedTime: %s (synchronise the stream first)",
+                     hipGetErrorString(e));
+        tot += ms;
+        ++n;
+    }
+    *total_ms = tot;
+    *count = n;
+    return MDNO_OK;
+}
+
+extern "C" int mdno_rollout_plan_timer_detach(mdno_rollout_plan* pl) {
+    if (!pl || !pl->timer) return MDNO_OK;
+    for (auto& r : pl->timer->recs) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    delete pl->timer;
+    pl->timer = nullptr;
+    return MDNO_OK;
+}
+
 extern "C" int mdno_rollout_plan_destroy(mdno_rollout_plan* pl) {
     if (!pl) return MDNO_OK;
+    (void)mdno_rollout_plan_timer_detach(pl);
     if (pl->exec) (void)hipGraphExecDestroy(pl->exec);
     if (pl->graph) (void)hipGraphDestroy(pl->graph);
     delete pl;

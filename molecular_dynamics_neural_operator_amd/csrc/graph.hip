@@ -182,6 +182,7 @@ int mdno::radius_graph(const float* frames, int frame, const int* t_dev, int M, 
     const int blocks = (R + kRowsPerBlock - 1) / kRowsPerBlock;
     // The in-degrees are staged in src[0..R) (needs edge_cap >= R); the fill pass overwrites them.
     MDNO_REQUIRE(edge_cap >= R, MDNO_EINVAL, "radius_graph: edge_cap (%lld) < rows (%d)", edge_cap, R);
+    TimedSection ts(KID_GRAPH, s);
     hipLaunchKernelGGL(radius_count_kernel, dim3(blocks), dim3(256), 0, s, frames, frame, t_dev, N, R, cutoff, src);
     hipLaunchKernelGGL(scan_rows_kernel, dim3(1), dim3(1024), 0, s, (const int*)src, R, edge_cap, row_ptr,
                        num_edges, status);

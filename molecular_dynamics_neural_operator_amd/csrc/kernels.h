@@ -8,6 +8,20 @@
 
 namespace mdno {
 
+// Optional per-kernel timing with HIP events on the launching stream (bench.py's roofline leg).
+// A timer is attached to a rollout plan by the caller; while an eager (non-graph) run of that plan
+// enqueues kernels on this thread, every launch site below brackets its kernel with two events.
+enum KernelId { KID_NNCONV = 0, KID_GEMM_L1 = 1, KID_GEMM_L2 = 2, KID_EDGE_L0 = 3, KID_GRAPH = 4,
+                KID_PROLOGUE = 5, KID_FC_OUT = 6, KID_COUNT = 7 };
+struct Timer;
+extern thread_local Timer* g_active_timer;
+void timer_mark(int kid, bool start, hipStream_t s);
+struct TimedSection {
+    int kid; hipStream_t s; bool on;
+    TimedSection(int k, hipStream_t st) : kid(k), s(st), on(g_active_timer != nullptr) { if (on) timer_mark(kid, true, s); }
+    ~TimedSection() { if (on) timer_mark(kid, false, s); }
+};
+
 int radius_graph(const float* frames, int frame, const int* t_dev, int M, int N, double cutoff, int* row_ptr,
                  int* src, int* dst, long long edge_cap, int* num_edges, int* status, hipStream_t s);
 

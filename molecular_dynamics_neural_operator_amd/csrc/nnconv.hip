@@ -142,6 +142,7 @@ int mdno::nnconv(const float* x, const int* row_ptr, const int* src, int num_row
     MDNO_REQUIRE(x != y, MDNO_EINVAL, "nnconv: y aliases x");
     const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_e) |
                            reinterpret_cast<uintptr_t>(root)) & 15) == 0;
+    TimedSection ts(KID_NNCONV, s);
     if (Cin == 64 && Cout == 64 && aligned) {
         hipLaunchKernelGGL(nnconv64_row_kernel, dim3(num_rows), dim3(256), 0, s, x, row_ptr, src, w_e, root, bias,
                            y, num_rows, aggr, relu);

@@ -137,6 +137,7 @@ int mdno::node_prologue(const mdno_kernelnn_params* p, const float* frames, int 
                    p->lstm_b_hh, p->lstm_fc_w, p->lstm_fc_b, p->emb_w, p->fc1_w, p->fc1_b, p->num_embeddings,
                    p->embedding_dim, p->width, x0, status};
     const int R = M * N;
+    TimedSection ts(KID_PROLOGUE, s);
     hipLaunchKernelGGL(node_prologue_kernel, dim3((R + 3) / 4), dim3(256), 0, s, a);
     return check_launch("node_prologue");
 }
@@ -145,6 +146,7 @@ int mdno::fc_out(const float* x, const float* w, const float* b, int rows, int w
                  float* out_frames, int t_out, const int* t_dev, hipStream_t s) {
     MDNO_REQUIRE(x && w && out_frames, MDNO_EINVAL, "fc_out: null pointer");
     MDNO_REQUIRE(rows > 0 && width > 0 && out_width > 0 && t_out >= 0, MDNO_EINVAL, "fc_out: bad sizes");
+    TimedSection ts(KID_FC_OUT, s);
     hipLaunchKernelGGL(fc_out_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, b, rows, width, out_width,
                        out_frames, t_out, t_dev);
     return check_launch("fc_out");

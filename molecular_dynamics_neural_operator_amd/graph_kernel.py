@@ -264,7 +264,14 @@ def recursive_propagation(model, dataset, device, num_steps: int, starting_point
         W, N, _ = win.shape
         eng = RolloutEngine(net, members=1, n_atoms=N, window=W, threshold=threshold, max_steps=num_steps,
                             device=device)
-        traj = eng.run(win.unsqueeze(1), sample.x_aminoacid, num_steps)        # [steps,1,N,3]
+        eng.reset(win.unsqueeze(1), sample.x_aminoacid)
+        if num_steps > 0:
+            # iteration 0 runs on the sample's own graph (first window frame), later ones on the
+            # graph rebuilt from the newest frame — exactly the reference's call sites
+            eng.first_step_from_sample(sample.edge_index, sample.edge_attr)
+            eng.step(num_steps - 1)
+        eng.synchronize()
+        traj = eng.frames()                                                      # [steps,1,N,3]
         frames = torch.cat([win.to(traj.device), traj[:, 0]], dim=0)             # [W+steps,N,3]
         for i in range(num_steps):
             pd = construct_pairdata(frames[i + 1:i + 1 + W], sample.x_aminoacid, threshold=threshold)

@@ -95,6 +95,21 @@ class RolloutEngine:
             self._create_plan()
         self.steps_done = 0
 
+    def first_step_from_sample(self, edge_index: torch.Tensor, edge_attr: torch.Tensor) -> None:
+        """Produce frame W from the start sample's OWN graph and edge attributes, as the reference's
+        first loop iteration does (graph_kernel.py:401-404: `dataset[start]` carries the graph of the
+        window's FIRST frame, dataset.py:189-201; only later steps rebuild it on the newest frame).
+        Single-member engines only; call after reset()."""
+        if self.M != 1 or self.steps_done != 0:
+            raise MdnoError("first_step_from_sample: needs M == 1 and a freshly reset engine")
+        graph = ops.coo_to_csr(edge_index.to(self.device), self.N)
+        out, _ = ops.kernelnn_forward(self.pack, self.traj[:self.W], self.aa, graph,
+                                      edge_attr=edge_attr.to(self.device))
+        self.traj[self.W, 0].copy_(out)
+        self.edges_per_step[0] = int(edge_index.shape[1])
+        torch.cuda.current_stream(self.device).synchronize()
+        self.steps_done = 1
+
     def step(self, steps: int) -> None:
         """Enqueue `steps` more frames on the engine's stream (asynchronous)."""
         if not self.plan:
@@ -102,6 +117,28 @@ class RolloutEngine:
         check(self.lib.mdno_rollout_plan_run(self.plan, self.steps_done, int(steps), self.stream.cuda_stream),
               "mdno_rollout_plan_run")
         self.steps_done += int(steps)
+
+    KERNEL_IDS = {"nnconv": 0, "edge_mlp_gemm1": 1, "edge_mlp_gemm2": 2, "edge_mlp_l0": 3, "radius_graph": 4,
+                  "node_prologue": 5, "fc_out": 6}
+
+    def attach_timer(self, max_records: int) -> None:
+        """Per-kernel HIP-event timing (measurement aid): subsequent step() calls issue plain
+        launches bracketed by events on the engine's stream."""
+        check(self.lib.mdno_rollout_plan_timer_attach(self.plan, int(max_records)), "timer_attach")
+
+    def read_timer(self) -> dict:
+        """{kernel: (total_ms, launches)}; synchronises the engine's stream first."""
+        self.stream.synchronize()
+        out = {}
+        for name, kid in self.KERNEL_IDS.items():
+            ms, n = C.c_double(0.0), C.c_int64(0)
+            check(self.lib.mdno_rollout_plan_timer_read(self.plan, kid, C.byref(ms), C.byref(n)), "timer_read")
+            out[name] = (ms.value, n.value)
+        return out
+
+    def detach_timer(self) -> None:
+        self.stream.synchronize()
+        check(self.lib.mdno_rollout_plan_timer_detach(self.plan), "timer_detach")
 
     def synchronize(self) -> None:
         self.stream.synchronize()

@@ -125,7 +125,7 @@ def main():
 
     N, W, M = a.atoms, a.window, a.members_per_gpu
     total_members = M * world
-    sd = near_identity_state_dict(a.width, a.kernel_width, seed=0, kernel_gain=2e-4, feature_gain=2e-3)
+    sd = near_identity_state_dict(a.width, a.kernel_width, seed=0, kernel_gain=1e-3, feature_gain=0.1)
     model = KernelNN(a.width, a.kernel_width, a.depth, 6, 7, 3, 20, 4)
     model.load_state_dict(sd)
     model.eval().to(dev)

@@ -93,6 +93,28 @@ struct GemmArgs {
     int N, K;
 };
 
+// One K-tile of MFMA work for a wave: 2x2 tiles of 32x32, BK/8 groups of 4 k-steps each.
+__device__ __forceinline__ void mma_tile(f32x16 (&acc)[2][2], const float* __restrict__ a_base,
+                                         const float* __restrict__ b_base) {
+#pragma unroll
+    for (int t = 0; t < BK / 8; ++t) {
+        const float4 a0 = *reinterpret_cast<const float4*>(a_base + 8 * t);
+        const float4 a1 = *reinterpret_cast<const float4*>(a_base + 32 * LDS_LD + 8 * t);
+        const float4 b0 = *reinterpret_cast<const float4*>(b_base + 8 * t);
+        const float4 b1 = *reinterpret_cast<const float4*>(b_base + 32 * LDS_LD + 8 * t);
+#define MDNO_MMA4(A, B, ACC)                                                   \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A.x, B.x, ACC, 0, 0, 0);        \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A.y, B.y, ACC, 0, 0, 0);        \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A.z, B.z, ACC, 0, 0, 0);        \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A.w, B.w, ACC, 0, 0, 0);
+        MDNO_MMA4(a0, b0, acc[0][0])
+        MDNO_MMA4(a0, b1, acc[0][1])
+        MDNO_MMA4(a1, b0, acc[1][0])
+        MDNO_MMA4(a1, b1, acc[1][1])
+#undef MDNO_MMA4
+    }
+}
+
 template <bool RELU>
 __global__ __launch_bounds__(256, 2) void gemm_tn_mfma_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -109,27 +131,34 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_mfma_kernel(GemmArgs g) {
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, h = lane >> 5;
 
-    // global -> register staging: thread covers rows (tid>>3) + 32*i, 16-B column chunk (tid&7)
+    // global -> register staging: thread covers rows (tid>>3) + 32*i, 16-B column chunk (tid&7).
+    // Named registers (no arrays, no lambdas): anything the compiler cannot keep in VGPRs here
+    // goes to scratch and serialises the loads.
     const int srow = tid >> 3, scol = (tid & 7) * 4;
-    const float* Ag = g.A + (size_t)(bm + srow) * g.K + scol;
-    const float* Bg = g.Bt + (size_t)(bn + srow) * g.K + scol;
-    float4 ra[4], rb[4];
-    auto load_tile = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ra[i] = *reinterpret_cast<const float4*>(Ag + (size_t)(32 * i) * g.K + kt * BK);
-            rb[i] = *reinterpret_cast<const float4*>(Bg + (size_t)(32 * i) * g.K + kt * BK);
-        }
-    };
-    auto store_tile = [&](int buf) {
-        float* a = As + buf * BM * LDS_LD + srow * LDS_LD + scol;
-        float* b = Bs + buf * BN * LDS_LD + srow * LDS_LD + scol;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<float4*>(a + 32 * i * LDS_LD) = ra[i];
-            *reinterpret_cast<float4*>(b + 32 * i * LDS_LD) = rb[i];
-        }
-    };
+    const size_t ldk = (size_t)g.K;
+    const float* Ag = g.A + (size_t)(bm + srow) * ldk + scol;
+    const float* Bg = g.Bt + (size_t)(bn + srow) * ldk + scol;
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+#define MDNO_LOAD_TILE(KOFF)                                                        \
+    ra0 = *reinterpret_cast<const float4*>(Ag + (KOFF));                            \
+    ra1 = *reinterpret_cast<const float4*>(Ag + 32 * ldk + (KOFF));                 \
+    ra2 = *reinterpret_cast<const float4*>(Ag + 64 * ldk + (KOFF));                 \
+    ra3 = *reinterpret_cast<const float4*>(Ag + 96 * ldk + (KOFF));                 \
+    rb0 = *reinterpret_cast<const float4*>(Bg + (KOFF));                            \
+    rb1 = *reinterpret_cast<const float4*>(Bg + 32 * ldk + (KOFF));                 \
+    rb2 = *reinterpret_cast<const float4*>(Bg + 64 * ldk + (KOFF));                 \
+    rb3 = *reinterpret_cast<const float4*>(Bg + 96 * ldk + (KOFF));
+    float* a_st = As + srow * LDS_LD + scol;
+    float* b_st = Bs + srow * LDS_LD + scol;
+#define MDNO_STORE_TILE(BUF)                                                                    \
+    *reinterpret_cast<float4*>(a_st + (BUF) * BM * LDS_LD) = ra0;                               \
+    *reinterpret_cast<float4*>(a_st + (BUF) * BM * LDS_LD + 32 * LDS_LD) = ra1;                 \
+    *reinterpret_cast<float4*>(a_st + (BUF) * BM * LDS_LD + 64 * LDS_LD) = ra2;                 \
+    *reinterpret_cast<float4*>(a_st + (BUF) * BM * LDS_LD + 96 * LDS_LD) = ra3;                 \
+    *reinterpret_cast<float4*>(b_st + (BUF) * BN * LDS_LD) = rb0;                               \
+    *reinterpret_cast<float4*>(b_st + (BUF) * BN * LDS_LD + 32 * LDS_LD) = rb1;                 \
+    *reinterpret_cast<float4*>(b_st + (BUF) * BN * LDS_LD + 64 * LDS_LD) = rb2;                 \
+    *reinterpret_cast<float4*>(b_st + (BUF) * BN * LDS_LD + 96 * LDS_LD) = rb3;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -139,36 +168,26 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_mfma_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    const float* a_rd = As + (wm * 64 + l31) * LDS_LD + 4 * h;
+    const float* b_rd = Bs + (wn * 64 + l31) * LDS_LD + 4 * h;
     const int nk = g.K / BK;
-    load_tile(0);
-    store_tile(0);
+    MDNO_LOAD_TILE(0)
+    MDNO_STORE_TILE(0)
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
+    // steady state: prefetch tile kt+1 into registers, multiply tile kt from LDS, publish kt+1
+    for (int kt = 0; kt < nk - 1; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
-        const float* a_base = As + buf * BM * LDS_LD + (wm * 64 + l31) * LDS_LD + 4 * h;
-        const float* b_base = Bs + buf * BN * LDS_LD + (wn * 64 + l31) * LDS_LD + 4 * h;
-#pragma unroll
-        for (int t = 0; t < BK / 8; ++t) {
-            float4 a[2], b[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                a[i] = *reinterpret_cast<const float4*>(a_base + i * 32 * LDS_LD + 8 * t);
-                b[i] = *reinterpret_cast<const float4*>(b_base + i * 32 * LDS_LD + 8 * t);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
-                }
-        }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
+        MDNO_LOAD_TILE((size_t)(kt + 1) * BK)
+        mma_tile(acc, a_rd + buf * BM * LDS_LD, b_rd + buf * BN * LDS_LD);
+        MDNO_STORE_TILE(buf ^ 1)
         __syncthreads();
     }
+    {
+        const int buf = (nk - 1) & 1;
+        mma_tile(acc, a_rd + buf * BM * LDS_LD, b_rd + buf * BN * LDS_LD);
+    }
+#undef MDNO_LOAD_TILE
+#undef MDNO_STORE_TILE
 
     // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll

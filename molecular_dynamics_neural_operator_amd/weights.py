@@ -15,7 +15,8 @@ update rule for which ``model(window) = last frame + small position-dependent di
   fc1 (:269)                   channels 0..2 = +x, 3..5 = -x (so ReLU keeps both signs), the
                                remaining channels are small random features of [emb, x]
   conv1/conv2 (:272-273)       root = I on channels 0..5 (+ small random block elsewhere),
-                               shared edge-MLP with the last layer scaled by `kernel_gain`
+                               shared edge-MLP with the last layer scaled by `kernel_gain` and its
+                               outputs into channels 0..5 scaled by `kernel_to_coords` (default 0)
   fc2 (:275)                   out = ch[0:3] - ch[3:6] + feature_gain * random(ch[6:])
 
 Every layer is still evaluated at full cost (the arithmetic does not depend on the values), so
@@ -34,7 +35,7 @@ def near_identity_state_dict(width: int = 64, ker_width: int = 1024, ker_in: int
                              num_embeddings: int = 20, embedding_dim: int = 4,
                              seed: int = 0, w_lstm: float = 1e-4,
                              kernel_gain: float = 1e-3, feature_gain: float = 1e-2,
-                             dtype=torch.float32) -> "OrderedDict[str, torch.Tensor]":
+                             kernel_to_coords: float = 0.0, dtype=torch.float32) -> "OrderedDict[str, torch.Tensor]":
     if width < 7:
         raise ValueError("near-identity weights need width >= 7 (6 coordinate channels + >=1 feature)")
     g = torch.Generator().manual_seed(seed)
@@ -77,6 +78,14 @@ def near_identity_state_dict(width: int = 64, ker_width: int = 1024, ker_in: int
     k0w, k0b = lin(ker_width, ker_in, gain=0.25)     # inputs are raw coordinates (|p| ~ 10 A)
     k2w, k2b = lin(ker_width, ker_width)
     k4w, k4b = lin(width * width, ker_width, gain=kernel_gain)
+    # W_e[:, i, o] for o < 6 (kernel integral INTO the coordinate channels) is scaled by
+    # `kernel_to_coords`.  0 (default, the benchmark): coordinates travel through `root` untouched and
+    # the per-step displacement is the fc2 read-out of the features alone, so the neighbour density
+    # stays put over 1000 steps.  1: neighbours push each other around (the graph changes within a
+    # few steps; used by the rollout fixtures and tests).
+    coord_out = (torch.arange(width * width) % width) < 6
+    k4w[coord_out] *= kernel_to_coords
+    k4b[coord_out] *= kernel_to_coords
     for conv in ("conv1", "conv2"):
         root = torch.zeros(width, width, dtype=torch.float64)
         root[0:6, 0:6] = torch.eye(6, dtype=torch.float64)

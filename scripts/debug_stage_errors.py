@@ -18,7 +18,7 @@ N, W = 28, 10
 win = syn.jitter_window(syn.chain_frame(N, seed=0), W, seed=0)
 aa = torch.from_numpy(syn.amino_acids(N, seed=0))
 for width, k, depth in ((8, 16, 2), (64, 128, 2)):
-    sd = near_identity_state_dict(width, k, seed=3, kernel_gain=1e-2, feature_gain=1e-1)
+    sd = near_identity_state_dict(width, k, seed=3, kernel_gain=1e-2, feature_gain=1e-1, kernel_to_coords=1.0)
     pack = ops.ParamPack(sd, depth, dev)
     frames = torch.from_numpy(win).to(dev).unsqueeze(1).contiguous()
     x0 = torch.empty((N, width), device=dev)

@@ -102,7 +102,7 @@ def test_no_gpu_means_loud_failure_not_cpu_fallback():
 
 
 def test_near_identity_weights_keep_the_cloud(tmp_path):
-    sd = near_identity_state_dict(8, 16, seed=3, kernel_gain=1e-3, feature_gain=1e-2)
+    sd = near_identity_state_dict(8, 16, seed=3, kernel_gain=1e-3, feature_gain=1e-2, kernel_to_coords=1.0)
     m = KernelNN(8, 16, 2, 6, 7, 3, 20, 4)
     m.load_state_dict(sd)                                  # reference key names
     N, W = 28, 10

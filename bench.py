@@ -46,6 +46,7 @@ sys.path.insert(0, str(REPO))
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 HBM_COPY_GBS = 6290.0
 MFMA_F32_PEAK_TFLOPS = 157.3  # fp32-input MFMA = vector fp32 peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
 def parse():
@@ -61,6 +62,8 @@ def parse():
     ap.add_argument("--window", type=int, default=10)
     ap.add_argument("--threshold", type=float, default=8.0)
     ap.add_argument("--no-graph", action="store_true", help="plain launches instead of hipGraph replay")
+    ap.add_argument("--gemm-mode", choices=["split_bf16", "f32"], default="split_bf16",
+                    help="edge-MLP GEMMs: exact 3-way bf16 split (6 products, fp32 accumulate) or fp32-input MFMA")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--skip-roofline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=45.0)
@@ -129,6 +132,7 @@ def main():
     model = KernelNN(a.width, a.kernel_width, a.depth, 6, 7, 3, 20, 4)
     model.load_state_dict(sd)
     model.eval().to(dev)
+    model.gemm_mode = a.gemm_mode
 
     base = syn.jitter_window(syn.box_frame(N, seed=1), W, seed=1)                  # [W,N,3]
     wins = np.stack([base if (total_members == 1) else
@@ -204,11 +208,21 @@ def main():
                 except Exception:
                     pass
         if "edge_mlp_gemm2" in kernels:
-            avg_s = kernels["edge_mlp_gemm2"]["avg_ms"] * 1e-3
-            flops = 2.0 * e2 * a.kernel_width * C * C
-            roof_mfma = {"bound": "mfma", "kernel": "gemm_tn_mfma_kernel<false>", "achieved": flops / avg_s / 1e12,
-                         "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": flops / avg_s / 1e12 / MFMA_F32_PEAK_TFLOPS, "avg_launch_ms": avg_s * 1e3}
+            # all launches of a step count (capacity-sized chunks past *num_edges exit at once)
+            step_s = tm["edge_mlp_gemm2"][0] * 1e-3 / a.steps
+            flops32 = 2.0 * e2 * a.kernel_width * C * C                        # fp32-equivalent work
+            kernels["edge_mlp_gemm2"]["ms_per_step"] = step_s * 1e3
+            kernels["edge_mlp_gemm1"]["ms_per_step"] = tm["edge_mlp_gemm1"][0] / a.steps
+            if a.gemm_mode == "f32":
+                roof_mfma = {"bound": "mfma", "kernel": "gemm_tn_mfma_kernel<false>", "achieved": flops32 / step_s / 1e12,
+                             "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": flops32 / step_s / 1e12 / MFMA_F32_PEAK_TFLOPS, "ms_per_step": step_s * 1e3}
+            else:
+                ach = 6.0 * flops32 / step_s / 1e12                            # 6 bf16 plane products executed
+                roof_mfma = {"bound": "mfma", "kernel": "gemm_split_bf16_kernel<false>", "achieved": ach,
+                             "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
+                             "fp32_equivalent_tflops": flops32 / step_s / 1e12, "ms_per_step": step_s * 1e3,
+                             "note": "executed bf16 MFMA flops (6 plane products per fp32 product) vs dense bf16 peak"}
 
     cpu = None
     if rank == 0 and world == 1 and not a.skip_cpu_baseline:
@@ -226,7 +240,7 @@ def main():
                        "members_per_gpu": M, "total_members": total_members, "mean_edges_per_member": e_mean / M,
                        "edges_first_last": [int(eps[0].item()), int(eps[-1].item())], "edge_cap": cap,
                        "parallelism": f"ensemble-sharded x{world}, one all-gather of trajectories",
-                       "launch": "plain" if a.no_graph else "hipGraph replay"},
+                       "launch": "plain" if a.no_graph else "hipGraph replay", "edge_mlp_gemm": a.gemm_mode},
             "roofline": roof, "roofline_mfma": roof_mfma, "cpu_baseline": cpu, "kernels": kernels,
         }
         print(json.dumps(line))

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDNO_ABI_VERSION 1
+#define MDNO_ABI_VERSION 2
 
 #define MDNO_OK            0
 #define MDNO_EINVAL       -1   /* bad argument (null pointer, non-positive size, unsupported dim) */
@@ -42,6 +42,15 @@ extern "C" {
 
 #define MDNO_AGGR_ADD  0
 #define MDNO_AGGR_MEAN 1
+
+/* How the two wide edge-MLP GEMMs are evaluated (fp32 in, fp32 out either way):
+ *   SPLIT_BF16  every fp32 operand is split exactly into 3 bf16 planes and the product accumulated
+ *               in fp32 from the 6 leading plane products on the bf16 matrix pipe; error vs fp64 at
+ *               the level of a plain fp32 GEMM (dropped terms <= 2^-24 |a b|).  Default.  Shapes the
+ *               tiles do not divide (ker_width % 128, out_dim % 128) silently use F32.
+ *   F32         v_mfma_f32_32x32x2_f32: bit-for-bit an fp32 fmaf chain. */
+#define MDNO_GEMM_SPLIT_BF16 0
+#define MDNO_GEMM_F32        1
 
 /* status word bits written by device code (read back by the caller after synchronising) */
 #define MDNO_STATUS_EDGE_OVERFLOW 1   /* radius graph found more than edge_cap edges; list truncated */
@@ -59,7 +68,7 @@ const char* mdno_last_error(void);
  * ---------------------------------------------------------------------------------------- */
 typedef struct mdno_kernelnn_params {
     int32_t width, ker_width, depth, ker_in, in_width, out_width;
-    int32_t num_embeddings, embedding_dim, x_position_dim, reserved0;
+    int32_t num_embeddings, embedding_dim, x_position_dim, gemm_mode;  /* gemm_mode: MDNO_GEMM_* */
     const float *lstm_w_ih, *lstm_w_hh, *lstm_b_ih, *lstm_b_hh;     /* lstm.*_l0            */
     const float *lstm_fc_w, *lstm_fc_b;                             /* lstm_fc.{weight,bias} */
     const float *emb_w;                                             /* emb.weight [20,4]     */
@@ -103,12 +112,13 @@ int mdno_coo_to_csr(const int64_t* edge_index, int64_t E, int num_nodes,
  *   (a) edge_pos f32 [R,3] + CSR (src,dst): attr[p] = [pos[src[p]], pos[dst[p]]]   (:372-379)
  *   (b) edge_attr f32 [E,ker_in] (+ perm i32 [E] or NULL): attr[p] = edge_attr[perm[p]]
  *   num_edges  i32 [1] device (rows >= *num_edges are not computed); edge_cap bounds it.
- *   workspace: mdno_edge_mlp_workspace_bytes(ker_width, edge_cap) for the two hidden activations.
+ *   workspace: mdno_edge_mlp_workspace_bytes(ker_width, out_dim, edge_cap, gemm_mode).
  * ---------------------------------------------------------------------------------------- */
-size_t mdno_edge_mlp_workspace_bytes(int ker_width, int64_t edge_cap);
+size_t mdno_edge_mlp_workspace_bytes(int ker_width, int out_dim, int64_t edge_cap, int gemm_mode);
 int mdno_edge_mlp_fwd(const float* edge_pos, const int32_t* src, const int32_t* dst,
                       const float* edge_attr, const int32_t* perm,
                       const int32_t* num_edges, int64_t edge_cap, int ker_in, int ker_width, int out_dim,
+                      int gemm_mode,
                       const float* w0, const float* b0, const float* w1, const float* b1,
                       const float* w2, const float* b2,
                       float* w_e, void* workspace, size_t workspace_bytes, void* stream);

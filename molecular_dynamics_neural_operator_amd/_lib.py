@@ -14,7 +14,8 @@ LIB_PATH = Path(os.environ.get("MDNO_LIB", _HERE / "libmdno.so"))
 OK, EINVAL, ELAUNCH, EWORKSPACE, EUNSUPPORTED = 0, -1, -2, -3, -4
 AGGR = {"add": 0, "mean": 1}
 STATUS_EDGE_OVERFLOW, STATUS_BAD_AMINOACID = 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
+GEMM_MODES = {"split_bf16": 0, "f32": 1}
 
 
 class MdnoError(RuntimeError):
@@ -24,7 +25,7 @@ class MdnoError(RuntimeError):
 class KernelNNParams(C.Structure):
     """struct mdno_kernelnn_params"""
     _INTS = ["width", "ker_width", "depth", "ker_in", "in_width", "out_width",
-             "num_embeddings", "embedding_dim", "x_position_dim", "reserved0"]
+             "num_embeddings", "embedding_dim", "x_position_dim", "gemm_mode"]
     _PTRS = ["lstm_w_ih", "lstm_w_hh", "lstm_b_ih", "lstm_b_hh", "lstm_fc_w", "lstm_fc_b", "emb_w",
              "fc1_w", "fc1_b", "k_w0", "k_b0", "k_w1", "k_b1", "k_w2", "k_b2",
              "k2_w0", "k2_b0", "k2_w1", "k2_b1", "k2_w2", "k2_b2",
@@ -45,8 +46,9 @@ SIGNATURES = {
     "mdno_radius_graph_csr": (_I, [_P, _I, _I, _D, _P, _P, _P, _L, _P, _P, _P]),
     "mdno_coo_to_csr_workspace_bytes": (_SZ, [_L, _I]),
     "mdno_coo_to_csr": (_I, [_P, _L, _I, _P, _P, _P, _P, _P, _SZ, _P]),
-    "mdno_edge_mlp_workspace_bytes": (_SZ, [_I, _L]),
-    "mdno_edge_mlp_fwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "mdno_edge_mlp_workspace_bytes": (_SZ, [_I, _I, _L, _I]),
+    "mdno_edge_mlp_fwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _SZ,
+                               _P]),
     "mdno_nnconv_fwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "mdno_node_prologue_fwd": (_I, [C.POINTER(KernelNNParams), _P, _I, _I, _I, _P, _I, _P, _P, _P]),
     "mdno_fc_out_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),

@@ -269,24 +269,32 @@ long long chunk_rows_for(long long edge_cap) {
 
 using namespace mdno;
 
-extern "C" size_t mdno_edge_mlp_workspace_bytes(int ker_width, int64_t edge_cap) {
-    if (ker_width <= 0 || edge_cap <= 0) return 0;
-    return align_up(2 * (size_t)chunk_rows_for(edge_cap) * (size_t)ker_width * sizeof(float) + 512, 256);
+extern "C" size_t mdno_edge_mlp_workspace_bytes(int ker_width, int out_dim, int64_t edge_cap, int gemm_mode) {
+    if (ker_width <= 0 || out_dim <= 0 || edge_cap <= 0) return 0;
+    const long long chunk = chunk_rows_for(edge_cap);
+    if (gemm_mode == MDNO_GEMM_SPLIT_BF16 && edge_mlp_split_supported(ker_width, out_dim))
+        return edge_mlp_split_workspace_bytes(ker_width, out_dim, chunk);
+    return align_up(2 * (size_t)chunk * (size_t)ker_width * sizeof(float) + 512, 256);
 }
 
 int mdno::edge_mlp(const float* frames, int frame, const int* t_dev, int rows_per_frame, const int* src,
                    const int* dst, const float* edge_attr, const int* perm, const int* num_edges,
-                   long long edge_cap, int ker_in, int ker_width, int out_dim, const EdgeMlpWeights& w, float* w_e,
-                   void* workspace, size_t workspace_bytes, hipStream_t s) {
+                   long long edge_cap, int ker_in, int ker_width, int out_dim, int gemm_mode,
+                   const EdgeMlpWeights& w, float* w_e, void* workspace, size_t workspace_bytes, hipStream_t s) {
     MDNO_REQUIRE(num_edges && w.w0 && w.b0 && w.w1 && w.b1 && w.w2 && w.b2 && w_e && workspace, MDNO_EINVAL,
                  "edge_mlp: null pointer");
     MDNO_REQUIRE((frames && src && dst) || edge_attr, MDNO_EINVAL, "edge_mlp: need (edge_pos, src, dst) or edge_attr");
     MDNO_REQUIRE(edge_cap > 0 && ker_width > 0 && out_dim > 0, MDNO_EINVAL, "edge_mlp: bad sizes");
     MDNO_REQUIRE(ker_in > 0 && ker_in <= MAX_F, MDNO_EUNSUPPORTED, "edge_mlp: ker_in=%d (1..%d)", ker_in, MAX_F);
     MDNO_REQUIRE(edge_attr || ker_in == 6, MDNO_EINVAL, "edge_mlp: position-derived attributes need ker_in == 6");
-    MDNO_REQUIRE(workspace_bytes >= mdno_edge_mlp_workspace_bytes(ker_width, edge_cap), MDNO_EWORKSPACE,
-                 "edge_mlp: workspace %zu < %zu", workspace_bytes, mdno_edge_mlp_workspace_bytes(ker_width, edge_cap));
+    MDNO_REQUIRE(gemm_mode == MDNO_GEMM_SPLIT_BF16 || gemm_mode == MDNO_GEMM_F32, MDNO_EINVAL,
+                 "edge_mlp: gemm_mode=%d", gemm_mode);
+    const size_t need = mdno_edge_mlp_workspace_bytes(ker_width, out_dim, edge_cap, gemm_mode);
+    MDNO_REQUIRE(workspace_bytes >= need, MDNO_EWORKSPACE, "edge_mlp: workspace %zu < %zu", workspace_bytes, need);
     const long long chunk = chunk_rows_for(edge_cap);
+    if (gemm_mode == MDNO_GEMM_SPLIT_BF16 && edge_mlp_split_supported(ker_width, out_dim))
+        return edge_mlp_split(frames, frame, t_dev, rows_per_frame, src, dst, edge_attr, perm, num_edges, edge_cap,
+                              chunk, ker_in, ker_width, out_dim, w, w_e, workspace, s);
     Carver cv(workspace);
     float* h1 = cv.take<float>((size_t)chunk * ker_width);
     float* h2 = cv.take<float>((size_t)chunk * ker_width);
@@ -311,11 +319,12 @@ int mdno::edge_mlp(const float* frames, int frame, const int* t_dev, int rows_pe
 
 extern "C" int mdno_edge_mlp_fwd(const float* edge_pos, const int32_t* src, const int32_t* dst,
                                  const float* edge_attr, const int32_t* perm, const int32_t* num_edges,
-                                 int64_t edge_cap, int ker_in, int ker_width, int out_dim, const float* w0,
-                                 const float* b0, const float* w1, const float* b1, const float* w2,
-                                 const float* b2, float* w_e, void* workspace, size_t workspace_bytes,
-                                 void* stream) {
+                                 int64_t edge_cap, int ker_in, int ker_width, int out_dim, int gemm_mode,
+                                 const float* w0, const float* b0, const float* w1, const float* b1,
+                                 const float* w2, const float* b2, float* w_e, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
     EdgeMlpWeights w{w0, b0, w1, b1, w2, b2};
     return mdno::edge_mlp(edge_pos, 0, nullptr, 0, src, dst, edge_attr, perm, num_edges, (long long)edge_cap, ker_in,
-                          ker_width, out_dim, w, w_e, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+                          ker_width, out_dim, gemm_mode, w, w_e, workspace, workspace_bytes,
+                          static_cast<hipStream_t>(stream));
 }

@@ -83,7 +83,7 @@ FwdWs carve_fwd(void* ws, const mdno_kernelnn_params* p, int M, int N, long long
     f.xa = cv.take<float>(R * p->width);
     f.xb = cv.take<float>(R * p->width);
     f.w_e = cv.take<float>((size_t)edge_cap * p->width * p->width);
-    f.mlp_bytes = mdno_edge_mlp_workspace_bytes(p->ker_width, edge_cap);
+    f.mlp_bytes = mdno_edge_mlp_workspace_bytes(p->ker_width, p->width * p->width, edge_cap, p->gemm_mode);
     f.mlp = cv.take<char>(f.mlp_bytes);
     f.total = cv.used();
     return f;
@@ -104,7 +104,7 @@ int forward_impl(const mdno_kernelnn_params* p, const float* frames, int t0, con
             EdgeMlpWeights w = (block == 0) ? EdgeMlpWeights{p->k_w0, p->k_b0, p->k_w1, p->k_b1, p->k_w2, p->k_b2}
                                             : EdgeMlpWeights{p->k2_w0, p->k2_b0, p->k2_w1, p->k2_b1, p->k2_w2, p->k2_b2};
             MDNO_TRY(edge_mlp(edge_frames, edge_frame, t_dev, R, src, dst, edge_attr, perm, num_edges, edge_cap,
-                              p->ker_in, p->ker_width, C * C, w, ws.w_e, ws.mlp, ws.mlp_bytes, s));
+                              p->ker_in, p->ker_width, C * C, p->gemm_mode, w, ws.w_e, ws.mlp, ws.mlp_bytes, s));
         }
         const float* root = block == 0 ? p->conv1_root : p->conv2_root;
         const float* bias = block == 0 ? p->conv1_bias : p->conv2_bias;

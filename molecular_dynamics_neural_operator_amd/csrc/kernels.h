@@ -29,10 +29,18 @@ struct EdgeMlpWeights {
     const float *w0, *b0, *w1, *b1, *w2, *b2;
 };
 
+// gemm_mode: MDNO_GEMM_SPLIT_BF16 (default; falls back to exact fp32 when the shape is not tileable)
+// or MDNO_GEMM_F32.
 int edge_mlp(const float* frames, int frame, const int* t_dev, int rows_per_frame, const int* src, const int* dst,
              const float* edge_attr, const int* perm, const int* num_edges, long long edge_cap, int ker_in,
-             int ker_width, int out_dim, const EdgeMlpWeights& w, float* w_e, void* workspace,
+             int ker_width, int out_dim, int gemm_mode, const EdgeMlpWeights& w, float* w_e, void* workspace,
              size_t workspace_bytes, hipStream_t s);
+bool edge_mlp_split_supported(int ker_width, int out_dim);
+size_t edge_mlp_split_workspace_bytes(int ker_width, int out_dim, long long chunk);
+int edge_mlp_split(const float* frames, int frame, const int* t_dev, int rows_per_frame, const int* src,
+                   const int* dst, const float* edge_attr, const int* perm, const int* num_edges,
+                   long long edge_cap, long long chunk, int ker_in, int ker_width, int out_dim,
+                   const EdgeMlpWeights& w, float* w_e, void* workspace, hipStream_t s);
 
 int nnconv(const float* x, const int* row_ptr, const int* src, int num_rows, const float* w_e, const float* root,
            const float* bias, int Cin, int Cout, int aggr, int relu, float* y, hipStream_t s);

@@ -196,14 +196,18 @@ class KernelNN(nn.Module):
         self.fc2 = nn.Linear(width, out_width)
         self._pack = None
         self._pack_key = None
+        # how the two wide edge-MLP GEMMs run (include/mdno.h MDNO_GEMM_*): "split_bf16" = exact 3-way
+        # bf16 split of the fp32 operands, 6 products, fp32 accumulation (fp32-level error, 2-3x faster);
+        # "f32" = fp32-input MFMA, bit-for-bit an fmaf chain
+        self.gemm_mode = "split_bf16"
 
     # -- parameter pack (device pointers) cached until a parameter changes
     def param_pack(self, device=None) -> ops.ParamPack:
         device = require_gpu(device)
         params = list(self.parameters())
-        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in params)
+        key = (str(device), self.gemm_mode) + tuple((p.data_ptr(), p._version) for p in params)
         if self._pack is None or self._pack_key != key:
-            self._pack = ops.ParamPack(self.state_dict(), self.depth, device)
+            self._pack = ops.ParamPack(self.state_dict(), self.depth, device, self.gemm_mode)
             self._pack_key = key
         return self._pack
 

@@ -77,7 +77,8 @@ def coo_to_csr(edge_index: torch.Tensor, num_nodes: int) -> CSRGraph:
 
 
 def edge_mlp(weights, ker_in: int, ker_width: int, out_dim: int, graph: CSRGraph,
-             edge_pos: Optional[torch.Tensor] = None, edge_attr: Optional[torch.Tensor] = None) -> torch.Tensor:
+             edge_pos: Optional[torch.Tensor] = None, edge_attr: Optional[torch.Tensor] = None,
+             gemm_mode: str = "split_bf16") -> torch.Tensor:
     """W_e f32 [cap, out_dim] in CSR edge order.  `weights` = (w0,b0,w1,b1,w2,b2) torch Linear
     layout.  Attributes from `edge_pos` [R,3] + CSR, or `edge_attr` [E,ker_in] (+ graph.perm)."""
     lib = _lib.load()
@@ -85,13 +86,14 @@ def edge_mlp(weights, ker_in: int, ker_width: int, out_dim: int, graph: CSRGraph
     dev = w[0].device
     cap = graph.edge_cap
     w_e = torch.empty((cap, out_dim), dtype=torch.float32, device=dev)
-    nbytes = lib.mdno_edge_mlp_workspace_bytes(ker_width, cap)
+    mode = _lib.GEMM_MODES[gemm_mode]
+    nbytes = lib.mdno_edge_mlp_workspace_bytes(ker_width, out_dim, cap, mode)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     ea = f32(edge_attr) if edge_attr is not None else None
     ep = f32(edge_pos).reshape(-1, 3) if edge_pos is not None else None
     check(lib.mdno_edge_mlp_fwd(ptr(ep), ptr(graph.src), ptr(graph.dst), ptr(ea),
                                 ptr(graph.perm) if ea is not None else None, ptr(graph.num_edges), cap,
-                                ker_in, ker_width, out_dim, *[ptr(t) for t in w], ptr(w_e), ptr(ws), nbytes,
+                                ker_in, ker_width, out_dim, mode, *[ptr(t) for t in w], ptr(w_e), ptr(ws), nbytes,
                                 stream_ptr(dev)), "mdno_edge_mlp_fwd")
     return w_e
 
@@ -132,7 +134,7 @@ class ParamPack:
         "fc2_w": "fc2.weight", "fc2_b": "fc2.bias",
     }
 
-    def __init__(self, state_dict, depth: int, device):
+    def __init__(self, state_dict, depth: int, device, gemm_mode: str = "split_bf16"):
         sd = {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
         self.tensors = {}
         p = KernelNNParams()
@@ -165,6 +167,8 @@ class ParamPack:
         p.out_width = self.tensors["fc2_w"].shape[0]
         p.num_embeddings, p.embedding_dim = self.tensors["emb_w"].shape
         p.x_position_dim = self.tensors["lstm_w_ih"].shape[1]
+        p.gemm_mode = _lib.GEMM_MODES[gemm_mode]
+        self.gemm_mode = gemm_mode
         if self.tensors["k_w2"].shape[0] != width * width:
             raise MdnoError("edge-MLP output size != width**2")
         self.struct = p

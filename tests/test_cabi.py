@@ -50,13 +50,16 @@ def test_exports_are_c_linkage_only_mdno(lib):
 
 def test_abi_version_struct_layout_and_error_string(lib):
     from molecular_dynamics_neural_operator_amd import _lib
-    assert lib.mdno_abi_version() == 1
+    assert lib.mdno_abi_version() == 2
     # 10 int32 + 27 pointers, no padding surprises
     assert ctypes.sizeof(_lib.KernelNNParams) == 10 * 4 + 27 * 8
     # argument validation happens before any device work: exercise it without a GPU
     rc = lib.mdno_nnconv_fwd(None, None, None, 1, None, None, None, 64, 64, 1, 0, None, None)
     assert rc == _lib.EINVAL and b"null pointer" in lib.mdno_last_error()
-    assert lib.mdno_edge_mlp_workspace_bytes(1024, 1000) == 2 * 1024 * 1024 * 4 + 512
+    assert lib.mdno_edge_mlp_workspace_bytes(1024, 4096, 1000, _lib.GEMM_MODES["f32"]) == 2 * 1024 * 1024 * 4 + 512
+    # split mode: 2 x 3 bf16 activation planes + the split weights; untileable shapes fall back to fp32 sizing
+    assert lib.mdno_edge_mlp_workspace_bytes(1024, 4096, 1000, 0) == 2 * 3 * 1024 * 1024 * 2 + 3 * 2 * (1024 + 4096) * 1024
+    assert lib.mdno_edge_mlp_workspace_bytes(16, 64, 1000, 0) == 2 * 1024 * 16 * 4 + 512
     assert lib.mdno_kernelnn_workspace_bytes(None, 1, 1, 1) == 0
     with pytest.raises(_lib.MdnoError):
         _lib.check(rc, "nnconv")

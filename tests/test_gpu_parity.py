@@ -121,9 +121,11 @@ def test_edge_mlp_small_golden(dev):
     close(w_e, z["w_e"])
 
 
+@pytest.mark.parametrize("mode", ["split_bf16", "f32"])
 @pytest.mark.parametrize("k", [128, 1024])
-def test_edge_mlp_mfma_vs_oracle(dev, O, k):
-    """64x64 output (4096 columns) exercises the fp32 MFMA GEMM; E not a multiple of the tile."""
+def test_edge_mlp_mfma_vs_oracle(dev, O, k, mode):
+    """64x64 output (4096 columns) exercises the MFMA GEMMs (exact-fp32 and 3-way bf16 split);
+    E is not a multiple of the tile."""
     from molecular_dynamics_neural_operator_amd import ops
     torch.manual_seed(7)
     E = 342 + 129
@@ -136,13 +138,36 @@ def test_edge_mlp_mfma_vs_oracle(dev, O, k):
     ne = torch.full((1,), E, dtype=torch.int32, device=dev)
     g = ops.CSRGraph(None, None, None, ne, E, None, None)
     w = [sd[f"layers.{j}.{n}"].to(dev) for j in (0, 2, 4) for n in ("weight", "bias")]
-    got = ops.edge_mlp(w, 6, k, 4096, g, edge_attr=ea.to(dev))
+    got = ops.edge_mlp(w, 6, k, 4096, g, edge_attr=ea.to(dev), gemm_mode=mode)
     close(got[:E], want)
     # permuted attributes: row p must come from edge_attr[perm[p]]
     perm = torch.randperm(E)
     g2 = ops.CSRGraph(None, None, None, ne, E, perm.to(torch.int32).to(dev), None)
-    got2 = ops.edge_mlp(w, 6, k, 4096, g2, edge_attr=ea.to(dev))
+    got2 = ops.edge_mlp(w, 6, k, 4096, g2, edge_attr=ea.to(dev), gemm_mode=mode)
     assert torch.equal(got2[:E].cpu(), got[:E].cpu()[perm])
+
+
+def test_split_bf16_gemm_is_fp32_accurate(dev):
+    """The 3-way bf16 split (6 plane products, fp32 accumulation) must be as close to the fp64
+    product as the exact-fp32 MFMA path, at K = 1024 on ReLU-like activations."""
+    from molecular_dynamics_neural_operator_amd import ops
+    torch.manual_seed(3)
+    E, k = 2000, 1024
+    ea = torch.randn(E, 6) * 4
+    lins = [torch.nn.Linear(6, k), torch.nn.Linear(k, k), torch.nn.Linear(k, 4096)]
+    w = [p.data for lin in lins for p in (lin.weight, lin.bias)]
+    h = torch.relu(torch.nn.functional.linear(ea.double(), w[0].double(), w[1].double()))
+    h = torch.relu(torch.nn.functional.linear(h, w[2].double(), w[3].double()))
+    ref = torch.nn.functional.linear(h, w[4].double(), w[5].double())
+    ne = torch.full((1,), E, dtype=torch.int32, device=dev)
+    g = ops.CSRGraph(None, None, None, ne, E, None, None)
+    wd = [t.to(dev) for t in w]
+    err = {}
+    for mode in ("split_bf16", "f32"):
+        got = ops.edge_mlp(wd, 6, k, 4096, g, edge_attr=ea.to(dev), gemm_mode=mode)[:E].cpu().double()
+        err[mode] = float(((got - ref).pow(2).mean().sqrt()) / ref.pow(2).mean().sqrt())
+    assert err["f32"] < 2e-6 and err["split_bf16"] < 2e-6, err
+    assert err["split_bf16"] < 3 * err["f32"], err
 
 
 def test_edge_mlp_attrs_from_positions(dev, O):
@@ -266,12 +291,14 @@ def test_kernelnn_full_seeded_init_and_forward(dev):
         assert float(sd[n].double().abs().sum()) == pytest.approx(float(a), rel=1e-12), n
     model.eval().to(dev)
     pd = PairData(t(z["x_aminoacid"]), t(z["x_position"]), None, t(z["edge_attr"]), t(z["edge_index"])).to(dev)
-    with torch.no_grad():
-        out, lat = model(pd, return_latent=True)
-        w0 = model.conv1.net(pd.edge_attr)[0]
-    close(w0, z["w_e_first_edge"])
-    close(lat, z["latent"])
-    close(out, z["out"])
+    for mode in ("split_bf16", "f32"):
+        model.gemm_mode = mode
+        with torch.no_grad():
+            out, lat = model(pd, return_latent=True)
+            w0 = model.conv1.net(pd.edge_attr)[0]
+        close(w0, z["w_e_first_edge"])
+        close(lat, z["latent"])
+        close(out, z["out"])
 
 
 def test_kernelnn_shapeB_reference_golden(dev):
@@ -284,10 +311,12 @@ def test_kernelnn_shapeB_reference_golden(dev):
     model = KernelNN(*[int(v) for v in z["ctor"]]).eval().to(dev)
     pd = construct_pairdata(z["x_position"], t(z["x_aminoacid"]), float(z["threshold"]))
     assert pd.edge_index.shape[1] == int(z["num_edges"])
-    with torch.no_grad():
-        out, lat = model(pd, return_latent=True)
-    close(lat, z["latent"])
-    close(out, z["out"])
+    for mode in ("f32", "split_bf16"):
+        model.gemm_mode = mode
+        with torch.no_grad():
+            out, lat = model(pd, return_latent=True)
+        close(lat, z["latent"])
+        close(out, z["out"])
     # position-derived attributes (the rollout path) give the same result as explicit edge_attr
     g = ops.radius_graph(pd.x_position[-1], 504, float(z["threshold"]))
     o2, _ = ops.kernelnn_forward(model.param_pack(dev), pd.x_position.unsqueeze(1), pd.x_aminoacid, g,

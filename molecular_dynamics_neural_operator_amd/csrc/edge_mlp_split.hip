@@ -10,20 +10,26 @@
 // (measured rms 9e-8 vs 2.4e-7 for an fp32 GEMM at K=1024; tests/test_gpu_parity.py).  6 MFMAs at 16x
 // the fp32-MFMA rate = 2.67x fewer matrix-pipe cycles than v_mfma_f32_32x32x2_f32.
 //
-// Data flow (all planes are bf16, plane-major [3][rows][K]):
-//   weights      fp32 [N,K] --split_planes_kernel--> Bp[3][N][K]          (once per forward, 40 MB)
-//   layer 0      edge attrs -> relu(linear)  --split--> H1p[3][chunk][k]   (edge_l0_split_kernel)
-//   layer 1      H1p x W1p -> relu -> split  -----> H2p[3][chunk][k]       (epilogue emits planes)
-//   layer 2      H2p x W2p + b  -> fp32 W_e[E, Cin*Cout]
+// Operand layout in HBM = the LDS image, tile by tile.  A [rows,K] operand is stored as
+//     [row_tile = rows/128][k_tile = K/32][plane 0..2][128 rows][32 k]  bf16,
+// each 8 KiB plane tile holding its rows as 64-B lines whose four 16-B chunks are XOR-swizzled by
+// (row>>2)&3 — exactly what the fragment reads want in LDS.  Staging a K-tile is then a straight,
+// fully coalesced 24 KiB copy per operand (16 B per lane, 1 KiB per wave-instruction) and a
+// workgroup walks one contiguous run of K/32 * 24 KiB.  We own both producers and consumers of
+// these buffers, so nothing else ever sees the layout:
+//   weights      fp32 [N,K] --split_planes_kernel--> tiled planes            (once per forward, 30 MB)
+//   layer 0      edge attrs -> relu(linear)  --split--> H1 tiled planes      (edge_l0_split_kernel)
+//   layer 1      H1 x W1 -> relu -> split  ---------> H2 tiled planes        (epilogue emits planes)
+//   layer 2      H2 x W2 + b  -> fp32 W_e[E, Cin*Cout]  (row-major, what the conv streams)
 // so no fp32 activation is ever stored.
 //
 // GEMM kernel: 128x128x32 block tile, 4 waves (2x2), wave tile 64x64 = 2x2 v_mfma_f32_32x32x16_bf16
 // tiles, 48 MFMAs per K-tile per wave.  Each staged operand fragment feeds 2-3 of the six products,
 // so LDS and global traffic per MFMA are half those of an ordinary bf16 GEMM.  Staging is
-// global -> registers -> LDS with the next tile's loads in flight during the MFMAs; LDS rows are
-// 64 B (32 bf16) with the 16-B chunk position XOR-swizzled by (row>>2)&3, which makes the
-// ds_read_b128 fragment reads bank-conflict-free.  Workgroups are numbered so that each XCD owns a
-// contiguous range of tiles (neighbouring tiles share the A row-panel through that XCD's L2).
+// global -> registers -> LDS with the next tile's loads in flight during the MFMAs; the swizzle
+// makes the ds_read_b128 fragment reads bank-conflict-free.  Workgroups are numbered so that each
+// XCD owns a contiguous range of tiles (neighbouring tiles share the A row-panel through that
+// XCD's L2).
 #include "kernels.h"
 
 namespace mdno {
@@ -44,37 +50,51 @@ __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l)
     l = (__bf16)r2;
 }
 
-// ---------------------------------------------------------------- fp32 [rows,cols] -> 3 bf16 planes
-__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ w, long long count,
-                                                           __bf16* __restrict__ planes) {
-    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i >= count) return;
-    const float4 v = *reinterpret_cast<const float4*>(w + i);
-    const float x[4] = {v.x, v.y, v.z, v.w};
-    __bf16 o[3][4];
+// Byte offset of element (row, kcol) of plane p in the tiled layout; nkt = K/32.
+__device__ __forceinline__ size_t tiled_off(long long row, int kcol, int nkt, int p) {
+    const long long rt = row >> 7;
+    const int r = (int)(row & 127), kt = kcol >> 5, c = (kcol >> 3) & 3, e = kcol & 7;
+    return ((size_t)((rt * nkt + kt) * 3 + p) << 13) + r * 64 + ((c ^ ((r >> 2) & 3)) << 4) + e * 2;
+}
+
+// ---------------------------------------------------------------- fp32 [rows,K] -> tiled planes
+// thread = one 16-B chunk (8 consecutive k of one row)
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ w, int rows, int K,
+                                                           unsigned char* __restrict__ planes) {
+    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int chunks_per_row = K >> 3;
+    if (id >= (long long)rows * chunks_per_row) return;
+    const int row = (int)(id / chunks_per_row), k0 = (int)(id % chunks_per_row) * 8;
+    const float4 v0 = *reinterpret_cast<const float4*>(w + (size_t)row * K + k0);
+    const float4 v1 = *reinterpret_cast<const float4*>(w + (size_t)row * K + k0 + 4);
+    const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    __bf16 o[3][8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) split3(x[j], o[0][j], o[1][j], o[2][j]);
+    for (int j = 0; j < 8; ++j) split3(x[j], o[0][j], o[1][j], o[2][j]);
+    const int nkt = K >> 5;
 #pragma unroll
     for (int p = 0; p < 3; ++p)
-        *reinterpret_cast<uint2*>(planes + (size_t)p * count + i) = *reinterpret_cast<const uint2*>(o[p]);
+        *reinterpret_cast<uint4*>(planes + tiled_off(row, k0, nkt, p)) = *reinterpret_cast<const uint4*>(o[p]);
 }
 
 // ---------------------------------------------------------------- layer 0 (+ attr gather) -> planes
-constexpr int EB = 16;
+// Block = 256 threads, EB edges.  Thread = one 16-B chunk (8 hidden units) of one edge at a time:
+// k/8 threads cover an edge, the block walks its edges in groups of 256/(k/8).
+constexpr int EB = 32;
 constexpr int MAX_F = 8;
 
 __global__ __launch_bounds__(256) void edge_l0_split_kernel(
     const float* __restrict__ frames, int frame, const int* __restrict__ t_dev, int rows_per_frame,
     const int* __restrict__ src, const int* __restrict__ dst, const float* __restrict__ edge_attr,
     const int* __restrict__ perm, const int* __restrict__ num_edges, long long e_begin, int e_count, int F, int k,
-    const float* __restrict__ w0, const float* __restrict__ b0, __bf16* __restrict__ hp, long long plane_stride) {
+    const float* __restrict__ w0, const float* __restrict__ b0, unsigned char* __restrict__ hp) {
     __shared__ float attr[EB][MAX_F];
     const long long E = *num_edges;
     const long long e0 = e_begin + (long long)blockIdx.x * EB;
     if (e0 >= E || (long long)blockIdx.x * EB >= e_count) return;
     const int tid = threadIdx.x;
-    if (tid < EB * MAX_F) {
-        const int le = tid / MAX_F, f = tid % MAX_F;
+    {
+        const int le = tid / MAX_F, f = tid % MAX_F;   // 256 threads = 32 edges x 8 features
         const long long e = e0 + le;
         float v = 0.f;
         if (e < E && f < F) {
@@ -90,41 +110,44 @@ __global__ __launch_bounds__(256) void edge_l0_split_kernel(
         attr[le][f] = v;
     }
     __syncthreads();
-    for (int c = tid; c < k; c += 256) {
-        float w[MAX_F];
+    const int cpr = k >> 3;                 // chunks per edge row
+    const int nkt = k >> 5;
+    for (int c0 = (tid % cpr) * 8, le0 = tid / cpr; c0 < k; c0 += 256 * 8) {   // one pass when k/8 <= 256
+        float w[8][MAX_F], bc[8];
 #pragma unroll
-        for (int f = 0; f < MAX_F; ++f) w[f] = (f < F) ? w0[(size_t)c * F + f] : 0.f;
-        const float bc = b0[c];
-#pragma unroll 4
-        for (int le = 0; le < EB; ++le) {
+        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+            for (int f = 0; f < MAX_F; ++f) w[j][f] = (f < F) ? w0[(size_t)(c0 + j) * F + f] : 0.f;
+            bc[j] = b0[c0 + j];
+        }
+        const int estep = (cpr >= 256) ? 1 : 256 / cpr;
+        for (int le = le0; le < EB; le += estep) {
             const long long e = e0 + le;
             if (e >= E || e - e_begin >= e_count) break;
-            float s = 0.f;
+            __bf16 o[3][8];
 #pragma unroll
-            for (int f = 0; f < MAX_F; ++f) s = fmaf(attr[le][f], w[f], s);
-            s = fmaxf(s + bc, 0.f);
-            __bf16 h, m, l;
-            split3(s, h, m, l);
-            const size_t o = (size_t)(e - e_begin) * k + c;
-            hp[o] = h;
-            hp[o + plane_stride] = m;
-            hp[o + 2 * plane_stride] = l;
+            for (int j = 0; j < 8; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int f = 0; f < MAX_F; ++f) s = fmaf(attr[le][f], w[j][f], s);
+                split3(fmaxf(s + bc[j], 0.f), o[0][j], o[1][j], o[2][j]);
+            }
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                *reinterpret_cast<uint4*>(hp + tiled_off(e - e_begin, c0, nkt, p)) = *reinterpret_cast<const uint4*>(o[p]);
         }
     }
 }
 
 // ---------------------------------------------------------------- split-bf16 GEMM
 struct SplitGemmArgs {
-    const __bf16* Ap;        // [3][a_rows][K]  (a_rows = chunk capacity)
-    const __bf16* Bp;        // [3][N][K]
-    const float* bias;       // [N]
-    float* C;                // fp32 [rows][N]            (OUT_PLANES = false)
-    __bf16* Cp;              // [3][a_rows][N] planes     (OUT_PLANES = true, ReLU applied)
+    const unsigned char* Ap;   // tiled planes of A  [rows/128][K/32][3][8 KiB]
+    const unsigned char* Bp;   // tiled planes of Bt [N/128][K/32][3][8 KiB]
+    const float* bias;         // [N]
+    float* C;                  // fp32 [rows][N] row-major            (OUT_PLANES = false)
+    unsigned char* Cp;         // tiled planes [rows/128][N/32][3][8 KiB], ReLU applied (OUT_PLANES = true)
     const int* num_edges;
     long long row_begin;
-    long long a_plane_stride;  // a_rows * K
-    long long b_plane_stride;  // N * K
-    long long c_plane_stride;  // a_rows * N
     int rows, N, K;
     int tiles_n, tiles_m;
 };
@@ -179,36 +202,30 @@ __global__ __launch_bounds__(256, 2) void gemm_split_bf16_kernel(SplitGemmArgs g
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, h = lane >> 5;
 
-    // ---- staging map: plane tile = 128 rows x 4 chunks(16 B); thread covers chunks tid and tid+256
-    const int srow0 = tid >> 2, sc = tid & 3;                  // rows srow0 and srow0+64
-    const size_t ldk = (size_t)g.K;
-    const __bf16* a_src = g.Ap + (size_t)(bm + srow0) * ldk + sc * 8;
-    const __bf16* b_src = g.Bp + (size_t)(bn + srow0) * ldk + sc * 8;
-    const int sw0 = (sc ^ ((srow0 >> 2) & 3)) * 16;            // (row+64)>>2 has the same low 2 bits
-    const int st_off = srow0 * 64 + sw0;                       // second row: + 64*64 B
-    // named registers only: arrays here end up in scratch and serialise the loads
-    uint4 a00, a01, a10, a11, a20, a21, b00, b01, b10, b11, b20, b21;
-    const __bf16* a_src1 = a_src + g.a_plane_stride;
-    const __bf16* a_src2 = a_src + 2 * g.a_plane_stride;
-    const __bf16* b_src1 = b_src + g.b_plane_stride;
-    const __bf16* b_src2 = b_src + 2 * g.b_plane_stride;
-    const size_t row64 = 64 * ldk;
+    // ---- staging: the operand's K-tile is a contiguous 24 KiB LDS image (3 planes x 8 KiB);
+    // thread copies 16 B at tid*16 + j*4 KiB, j = 0..5, for A and for B.
+    // Named registers only: arrays here end up in scratch and serialise the loads.
+    const int nkt = g.K / TK;
+    const unsigned char* a_src = g.Ap + ((size_t)(bm >> 7) * nkt * 3 << 13) + tid * 16;
+    const unsigned char* b_src = g.Bp + ((size_t)(bn >> 7) * nkt * 3 << 13) + tid * 16;
+    const int st_off = tid * 16;
+    uint4 a0, a1, a2, a3, a4, a5, b0, b1, b2, b3, b4, b5;
 #define MDNO_LD16(P) (*reinterpret_cast<const uint4*>(P))
-#define MDNO_SPLIT_LOAD(KOFF)                                                      \
-    a00 = MDNO_LD16(a_src + (KOFF));  a01 = MDNO_LD16(a_src + row64 + (KOFF));      \
-    a10 = MDNO_LD16(a_src1 + (KOFF)); a11 = MDNO_LD16(a_src1 + row64 + (KOFF));     \
-    a20 = MDNO_LD16(a_src2 + (KOFF)); a21 = MDNO_LD16(a_src2 + row64 + (KOFF));     \
-    b00 = MDNO_LD16(b_src + (KOFF));  b01 = MDNO_LD16(b_src + row64 + (KOFF));      \
-    b10 = MDNO_LD16(b_src1 + (KOFF)); b11 = MDNO_LD16(b_src1 + row64 + (KOFF));     \
-    b20 = MDNO_LD16(b_src2 + (KOFF)); b21 = MDNO_LD16(b_src2 + row64 + (KOFF));
+#define MDNO_SPLIT_LOAD(KT)                                                                   \
+    {                                                                                         \
+        const unsigned char* pa = a_src + (size_t)(KT) * (3 * PLANE_BYTES);                   \
+        const unsigned char* pb = b_src + (size_t)(KT) * (3 * PLANE_BYTES);                   \
+        a0 = MDNO_LD16(pa);          a1 = MDNO_LD16(pa + 4096);  a2 = MDNO_LD16(pa + 8192);   \
+        a3 = MDNO_LD16(pa + 12288);  a4 = MDNO_LD16(pa + 16384); a5 = MDNO_LD16(pa + 20480);  \
+        b0 = MDNO_LD16(pb);          b1 = MDNO_LD16(pb + 4096);  b2 = MDNO_LD16(pb + 8192);   \
+        b3 = MDNO_LD16(pb + 12288);  b4 = MDNO_LD16(pb + 16384); b5 = MDNO_LD16(pb + 20480);  \
+    }
 #define MDNO_ST16(OFF, V) *reinterpret_cast<uint4*>(lds + (OFF)) = (V)
-#define MDNO_SPLIT_STORE()                                                                                  \
-    MDNO_ST16(st_off, a00);                    MDNO_ST16(st_off + 4096, a01);                                \
-    MDNO_ST16(PLANE_BYTES + st_off, a10);      MDNO_ST16(PLANE_BYTES + st_off + 4096, a11);                  \
-    MDNO_ST16(2 * PLANE_BYTES + st_off, a20);  MDNO_ST16(2 * PLANE_BYTES + st_off + 4096, a21);              \
-    MDNO_ST16(3 * PLANE_BYTES + st_off, b00);  MDNO_ST16(3 * PLANE_BYTES + st_off + 4096, b01);              \
-    MDNO_ST16(4 * PLANE_BYTES + st_off, b10);  MDNO_ST16(4 * PLANE_BYTES + st_off + 4096, b11);              \
-    MDNO_ST16(5 * PLANE_BYTES + st_off, b20);  MDNO_ST16(5 * PLANE_BYTES + st_off + 4096, b21);
+#define MDNO_SPLIT_STORE()                                                                              \
+    MDNO_ST16(st_off, a0);          MDNO_ST16(st_off + 4096, a1);   MDNO_ST16(st_off + 8192, a2);        \
+    MDNO_ST16(st_off + 12288, a3);  MDNO_ST16(st_off + 16384, a4);  MDNO_ST16(st_off + 20480, a5);       \
+    MDNO_ST16(st_off + 24576, b0);  MDNO_ST16(st_off + 28672, b1);  MDNO_ST16(st_off + 32768, b2);       \
+    MDNO_ST16(st_off + 36864, b3);  MDNO_ST16(st_off + 40960, b4);  MDNO_ST16(st_off + 45056, b5);
 
     // ---- fragment read map: row = w*64 + i*32 + l31, logical chunk = 2*s + h, swizzled by (row>>2)&3
     const int fsw = (l31 >> 2) & 3;
@@ -223,13 +240,13 @@ __global__ __launch_bounds__(256, 2) void gemm_split_bf16_kernel(SplitGemmArgs g
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int nk = g.K / TK;
+    const int nk = nkt;
     MDNO_SPLIT_LOAD(0)
     MDNO_SPLIT_STORE()
     __syncthreads();
     // steady state: next tile's global loads are in flight while this tile is multiplied
     for (int kt = 0; kt < nk - 1; ++kt) {
-        MDNO_SPLIT_LOAD((size_t)(kt + 1) * TK)
+        MDNO_SPLIT_LOAD(kt + 1)
         mma_split_tile(acc, lds, a_rd, b_rd, fsw, h);
         __syncthreads();                       // every wave is done reading this tile
         MDNO_SPLIT_STORE()
@@ -256,10 +273,10 @@ __global__ __launch_bounds__(256, 2) void gemm_split_bf16_kernel(SplitGemmArgs g
                     if (OUT_PLANES) {
                         __bf16 ph, pm, pl;
                         split3(fmaxf(v, 0.f), ph, pm, pl);
-                        const size_t o = (size_t)m * g.N + n;
-                        g.Cp[o] = ph;
-                        g.Cp[o + g.c_plane_stride] = pm;
-                        g.Cp[o + 2 * g.c_plane_stride] = pl;
+                        const size_t o = tiled_off(m, n, g.N >> 5, 0);
+                        *reinterpret_cast<__bf16*>(g.Cp + o) = ph;
+                        *reinterpret_cast<__bf16*>(g.Cp + o + PLANE_BYTES) = pm;
+                        *reinterpret_cast<__bf16*>(g.Cp + o + 2 * PLANE_BYTES) = pl;
                     } else {
                         g.C[(size_t)m * g.N + n] = v;
                     }
@@ -308,33 +325,32 @@ int edge_mlp_split(const float* frames, int frame, const int* t_dev, int rows_pe
                  "edge_mlp: weight pointers must be 16-byte aligned");
     const int k = ker_width;
     Carver cv(workspace);
-    __bf16* h1p = cv.take<__bf16>(3 * (size_t)chunk * k);
-    __bf16* h2p = cv.take<__bf16>(3 * (size_t)chunk * k);
-    __bf16* w1p = cv.take<__bf16>(3 * (size_t)k * k);
-    __bf16* w2p = cv.take<__bf16>(3 * (size_t)out_dim * k);
+    unsigned char* h1p = reinterpret_cast<unsigned char*>(cv.take<__bf16>(3 * (size_t)chunk * k));
+    unsigned char* h2p = reinterpret_cast<unsigned char*>(cv.take<__bf16>(3 * (size_t)chunk * k));
+    unsigned char* w1p = reinterpret_cast<unsigned char*>(cv.take<__bf16>(3 * (size_t)k * k));
+    unsigned char* w2p = reinterpret_cast<unsigned char*>(cv.take<__bf16>(3 * (size_t)out_dim * k));
     {
         TimedSection ts(KID_EDGE_L0, s);
-        const long long c1 = (long long)k * k, c2 = (long long)out_dim * k;
-        hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((c1 / 4 + 255) / 256)), dim3(256), 0, s, w.w1, c1, w1p);
-        hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((c2 / 4 + 255) / 256)), dim3(256), 0, s, w.w2, c2, w2p);
+        const long long c1 = (long long)k * (k / 8), c2 = (long long)out_dim * (k / 8);
+        hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((c1 + 255) / 256)), dim3(256), 0, s, w.w1, k, k, w1p);
+        hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((c2 + 255) / 256)), dim3(256), 0, s, w.w2, out_dim, k,
+                           w2p);
     }
     MDNO_TRY(check_launch("split_planes_kernel"));
     const float* pos_mode = edge_attr ? nullptr : frames;
-    const long long hstride = chunk * k;
     for (long long e0 = 0; e0 < edge_cap; e0 += chunk) {
         const int cnt = (int)((edge_cap - e0) < chunk ? (edge_cap - e0) : chunk);
         {
             TimedSection ts(KID_EDGE_L0, s);
             hipLaunchKernelGGL(edge_l0_split_kernel, dim3((cnt + EB - 1) / EB), dim3(256), 0, s, pos_mode, frame, t_dev,
                                rows_per_frame, src, dst, edge_attr, perm, num_edges, e0, cnt, ker_in, k, w.w0, w.b0,
-                               h1p, hstride);
+                               h1p);
         }
         MDNO_TRY(check_launch("edge_l0_split_kernel"));
-        SplitGemmArgs g1{h1p, w1p, w.b1, nullptr, h2p, num_edges, e0, hstride, (long long)k * k, hstride,
-                         (int)chunk, k, k, 0, 0};
+        SplitGemmArgs g1{h1p, w1p, w.b1, nullptr, h2p, num_edges, e0, (int)chunk, k, k, 0, 0};
         MDNO_TRY(launch_split_gemm<true>(g1, KID_GEMM_L1, s));
-        SplitGemmArgs g2{h2p, w2p, w.b2, w_e + (size_t)e0 * out_dim, nullptr, num_edges, e0, hstride,
-                         (long long)out_dim * k, 0, (int)chunk, out_dim, k, 0, 0};
+        SplitGemmArgs g2{h2p, w2p, w.b2, w_e + (size_t)e0 * out_dim, nullptr, num_edges, e0, (int)chunk, out_dim, k,
+                         0, 0};
         MDNO_TRY(launch_split_gemm<false>(g2, KID_GEMM_L2, s));
     }
     return MDNO_OK;

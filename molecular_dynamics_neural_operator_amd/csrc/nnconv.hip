@@ -9,14 +9,19 @@
 // Algorithmic bytes per launch: E*(Cin*Cout*4 + 4) + (R+1)*4 + 2*R*C*4.
 //
 // Layout / mapping (64x64 specialisation): edges are sorted by destination, so a row's W_e block
-// is ONE contiguous run of deg*16 KiB.  One 256-thread workgroup owns one destination row; its 4
-// waves take the row's edges round-robin.  Inside a wave, lane l = (g, q) with g = l>>4, q = l&15
+// is ONE contiguous run of deg*16 KiB.  One workgroup owns one destination row; its 4 (many rows)
+// or 16 (few rows) waves take the row's edges round-robin.  Inside a wave, lane l = (g, q) with g = l>>4, q = l&15
 // accumulates output columns 4q..4q+3 over input rows 16g..16g+15: every wave-instruction is a
 // 16 B/lane load covering four whole 256-B rows of W_e[p] (fully coalesced), 16 such loads per
 // edge, 64 FMAs per lane.  Partial sums stay in registers across ALL edges of the row; the
-// reduction over g (2 shuffles) and over the 4 waves (LDS) happens once per row, in a fixed order,
+// reduction over g (2 shuffles) and over the waves (LDS) happens once per row, in a fixed order,
 // so results are bitwise reproducible (no atomics).  The root term x[r].root is folded in as one
 // more "edge" (weight matrix = root) with its own accumulator.
+//
+// Measured against a pure streaming read of the same bytes (scripts/micro/stream_read.hip: 1 GB in
+// 178 us = 6.04 TB/s incl. ~7 us of ramp): 993 MB in 187 us at N=504 (92 % of that), 6.1 TB/s at 8
+// members.  Splitting rows into 16-edge segments balanced over waves (two-pass, partial sums) was
+// built and measured: no gain (192 us) — the kernel is bandwidth-, not balance-limited.
 #include "kernels.h"
 
 namespace mdno {
@@ -57,11 +62,12 @@ __device__ __forceinline__ float4 reduce_over_g(float4 a) {
     return a;
 }
 
-__global__ __launch_bounds__(256) void nnconv64_row_kernel(
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void nnconv64_row_kernel(
     const float* __restrict__ x, const int* __restrict__ row_ptr, const int* __restrict__ src,
     const float* __restrict__ w_e, const float* __restrict__ root, const float* __restrict__ bias,
     float* __restrict__ y, int num_rows, int aggr, int relu) {
-    __shared__ float red[4][2][64];
+    __shared__ float red[WAVES][2][64];
     const int row = blockIdx.x;
     if (row >= num_rows) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -70,12 +76,12 @@ __global__ __launch_bounds__(256) void nnconv64_row_kernel(
     const int deg = end - beg;
 
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int p = beg + wave; p < end; p += 4) {
+    for (int p = beg + wave; p < end; p += WAVES) {
         const int j = src[p];
         edge_accumulate64(acc, x + (size_t)j * 64, w_e + (size_t)p * 4096, g, q);
     }
     float4 racc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (root != nullptr && wave == (deg & 3)) edge_accumulate64(racc, x + (size_t)row * 64, root, g, q);
+    if (root != nullptr && wave == (deg % WAVES)) edge_accumulate64(racc, x + (size_t)row * 64, root, g, q);
 
     acc = reduce_over_g(acc);
     racc = reduce_over_g(racc);
@@ -85,8 +91,12 @@ __global__ __launch_bounds__(256) void nnconv64_row_kernel(
     }
     __syncthreads();
     if (tid < 64) {
-        float s = (red[0][0][tid] + red[1][0][tid]) + (red[2][0][tid] + red[3][0][tid]);
-        const float rs = (red[0][1][tid] + red[1][1][tid]) + (red[2][1][tid] + red[3][1][tid]);
+        float s = 0.f, rs = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {   // fixed order: bitwise reproducible
+            s += red[w][0][tid];
+            rs += red[w][1][tid];
+        }
         if (aggr == MDNO_AGGR_MEAN) s = s / (float)(deg > 1 ? deg : 1);
         s += rs;
         if (bias != nullptr) s += bias[tid];
@@ -144,8 +154,15 @@ int mdno::nnconv(const float* x, const int* row_ptr, const int* src, int num_row
                            reinterpret_cast<uintptr_t>(root)) & 15) == 0;
     TimedSection ts(KID_NNCONV, s);
     if (Cin == 64 && Cout == 64 && aligned) {
-        hipLaunchKernelGGL(nnconv64_row_kernel, dim3(num_rows), dim3(256), 0, s, x, row_ptr, src, w_e, root, bias,
-                           y, num_rows, aggr, relu);
+        // waves per destination row: with only a few hundred rows (one ~500-atom trajectory) more
+        // waves per row keep enough loads in flight on every CU; the wave count is a function of the
+        // row count only, so a row's summation order never depends on what it is batched with
+        if (num_rows >= 4096)
+            hipLaunchKernelGGL(nnconv64_row_kernel<4>, dim3(num_rows), dim3(256), 0, s, x, row_ptr, src, w_e, root,
+                               bias, y, num_rows, aggr, relu);
+        else
+            hipLaunchKernelGGL(nnconv64_row_kernel<16>, dim3(num_rows), dim3(1024), 0, s, x, row_ptr, src, w_e, root,
+                               bias, y, num_rows, aggr, relu);
     } else {
         hipLaunchKernelGGL(nnconv_generic_kernel, dim3((num_rows + 3) / 4), dim3(256), 0, s, x, row_ptr, src, w_e,
                            root, bias, y, num_rows, Cin, Cout, aggr, relu);

@@ -1,0 +1,42 @@
+"""Dev tool: the conv kernel alone (back-to-back launches, HIP events) at M members of N atoms."""
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from molecular_dynamics_neural_operator_amd import _lib, ops, synthetic as syn  # noqa: E402
+
+dev = torch.device("cuda:0")
+lib = _lib.load()
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 504
+reps = 40
+for M in (1, 2, 4, 8):
+    frames = np.concatenate([syn.box_frame(N, seed=1 + m) for m in range(M)])
+    g = ops.radius_graph(torch.from_numpy(frames).to(dev), N, 8.0)
+    E = g.edge_count()
+    g.edge_cap = E
+    x = torch.randn(M * N, 64, device=dev)
+    w_e = torch.randn(E, 4096, device=dev) * 0.05
+    root = torch.randn(64, 64, device=dev) * 0.1
+    bias = torch.randn(64, device=dev)
+    y = torch.empty(M * N, 64, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+
+    def launch():
+        _lib.check(lib.mdno_nnconv_fwd(x.data_ptr(), g.row_ptr.data_ptr(), g.src.data_ptr(), M * N, w_e.data_ptr(),
+                                       root.data_ptr(), bias.data_ptr(), 64, 64, 1, 1, y.data_ptr(), s))
+    for _ in range(5):
+        launch()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    byts = E * 16388 + 516 * M * N + 4
+    print(f"M={M} N={N} E={E}: {ms*1e3:8.1f} us/launch  {byts/ms/1e6:7.0f} GB/s (algorithmic)")

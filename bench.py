@@ -64,6 +64,10 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="plain launches instead of hipGraph replay")
     ap.add_argument("--gemm-mode", choices=["split_bf16", "f32"], default="split_bf16",
                     help="edge-MLP GEMMs: exact 3-way bf16 split (6 products, fp32 accumulate) or fp32-input MFMA")
+    ap.add_argument("--variant", choices=["intree", "notebook"], default="intree",
+                    help="notebook = the model the reference's notebook ran (no LSTM, conv1 only; use with "
+                         "--atoms 28 --window 1 --kernel-width 512 --chain for the nb:370 shape)")
+    ap.add_argument("--chain", action="store_true", help="random-walk C-alpha chain frame instead of the uniform box")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--skip-roofline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=45.0)
@@ -116,25 +120,36 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(ndev, 1)     # rehearsal on a 1-GPU box: ranks share the card
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    backend = os.environ.get("MDNO_BENCH_BACKEND", "nccl")   # "gloo" only to rehearse N>1 on one GPU
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from molecular_dynamics_neural_operator_amd import synthetic as syn
-    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN, KernelNNNotebook
     from molecular_dynamics_neural_operator_amd.rollout import RolloutEngine, default_edge_cap, gather_trajectories
     from molecular_dynamics_neural_operator_amd.weights import near_identity_state_dict
 
     N, W, M = a.atoms, a.window, a.members_per_gpu
     total_members = M * world
     sd = near_identity_state_dict(a.width, a.kernel_width, seed=0, kernel_gain=1e-3, feature_gain=0.1)
-    model = KernelNN(a.width, a.kernel_width, a.depth, 6, 7, 3, 20, 4)
+    if a.variant == "notebook":
+        sd = {k: v for k, v in sd.items() if not k.startswith(("lstm", "conv2"))}
+        model = KernelNNNotebook(a.width, a.kernel_width, a.depth, 6, 7, 3, 20, 4)
+    else:
+        model = KernelNN(a.width, a.kernel_width, a.depth, 6, 7, 3, 20, 4)
     model.load_state_dict(sd)
     model.eval().to(dev)
     model.gemm_mode = a.gemm_mode
 
-    base = syn.jitter_window(syn.box_frame(N, seed=1), W, seed=1)                  # [W,N,3]
+    frame0 = syn.chain_frame(N, seed=1) if a.chain else syn.box_frame(N, seed=1)
+    base = syn.jitter_window(frame0, W, seed=1)                                    # [W,N,3]
     wins = np.stack([base if (total_members == 1) else
                      syn.ensemble_windows(base, 1, sigma=0.1, seed0=100 + rank + world * m)[0]
                      for m in range(M)], axis=1)                                   # [W,M,N,3] member = rank + world*m
@@ -166,7 +181,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     eng.synchronize()   # raises on edge overflow / bad input
@@ -225,7 +240,7 @@ def main():
                              "note": "executed bf16 MFMA flops (6 plane products per fp32 product) vs dense bf16 peak"}
 
     cpu = None
-    if rank == 0 and world == 1 and not a.skip_cpu_baseline:
+    if rank == 0 and world == 1 and not a.skip_cpu_baseline and a.variant == "intree":
         cpu = cpu_baseline(sd, a.depth, base, aa, a.threshold, a.cpu_budget_s)
 
     if rank == 0:
@@ -240,7 +255,8 @@ def main():
                        "members_per_gpu": M, "total_members": total_members, "mean_edges_per_member": e_mean / M,
                        "edges_first_last": [int(eps[0].item()), int(eps[-1].item())], "edge_cap": cap,
                        "parallelism": f"ensemble-sharded x{world}, one all-gather of trajectories",
-                       "launch": "plain" if a.no_graph else "hipGraph replay", "edge_mlp_gemm": a.gemm_mode},
+                       "launch": "plain" if a.no_graph else "hipGraph replay", "edge_mlp_gemm": a.gemm_mode,
+                       "variant": a.variant},
             "roofline": roof, "roofline_mfma": roof_mfma, "cpu_baseline": cpu, "kernels": kernels,
         }
         print(json.dumps(line))

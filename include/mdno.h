@@ -65,6 +65,9 @@ const char* mdno_last_error(void);
  * gate order i,f,g,o; NNConv_old.root [Cin,Cout].  conv1.net and conv2.net are ONE module in the
  * reference (graph_kernel.py:271-273): set k2_* = NULL to share k_* (edge weights then evaluated
  * once per forward instead of 2*depth times — same values, the inputs never change, :278-302).
+ * Notebook-era variant (bba_analysis.ipynb:123-128: emb, fc1, conv1, fc2 only, window 1): set all
+ * lstm_* pointers and conv2_root/conv2_bias to NULL — the node feature is then [emb, newest frame]
+ * and only `depth` conv1 applications run.
  * ---------------------------------------------------------------------------------------- */
 typedef struct mdno_kernelnn_params {
     int32_t width, ker_width, depth, ker_in, in_width, out_width;

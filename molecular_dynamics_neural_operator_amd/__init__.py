@@ -8,9 +8,9 @@ The arithmetic lives in libmdno.so (hand-written HIP for gfx950, C ABI in includ
 from . import dataset, graph_kernel, synthetic, weights  # noqa: F401
 from ._lib import MdnoError  # noqa: F401
 from .dataset import ContactMapDataset, PairData  # noqa: F401
-from .graph_kernel import (DenseNet, KernelNN, LpLoss, NNConv_old, construct_pairdata,  # noqa: F401
+from .graph_kernel import (DenseNet, KernelNN, KernelNNNotebook, LpLoss, NNConv_old, construct_pairdata,  # noqa: F401
                            propogate, recursive_propagation)
 
 __all__ = ["dataset", "graph_kernel", "synthetic", "weights", "MdnoError", "ContactMapDataset", "PairData",
-           "DenseNet", "KernelNN", "LpLoss", "NNConv_old", "construct_pairdata", "propogate",
+           "DenseNet", "KernelNN", "KernelNNNotebook", "LpLoss", "NNConv_old", "construct_pairdata", "propogate",
            "recursive_propagation"]

@@ -60,8 +60,10 @@ int validate_params(const mdno_kernelnn_params* p) {
                  "params: width=%d ker_width=%d depth=%d ker_in=%d out_width=%d", p->width, p->ker_width, p->depth,
                  p->ker_in, p->out_width);
     MDNO_REQUIRE(p->k_w0 && p->k_b0 && p->k_w1 && p->k_b1 && p->k_w2 && p->k_b2 && p->conv1_root && p->conv1_bias &&
-                     p->conv2_root && p->conv2_bias && p->fc2_w && p->fc2_b,
+                     p->fc2_w && p->fc2_b,
                  MDNO_EINVAL, "params: null weight pointer");
+    MDNO_REQUIRE((p->conv2_root == nullptr) == (p->conv2_bias == nullptr), MDNO_EINVAL,
+                 "params: conv2_root and conv2_bias must both be set or both be NULL");
     return MDNO_OK;
 }
 
@@ -99,7 +101,8 @@ int forward_impl(const mdno_kernelnn_params* p, const float* frames, int t0, con
     MDNO_TRY(node_prologue(p, frames, t0, t_dev, M, W, N, aa, aa_per_member, ws.xa, status, s));
     float* cur = ws.xa;
     float* nxt = ws.xb;
-    for (int block = 0; block < 2; ++block) {
+    const int blocks = p->conv2_root ? 2 : 1;   // notebook-era model: conv1 only (lstm_* NULL as well)
+    for (int block = 0; block < blocks; ++block) {
         if (block == 0 || separate_conv2_kernel(p)) {
             EdgeMlpWeights w = (block == 0) ? EdgeMlpWeights{p->k_w0, p->k_b0, p->k_w1, p->k_b1, p->k_w2, p->k_b2}
                                             : EdgeMlpWeights{p->k2_w0, p->k2_b0, p->k2_w1, p->k2_b1, p->k2_w2, p->k2_b2};

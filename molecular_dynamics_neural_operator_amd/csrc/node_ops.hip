@@ -39,37 +39,40 @@ __global__ __launch_bounds__(256) void node_prologue_kernel(PrologueArgs a) {
     const int t0 = a.t0 + (a.t0_dev ? *a.t0_dev : 0);
     const float* f0 = a.frames + ((size_t)t0 * R + r) * 3;  // frames are time-major [T, M*N, 3]
 
-    // LSTM weights are 2*36 + 24 floats: every lane keeps them in registers (wave-uniform loads)
-    float wih[4 * H][H], whh[4 * H][H], bsum[4 * H];
-#pragma unroll
-    for (int g = 0; g < 4 * H; ++g) {
-#pragma unroll
-        for (int k = 0; k < H; ++k) {
-            wih[g][k] = a.w_ih[g * H + k];
-            whh[g][k] = a.w_hh[g * H + k];
-        }
-        bsum[g] = a.b_ih[g] + a.b_hh[g];
-    }
-    float h[H] = {0.f, 0.f, 0.f}, c[H] = {0.f, 0.f, 0.f};
-    for (int t = 0; t < a.W; ++t) {
-        const float* p = f0 + (size_t)t * R * 3;
-        const float x[H] = {p[0], p[1], p[2]};
-        float gate[4 * H];
+    float h[H] = {0.f, 0.f, 0.f};
+    if (a.w_ih != nullptr) {
+        // LSTM weights are 2*36 + 24 floats: every lane keeps them in registers (wave-uniform loads)
+        float wih[4 * H][H], whh[4 * H][H], bsum[4 * H];
 #pragma unroll
         for (int g = 0; g < 4 * H; ++g) {
-            float s = bsum[g];
 #pragma unroll
-            for (int k = 0; k < H; ++k) s = fmaf(wih[g][k], x[k], s);
-#pragma unroll
-            for (int k = 0; k < H; ++k) s = fmaf(whh[g][k], h[k], s);
-            gate[g] = s;
+            for (int k = 0; k < H; ++k) {
+                wih[g][k] = a.w_ih[g * H + k];
+                whh[g][k] = a.w_hh[g * H + k];
+            }
+            bsum[g] = a.b_ih[g] + a.b_hh[g];
         }
+        float c[H] = {0.f, 0.f, 0.f};
+        for (int t = 0; t < a.W; ++t) {
+            const float* p = f0 + (size_t)t * R * 3;
+            const float x[H] = {p[0], p[1], p[2]};
+            float gate[4 * H];
 #pragma unroll
-        for (int k = 0; k < H; ++k) {
-            const float ig = sigmoidf_(gate[k]), fg = sigmoidf_(gate[H + k]);
-            const float gg = tanhf(gate[2 * H + k]), og = sigmoidf_(gate[3 * H + k]);
-            c[k] = fg * c[k] + ig * gg;
-            h[k] = og * tanhf(c[k]);
+            for (int g = 0; g < 4 * H; ++g) {
+                float s = bsum[g];
+#pragma unroll
+                for (int k = 0; k < H; ++k) s = fmaf(wih[g][k], x[k], s);
+#pragma unroll
+                for (int k = 0; k < H; ++k) s = fmaf(whh[g][k], h[k], s);
+                gate[g] = s;
+            }
+#pragma unroll
+            for (int k = 0; k < H; ++k) {
+                const float ig = sigmoidf_(gate[k]), fg = sigmoidf_(gate[H + k]);
+                const float gg = tanhf(gate[2 * H + k]), og = sigmoidf_(gate[3 * H + k]);
+                c[k] = fg * c[k] + ig * gg;
+                h[k] = og * tanhf(c[k]);
+            }
         }
     }
     float feat[MAX_EMB + H];
@@ -80,12 +83,20 @@ __global__ __launch_bounds__(256) void node_prologue_kernel(PrologueArgs a) {
     }
 #pragma unroll
     for (int e = 0; e < MAX_EMB; ++e) feat[e] = (e < a.emb_dim) ? a.emb_w[id * a.emb_dim + e] : 0.f;
+    if (a.w_ih != nullptr) {
 #pragma unroll
-    for (int k = 0; k < H; ++k) {
-        float s = a.fc_b[k];
+        for (int k = 0; k < H; ++k) {
+            float s = a.fc_b[k];
 #pragma unroll
-        for (int j = 0; j < H; ++j) s = fmaf(a.fc_w[k * H + j], h[j], s);
-        feat[MAX_EMB + k] = s;
+            for (int j = 0; j < H; ++j) s = fmaf(a.fc_w[k * H + j], h[j], s);
+            feat[MAX_EMB + k] = s;
+        }
+    } else {
+        // notebook-era model (bba_analysis.ipynb:123-128: emb, fc1, conv1, fc2 only): the node
+        // feature is the raw position of the newest window frame
+        const float* p = f0 + (size_t)(a.W - 1) * R * 3;
+#pragma unroll
+        for (int k = 0; k < H; ++k) feat[MAX_EMB + k] = p[k];
     }
     const int in_w = a.emb_dim + H;
     for (int o = lane; o < a.width; o += 64) {
@@ -123,9 +134,10 @@ __global__ __launch_bounds__(256) void fc_out_kernel(const float* __restrict__ x
 int mdno::node_prologue(const mdno_kernelnn_params* p, const float* frames, int t0, const int* t_dev, int M, int W,
                         int N, const long long* aa, int aa_per_member, float* x0, int* status, hipStream_t s) {
     MDNO_REQUIRE(p && frames && aa && x0, MDNO_EINVAL, "node_prologue: null pointer");
-    MDNO_REQUIRE(p->lstm_w_ih && p->lstm_w_hh && p->lstm_b_ih && p->lstm_b_hh && p->lstm_fc_w && p->lstm_fc_b &&
-                     p->emb_w && p->fc1_w && p->fc1_b,
-                 MDNO_EINVAL, "node_prologue: null weight pointer");
+    MDNO_REQUIRE(p->emb_w && p->fc1_w && p->fc1_b, MDNO_EINVAL, "node_prologue: null weight pointer");
+    const bool lstm = p->lstm_w_ih != nullptr;
+    MDNO_REQUIRE(!lstm || (p->lstm_w_hh && p->lstm_b_ih && p->lstm_b_hh && p->lstm_fc_w && p->lstm_fc_b), MDNO_EINVAL,
+                 "node_prologue: partial LSTM weight set");
     MDNO_REQUIRE(M > 0 && W > 0 && N > 0 && t0 >= 0, MDNO_EINVAL, "node_prologue: M=%d W=%d N=%d", M, W, N);
     MDNO_REQUIRE(p->x_position_dim == H, MDNO_EUNSUPPORTED, "x_position_dim=%d (only 3)", p->x_position_dim);
     MDNO_REQUIRE(p->embedding_dim >= 0 && p->embedding_dim <= MAX_EMB, MDNO_EUNSUPPORTED, "embedding_dim=%d (0..%d)",

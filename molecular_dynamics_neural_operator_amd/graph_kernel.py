@@ -231,6 +231,32 @@ class KernelNN(nn.Module):
         return [out, latent] if return_latent else out
 
 
+class KernelNNNotebook(KernelNN):
+    """The model the notebook was run with (bba_analysis.ipynb:45-47, 61-70, 123-128): window 1, no
+    LSTM, ONE conv block applied `depth` times, `kernel_width` 512 —
+    ``Embedding(20,4), Linear(7,64), NNConv_old(64,64), Linear(64,3)``.  Its source is not in the
+    reference tree (the in-tree file is a later commit); the forward is inferred from
+    the repr, the checkpoint keys and the in-tree forward with the LSTM and conv2 removed:
+    ``x = relu(fc1(cat(emb(aa), pos)))``; ``depth`` x ``relu(conv1)``; ``fc2``.  Parity for this variant
+    is therefore against this repo's oracle only."""
+
+    def __init__(self, width: int, ker_width: int, depth: int, ker_in: int, in_width: int = 1,
+                 out_width: int = 1, num_embeddings: int = 20, embedding_dim: int = 4) -> None:
+        nn.Module.__init__(self)
+        self.depth = depth
+        self.num_embeddings = num_embeddings
+        self.embedding_dim = embedding_dim
+        self.x_position_dim = 3
+        self.emb = nn.Embedding(num_embeddings, embedding_dim)
+        self.fc1 = nn.Linear(in_width, width)
+        kernel = DenseNet([ker_in, ker_width, ker_width, width ** 2], nn.ReLU)
+        self.conv1 = NNConv_old(width, width, kernel, aggr="mean")
+        self.fc2 = nn.Linear(width, out_width)
+        self._pack = None
+        self._pack_key = None
+        self.gemm_mode = "split_bf16"
+
+
 # --------------------------------------------------------------------------- graph construction
 def construct_pairdata(x_position, x_aminoacid, threshold: float = 8.0) -> PairData:
     """Radius graph + edge attributes of the LAST frame of ``x_position`` ([W,N,3]; a single frame

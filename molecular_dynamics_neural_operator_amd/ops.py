@@ -140,7 +140,9 @@ class ParamPack:
         p = KernelNNParams()
         for field, key in self.KEYS.items():
             if key not in sd:
-                if field.startswith("k2_"):
+                # optional groups: conv2's own kernel (shared otherwise), and — notebook-era model
+                # (bba_analysis.ipynb:123-128) — the LSTM front-end and the whole conv2 block
+                if field.startswith(("k2_", "lstm_", "conv2_")):
                     setattr(p, field, None)
                     continue
                 raise MdnoError(f"state_dict lacks {key!r}")
@@ -166,7 +168,10 @@ class ParamPack:
         p.in_width = self.tensors["fc1_w"].shape[1]
         p.out_width = self.tensors["fc2_w"].shape[0]
         p.num_embeddings, p.embedding_dim = self.tensors["emb_w"].shape
-        p.x_position_dim = self.tensors["lstm_w_ih"].shape[1]
+        p.x_position_dim = self.tensors["lstm_w_ih"].shape[1] if "lstm_w_ih" in self.tensors else 3
+        if ("lstm_w_ih" in self.tensors) != ("lstm_fc_w" in self.tensors) or \
+                ("conv2_root" in self.tensors) != ("conv2_bias" in self.tensors):
+            raise MdnoError("state_dict has a partial lstm/conv2 parameter group")
         p.gemm_mode = _lib.GEMM_MODES[gemm_mode]
         self.gemm_mode = gemm_mode
         if self.tensors["k_w2"].shape[0] != width * width:

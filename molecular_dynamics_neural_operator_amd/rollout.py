@@ -201,8 +201,13 @@ def gather_trajectories(local: torch.Tensor, total_members: int, group=None) -> 
         pad = torch.zeros((T, m_max - counts[rank], N, D), dtype=local.dtype, device=local.device)
         send = torch.cat([local, pad], dim=1)
     send = send.contiguous()
-    recv = torch.empty((world * T, m_max, N, D), dtype=local.dtype, device=local.device)
+    staged = local.is_cuda and dist.get_backend(group) == "gloo"     # CPU rehearsal backend: stage through host
+    if staged:
+        send = send.cpu()
+    recv = torch.empty((world * T, m_max, N, D), dtype=local.dtype, device=send.device)
     dist.all_gather_into_tensor(recv, send, group=group)   # rank r's shard = rows [r*T, (r+1)*T)
+    if staged:
+        recv = recv.to(local.device)
     recv = recv.view(world, T, m_max, N, D)
     out = torch.empty((T, total_members, N, D), dtype=local.dtype, device=local.device)
     for r in range(world):

@@ -122,6 +122,23 @@ def kernelnn_forward(sd: StateDict, x_position: Tensor, x_aminoacid: Tensor, edg
     return (out, latent) if return_latent else out
 
 
+def kernelnn_notebook_forward(sd: StateDict, x_position: Tensor, x_aminoacid: Tensor, edge_index: Tensor,
+                              edge_attr: Tensor, depth: int, hoist: bool = True) -> Tensor:
+    """Notebook-era model (bba_analysis.ipynb:123-128: emb, fc1, conv1, fc2; window 1).  Its source is
+    not in the reference tree; this restates the in-tree forward (graph_kernel.py:292-305) without the
+    LSTM front-end and the conv2 block.  x_position [N,3] (or [1,N,3])."""
+    with torch.no_grad():
+        pos = x_position.reshape(-1, 3).to(torch.float32)
+        x = torch.cat((F.embedding(x_aminoacid, sd["emb.weight"]), pos), dim=1)
+        x = F.relu(F.linear(x, sd["fc1.weight"], sd["fc1.bias"]))
+        w_e = edge_mlp(edge_attr, sd, "conv1.net.") if hoist else None
+        for _ in range(depth):
+            if not hoist:
+                w_e = edge_mlp(edge_attr, sd, "conv1.net.")
+            x = F.relu(nnconv_apply(x, edge_index, w_e, sd["conv1.root"], sd["conv1.bias"], "mean"))
+        return F.linear(x, sd["fc2.weight"], sd["fc2.bias"])
+
+
 # --------------------------------------------------------------------------- graph
 def radius_graph_coo(frame: np.ndarray, threshold: float = 8.0) -> np.ndarray:
     """Row-major COO of ``distance_matrix(frame, frame) < threshold`` (f64 distances, strict <,

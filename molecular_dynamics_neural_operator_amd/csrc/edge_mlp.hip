@@ -260,7 +260,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t s) {
 constexpr long long kMaxChunkRows = 262144;
 
 long long chunk_rows_for(long long edge_cap) {
-    long long r = (edge_cap + BM - 1) / BM * BM;
+    long long r = (edge_cap + 255) / 256 * 256;   // multiple of both GEMM kernels' row tiles (128, 256)
     return r < kMaxChunkRows ? r : kMaxChunkRows;
 }
 

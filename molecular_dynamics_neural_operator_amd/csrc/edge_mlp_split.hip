@@ -11,11 +11,11 @@
 // the fp32-MFMA rate = 2.67x fewer matrix-pipe cycles than v_mfma_f32_32x32x2_f32.
 //
 // Operand layout in HBM = the LDS image, tile by tile.  A [rows,K] operand is stored as
-//     [row_tile = rows/128][k_tile = K/32][plane 0..2][128 rows][32 k]  bf16,
-// each 8 KiB plane tile holding its rows as 64-B lines whose four 16-B chunks are XOR-swizzled by
-// (row>>2)&3 — exactly what the fragment reads want in LDS.  Staging a K-tile is then a straight,
-// fully coalesced 24 KiB copy per operand (16 B per lane, 1 KiB per wave-instruction) and a
-// workgroup walks one contiguous run of K/32 * 24 KiB.  We own both producers and consumers of
+//     [row_tile = rows/128][k_tile = K/16][plane 0..2][128 rows][16 k]  bf16,
+// each 4 KiB plane tile holding its rows as 32-B lines whose two 16-B halves are swapped when
+// (row>>3)&1 — exactly what the fragment reads want in LDS.  Staging a k-step is then a straight
+// 12 KiB copy per operand, done by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction,
+// no VGPRs, no ds_write), and a workgroup walks one contiguous run of K/16 * 12 KiB.  We own both producers and consumers of
 // these buffers, so nothing else ever sees the layout:
 //   weights      fp32 [N,K] --split_planes_kernel--> tiled planes            (once per forward, 30 MB)
 //   layer 0      edge attrs -> relu(linear)  --split--> H1 tiled planes      (edge_l0_split_kernel)
@@ -23,11 +23,14 @@
 //   layer 2      H2 x W2 + b  -> fp32 W_e[E, Cin*Cout]  (row-major, what the conv streams)
 // so no fp32 activation is ever stored.
 //
-// GEMM kernel: 128x128x32 block tile, 4 waves (2x2), wave tile 64x64 = 2x2 v_mfma_f32_32x32x16_bf16
-// tiles, 48 MFMAs per K-tile per wave.  Each staged operand fragment feeds 2-3 of the six products,
-// so LDS and global traffic per MFMA are half those of an ordinary bf16 GEMM.  Staging is
-// global -> registers -> LDS with the next tile's loads in flight during the MFMAs; the swizzle
-// makes the ds_read_b128 fragment reads bank-conflict-free.  Workgroups are numbered so that each
+// GEMM kernel: 256x128 block tile, k-step 16 per stage, 8 waves (4x2), wave tile 64x64 = 2x2
+// v_mfma_f32_32x32x16_bf16 tiles, 24 MFMAs + 12 fragment reads per stage per wave.  Each staged
+// fragment feeds 2-3 of the six products, so LDS traffic per MFMA is half that of an ordinary bf16
+// GEMM; the 256-row tile keeps the L2->LDS fill (36 KiB per 192 MFMAs) under the ~70 GB/s a CU
+// can pull from L2 (a 128x128 tile needed 52 GB/s per CU at 65 % MFMA utilisation and stalled
+// there).  Two LDS stage buffers (72 KiB, 2 workgroups = 16 waves per CU): the DMA of stage k+1
+// runs under the MFMAs of stage k, one barrier per stage; the swizzle makes the ds_read_b128
+// fragment reads bank-conflict-free.  Workgroups are numbered so that each
 // XCD owns a contiguous range of tiles (neighbouring tiles share the A row-panel through that
 // XCD's L2).
 #include "kernels.h"
@@ -38,9 +41,14 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int TM = 128, TN = 128, TK = 32;
-constexpr int PLANE_BYTES = TM * TK * 2;       // 8 KiB per operand plane tile
-constexpr int LDS_BYTES = 6 * PLANE_BYTES;     // A[3] + B[3] = 48 KiB
+constexpr int TN = 128, TK = 16;               // block tile is TM x 128 (TM = 128 or 256); one MFMA k-step per stage
+constexpr int PLANE_BYTES = 128 * TK * 2;      // 4 KiB per (128-row) operand plane tile
+// stage = A: TM/128 row tiles x 3 planes, B: 3 planes.  TM=256: 36 KiB (x2 buffers = 72 KiB, 2 workgroups
+// of 8 waves per CU); TM=128: 24 KiB (48 KiB, 3 workgroups of 4 waves per CU)
+constexpr int stage_bytes(int tm) { return (3 * tm / 128 + 3) * PLANE_BYTES; }
+
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+typedef __attribute__((address_space(1))) const unsigned char glb_u8;
 
 __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
     h = (__bf16)x;
@@ -50,11 +58,13 @@ __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l)
     l = (__bf16)r2;
 }
 
-// Byte offset of element (row, kcol) of plane p in the tiled layout; nkt = K/32.
+// Byte offset of element (row, kcol) of plane p in the tiled layout; nkt = K/16.  A plane tile is
+// 128 rows of 32 B (16 k); the two 16-B halves of a row are swapped when (row>>3)&1, which spreads
+// the ds_read_b128 fragment reads of a 16-lane group over all 16 slots of a 256-B bank row.
 __device__ __forceinline__ size_t tiled_off(long long row, int kcol, int nkt, int p) {
     const long long rt = row >> 7;
-    const int r = (int)(row & 127), kt = kcol >> 5, c = (kcol >> 3) & 3, e = kcol & 7;
-    return ((size_t)((rt * nkt + kt) * 3 + p) << 13) + r * 64 + ((c ^ ((r >> 2) & 3)) << 4) + e * 2;
+    const int r = (int)(row & 127), kt = kcol >> 4, c = (kcol >> 3) & 1, e = kcol & 7;
+    return ((size_t)((rt * nkt + kt) * 3 + p) << 12) + r * 32 + ((c ^ ((r >> 3) & 1)) << 4) + e * 2;
 }
 
 // ---------------------------------------------------------------- fp32 [rows,K] -> tiled planes
@@ -71,7 +81,7 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     __bf16 o[3][8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) split3(x[j], o[0][j], o[1][j], o[2][j]);
-    const int nkt = K >> 5;
+    const int nkt = K >> 4;
 #pragma unroll
     for (int p = 0; p < 3; ++p)
         *reinterpret_cast<uint4*>(planes + tiled_off(row, k0, nkt, p)) = *reinterpret_cast<const uint4*>(o[p]);
@@ -111,7 +121,7 @@ __global__ __launch_bounds__(256) void edge_l0_split_kernel(
     }
     __syncthreads();
     const int cpr = k >> 3;                 // chunks per edge row
-    const int nkt = k >> 5;
+    const int nkt = k >> 4;
     for (int c0 = (tid % cpr) * 8, le0 = tid / cpr; c0 < k; c0 += 256 * 8) {   // one pass when k/8 <= 256
         float w[8][MAX_F], bc[8];
 #pragma unroll
@@ -152,38 +162,38 @@ struct SplitGemmArgs {
     int tiles_n, tiles_m;
 };
 
-// One K-tile (32) for a wave: 2 k-steps x (2x2 tiles) x 6 plane products = 48 MFMAs.
-__device__ __forceinline__ void mma_split_tile(f32x16 (&acc)[2][2], const unsigned char* lds, int a_rd, int b_rd,
-                                               int fsw, int h) {
+// One stage (k-step of 16) for a wave: (2x2 tiles) x 6 plane products = 24 MFMAs, 12 fragment reads.
+__device__ __forceinline__ void mma_split_stage(f32x16 (&acc)[2][2], const unsigned char* st, int a_rd, int b_rd) {
+    bf16x8 a[2][3], b[2][3];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const int coff = ((2 * s + h) ^ fsw) * 16;
-        bf16x8 a[2][3], b[2][3];
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int p = 0; p < 3; ++p) {
+            a[i][p] = *reinterpret_cast<const bf16x8*>(st + p * PLANE_BYTES + a_rd + i * 32 * 32);
+            b[i][p] = *reinterpret_cast<const bf16x8*>(st + p * PLANE_BYTES + b_rd + i * 32 * 32);
+        }
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                a[i][p] = *reinterpret_cast<const bf16x8*>(lds + p * PLANE_BYTES + a_rd + i * 32 * 64 + coff);
-                b[i][p] = *reinterpret_cast<const bf16x8*>(lds + p * PLANE_BYTES + b_rd + i * 32 * 64 + coff);
-            }
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                // smallest terms first
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
-            }
-    }
+        for (int j = 0; j < 2; ++j) {
+            // smallest terms first
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+        }
 }
 
-template <bool OUT_PLANES>
-__global__ __launch_bounds__(256, 2) void gemm_split_bf16_kernel(SplitGemmArgs g) {
+template <int TM, bool OUT_PLANES>
+__global__ __launch_bounds__(TM * 2, 2) void gemm_split_bf16_kernel(SplitGemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int WAVES = TM / 32;                       // (TM/64) x 2 waves of 64x64
+    constexpr int STAGE_BYTES = stage_bytes(TM);
+    constexpr int PIECES = STAGE_BYTES / 1024;           // 1 KiB DMA pieces per stage: 24 or 36
+    constexpr int A_PIECES = PIECES - 12;
+    constexpr int PPW = (PIECES + WAVES - 1) / WAVES;    // pieces per wave: 6 or 5
 
     long long valid = (long long)(*g.num_edges) - g.row_begin;
     if (valid > g.rows) valid = g.rows;
@@ -198,39 +208,43 @@ __global__ __launch_bounds__(256, 2) void gemm_split_bf16_kernel(SplitGemmArgs g
     const int bm = (tile / g.tiles_n) * TM;
     const int bn = (tile % g.tiles_n) * TN;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
+    const int wm = wave >> 1, wn = wave & 1;                      // (TM/64) x 2 waves, 64x64 each
     const int l31 = lane & 31, h = lane >> 5;
 
-    // ---- staging: the operand's K-tile is a contiguous 24 KiB LDS image (3 planes x 8 KiB);
-    // thread copies 16 B at tid*16 + j*4 KiB, j = 0..5, for A and for B.
-    // Named registers only: arrays here end up in scratch and serialise the loads.
+    // ---- staging by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, no VGPRs, no
+    // ds_write).  A stage is PIECES pieces of 1 KiB, already in LDS-image order in HBM: 12 per A
+    // row tile (planes 0-2, contiguous), then 12 for the B row tile.  Wave w moves pieces
+    // w, w+WAVES, w+2*WAVES, ...
     const int nkt = g.K / TK;
-    const unsigned char* a_src = g.Ap + ((size_t)(bm >> 7) * nkt * 3 << 13) + tid * 16;
-    const unsigned char* b_src = g.Bp + ((size_t)(bn >> 7) * nkt * 3 << 13) + tid * 16;
-    const int st_off = tid * 16;
-    uint4 a0, a1, a2, a3, a4, a5, b0, b1, b2, b3, b4, b5;
-#define MDNO_LD16(P) (*reinterpret_cast<const uint4*>(P))
-#define MDNO_SPLIT_LOAD(KT)                                                                   \
-    {                                                                                         \
-        const unsigned char* pa = a_src + (size_t)(KT) * (3 * PLANE_BYTES);                   \
-        const unsigned char* pb = b_src + (size_t)(KT) * (3 * PLANE_BYTES);                   \
-        a0 = MDNO_LD16(pa);          a1 = MDNO_LD16(pa + 4096);  a2 = MDNO_LD16(pa + 8192);   \
-        a3 = MDNO_LD16(pa + 12288);  a4 = MDNO_LD16(pa + 16384); a5 = MDNO_LD16(pa + 20480);  \
-        b0 = MDNO_LD16(pb);          b1 = MDNO_LD16(pb + 4096);  b2 = MDNO_LD16(pb + 8192);   \
-        b3 = MDNO_LD16(pb + 12288);  b4 = MDNO_LD16(pb + 16384); b5 = MDNO_LD16(pb + 20480);  \
+    const size_t stage_stride = 3 * PLANE_BYTES;   // 12 KiB per k-step per 128-row tile
+    const unsigned char* a_base = g.Ap + ((size_t)(bm >> 7) * nkt * 3 << 12);
+    const unsigned char* b_base = g.Bp + ((size_t)(bn >> 7) * nkt * 3 << 12);
+    const size_t a_tile_stride = (size_t)nkt * 3 << 12;
+    const unsigned char* psrc[PPW];
+#pragma unroll
+    for (int t = 0; t < PPW; ++t) {
+        int qq = wave + t * WAVES;
+        if (qq >= PIECES) qq = wave;               // unused slot (guarded below), keep the pointer valid
+        psrc[t] = (qq < A_PIECES ? a_base + (size_t)(qq / 12) * a_tile_stride + (qq % 12) * 1024
+                                 : b_base + (qq - A_PIECES) * 1024) + lane * 16;
     }
-#define MDNO_ST16(OFF, V) *reinterpret_cast<uint4*>(lds + (OFF)) = (V)
-#define MDNO_SPLIT_STORE()                                                                              \
-    MDNO_ST16(st_off, a0);          MDNO_ST16(st_off + 4096, a1);   MDNO_ST16(st_off + 8192, a2);        \
-    MDNO_ST16(st_off + 12288, a3);  MDNO_ST16(st_off + 16384, a4);  MDNO_ST16(st_off + 20480, a5);       \
-    MDNO_ST16(st_off + 24576, b0);  MDNO_ST16(st_off + 28672, b1);  MDNO_ST16(st_off + 32768, b2);       \
-    MDNO_ST16(st_off + 36864, b3);  MDNO_ST16(st_off + 40960, b4);  MDNO_ST16(st_off + 45056, b5);
+    const int d0 = wave * 1024;
+#define MDNO_DMA_STAGE(KT, BUF)                                                                       \
+    {                                                                                                 \
+        const size_t ko = (size_t)(KT) * stage_stride;                                                \
+        lds_u8* ldst = (lds_u8*)(lds + (BUF) * STAGE_BYTES + d0);                                     \
+        _Pragma("unroll") for (int t = 0; t < PPW; ++t)                                               \
+            if (PIECES % WAVES == 0 || t < PPW - 1 || wave + t * WAVES < PIECES)                      \
+                __builtin_amdgcn_global_load_lds((glb_u8*)(psrc[t] + ko), ldst + t * WAVES * 1024, 16, 0, 0); \
+    }
 
-    // ---- fragment read map: row = w*64 + i*32 + l31, logical chunk = 2*s + h, swizzled by (row>>2)&3
-    const int fsw = (l31 >> 2) & 3;
-    const int a_rd = (wm * 64 + l31) * 64;
-    const int b_rd = 3 * PLANE_BYTES + (wn * 64 + l31) * 64;
+    // ---- fragment read map: 32-B rows, 16-B half h swapped by (row>>3)&1.  A rows of wave wm live
+    // in row-tile wm>>1 at (wm&1)*64 + i*32 + l31; B rows at wn*64 + i*32 + l31 behind the A planes.
+    const int hsw = (h ^ ((l31 >> 3) & 1)) << 4;
+    const int a_rd = (wm >> 1) * 3 * PLANE_BYTES + ((wm & 1) * 64 + l31) * 32 + hsw;
+    const int b_rd = A_PIECES * 1024 + (wn * 64 + l31) * 32 + hsw;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -240,23 +254,19 @@ __global__ __launch_bounds__(256, 2) void gemm_split_bf16_kernel(SplitGemmArgs g
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int nk = nkt;
-    MDNO_SPLIT_LOAD(0)
-    MDNO_SPLIT_STORE()
-    __syncthreads();
-    // steady state: next tile's global loads are in flight while this tile is multiplied
-    for (int kt = 0; kt < nk - 1; ++kt) {
-        MDNO_SPLIT_LOAD(kt + 1)
-        mma_split_tile(acc, lds, a_rd, b_rd, fsw, h);
-        __syncthreads();                       // every wave is done reading this tile
-        MDNO_SPLIT_STORE()
+    // Pipeline: stage kt+1 is in flight (DMA) while stage kt is multiplied.  __syncthreads() waits
+    // for this wave's outstanding DMA (vmcnt(0)) and then for every wave: after it, stage kt is
+    // complete in LDS and nobody still reads the buffer stage kt+1 is about to overwrite.
+    MDNO_DMA_STAGE(0, 0)
+    for (int kt = 0; kt < nkt; kt += 2) {      // K is a multiple of 32: stages come in pairs
         __syncthreads();
+        MDNO_DMA_STAGE(kt + 1, 1)
+        mma_split_stage(acc, lds, a_rd, b_rd);
+        __syncthreads();
+        if (kt + 2 < nkt) MDNO_DMA_STAGE(kt + 2, 0)
+        mma_split_stage(acc, lds + STAGE_BYTES, a_rd, b_rd);
     }
-    mma_split_tile(acc, lds, a_rd, b_rd, fsw, h);
-#undef MDNO_SPLIT_LOAD
-#undef MDNO_SPLIT_STORE
-#undef MDNO_LD16
-#undef MDNO_ST16
+#undef MDNO_DMA_STAGE
 
     // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
@@ -273,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_bf16_kernel(SplitGemmArgs g
                     if (OUT_PLANES) {
                         __bf16 ph, pm, pl;
                         split3(fmaxf(v, 0.f), ph, pm, pl);
-                        const size_t o = tiled_off(m, n, g.N >> 5, 0);
+                        const size_t o = tiled_off(m, n, g.N >> 4, 0);
                         *reinterpret_cast<__bf16*>(g.Cp + o) = ph;
                         *reinterpret_cast<__bf16*>(g.Cp + o + PLANE_BYTES) = pm;
                         *reinterpret_cast<__bf16*>(g.Cp + o + 2 * PLANE_BYTES) = pl;
@@ -286,25 +296,34 @@ __global__ __launch_bounds__(256, 2) void gemm_split_bf16_kernel(SplitGemmArgs g
     }
 }
 
-template <bool OUT_PLANES>
-int launch_split_gemm(SplitGemmArgs g, int kid, hipStream_t s) {
-    TimedSection ts(kid, s);
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[OUT_PLANES]) {
-        MDNO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_bf16_kernel<OUT_PLANES>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr_set[OUT_PLANES] = true;
+template <int TM, bool OUT_PLANES>
+int launch_split_gemm_tm(SplitGemmArgs g, hipStream_t s) {
+    constexpr int lds_bytes = 2 * stage_bytes(TM);
+    static bool attr_set = false;
+    if (!attr_set) {
+        MDNO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_bf16_kernel<TM, OUT_PLANES>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        attr_set = true;
     }
     g.tiles_n = g.N / TN;
     g.tiles_m = g.rows / TM;
-    hipLaunchKernelGGL(gemm_split_bf16_kernel<OUT_PLANES>, dim3(g.tiles_n * g.tiles_m), dim3(256), LDS_BYTES, s, g);
+    hipLaunchKernelGGL((gemm_split_bf16_kernel<TM, OUT_PLANES>), dim3(g.tiles_n * g.tiles_m), dim3(TM * 2), lds_bytes,
+                       s, g);
     return check_launch("split-bf16 GEMM");
+}
+
+// 256-row tiles need 1.5x fewer staged bytes per MFMA; 128-row tiles give twice the workgroups.
+// The wide last layer (N = Cin*Cout = 4096) has tiles to spare, the k x k middle layer does not.
+template <bool OUT_PLANES>
+int launch_split_gemm(const SplitGemmArgs& g, int kid, hipStream_t s) {
+    TimedSection ts(kid, s);
+    return g.N >= 2048 ? launch_split_gemm_tm<256, OUT_PLANES>(g, s) : launch_split_gemm_tm<128, OUT_PLANES>(g, s);
 }
 
 }  // namespace
 
 bool edge_mlp_split_supported(int ker_width, int out_dim) {
-    return ker_width % TK == 0 && ker_width % TN == 0 && out_dim % TN == 0;
+    return ker_width % 32 == 0 && ker_width % TN == 0 && out_dim % TN == 0;
 }
 
 size_t edge_mlp_split_workspace_bytes(int ker_width, int out_dim, long long chunk) {

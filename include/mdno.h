@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDNO_ABI_VERSION 2
+#define MDNO_ABI_VERSION 3
 
 #define MDNO_OK            0
 #define MDNO_EINVAL       -1   /* bad argument (null pointer, non-positive size, unsupported dim) */
@@ -52,9 +52,20 @@ extern "C" {
 #define MDNO_GEMM_SPLIT_BF16 0
 #define MDNO_GEMM_F32        1
 
+/* How a conv application is evaluated inside mdno_kernelnn_fwd / the rollout (same function either way):
+ *   MATERIALIZED  the reference's formulation: W_e = net(edge_attr) [E,Cin,Cout] is written once per
+ *                 forward and streamed by every conv application (HBM-bound gather/matvec/scatter).
+ *   FACTORED      m_e = h_e . Y_src^T + q_src with Y = X . W3 evaluated per NODE (see csrc/factored.hip):
+ *                 a reassociation of the same sums that never forms W_e.  Used only for graphs the
+ *                 library builds itself from positions (symmetric radius graphs, width 64); everything
+ *                 else runs MATERIALIZED. */
+#define MDNO_CONV_MATERIALIZED 0
+#define MDNO_CONV_FACTORED     1
+
 /* status word bits written by device code (read back by the caller after synchronising) */
 #define MDNO_STATUS_EDGE_OVERFLOW 1   /* radius graph found more than edge_cap edges; list truncated */
 #define MDNO_STATUS_BAD_AMINOACID 2   /* x_aminoacid outside [0, num_embeddings) */
+#define MDNO_STATUS_ASYMMETRIC_GRAPH 4 /* factored conv: an edge has no reverse edge */
 
 int         mdno_abi_version(void);
 const char* mdno_last_error(void);
@@ -72,6 +83,7 @@ const char* mdno_last_error(void);
 typedef struct mdno_kernelnn_params {
     int32_t width, ker_width, depth, ker_in, in_width, out_width;
     int32_t num_embeddings, embedding_dim, x_position_dim, gemm_mode;  /* gemm_mode: MDNO_GEMM_* */
+    int32_t conv_mode, reserved0;                                       /* conv_mode: MDNO_CONV_* */
     const float *lstm_w_ih, *lstm_w_hh, *lstm_b_ih, *lstm_b_hh;     /* lstm.*_l0            */
     const float *lstm_fc_w, *lstm_fc_b;                             /* lstm_fc.{weight,bias} */
     const float *emb_w;                                             /* emb.weight [20,4]     */

@@ -14,8 +14,10 @@ LIB_PATH = Path(os.environ.get("MDNO_LIB", _HERE / "libmdno.so"))
 OK, EINVAL, ELAUNCH, EWORKSPACE, EUNSUPPORTED = 0, -1, -2, -3, -4
 AGGR = {"add": 0, "mean": 1}
 STATUS_EDGE_OVERFLOW, STATUS_BAD_AMINOACID = 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 GEMM_MODES = {"split_bf16": 0, "f32": 1}
+CONV_MODES = {"materialized": 0, "factored": 1}
+STATUS_ASYMMETRIC_GRAPH = 4
 
 
 class MdnoError(RuntimeError):
@@ -25,7 +27,7 @@ class MdnoError(RuntimeError):
 class KernelNNParams(C.Structure):
     """struct mdno_kernelnn_params"""
     _INTS = ["width", "ker_width", "depth", "ker_in", "in_width", "out_width",
-             "num_embeddings", "embedding_dim", "x_position_dim", "gemm_mode"]
+             "num_embeddings", "embedding_dim", "x_position_dim", "gemm_mode", "conv_mode", "reserved0"]
     _PTRS = ["lstm_w_ih", "lstm_w_hh", "lstm_b_ih", "lstm_b_hh", "lstm_fc_w", "lstm_fc_b", "emb_w",
              "fc1_w", "fc1_b", "k_w0", "k_b0", "k_w1", "k_b1", "k_w2", "k_b2",
              "k2_w0", "k2_b0", "k2_w1", "k2_b1", "k2_w2", "k2_b2",

@@ -317,6 +317,39 @@ int mdno::edge_mlp(const float* frames, int frame, const int* t_dev, int rows_pe
     return MDNO_OK;
 }
 
+int mdno::edge_mlp_hidden(const float* frames, int frame, const int* t_dev, int rows_per_frame, const int* src,
+                          const int* dst, const float* edge_attr, const int* perm, const int* num_edges,
+                          long long edge_cap, int ker_in, int ker_width, int gemm_mode, const EdgeMlpWeights& w,
+                          float* h_out, void* workspace, size_t workspace_bytes, hipStream_t s) {
+    MDNO_REQUIRE(num_edges && w.w0 && w.b0 && w.w1 && w.b1 && h_out && workspace, MDNO_EINVAL,
+                 "edge_mlp_hidden: null pointer");
+    MDNO_REQUIRE((frames && src && dst) || edge_attr, MDNO_EINVAL, "edge_mlp_hidden: need positions+CSR or edge_attr");
+    MDNO_REQUIRE(ker_in > 0 && ker_in <= MAX_F, MDNO_EUNSUPPORTED, "edge_mlp: ker_in=%d (1..%d)", ker_in, MAX_F);
+    MDNO_REQUIRE(edge_attr || ker_in == 6, MDNO_EINVAL, "edge_mlp: position-derived attributes need ker_in == 6");
+    const size_t need = mdno_edge_mlp_workspace_bytes(ker_width, ker_width, edge_cap, gemm_mode);
+    MDNO_REQUIRE(workspace_bytes >= need, MDNO_EWORKSPACE, "edge_mlp_hidden: workspace %zu < %zu", workspace_bytes, need);
+    const long long chunk = chunk_rows_for(edge_cap);
+    if (gemm_mode == MDNO_GEMM_SPLIT_BF16 && edge_mlp_split_supported(ker_width, ker_width))
+        return edge_mlp_split_hidden(frames, frame, t_dev, rows_per_frame, src, dst, edge_attr, perm, num_edges,
+                                     edge_cap, chunk, ker_in, ker_width, w, h_out, workspace, s);
+    Carver cv(workspace);
+    float* h1 = cv.take<float>((size_t)chunk * ker_width);
+    const float* pos_mode = edge_attr ? nullptr : frames;
+    for (long long e0 = 0; e0 < edge_cap; e0 += chunk) {
+        const int cnt = (int)((edge_cap - e0) < chunk ? (edge_cap - e0) : chunk);
+        {
+            TimedSection ts(KID_EDGE_L0, s);
+            hipLaunchKernelGGL(edge_l0_kernel, dim3((cnt + EB - 1) / EB), dim3(256), 0, s, pos_mode, frame, t_dev,
+                               rows_per_frame, src, dst, edge_attr, perm, num_edges, e0, cnt, ker_in, ker_width,
+                               w.w0, w.b0, h1);
+        }
+        MDNO_TRY(check_launch("edge_l0_kernel"));
+        GemmArgs g1{h1, w.w1, w.b1, h_out + (size_t)e0 * ker_width, num_edges, e0, (int)chunk, ker_width, ker_width};
+        MDNO_TRY(launch_gemm<true>(g1, s));
+    }
+    return MDNO_OK;
+}
+
 extern "C" int mdno_edge_mlp_fwd(const float* edge_pos, const int32_t* src, const int32_t* dst,
                                  const float* edge_attr, const int32_t* perm, const int32_t* num_edges,
                                  int64_t edge_cap, int ker_in, int ker_width, int out_dim, int gemm_mode,

@@ -186,7 +186,9 @@ __device__ __forceinline__ void mma_split_stage(f32x16 (&acc)[2][2], const unsig
         }
 }
 
-template <int TM, bool OUT_PLANES>
+// OUT: 0 = fp32 row-major (W_e), 1 = tiled bf16 planes after ReLU (next GEMM's operand),
+//      2 = fp32 row-major after ReLU (the hidden activation the factored conv consumes)
+template <int TM, int OUT>
 __global__ __launch_bounds__(TM * 2, 2) void gemm_split_bf16_kernel(SplitGemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int WAVES = TM / 32;                       // (TM/64) x 2 waves of 64x64
@@ -280,7 +282,9 @@ __global__ __launch_bounds__(TM * 2, 2) void gemm_split_bf16_kernel(SplitGemmArg
                 const int m = bm + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (m < valid) {
                     const float v = acc[i][j][e] + bv;
-                    if (OUT_PLANES) {
+                    if (OUT == 2) {
+                        g.C[(size_t)m * g.N + n] = fmaxf(v, 0.f);
+                    } else if (OUT == 1) {
                         __bf16 ph, pm, pl;
                         split3(fmaxf(v, 0.f), ph, pm, pl);
                         const size_t o = tiled_off(m, n, g.N >> 4, 0);
@@ -296,28 +300,28 @@ __global__ __launch_bounds__(TM * 2, 2) void gemm_split_bf16_kernel(SplitGemmArg
     }
 }
 
-template <int TM, bool OUT_PLANES>
+template <int TM, int OUT>
 int launch_split_gemm_tm(SplitGemmArgs g, hipStream_t s) {
     constexpr int lds_bytes = 2 * stage_bytes(TM);
     static bool attr_set = false;
     if (!attr_set) {
-        MDNO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_bf16_kernel<TM, OUT_PLANES>),
+        MDNO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_bf16_kernel<TM, OUT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         attr_set = true;
     }
     g.tiles_n = g.N / TN;
     g.tiles_m = g.rows / TM;
-    hipLaunchKernelGGL((gemm_split_bf16_kernel<TM, OUT_PLANES>), dim3(g.tiles_n * g.tiles_m), dim3(TM * 2), lds_bytes,
+    hipLaunchKernelGGL((gemm_split_bf16_kernel<TM, OUT>), dim3(g.tiles_n * g.tiles_m), dim3(TM * 2), lds_bytes,
                        s, g);
     return check_launch("split-bf16 GEMM");
 }
 
 // 256-row tiles need 1.5x fewer staged bytes per MFMA; 128-row tiles give twice the workgroups.
 // The wide last layer (N = Cin*Cout = 4096) has tiles to spare, the k x k middle layer does not.
-template <bool OUT_PLANES>
+template <int OUT>
 int launch_split_gemm(const SplitGemmArgs& g, int kid, hipStream_t s) {
     TimedSection ts(kid, s);
-    return g.N >= 2048 ? launch_split_gemm_tm<256, OUT_PLANES>(g, s) : launch_split_gemm_tm<128, OUT_PLANES>(g, s);
+    return g.N >= 2048 ? launch_split_gemm_tm<256, OUT>(g, s) : launch_split_gemm_tm<128, OUT>(g, s);
 }
 
 }  // namespace
@@ -367,10 +371,44 @@ int edge_mlp_split(const float* frames, int frame, const int* t_dev, int rows_pe
         }
         MDNO_TRY(check_launch("edge_l0_split_kernel"));
         SplitGemmArgs g1{h1p, w1p, w.b1, nullptr, h2p, num_edges, e0, (int)chunk, k, k, 0, 0};
-        MDNO_TRY(launch_split_gemm<true>(g1, KID_GEMM_L1, s));
+        MDNO_TRY(launch_split_gemm<1>(g1, KID_GEMM_L1, s));
         SplitGemmArgs g2{h2p, w2p, w.b2, w_e + (size_t)e0 * out_dim, nullptr, num_edges, e0, (int)chunk, out_dim, k,
                          0, 0};
-        MDNO_TRY(launch_split_gemm<false>(g2, KID_GEMM_L2, s));
+        MDNO_TRY(launch_split_gemm<0>(g2, KID_GEMM_L2, s));
+    }
+    return MDNO_OK;
+}
+
+int edge_mlp_split_hidden(const float* frames, int frame, const int* t_dev, int rows_per_frame, const int* src,
+                          const int* dst, const float* edge_attr, const int* perm, const int* num_edges,
+                          long long edge_cap, long long chunk, int ker_in, int ker_width, const EdgeMlpWeights& w,
+                          float* h_out, void* workspace, hipStream_t s) {
+    MDNO_REQUIRE(ker_in > 0 && ker_in <= MAX_F, MDNO_EUNSUPPORTED, "edge_mlp: ker_in=%d (1..%d)", ker_in, MAX_F);
+    MDNO_REQUIRE((reinterpret_cast<uintptr_t>(w.w1) & 15) == 0, MDNO_EINVAL,
+                 "edge_mlp: weight pointers must be 16-byte aligned");
+    const int k = ker_width;
+    Carver cv(workspace);
+    unsigned char* h1p = reinterpret_cast<unsigned char*>(cv.take<__bf16>(3 * (size_t)chunk * k));
+    cv.take<__bf16>(3 * (size_t)chunk * k);   // (layout shared with the full MLP: second activation buffer unused)
+    unsigned char* w1p = reinterpret_cast<unsigned char*>(cv.take<__bf16>(3 * (size_t)k * k));
+    {
+        TimedSection ts(KID_EDGE_L0, s);
+        const long long c1 = (long long)k * (k / 8);
+        hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((c1 + 255) / 256)), dim3(256), 0, s, w.w1, k, k, w1p);
+    }
+    MDNO_TRY(check_launch("split_planes_kernel"));
+    const float* pos_mode = edge_attr ? nullptr : frames;
+    for (long long e0 = 0; e0 < edge_cap; e0 += chunk) {
+        const int cnt = (int)((edge_cap - e0) < chunk ? (edge_cap - e0) : chunk);
+        {
+            TimedSection ts(KID_EDGE_L0, s);
+            hipLaunchKernelGGL(edge_l0_split_kernel, dim3((cnt + EB - 1) / EB), dim3(256), 0, s, pos_mode, frame, t_dev,
+                               rows_per_frame, src, dst, edge_attr, perm, num_edges, e0, cnt, ker_in, k, w.w0, w.b0,
+                               h1p);
+        }
+        MDNO_TRY(check_launch("edge_l0_split_kernel"));
+        SplitGemmArgs g1{h1p, w1p, w.b1, h_out + (size_t)e0 * k, nullptr, num_edges, e0, (int)chunk, k, k, 0, 0};
+        MDNO_TRY(launch_split_gemm<2>(g1, KID_GEMM_L1, s));
     }
     return MDNO_OK;
 }

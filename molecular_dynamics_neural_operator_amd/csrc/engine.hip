@@ -73,10 +73,16 @@ bool separate_conv2_kernel(const mdno_kernelnn_params* p) {
 }
 
 struct FwdWs {
-    float *xa, *xb, *w_e;
-    void* mlp;
+    float *xa, *xb, *w_e, *h2;
+    void *mlp, *fact;
     size_t mlp_bytes, total;
+    bool factored;
 };
+
+// The factored conv applies to graphs the library builds itself (symmetric radius graphs) at width 64.
+bool use_factored(const mdno_kernelnn_params* p) {
+    return p->conv_mode == MDNO_CONV_FACTORED && factored_supported(p->width, p->ker_width);
+}
 
 FwdWs carve_fwd(void* ws, const mdno_kernelnn_params* p, int M, int N, long long edge_cap) {
     FwdWs f{};
@@ -84,8 +90,17 @@ FwdWs carve_fwd(void* ws, const mdno_kernelnn_params* p, int M, int N, long long
     const size_t R = (size_t)M * N;
     f.xa = cv.take<float>(R * p->width);
     f.xb = cv.take<float>(R * p->width);
-    f.w_e = cv.take<float>((size_t)edge_cap * p->width * p->width);
-    f.mlp_bytes = mdno_edge_mlp_workspace_bytes(p->ker_width, p->width * p->width, edge_cap, p->gemm_mode);
+    f.factored = use_factored(p);
+    if (f.factored) {
+        // no W_e at all: the last hidden activation H [edge_cap, k] plus the per-node Y and per-edge M
+        f.h2 = cv.take<float>((size_t)edge_cap * p->ker_width);
+        f.fact = cv.take<char>(factored_workspace_bytes((int)R, p->ker_width, edge_cap));
+        f.mlp_bytes = mdno_edge_mlp_workspace_bytes(p->ker_width, p->ker_width, edge_cap, p->gemm_mode);
+    } else {
+        f.mlp_bytes = mdno_edge_mlp_workspace_bytes(p->ker_width, p->width * p->width, edge_cap, p->gemm_mode);
+    }
+    // the materialised path also serves explicit-edge_attr calls when conv_mode asks for factored
+    f.w_e = cv.take<float>(f.factored ? 0 : (size_t)edge_cap * p->width * p->width);
     f.mlp = cv.take<char>(f.mlp_bytes);
     f.total = cv.used();
     return f;
@@ -102,18 +117,48 @@ int forward_impl(const mdno_kernelnn_params* p, const float* frames, int t0, con
     float* cur = ws.xa;
     float* nxt = ws.xb;
     const int blocks = p->conv2_root ? 2 : 1;   // notebook-era model: conv1 only (lstm_* NULL as well)
-    for (int block = 0; block < blocks; ++block) {
-        if (block == 0 || separate_conv2_kernel(p)) {
-            EdgeMlpWeights w = (block == 0) ? EdgeMlpWeights{p->k_w0, p->k_b0, p->k_w1, p->k_b1, p->k_w2, p->k_b2}
-                                            : EdgeMlpWeights{p->k2_w0, p->k2_b0, p->k2_w1, p->k2_b1, p->k2_w2, p->k2_b2};
-            MDNO_TRY(edge_mlp(edge_frames, edge_frame, t_dev, R, src, dst, edge_attr, perm, num_edges, edge_cap,
-                              p->ker_in, p->ker_width, C * C, p->gemm_mode, w, ws.w_e, ws.mlp, ws.mlp_bytes, s));
+    if (ws.factored) {
+        // symmetric radius graph, attributes from positions: row r = SOURCE r -> destinations src[p]
+        // (the CSR arrays' names refer to the materialised reading; here their roles are swapped)
+        MDNO_REQUIRE(edge_frames && !edge_attr && dst, MDNO_EINVAL,
+                     "factored conv needs a position-derived radius graph (edge_pos, dst)");
+        const FactoredWs fw = factored_carve(ws.fact, R, p->ker_width, edge_cap);
+        MDNO_TRY(factored_prepare_graph(row_ptr, src, dst, R, edge_cap, fw, status, s));
+        for (int block = 0; block < blocks; ++block) {
+            const bool own = block == 1 && separate_conv2_kernel(p);
+            if (block == 0 || own) {
+                EdgeMlpWeights w = own ? EdgeMlpWeights{p->k2_w0, p->k2_b0, p->k2_w1, p->k2_b1, p->k2_w2, p->k2_b2}
+                                       : EdgeMlpWeights{p->k_w0, p->k_b0, p->k_w1, p->k_b1, p->k_w2, p->k_b2};
+                // attr = [pos[source], pos[destination]] = [pos[row], pos[col]]: pass (dst, src) swapped
+                MDNO_TRY(edge_mlp_hidden(edge_frames, edge_frame, t_dev, R, /*src=*/dst, /*dst=*/src, nullptr, nullptr,
+                                         num_edges, edge_cap, p->ker_in, p->ker_width, p->gemm_mode, w, ws.h2, ws.mlp,
+                                         ws.mlp_bytes, s));
+                MDNO_TRY(factored_prepare_weights(w.w2, p->ker_width, fw, s));
+            }
+            const float* b3 = (block == 1 && separate_conv2_kernel(p)) ? p->k2_b2 : p->k_b2;
+            const float* root = block == 0 ? p->conv1_root : p->conv2_root;
+            const float* bias = block == 0 ? p->conv1_bias : p->conv2_bias;
+            for (int d = 0; d < p->depth; ++d) {
+                MDNO_TRY(factored_conv(cur, ws.h2, row_ptr, R, N, p->ker_width, b3, root, bias, MDNO_AGGR_MEAN,
+                                       /*relu=*/1, nxt, fw, s));
+                float* t = cur; cur = nxt; nxt = t;
+            }
         }
-        const float* root = block == 0 ? p->conv1_root : p->conv2_root;
-        const float* bias = block == 0 ? p->conv1_bias : p->conv2_bias;
-        for (int d = 0; d < p->depth; ++d) {
-            MDNO_TRY(nnconv(cur, row_ptr, src, R, ws.w_e, root, bias, C, C, MDNO_AGGR_MEAN, /*relu=*/1, nxt, s));
-            float* t = cur; cur = nxt; nxt = t;
+    } else {
+        for (int block = 0; block < blocks; ++block) {
+            if (block == 0 || separate_conv2_kernel(p)) {
+                EdgeMlpWeights w = (block == 0)
+                                       ? EdgeMlpWeights{p->k_w0, p->k_b0, p->k_w1, p->k_b1, p->k_w2, p->k_b2}
+                                       : EdgeMlpWeights{p->k2_w0, p->k2_b0, p->k2_w1, p->k2_b1, p->k2_w2, p->k2_b2};
+                MDNO_TRY(edge_mlp(edge_frames, edge_frame, t_dev, R, src, dst, edge_attr, perm, num_edges, edge_cap,
+                                  p->ker_in, p->ker_width, C * C, p->gemm_mode, w, ws.w_e, ws.mlp, ws.mlp_bytes, s));
+            }
+            const float* root = block == 0 ? p->conv1_root : p->conv2_root;
+            const float* bias = block == 0 ? p->conv1_bias : p->conv2_bias;
+            for (int d = 0; d < p->depth; ++d) {
+                MDNO_TRY(nnconv(cur, row_ptr, src, R, ws.w_e, root, bias, C, C, MDNO_AGGR_MEAN, /*relu=*/1, nxt, s));
+                float* t = cur; cur = nxt; nxt = t;
+            }
         }
     }
     if (latent) MDNO_HIP(hipMemcpyAsync(latent, cur, sizeof(float) * (size_t)R * C, hipMemcpyDeviceToDevice, s));

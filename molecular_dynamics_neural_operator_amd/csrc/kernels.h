@@ -12,7 +12,7 @@ namespace mdno {
 // A timer is attached to a rollout plan by the caller; while an eager (non-graph) run of that plan
 // enqueues kernels on this thread, every launch site below brackets its kernel with two events.
 enum KernelId { KID_NNCONV = 0, KID_GEMM_L1 = 1, KID_GEMM_L2 = 2, KID_EDGE_L0 = 3, KID_GRAPH = 4,
-                KID_PROLOGUE = 5, KID_FC_OUT = 6, KID_COUNT = 7 };
+                KID_PROLOGUE = 5, KID_FC_OUT = 6, KID_NNCONV_COMBINE = 7, KID_FACT_Y = 8, KID_COUNT = 9 };
 struct Timer;
 extern thread_local Timer* g_active_timer;
 void timer_mark(int kid, bool start, hipStream_t s);
@@ -41,6 +41,32 @@ int edge_mlp_split(const float* frames, int frame, const int* t_dev, int rows_pe
                    const int* dst, const float* edge_attr, const int* perm, const int* num_edges,
                    long long edge_cap, long long chunk, int ker_in, int ker_width, int out_dim,
                    const EdgeMlpWeights& w, float* w_e, void* workspace, hipStream_t s);
+
+// Edge-MLP up to its last hidden activation: H = relu(L1(relu(L0(attr)))) as fp32 [edge_cap, ker_width]
+// row-major (what the factored conv consumes); same attr modes and gemm_mode as edge_mlp.
+int edge_mlp_hidden(const float* frames, int frame, const int* t_dev, int rows_per_frame, const int* src,
+                    const int* dst, const float* edge_attr, const int* perm, const int* num_edges,
+                    long long edge_cap, int ker_in, int ker_width, int gemm_mode, const EdgeMlpWeights& w,
+                    float* h_out, void* workspace, size_t workspace_bytes, hipStream_t s);
+int edge_mlp_split_hidden(const float* frames, int frame, const int* t_dev, int rows_per_frame, const int* src,
+                          const int* dst, const float* edge_attr, const int* perm, const int* num_edges,
+                          long long edge_cap, long long chunk, int ker_in, int ker_width, const EdgeMlpWeights& w,
+                          float* h_out, void* workspace, hipStream_t s);
+
+// Factored conv (factored.hip): see the file header.
+struct FactoredWs {
+    float *w3t, *y, *m;
+    int* rev;
+};
+bool factored_supported(int width, int ker_width);
+size_t factored_workspace_bytes(int num_rows, int ker_width, long long edge_cap);
+FactoredWs factored_carve(void* ws, int num_rows, int ker_width, long long edge_cap);
+int factored_prepare_weights(const float* w3, int ker_width, const FactoredWs& f, hipStream_t s);
+int factored_prepare_graph(const int* row_ptr, const int* col, const int* rowid, int num_rows, long long edge_cap,
+                           const FactoredWs& f, int* status, hipStream_t s);
+int factored_conv(const float* x, const float* h2, const int* row_ptr, int num_rows, int max_degree, int ker_width,
+                  const float* b3, const float* root, const float* bias, int aggr, int relu, float* y,
+                  const FactoredWs& f, hipStream_t s);
 
 int nnconv(const float* x, const int* row_ptr, const int* src, int num_rows, const float* w_e, const float* root,
            const float* bias, int Cin, int Cout, int aggr, int relu, float* y, hipStream_t s);

@@ -200,14 +200,20 @@ class KernelNN(nn.Module):
         # bf16 split of the fp32 operands, 6 products, fp32 accumulation (fp32-level error, 2-3x faster);
         # "f32" = fp32-input MFMA, bit-for-bit an fmaf chain
         self.gemm_mode = "split_bf16"
+        # how conv applications run inside the on-device rollout / position-graph forward
+        # (include/mdno.h MDNO_CONV_*): "materialized" = the reference's W_e formulation;
+        # "factored" = same sums reassociated per node, no W_e (csrc/factored.hip).  forward(data)
+        # with an explicit edge_index/edge_attr always runs materialized.
+        self.conv_mode = "materialized"
 
     # -- parameter pack (device pointers) cached until a parameter changes
-    def param_pack(self, device=None) -> ops.ParamPack:
+    def param_pack(self, device=None, conv_mode: Optional[str] = None) -> ops.ParamPack:
         device = require_gpu(device)
+        conv_mode = conv_mode or self.conv_mode
         params = list(self.parameters())
-        key = (str(device), self.gemm_mode) + tuple((p.data_ptr(), p._version) for p in params)
+        key = (str(device), self.gemm_mode, conv_mode) + tuple((p.data_ptr(), p._version) for p in params)
         if self._pack is None or self._pack_key != key:
-            self._pack = ops.ParamPack(self.state_dict(), self.depth, device, self.gemm_mode)
+            self._pack = ops.ParamPack(self.state_dict(), self.depth, device, self.gemm_mode, conv_mode)
             self._pack_key = key
         return self._pack
 
@@ -224,7 +230,7 @@ class KernelNN(nn.Module):
                 f"x_position {tuple(x_position.shape)} vs {n_nodes} nodes: batched samples go through "
                 "rollout.RolloutEngine / ops.kernelnn_forward (one PairData per forward here)")
         with torch.no_grad():
-            pack = self.param_pack(x_position.device)
+            pack = self.param_pack(x_position.device, conv_mode="materialized")
             graph = ops.coo_to_csr(data.edge_index, n_nodes)
             out, latent = ops.kernelnn_forward(pack, x_position.unsqueeze(1), data.x_aminoacid, graph,
                                                edge_attr=data.edge_attr, return_latent=return_latent)
@@ -255,6 +261,11 @@ class KernelNNNotebook(KernelNN):
         self._pack = None
         self._pack_key = None
         self.gemm_mode = "split_bf16"
+        # how conv applications run inside the on-device rollout / position-graph forward
+        # (include/mdno.h MDNO_CONV_*): "materialized" = the reference's W_e formulation;
+        # "factored" = same sums reassociated per node, no W_e (csrc/factored.hip).  forward(data)
+        # with an explicit edge_index/edge_attr always runs materialized.
+        self.conv_mode = "materialized"
 
 
 # --------------------------------------------------------------------------- graph construction

@@ -134,7 +134,8 @@ class ParamPack:
         "fc2_w": "fc2.weight", "fc2_b": "fc2.bias",
     }
 
-    def __init__(self, state_dict, depth: int, device, gemm_mode: str = "split_bf16"):
+    def __init__(self, state_dict, depth: int, device, gemm_mode: str = "split_bf16",
+                 conv_mode: str = "materialized"):
         sd = {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
         self.tensors = {}
         p = KernelNNParams()
@@ -174,6 +175,8 @@ class ParamPack:
             raise MdnoError("state_dict has a partial lstm/conv2 parameter group")
         p.gemm_mode = _lib.GEMM_MODES[gemm_mode]
         self.gemm_mode = gemm_mode
+        p.conv_mode = _lib.CONV_MODES[conv_mode]
+        self.conv_mode = conv_mode
         if self.tensors["k_w2"].shape[0] != width * width:
             raise MdnoError("edge-MLP output size != width**2")
         self.struct = p
@@ -208,6 +211,9 @@ def kernelnn_forward(pack: ParamPack, frames: torch.Tensor, x_aminoacid: torch.T
     status = graph.status if graph.status is not None else torch.zeros(1, dtype=torch.int32, device=dev)
     ea = f32(edge_attr) if edge_attr is not None else None
     ep = f32(edge_pos).reshape(-1, 3) if edge_pos is not None else None
+    if pack.conv_mode == "factored" and (ea is not None or ep is None):
+        raise MdnoError("conv_mode='factored' needs a radius graph with position-derived attributes "
+                        "(edge_pos); explicit edge_attr runs with conv_mode='materialized'")
     check(lib.mdno_kernelnn_fwd(pack.ref, ptr(frames), M, W, N, ptr(aa), aa_pm, ptr(graph.row_ptr), ptr(graph.src),
                                 ptr(graph.dst), ptr(graph.num_edges), graph.edge_cap, ptr(ep), ptr(ea),
                                 ptr(graph.perm) if ea is not None else None, ptr(out), ptr(latent), ptr(workspace),

@@ -19,7 +19,8 @@ from typing import List, Optional, Tuple
 import torch
 
 from . import _lib, ops
-from ._lib import MdnoError, STATUS_BAD_AMINOACID, STATUS_EDGE_OVERFLOW, check, f32, ptr, require_gpu
+from ._lib import (MdnoError, STATUS_ASYMMETRIC_GRAPH, STATUS_BAD_AMINOACID, STATUS_EDGE_OVERFLOW, check, f32, ptr,
+                   require_gpu)
 
 
 def default_edge_cap(members: int, n_atoms: int, threshold: float, density: float = 0.1, slack: float = 1.6) -> int:
@@ -119,7 +120,7 @@ class RolloutEngine:
         self.steps_done += int(steps)
 
     KERNEL_IDS = {"nnconv": 0, "edge_mlp_gemm1": 1, "edge_mlp_gemm2": 2, "edge_mlp_l0": 3, "radius_graph": 4,
-                  "node_prologue": 5, "fc_out": 6}
+                  "node_prologue": 5, "fc_out": 6, "nnconv_combine": 7, "factored_y": 8}
 
     def attach_timer(self, max_records: int) -> None:
         """Per-kernel HIP-event timing (measurement aid): subsequent step() calls issue plain
@@ -147,6 +148,8 @@ class RolloutEngine:
             raise MdnoError(f"radius graph exceeded edge_cap={self.edge_cap}; construct the engine with a larger cap")
         if st & STATUS_BAD_AMINOACID:
             raise MdnoError("x_aminoacid outside [0, num_embeddings)")
+        if st & STATUS_ASYMMETRIC_GRAPH:
+            raise MdnoError("factored conv met an edge without a reverse edge (graph not symmetric)")
 
     def run(self, window: torch.Tensor, x_aminoacid: torch.Tensor, steps: int) -> torch.Tensor:
         """reset + step + synchronize; returns the produced frames f32 [steps, M, N, 3] (a view)."""

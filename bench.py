@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="plain launches instead of hipGraph replay")
     ap.add_argument("--gemm-mode", choices=["split_bf16", "f32"], default="split_bf16",
                     help="edge-MLP GEMMs: exact 3-way bf16 split (6 products, fp32 accumulate) or fp32-input MFMA")
+    ap.add_argument("--conv-mode", choices=["materialized", "factored"], default="materialized",
+                    help="materialized = W_e written once and streamed by every conv application (the reference's "
+                         "formulation); factored = same sums reassociated per node, W_e never formed")
     ap.add_argument("--variant", choices=["intree", "notebook"], default="intree",
                     help="notebook = the model the reference's notebook ran (no LSTM, conv1 only; use with "
                          "--atoms 28 --window 1 --kernel-width 512 --chain for the nb:370 shape)")
@@ -147,6 +150,7 @@ def main():
     model.load_state_dict(sd)
     model.eval().to(dev)
     model.gemm_mode = a.gemm_mode
+    model.conv_mode = a.conv_mode
 
     frame0 = syn.chain_frame(N, seed=1) if a.chain else syn.box_frame(N, seed=1)
     base = syn.jitter_window(frame0, W, seed=1)                                    # [W,N,3]
@@ -195,7 +199,7 @@ def main():
     roof = roof_mfma = None
     kernels = {}
     if not a.skip_roofline:
-        launches_per_step = 2 * a.depth + 8
+        launches_per_step = 6 * a.depth + 16
         eng.attach_timer(a.steps * (launches_per_step + 4))
         eng.step(a.steps)
         tm = eng.read_timer()
@@ -208,7 +212,7 @@ def main():
         for k, (ms, n) in tm.items():
             if n:
                 kernels[k] = {"avg_ms": ms / n, "launches": int(n)}
-        if "nnconv" in kernels:
+        if "nnconv" in kernels and a.conv_mode == "materialized":
             avg_s = kernels["nnconv"]["avg_ms"] * 1e-3
             alg_bytes = e2 * (C * C * 4 + 4) + (R + 1) * 4 + 2 * R * C * 4
             ach = alg_bytes / avg_s / 1e9
@@ -222,6 +226,8 @@ def main():
                     roof["traffic"] = json.loads(tf.read_text()).get("nnconv_hbm_bytes_per_launch")
                 except Exception:
                     pass
+        for k in kernels:
+            kernels[k]["ms_per_step"] = tm[k][0] / a.steps
         if "edge_mlp_gemm2" in kernels:
             # all launches of a step count (capacity-sized chunks past *num_edges exit at once)
             step_s = tm["edge_mlp_gemm2"][0] * 1e-3 / a.steps
@@ -256,7 +262,7 @@ def main():
                        "edges_first_last": [int(eps[0].item()), int(eps[-1].item())], "edge_cap": cap,
                        "parallelism": f"ensemble-sharded x{world}, one all-gather of trajectories",
                        "launch": "plain" if a.no_graph else "hipGraph replay", "edge_mlp_gemm": a.gemm_mode,
-                       "variant": a.variant},
+                       "variant": a.variant, "conv_mode": a.conv_mode},
             "roofline": roof, "roofline_mfma": roof_mfma, "cpu_baseline": cpu, "kernels": kernels,
         }
         print(json.dumps(line))

@@ -91,6 +91,7 @@ struct GemmArgs {
     long long row_begin;  // global edge index of local row 0
     int rows;             // chunk rows (capacity)
     int N, K;
+    int tiled_out;        // 1: C written k-tiled [rows/128][N/32][128][32] (csrc/factored.hip step (2))
 };
 
 // One K-tile of MFMA work for a wave: 2x2 tiles of 32x32, BK/8 groups of 4 k-steps each.
@@ -202,7 +203,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_mfma_kernel(GemmArgs g) {
                 if (m < valid) {
                     float v = acc[i][j][r] + bv;
                     if (RELU) v = fmaxf(v, 0.f);
-                    g.C[(size_t)m * g.N + n] = v;
+                    if (g.tiled_out)
+                        g.C[((size_t)(m >> 7) * (g.N >> 5) + (n >> 5)) * 4096 + (m & 127) * 32 + (n & 31)] = v;
+                    else
+                        g.C[(size_t)m * g.N + n] = v;
                 }
             }
         }
@@ -308,10 +312,10 @@ int mdno::edge_mlp(const float* frames, int frame, const int* t_dev, int rows_pe
                                w.w0, w.b0, h1);
         }
         MDNO_TRY(check_launch("edge_l0_kernel"));
-        GemmArgs g1{h1, w.w1, w.b1, h2, num_edges, e0, (int)chunk, ker_width, ker_width};
+        GemmArgs g1{h1, w.w1, w.b1, h2, num_edges, e0, (int)chunk, ker_width, ker_width, 0};
         MDNO_TRY(launch_gemm<true>(g1, s));
         // the last layer writes straight into W_e; rows past *num_edges are masked by `valid`
-        GemmArgs g2{h2, w.w2, w.b2, w_e + (size_t)e0 * out_dim, num_edges, e0, (int)chunk, out_dim, ker_width};
+        GemmArgs g2{h2, w.w2, w.b2, w_e + (size_t)e0 * out_dim, num_edges, e0, (int)chunk, out_dim, ker_width, 0};
         MDNO_TRY(launch_gemm<false>(g2, s));
     }
     return MDNO_OK;
@@ -332,6 +336,8 @@ int mdno::edge_mlp_hidden(const float* frames, int frame, const int* t_dev, int 
     if (gemm_mode == MDNO_GEMM_SPLIT_BF16 && edge_mlp_split_supported(ker_width, ker_width))
         return edge_mlp_split_hidden(frames, frame, t_dev, rows_per_frame, src, dst, edge_attr, perm, num_edges,
                                      edge_cap, chunk, ker_in, ker_width, w, h_out, workspace, s);
+    MDNO_REQUIRE(ker_width % BN == 0 && (reinterpret_cast<uintptr_t>(w.w1) & 15) == 0, MDNO_EUNSUPPORTED,
+                 "edge_mlp_hidden: ker_width=%d must be a multiple of %d", ker_width, BN);
     Carver cv(workspace);
     float* h1 = cv.take<float>((size_t)chunk * ker_width);
     const float* pos_mode = edge_attr ? nullptr : frames;
@@ -344,7 +350,7 @@ int mdno::edge_mlp_hidden(const float* frames, int frame, const int* t_dev, int 
                                w.w0, w.b0, h1);
         }
         MDNO_TRY(check_launch("edge_l0_kernel"));
-        GemmArgs g1{h1, w.w1, w.b1, h_out + (size_t)e0 * ker_width, num_edges, e0, (int)chunk, ker_width, ker_width};
+        GemmArgs g1{h1, w.w1, w.b1, h_out + (size_t)e0 * ker_width, num_edges, e0, (int)chunk, ker_width, ker_width, 1};
         MDNO_TRY(launch_gemm<true>(g1, s));
     }
     return MDNO_OK;

@@ -187,7 +187,7 @@ __device__ __forceinline__ void mma_split_stage(f32x16 (&acc)[2][2], const unsig
 }
 
 // OUT: 0 = fp32 row-major (W_e), 1 = tiled bf16 planes after ReLU (next GEMM's operand),
-//      2 = fp32 row-major after ReLU (the hidden activation the factored conv consumes)
+//      2 = fp32 k-tiled [rows/128][N/32][128][32] after ReLU (the hidden activation the factored conv streams)
 template <int TM, int OUT>
 __global__ __launch_bounds__(TM * 2, 2) void gemm_split_bf16_kernel(SplitGemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -282,8 +282,8 @@ __global__ __launch_bounds__(TM * 2, 2) void gemm_split_bf16_kernel(SplitGemmArg
                 const int m = bm + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (m < valid) {
                     const float v = acc[i][j][e] + bv;
-                    if (OUT == 2) {
-                        g.C[(size_t)m * g.N + n] = fmaxf(v, 0.f);
+                    if (OUT == 2) {   // k-tiled fp32 image [m/128][n/32][128][32] (csrc/factored.hip step (2))
+                        g.C[((size_t)(m >> 7) * (g.N >> 5) + (n >> 5)) * 4096 + (m & 127) * 32 + (n & 31)] = fmaxf(v, 0.f);
                     } else if (OUT == 1) {
                         __bf16 ph, pm, pl;
                         split3(fmaxf(v, 0.f), ph, pm, pl);
@@ -408,7 +408,7 @@ int edge_mlp_split_hidden(const float* frames, int frame, const int* t_dev, int 
         }
         MDNO_TRY(check_launch("edge_l0_split_kernel"));
         SplitGemmArgs g1{h1p, w1p, w.b1, h_out + (size_t)e0 * k, nullptr, num_edges, e0, (int)chunk, k, k, 0, 0};
-        MDNO_TRY(launch_split_gemm<2>(g1, KID_GEMM_L1, s));
+        MDNO_TRY(launch_split_gemm<2>(g1, KID_GEMM_L1, s));   // chunk % 128 == 0: tile index continues across chunks
     }
     return MDNO_OK;
 }

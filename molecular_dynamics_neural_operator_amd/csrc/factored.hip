@@ -59,16 +59,18 @@ __device__ __forceinline__ void mma_32x64(f32x16& acc0, f32x16& acc1, const floa
     }
 }
 
-// ---------------------------------------------------------------- W3 [Cin*Cout, k] -> W3T [(o*k + c), i]
+// ---------------------------------------------------------------- W3 [Cin*Cout, k] -> W3T [n', i]
+// Row order n' = (c/32)*(C*32) + o*32 + c%32: the GEMM output row  Y[node][n']  is then already the
+// k-tiled image  [k_tile][o][32]  that step (2) streams as contiguous 8 KiB pieces.
 __global__ __launch_bounds__(256) void w3_transpose_kernel(const float* __restrict__ w3, int C, int k,
                                                            float* __restrict__ w3t) {
-    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;   // over (o, c, i), i fastest
+    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;   // over (n', i), i fastest
     const long long total = (long long)C * k * C;
     if (id >= total) return;
     const int i = (int)(id % C);
-    const long long oc = id / C;
-    const int c = (int)(oc % k), o = (int)(oc / k);
-    w3t[id] = w3[((size_t)i * C + o) * k + c];
+    const long long n = id / C;
+    const int cc = (int)(n % 32), o = (int)((n / 32) % C), kt = (int)(n / (32 * C));
+    w3t[id] = w3[((size_t)i * C + o) * k + kt * 32 + cc];
 }
 
 // ---------------------------------------------------------------- (1) Y = X . W3T^T, rows guarded
@@ -149,75 +151,95 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_guarded_kernel(const float* 
 }
 
 // ---------------------------------------------------------------- (2) grouped: M_j = H_j . Y_j^T + q_j
-// Workgroup (m-tile, source j): rows beg_j + 128*mt .. of H [E,k] against Y_j [64,k] -> M [E,64].
-// Tile 128 x 64 x 32, 4 waves, wave w owns rows 32w..32w+31 and both 32-column halves.
-__global__ __launch_bounds__(256, 2) void gemm_per_source_kernel(const float* __restrict__ Hm,
+// Workgroup (m-tile, source j, k-slice): rows beg_j + 128*mt .. of H [E,k] against Y_j [64,k] over
+// k in [slice*k/KS, (slice+1)*k/KS) -> partial sums Mp[slice][E][64] (added in fixed order by the
+// aggregation kernel; slice 0 carries q_j).  Both operands are stored k-tiled — H as
+// [e/128][k/32][128][32], Y_j as [k/32][64][32] — so a K-tile is one contiguous 16 KiB / 8 KiB run
+// (row-major H cost 128-B granules at a 4 KiB stride: 1.5 TB/s).  Tile 128 x 64 x 32, 4 waves, wave w owns rows
+// 32w..32w+31 and both 32-column halves.  The GEMM reads every H row and every Y_j once and needs
+// 32 flop per H byte, so it sits at the corner of HBM and the fp32 matrix rate: many small
+// workgroups (single LDS buffer, 27 KiB, 5 per CU; k split KS ways) keep enough loads in flight.
+constexpr int KS = 2;
+
+__global__ __launch_bounds__(256, 4) void gemm_per_source_kernel(const float* __restrict__ Hm,
                                                                  const float* __restrict__ Y,
                                                                  const float* __restrict__ x,
                                                                  const float* __restrict__ b3,
                                                                  const int* __restrict__ row_ptr,
-                                                                 float* __restrict__ Mo, int K) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                    // [2][128][LD]
-    float* Bs = smem + 2 * 128 * LD;     // [2][64][LD]
-    const int j = blockIdx.y;
+                                                                 float* __restrict__ Mp, long long part_stride,
+                                                                 int K) {
+    __shared__ __attribute__((aligned(16))) float As[128 * LD];
+    __shared__ __attribute__((aligned(16))) float Bs[64 * LD];
+    // source j is the fastest grid dimension: workgroups are dealt round-robin over the 8 XCDs by
+    // linear id, and with the m-tile fastest (most sources have one tile) 3/4 of the work landed on
+    // two XCDs
+    const int j = blockIdx.x, slice = blockIdx.z;
     const int beg = row_ptr[j], end = row_ptr[j + 1];
-    const int r0 = beg + blockIdx.x * 128;
+    const int r0 = beg + blockIdx.y * 128;
     if (r0 >= end) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int srow = tid >> 3, scol = (tid & 7) * 4;
-    const size_t ldk = (size_t)K;
-    auto arow = [&](int r) { const int rr = r0 + r; return (size_t)(rr < end ? rr : end - 1); };
-    const float* A0 = Hm + arow(srow) * ldk + scol;
-    const float* A1 = Hm + arow(srow + 32) * ldk + scol;
-    const float* A2 = Hm + arow(srow + 64) * ldk + scol;
-    const float* A3 = Hm + arow(srow + 96) * ldk + scol;
-    const float* Bg = Y + ((size_t)j * 64 + srow) * ldk + scol;
+    const int nkt = K / BK, nk = nkt / KS, kt0 = slice * nk;
+    // element (e, kt) of the k-tiled H: ((e>>7)*nkt + kt)*4096 + (e&127)*32 floats; rows past the
+    // group's end re-read its last row (never stored)
+    auto aptr = [&](int r) {
+        const int rr = r0 + r, e = rr < end ? rr : end - 1;
+        return Hm + ((size_t)(e >> 7) * nkt + kt0) * 4096 + (e & 127) * 32 + scol;
+    };
+    const float* A0 = aptr(srow);
+    const float* A1 = aptr(srow + 32);
+    const float* A2 = aptr(srow + 64);
+    const float* A3 = aptr(srow + 96);
+    const float* Bg = Y + (size_t)j * 64 * K + (size_t)kt0 * 2048 + srow * 32 + scol;
     float4 ra0, ra1, ra2, ra3, rb0, rb1;
-#define MDNO_LOAD(KOFF)                                                  \
-    ra0 = *reinterpret_cast<const float4*>(A0 + (KOFF));                 \
-    ra1 = *reinterpret_cast<const float4*>(A1 + (KOFF));                 \
-    ra2 = *reinterpret_cast<const float4*>(A2 + (KOFF));                 \
-    ra3 = *reinterpret_cast<const float4*>(A3 + (KOFF));                 \
-    rb0 = *reinterpret_cast<const float4*>(Bg + (KOFF));                 \
-    rb1 = *reinterpret_cast<const float4*>(Bg + 32 * ldk + (KOFF));
+#define MDNO_LOAD(KT)                                                         \
+    ra0 = *reinterpret_cast<const float4*>(A0 + (size_t)(KT) * 4096);         \
+    ra1 = *reinterpret_cast<const float4*>(A1 + (size_t)(KT) * 4096);         \
+    ra2 = *reinterpret_cast<const float4*>(A2 + (size_t)(KT) * 4096);         \
+    ra3 = *reinterpret_cast<const float4*>(A3 + (size_t)(KT) * 4096);         \
+    rb0 = *reinterpret_cast<const float4*>(Bg + (size_t)(KT) * 2048);         \
+    rb1 = *reinterpret_cast<const float4*>(Bg + (size_t)(KT) * 2048 + 1024);
     float* a_st = As + srow * LD + scol;
     float* b_st = Bs + srow * LD + scol;
-#define MDNO_STORE(BUF)                                                            \
-    *reinterpret_cast<float4*>(a_st + (BUF) * 128 * LD) = ra0;                     \
-    *reinterpret_cast<float4*>(a_st + (BUF) * 128 * LD + 32 * LD) = ra1;           \
-    *reinterpret_cast<float4*>(a_st + (BUF) * 128 * LD + 64 * LD) = ra2;           \
-    *reinterpret_cast<float4*>(a_st + (BUF) * 128 * LD + 96 * LD) = ra3;           \
-    *reinterpret_cast<float4*>(b_st + (BUF) * 64 * LD) = rb0;                      \
-    *reinterpret_cast<float4*>(b_st + (BUF) * 64 * LD + 32 * LD) = rb1;
+#define MDNO_STORE()                                                  \
+    *reinterpret_cast<float4*>(a_st) = ra0;                           \
+    *reinterpret_cast<float4*>(a_st + 32 * LD) = ra1;                 \
+    *reinterpret_cast<float4*>(a_st + 64 * LD) = ra2;                 \
+    *reinterpret_cast<float4*>(a_st + 96 * LD) = ra3;                 \
+    *reinterpret_cast<float4*>(b_st) = rb0;                           \
+    *reinterpret_cast<float4*>(b_st + 32 * LD) = rb1;
     f32x16 acc0, acc1;
 #pragma unroll
     for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
     const float* a_rd = As + (wave * 32 + l31) * LD + 4 * h;
     const float* b_rd = Bs + l31 * LD + 4 * h;
-    const int nk = K / BK;
     MDNO_LOAD(0)
-    MDNO_STORE(0)
+    MDNO_STORE()
     __syncthreads();
     for (int kt = 0; kt < nk - 1; ++kt) {
-        MDNO_LOAD((size_t)(kt + 1) * BK)
-        mma_32x64(acc0, acc1, a_rd + (kt & 1) * 128 * LD, b_rd + (kt & 1) * 64 * LD);
-        MDNO_STORE((kt & 1) ^ 1)
+        MDNO_LOAD(kt + 1)
+        __builtin_amdgcn_sched_barrier(0);      // keep the prefetch above the MFMAs
+        mma_32x64(acc0, acc1, a_rd, b_rd);
+        __syncthreads();
+        MDNO_STORE()
         __syncthreads();
     }
-    mma_32x64(acc0, acc1, a_rd + ((nk - 1) & 1) * 128 * LD, b_rd + ((nk - 1) & 1) * 64 * LD);
+    mma_32x64(acc0, acc1, a_rd, b_rd);
 #undef MDNO_LOAD
 #undef MDNO_STORE
     // q_j[o] = sum_i x_j[i] * b3[i*64 + o] for this lane's two columns (bias of the last MLP layer)
-    const float* xj = x + (size_t)j * 64;
     float q0 = 0.f, q1 = 0.f;
+    if (slice == 0) {
+        const float* xj = x + (size_t)j * 64;
 #pragma unroll 16
-    for (int i = 0; i < 64; ++i) {
-        const float xi = xj[i];
-        q0 = fmaf(xi, b3[i * 64 + l31], q0);
-        q1 = fmaf(xi, b3[i * 64 + 32 + l31], q1);
+        for (int i = 0; i < 64; ++i) {
+            const float xi = xj[i];
+            q0 = fmaf(xi, b3[i * 64 + l31], q0);
+            q1 = fmaf(xi, b3[i * 64 + 32 + l31], q1);
+        }
     }
+    float* Mo = Mp + (size_t)slice * part_stride;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int m = r0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -253,50 +275,77 @@ __global__ __launch_bounds__(256) void reverse_edges_kernel(const int* __restric
 }
 
 // ---------------------------------------------------------------- (3) aggregate + root + bias + act
-__global__ __launch_bounds__(256) void aggregate_rev_kernel(const float* __restrict__ Mo, const int* __restrict__ rev,
+// One wave per destination row; lane = (es, q): four in-edges are gathered per step (es = lane>>4),
+// 16 B of the 64-float message per lane (q = lane&15).  Each es-chain adds its edges in row order
+// (and an edge's KS k-slice partials in slice order); the four chains are combined by two xor
+// shuffles at the end — a fixed order, so the result is deterministic.  The root term x_t.root is
+// accumulated the same way (es picks 16 of the 64 input channels).
+__global__ __launch_bounds__(256) void aggregate_rev_kernel(const float* __restrict__ Mp, long long part_stride,
+                                                            const int* __restrict__ rev,
                                                             const int* __restrict__ row_ptr,
                                                             const float* __restrict__ x,
                                                             const float* __restrict__ root,
                                                             const float* __restrict__ bias, float* __restrict__ y,
                                                             int num_rows, int aggr, int relu) {
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, es = lane >> 4, q = lane & 15;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= num_rows) return;
     const int beg = row_ptr[t], end = row_ptr[t + 1];
     const int deg = end - beg;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // 4 chains, fixed order: deterministic
-    int p = beg;
-    for (; p + 3 < end; p += 4) {
-        s0 += Mo[(size_t)rev[p] * 64 + lane];
-        s1 += Mo[(size_t)rev[p + 1] * 64 + lane];
-        s2 += Mo[(size_t)rev[p + 2] * 64 + lane];
-        s3 += Mo[(size_t)rev[p + 3] * 64 + lane];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = beg + es; p < end; p += 4) {
+        const float* m = Mp + (size_t)rev[p] * 64 + 4 * q;
+        float4 e = *reinterpret_cast<const float4*>(m);
+#pragma unroll
+        for (int k = 1; k < KS; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(m + (size_t)k * part_stride);
+            e.x += v.x; e.y += v.y; e.z += v.z; e.w += v.w;
+        }
+        acc.x += e.x; acc.y += e.y; acc.z += e.z; acc.w += e.w;
     }
-    for (; p < end; ++p) s0 += Mo[(size_t)rev[p] * 64 + lane];
-    float s = (s0 + s1) + (s2 + s3);
-    if (aggr == MDNO_AGGR_MEAN) s = s / (float)(deg > 1 ? deg : 1);
+    float4 racc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (root != nullptr) {
-        const float* xr = x + (size_t)t * 64;
-        float rs = 0.f;
-#pragma unroll 16
-        for (int i = 0; i < 64; ++i) rs = fmaf(xr[i], root[i * 64 + lane], rs);
-        s += rs;
+        const float* xr = x + (size_t)t * 64 + 16 * es;
+        const float* rp = root + (16 * es) * 64 + 4 * q;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float xi = xr[i];
+            const float4 w = *reinterpret_cast<const float4*>(rp + i * 64);
+            racc.x = fmaf(xi, w.x, racc.x); racc.y = fmaf(xi, w.y, racc.y);
+            racc.z = fmaf(xi, w.z, racc.z); racc.w = fmaf(xi, w.w, racc.w);
+        }
     }
-    if (bias != nullptr) s += bias[lane];
-    if (relu) s = fmaxf(s, 0.f);
-    y[(size_t)t * 64 + lane] = s;
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+        acc.x += __shfl_xor(acc.x, o); acc.y += __shfl_xor(acc.y, o);
+        acc.z += __shfl_xor(acc.z, o); acc.w += __shfl_xor(acc.w, o);
+        racc.x += __shfl_xor(racc.x, o); racc.y += __shfl_xor(racc.y, o);
+        racc.z += __shfl_xor(racc.z, o); racc.w += __shfl_xor(racc.w, o);
+    }
+    if (es == 0) {
+        const float inv = (float)(deg > 1 ? deg : 1);
+        float4 s = acc;
+        if (aggr == MDNO_AGGR_MEAN) { s.x /= inv; s.y /= inv; s.z /= inv; s.w /= inv; }
+        s.x += racc.x; s.y += racc.y; s.z += racc.z; s.w += racc.w;
+        if (bias != nullptr) {
+            const float4 b = *reinterpret_cast<const float4*>(bias + 4 * q);
+            s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+        }
+        if (relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
+        *reinterpret_cast<float4*>(y + (size_t)t * 64 + 4 * q) = s;
+    }
 }
 
 }  // namespace
 
 // ---------------------------------------------------------------- host side
-bool factored_supported(int width, int ker_width) { return width == 64 && ker_width % 128 == 0; }
+bool factored_supported(int width, int ker_width) { return width == 64 && ker_width % (KS * BK) == 0; }
 
 size_t factored_workspace_bytes(int num_rows, int ker_width, long long edge_cap) {
     Carver cv(nullptr);
     cv.take<float>((size_t)64 * ker_width * 64);               // W3T
     cv.take<float>((size_t)num_rows * 64 * ker_width);         // Y
-    cv.take<float>((size_t)edge_cap * 64);                     // M
+    cv.take<float>((size_t)KS * edge_cap * 64);                // M: KS k-slice partials
     cv.take<int>((size_t)edge_cap);                            // rev
     return cv.used();
 }
@@ -306,7 +355,8 @@ FactoredWs factored_carve(void* ws, int num_rows, int ker_width, long long edge_
     Carver cv(ws);
     f.w3t = cv.take<float>((size_t)64 * ker_width * 64);
     f.y = cv.take<float>((size_t)num_rows * 64 * ker_width);
-    f.m = cv.take<float>((size_t)edge_cap * 64);
+    f.m = cv.take<float>((size_t)KS * edge_cap * 64);
+    f.part_stride = (long long)edge_cap * 64;
     f.rev = cv.take<int>((size_t)edge_cap);
     return f;
 }
@@ -331,12 +381,9 @@ int factored_conv(const float* x, const float* h2, const int* row_ptr, int num_r
                   const FactoredWs& f, hipStream_t s) {
     static bool attr_set = false;
     const size_t lds1 = sizeof(float) * 2 * 256 * LD;   // 73,728 B
-    const size_t lds2 = sizeof(float) * 2 * 192 * LD;   // 55,296 B
     if (!attr_set) {
         MDNO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rows_guarded_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-        MDNO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_per_source_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
         attr_set = true;
     }
     const int ncols = 64 * ker_width;
@@ -347,13 +394,13 @@ int factored_conv(const float* x, const float* h2, const int* row_ptr, int num_r
     }
     {
         TimedSection ts(KID_NNCONV, s);
-        hipLaunchKernelGGL(gemm_per_source_kernel, dim3((max_degree + 127) / 128, num_rows), dim3(256), lds2, s, h2,
-                           (const float*)f.y, x, b3, row_ptr, f.m, ker_width);
+        hipLaunchKernelGGL(gemm_per_source_kernel, dim3(num_rows, (max_degree + 127) / 128, KS), dim3(256), 0, s, h2,
+                           (const float*)f.y, x, b3, row_ptr, f.m, f.part_stride, ker_width);
     }
     {
         TimedSection ts(KID_NNCONV_COMBINE, s);
         hipLaunchKernelGGL(aggregate_rev_kernel, dim3((num_rows + 3) / 4), dim3(256), 0, s, (const float*)f.m,
-                           (const int*)f.rev, row_ptr, x, root, bias, y, num_rows, aggr, relu);
+                           f.part_stride, (const int*)f.rev, row_ptr, x, root, bias, y, num_rows, aggr, relu);
     }
     return check_launch("factored_conv");
 }

@@ -57,6 +57,7 @@ int edge_mlp_split_hidden(const float* frames, int frame, const int* t_dev, int 
 struct FactoredWs {
     float *w3t, *y, *m;
     int* rev;
+    long long part_stride;
 };
 bool factored_supported(int width, int ker_width);
 size_t factored_workspace_bytes(int num_rows, int ker_width, long long edge_cap);

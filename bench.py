@@ -64,7 +64,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="plain launches instead of hipGraph replay")
     ap.add_argument("--gemm-mode", choices=["split_bf16", "f32"], default="split_bf16",
                     help="edge-MLP GEMMs: exact 3-way bf16 split (6 products, fp32 accumulate) or fp32-input MFMA")
-    ap.add_argument("--conv-mode", choices=["materialized", "factored"], default="materialized",
+    ap.add_argument("--single-mode", action="store_true", help="skip the comparison leg in the other conv mode")
+    ap.add_argument("--conv-mode", choices=["materialized", "factored"], default="factored",
                     help="materialized = W_e written once and streamed by every conv application (the reference's "
                          "formulation); factored = same sums reassociated per node, W_e never formed")
     ap.add_argument("--variant", choices=["intree", "notebook"], default="intree",
@@ -195,55 +196,108 @@ def main():
     frames = a.steps * total_members
     value = frames / elapsed
 
-    # ---- roofline leg: K more steps, plain launches bracketed by HIP events on the launch stream
-    roof = roof_mfma = None
+    # ---- roofline leg: K more steps of the SAME rollout, plain launches bracketed by HIP events on
+    # the launch stream (events cannot sit inside a hipGraph replay)
+    roofs = {}
     kernels = {}
+    other_mode = None
+    R, C, KW = M * N, a.width, a.kernel_width
+
+    def timed_leg(engine, first_step):
+        engine.attach_timer(a.steps * (6 * a.depth + 20))
+        engine.step(a.steps)
+        tm = engine.read_timer()
+        engine.detach_timer()
+        engine.synchronize()
+        e = float(engine.edges_per_step[first_step:first_step + a.steps].double().mean().item())
+        ks = {k: {"avg_ms": ms / n, "launches": int(n), "ms_per_step": ms / a.steps} for k, (ms, n) in tm.items() if n}
+        return ks, e
+
+    def conv_roofline(ks, e):      # the metric's kernel: gather -> per-edge matvec -> scatter-mean, HBM-bound
+        avg_s = ks["nnconv"]["avg_ms"] * 1e-3
+        alg = e * (C * C * 4 + 4) + (R + 1) * 4 + 2 * R * C * 4
+        r = {"bound": "hbm", "kernel": "nnconv64_row_kernel", "conv_mode": "materialized", "achieved": alg / avg_s / 1e9,
+             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / avg_s / 1e9 / HBM_PEAK_GBS,
+             "frac_of_measured_copy_peak": alg / avg_s / 1e9 / HBM_COPY_GBS, "traffic": None,
+             "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_s * 1e3, "edges_per_launch": e,
+             "rows_per_launch": R}
+        tf = REPO / "profiles" / "roofline_traffic.json"
+        if tf.exists():
+            try:
+                r["traffic"] = json.loads(tf.read_text()).get("nnconv_hbm_bytes_per_launch")
+            except Exception:
+                pass
+        return r
+
+    def gemm_roofline(ks, e, which, n_out):
+        step_s = ks[which]["ms_per_step"] * 1e-3     # all launches of a step (capacity-sized chunks past E exit at once)
+        flops32 = 2.0 * e * KW * n_out                # fp32-equivalent work
+        if a.gemm_mode == "f32":
+            return {"bound": "mfma", "kernel": "gemm_tn_mfma_kernel", "achieved": flops32 / step_s / 1e12,
+                    "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops32 / step_s / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                    "ms_per_step": step_s * 1e3}
+        ach = 6.0 * flops32 / step_s / 1e12           # 6 bf16 plane products executed per fp32 product
+        return {"bound": "mfma", "kernel": "gemm_split_bf16_kernel", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "fp32_equivalent_tflops": flops32 / step_s / 1e12,
+                "ms_per_step": step_s * 1e3,
+                "note": "executed bf16 MFMA flops (6 plane products per fp32 product) vs dense bf16 peak"}
+
+    def per_source_roofline(ks, e):   # factored path: M_j = H_j . Y_j^T, one launch per conv application
+        avg_s = ks["nnconv"]["avg_ms"] * 1e-3
+        alg = e * KW * 4 + R * C * KW * 4 + 2 * e * C * 4 + (R + 1) * 4        # H once + Y once + 2 k-slice partials out
+        flops = 2.0 * e * KW * C
+        t_hbm, t_mfma = alg / (HBM_PEAK_GBS * 1e9), flops / (MFMA_F32_PEAK_TFLOPS * 1e12)
+        r = {"kernel": "gemm_per_source_kernel", "conv_mode": "factored", "avg_launch_ms": avg_s * 1e3,
+             "algorithmic_bytes_per_launch": alg, "flops_per_launch": flops, "traffic": None,
+             "hbm_GBps": alg / avg_s / 1e9, "hbm_frac": alg / avg_s / 1e9 / HBM_PEAK_GBS,
+             "mfma_TFLOPs": flops / avg_s / 1e12, "mfma_frac": flops / avg_s / 1e12 / MFMA_F32_PEAK_TFLOPS}
+        if t_hbm >= t_mfma:
+            r.update(bound="hbm", achieved=r["hbm_GBps"], peak=HBM_PEAK_GBS, unit="GB/s", frac=r["hbm_frac"])
+        else:
+            r.update(bound="mfma", achieved=r["mfma_TFLOPs"], peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=r["mfma_frac"])
+        return r
+
     if not a.skip_roofline:
-        launches_per_step = 6 * a.depth + 16
-        eng.attach_timer(a.steps * (launches_per_step + 4))
-        eng.step(a.steps)
-        tm = eng.read_timer()
-        eng.detach_timer()
-        eng.synchronize()
-        eps2 = eng.edges_per_step[a.warmup + a.steps:a.warmup + 2 * a.steps].double()
-        e2 = float(eps2.mean().item())
-        R = M * N
-        C = a.width
-        for k, (ms, n) in tm.items():
-            if n:
-                kernels[k] = {"avg_ms": ms / n, "launches": int(n)}
-        if "nnconv" in kernels and a.conv_mode == "materialized":
-            avg_s = kernels["nnconv"]["avg_ms"] * 1e-3
-            alg_bytes = e2 * (C * C * 4 + 4) + (R + 1) * 4 + 2 * R * C * 4
-            ach = alg_bytes / avg_s / 1e9
-            roof = {"bound": "hbm", "kernel": "nnconv64_row_kernel", "achieved": ach, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "frac_of_measured_copy_peak": ach / HBM_COPY_GBS,
-                    "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_s * 1e3,
-                    "edges_per_launch": e2, "rows_per_launch": R}
-            tf = REPO / "profiles" / "roofline_traffic.json"
-            if tf.exists():
-                try:
-                    roof["traffic"] = json.loads(tf.read_text()).get("nnconv_hbm_bytes_per_launch")
-                except Exception:
-                    pass
-        for k in kernels:
-            kernels[k]["ms_per_step"] = tm[k][0] / a.steps
-        if "edge_mlp_gemm2" in kernels:
-            # all launches of a step count (capacity-sized chunks past *num_edges exit at once)
-            step_s = tm["edge_mlp_gemm2"][0] * 1e-3 / a.steps
-            flops32 = 2.0 * e2 * a.kernel_width * C * C                        # fp32-equivalent work
-            kernels["edge_mlp_gemm2"]["ms_per_step"] = step_s * 1e3
-            kernels["edge_mlp_gemm1"]["ms_per_step"] = tm["edge_mlp_gemm1"][0] / a.steps
-            if a.gemm_mode == "f32":
-                roof_mfma = {"bound": "mfma", "kernel": "gemm_tn_mfma_kernel<false>", "achieved": flops32 / step_s / 1e12,
-                             "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": flops32 / step_s / 1e12 / MFMA_F32_PEAK_TFLOPS, "ms_per_step": step_s * 1e3}
+        kernels, e2 = timed_leg(eng, a.warmup + a.steps)
+        if a.conv_mode == "materialized":
+            roofs["conv_materialized"] = conv_roofline(kernels, e2)
+            roofs["edge_mlp_last_gemm"] = gemm_roofline(kernels, e2, "edge_mlp_gemm2", C * C)
+        else:
+            roofs["conv_factored_per_source_gemm"] = per_source_roofline(kernels, e2)
+        roofs["edge_mlp_hidden_gemm"] = gemm_roofline(kernels, e2, "edge_mlp_gemm1", KW)
+        # ---- the other conv formulation on the same start window: frames/s and, for the materialised
+        # one, the HBM roofline of the gather/matvec/scatter kernel BASELINE.json's target is stated on
+        if a.variant == "intree" and not a.single_mode:
+            om = "materialized" if a.conv_mode == "factored" else "factored"
+            model.conv_mode = om
+            eng2 = RolloutEngine(model, M, N, W, a.threshold, max_steps=a.warmup + 2 * a.steps, edge_cap=cap, device=dev,
+                                 use_graph=not a.no_graph)
+            eng2.reset(torch.from_numpy(wins), aa)
+            eng2.step(a.warmup)
+            eng2.synchronize()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            eng2.step(a.steps)
+            eng2.stream.synchronize()
+            dt = time.perf_counter() - t0
+            k2, e3 = timed_leg(eng2, a.warmup + a.steps)
+            other_mode = {"conv_mode": om, "frames_per_s_this_rank": a.steps * M / dt, "ms_per_step": dt / a.steps * 1e3,
+                          "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in k2.items()}}
+            if om == "materialized":
+                roofs["conv_materialized"] = conv_roofline(k2, e3)
+                roofs["edge_mlp_last_gemm"] = gemm_roofline(k2, e3, "edge_mlp_gemm2", C * C)
             else:
-                ach = 6.0 * flops32 / step_s / 1e12                            # 6 bf16 plane products executed
-                roof_mfma = {"bound": "mfma", "kernel": "gemm_split_bf16_kernel<false>", "achieved": ach,
-                             "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
-                             "fp32_equivalent_tflops": flops32 / step_s / 1e12, "ms_per_step": step_s * 1e3,
-                             "note": "executed bf16 MFMA flops (6 plane products per fp32 product) vs dense bf16 peak"}
+                roofs["conv_factored_per_source_gemm"] = per_source_roofline(k2, e3)
+            eng2.close()
+            model.conv_mode = a.conv_mode
+    # "roofline" = the dominant kernel of the TIMED path
+    dominant = None
+    if kernels:
+        name = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+        dominant = {"nnconv": roofs.get("conv_materialized" if a.conv_mode == "materialized"
+                                        else "conv_factored_per_source_gemm"),
+                    "edge_mlp_gemm2": roofs.get("edge_mlp_last_gemm"),
+                    "edge_mlp_gemm1": roofs.get("edge_mlp_hidden_gemm")}.get(name)
 
     cpu = None
     if rank == 0 and world == 1 and not a.skip_cpu_baseline and a.variant == "intree":
@@ -263,7 +317,8 @@ def main():
                        "parallelism": f"ensemble-sharded x{world}, one all-gather of trajectories",
                        "launch": "plain" if a.no_graph else "hipGraph replay", "edge_mlp_gemm": a.gemm_mode,
                        "variant": a.variant, "conv_mode": a.conv_mode},
-            "roofline": roof, "roofline_mfma": roof_mfma, "cpu_baseline": cpu, "kernels": kernels,
+            "roofline": dominant, "rooflines": roofs, "other_conv_mode": other_mode, "cpu_baseline": cpu,
+            "kernels": kernels,
         }
         print(json.dumps(line))
     eng.close()

@@ -217,15 +217,18 @@ __global__ __launch_bounds__(256, 4) void gemm_per_source_kernel(const float* __
     MDNO_LOAD(0)
     MDNO_STORE()
     __syncthreads();
+    // a wave whose 32 rows all lie past the group's end stages data but issues no MFMAs (the
+    // matrix pipe of its SIMD goes to other workgroups): padding costs per 32 rows, not per 128
+    const bool rows_live = __builtin_amdgcn_readfirstlane(r0 + wave * 32) < end;
     for (int kt = 0; kt < nk - 1; ++kt) {
         MDNO_LOAD(kt + 1)
         __builtin_amdgcn_sched_barrier(0);      // keep the prefetch above the MFMAs
-        mma_32x64(acc0, acc1, a_rd, b_rd);
+        if (rows_live) mma_32x64(acc0, acc1, a_rd, b_rd);
         __syncthreads();
         MDNO_STORE()
         __syncthreads();
     }
-    mma_32x64(acc0, acc1, a_rd, b_rd);
+    if (rows_live) mma_32x64(acc0, acc1, a_rd, b_rd);
 #undef MDNO_LOAD
 #undef MDNO_STORE
     // q_j[o] = sum_i x_j[i] * b3[i*64 + o] for this lane's two columns (bias of the last MLP layer)

@@ -201,10 +201,11 @@ class KernelNN(nn.Module):
         # "f32" = fp32-input MFMA, bit-for-bit an fmaf chain
         self.gemm_mode = "split_bf16"
         # how conv applications run inside the on-device rollout / position-graph forward
-        # (include/mdno.h MDNO_CONV_*): "materialized" = the reference's W_e formulation;
-        # "factored" = same sums reassociated per node, no W_e (csrc/factored.hip).  forward(data)
-        # with an explicit edge_index/edge_attr always runs materialized.
-        self.conv_mode = "materialized"
+        # (include/mdno.h MDNO_CONV_*): "factored" (default) = the reference's sums reassociated per
+        # node, W_e never formed (csrc/factored.hip; needs width 64 and a radius graph built by the
+        # library, otherwise the library itself runs materialized); "materialized" = the reference's
+        # W_e formulation.  forward(data) with an explicit edge_index/edge_attr always runs materialized.
+        self.conv_mode = "factored"
 
     # -- parameter pack (device pointers) cached until a parameter changes
     def param_pack(self, device=None, conv_mode: Optional[str] = None) -> ops.ParamPack:
@@ -262,10 +263,11 @@ class KernelNNNotebook(KernelNN):
         self._pack_key = None
         self.gemm_mode = "split_bf16"
         # how conv applications run inside the on-device rollout / position-graph forward
-        # (include/mdno.h MDNO_CONV_*): "materialized" = the reference's W_e formulation;
-        # "factored" = same sums reassociated per node, no W_e (csrc/factored.hip).  forward(data)
-        # with an explicit edge_index/edge_attr always runs materialized.
-        self.conv_mode = "materialized"
+        # (include/mdno.h MDNO_CONV_*): "factored" (default) = the reference's sums reassociated per
+        # node, W_e never formed (csrc/factored.hip; needs width 64 and a radius graph built by the
+        # library, otherwise the library itself runs materialized); "materialized" = the reference's
+        # W_e formulation.  forward(data) with an explicit edge_index/edge_attr always runs materialized.
+        self.conv_mode = "factored"
 
 
 # --------------------------------------------------------------------------- graph construction

@@ -104,7 +104,12 @@ class RolloutEngine:
         if self.M != 1 or self.steps_done != 0:
             raise MdnoError("first_step_from_sample: needs M == 1 and a freshly reset engine")
         graph = ops.coo_to_csr(edge_index.to(self.device), self.N)
-        out, _ = ops.kernelnn_forward(self.pack, self.traj[:self.W], self.aa, graph,
+        # an explicit edge list always runs the materialised formulation
+        pack = self.pack
+        if pack.conv_mode != "materialized":
+            pack = ops.ParamPack({v: pack.tensors[k] for k, v in ops.ParamPack.KEYS.items() if k in pack.tensors},
+                                 pack.struct.depth, self.device, pack.gemm_mode, "materialized")
+        out, _ = ops.kernelnn_forward(pack, self.traj[:self.W], self.aa, graph,
                                       edge_attr=edge_attr.to(self.device))
         self.traj[self.W, 0].copy_(out)
         self.edges_per_step[0] = int(edge_index.shape[1])

@@ -251,6 +251,12 @@ def main():
              "algorithmic_bytes_per_launch": alg, "flops_per_launch": flops, "traffic": None,
              "hbm_GBps": alg / avg_s / 1e9, "hbm_frac": alg / avg_s / 1e9 / HBM_PEAK_GBS,
              "mfma_TFLOPs": flops / avg_s / 1e12, "mfma_frac": flops / avg_s / 1e12 / MFMA_F32_PEAK_TFLOPS}
+        tf = REPO / "profiles" / "roofline_traffic.json"
+        if tf.exists():
+            try:
+                r["traffic"] = json.loads(tf.read_text()).get("per_source_gemm_hbm_bytes_per_launch")
+            except Exception:
+                pass
         if t_hbm >= t_mfma:
             r.update(bound="hbm", achieved=r["hbm_GBps"], peak=HBM_PEAK_GBS, unit="GB/s", frac=r["hbm_frac"])
         else:

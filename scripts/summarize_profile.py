@@ -56,11 +56,13 @@ if pmc:
             d["hbm_bytes_per_launch_corrected"] = 2.0 * f * 1024 + w * 1024
     (out / f"{tag}_pmc.json").write_text(json.dumps(pmc, indent=1, sort_keys=True))
     print("wrote", out / f"{tag}_pmc.json")
-    k = "nnconv64_row_kernel"
-    if k in pmc and "hbm_bytes_per_launch_corrected" in pmc[k]:
-        (out / "roofline_traffic.json").write_text(json.dumps({
-            "source": f"profiles/{tag}_pmc.json",
-            "nnconv_hbm_bytes_per_launch": pmc[k]["hbm_bytes_per_launch_corrected"],
-            "note": "2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 read-side correction), separate --pmc passes"},
-            indent=1))
-        print("wrote profiles/roofline_traffic.json")
+    def corrected(prefix):
+        n = next((n for n in pmc if n.startswith(prefix) and "hbm_bytes_per_launch_corrected" in pmc[n]), None)
+        return None if n is None else pmc[n]["hbm_bytes_per_launch_corrected"]
+
+    traffic = {"source": f"profiles/{tag}_pmc.json",
+               "nnconv_hbm_bytes_per_launch": corrected("nnconv64_row_kernel"),
+               "per_source_gemm_hbm_bytes_per_launch": corrected("gemm_per_source_kernel"),
+               "note": "2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 read-side correction), separate --pmc passes"}
+    (out / "roofline_traffic.json").write_text(json.dumps(traffic, indent=1))
+    print("wrote profiles/roofline_traffic.json")

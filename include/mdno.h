@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDNO_ABI_VERSION 3
+#define MDNO_ABI_VERSION 4
 
 #define MDNO_OK            0
 #define MDNO_EINVAL       -1   /* bad argument (null pointer, non-positive size, unsupported dim) */
@@ -66,6 +66,7 @@ extern "C" {
 #define MDNO_STATUS_EDGE_OVERFLOW 1   /* radius graph found more than edge_cap edges; list truncated */
 #define MDNO_STATUS_BAD_AMINOACID 2   /* x_aminoacid outside [0, num_embeddings) */
 #define MDNO_STATUS_ASYMMETRIC_GRAPH 4 /* factored conv: an edge has no reverse edge */
+#define MDNO_STATUS_DEGREE_OVERFLOW  8 /* factored conv: a node has more edges than the max_degree bound */
 
 int         mdno_abi_version(void);
 const char* mdno_last_error(void);
@@ -173,7 +174,9 @@ int mdno_fc_out_fwd(const float* x, const float* w, const float* b, int rows, in
  * Whole forward — replaces KernelNN.forward (graph_kernel.py:277-309) for M independent samples
  * (B=1 semantics each).  frames f32 [W,M,N,3].  Graph given as CSR over the M*N rows; edge
  * attributes by (a) edge_pos f32 [M*N,3] (the frame the graph was built on) or (b) edge_attr
- * (+perm), as in mdno_edge_mlp_fwd.  out f32 [M*N,out_width]; latent f32 [M*N,width] (the
+ * (+perm), as in mdno_edge_mlp_fwd.  max_degree: an upper bound on any node's degree, used to size
+ * the factored conv's grid (0 = N, always safe; give a tighter bound for large N — exceeding it sets
+ * MDNO_STATUS_DEGREE_OVERFLOW).  out f32 [M*N,out_width]; latent f32 [M*N,width] (the
  * return_latent=True output, :303) may be NULL.
  * Workspace: mdno_kernelnn_workspace_bytes(p, M, N, edge_cap).
  * ---------------------------------------------------------------------------------------- */
@@ -181,7 +184,7 @@ size_t mdno_kernelnn_workspace_bytes(const mdno_kernelnn_params* p, int M, int N
 int mdno_kernelnn_fwd(const mdno_kernelnn_params* p, const float* frames, int M, int W, int N,
                       const int64_t* x_aminoacid, int aa_per_member,
                       const int32_t* row_ptr, const int32_t* src, const int32_t* dst,
-                      const int32_t* num_edges, int64_t edge_cap,
+                      const int32_t* num_edges, int64_t edge_cap, int max_degree,
                       const float* edge_pos, const float* edge_attr, const int32_t* perm,
                       float* out, float* latent, void* workspace, size_t workspace_bytes,
                       int32_t* status, void* stream);
@@ -207,12 +210,13 @@ int mdno_rollout(const mdno_kernelnn_params* p, float* traj, int M, int W, int N
  * executes), then any range of steps is replayed without re-capturing and without synchronising.
  *   traj f32 [W+max_steps, M, N, 3]; run(start_step, steps) produces frames W+start_step ..
  *   W+start_step+steps-1 from the frames before them.  The plan keeps a copy of *p (the weight
- *   pointers must stay valid) and must be destroyed only after its enqueued work has completed. */
+ *   pointers must stay valid) and must be destroyed only after its enqueued work has completed.
+ *   max_degree as in mdno_kernelnn_fwd (0 = N). */
 typedef struct mdno_rollout_plan mdno_rollout_plan;
 int mdno_rollout_plan_create(mdno_rollout_plan** plan, const mdno_kernelnn_params* p, float* traj,
                              int M, int W, int N, int max_steps,
                              const int64_t* x_aminoacid, int aa_per_member, double threshold,
-                             int64_t edge_cap, void* workspace, size_t workspace_bytes,
+                             int64_t edge_cap, int max_degree, void* workspace, size_t workspace_bytes,
                              int32_t* edges_per_step, int32_t* status, int use_graph, void* stream);
 int mdno_rollout_plan_run(mdno_rollout_plan* plan, int start_step, int steps, void* stream);
 int mdno_rollout_plan_destroy(mdno_rollout_plan* plan);

@@ -14,10 +14,11 @@ LIB_PATH = Path(os.environ.get("MDNO_LIB", _HERE / "libmdno.so"))
 OK, EINVAL, ELAUNCH, EWORKSPACE, EUNSUPPORTED = 0, -1, -2, -3, -4
 AGGR = {"add": 0, "mean": 1}
 STATUS_EDGE_OVERFLOW, STATUS_BAD_AMINOACID = 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 GEMM_MODES = {"split_bf16": 0, "f32": 1}
 CONV_MODES = {"materialized": 0, "factored": 1}
 STATUS_ASYMMETRIC_GRAPH = 4
+STATUS_DEGREE_OVERFLOW = 8
 
 
 class MdnoError(RuntimeError):
@@ -55,11 +56,11 @@ SIGNATURES = {
     "mdno_node_prologue_fwd": (_I, [C.POINTER(KernelNNParams), _P, _I, _I, _I, _P, _I, _P, _P, _P]),
     "mdno_fc_out_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
     "mdno_kernelnn_workspace_bytes": (_SZ, [C.POINTER(KernelNNParams), _I, _I, _L]),
-    "mdno_kernelnn_fwd": (_I, [C.POINTER(KernelNNParams), _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _L,
+    "mdno_kernelnn_fwd": (_I, [C.POINTER(KernelNNParams), _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _L, _I,
                                _P, _P, _P, _P, _P, _P, _SZ, _P, _P]),
     "mdno_rollout_workspace_bytes": (_SZ, [C.POINTER(KernelNNParams), _I, _I, _L]),
     "mdno_rollout": (_I, [C.POINTER(KernelNNParams), _P, _I, _I, _I, _I, _P, _I, _D, _L, _P, _SZ, _P, _P, _I, _P]),
-    "mdno_rollout_plan_create": (_I, [C.POINTER(_P), C.POINTER(KernelNNParams), _P, _I, _I, _I, _I, _P, _I, _D, _L,
+    "mdno_rollout_plan_create": (_I, [C.POINTER(_P), C.POINTER(KernelNNParams), _P, _I, _I, _I, _I, _P, _I, _D, _L, _I,
                                       _P, _SZ, _P, _P, _I, _P]),
     "mdno_rollout_plan_run": (_I, [_P, _I, _I, _P]),
     "mdno_rollout_plan_destroy": (_I, [_P]),

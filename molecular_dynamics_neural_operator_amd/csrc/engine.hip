@@ -109,7 +109,7 @@ FwdWs carve_fwd(void* ws, const mdno_kernelnn_params* p, int M, int N, long long
 // frames/t0/t_dev address the window; edge_frames/edge_frame the frame the graph was built on.
 int forward_impl(const mdno_kernelnn_params* p, const float* frames, int t0, const int* t_dev, int M, int W, int N,
                  const long long* aa, int aa_per_member, const int* row_ptr, const int* src, const int* dst,
-                 const int* num_edges, long long edge_cap, const float* edge_frames, int edge_frame,
+                 const int* num_edges, long long edge_cap, int max_degree, const float* edge_frames, int edge_frame,
                  const float* edge_attr, const int* perm, float* out_frames, int t_out, float* latent,
                  const FwdWs& ws, int* status, hipStream_t s) {
     const int R = M * N, C = p->width;
@@ -139,8 +139,8 @@ int forward_impl(const mdno_kernelnn_params* p, const float* frames, int t0, con
             const float* root = block == 0 ? p->conv1_root : p->conv2_root;
             const float* bias = block == 0 ? p->conv1_bias : p->conv2_bias;
             for (int d = 0; d < p->depth; ++d) {
-                MDNO_TRY(factored_conv(cur, ws.h2, row_ptr, R, N, p->ker_width, b3, root, bias, MDNO_AGGR_MEAN,
-                                       /*relu=*/1, nxt, fw, s));
+                MDNO_TRY(factored_conv(cur, ws.h2, row_ptr, R, max_degree > 0 ? max_degree : N, p->ker_width, b3, root,
+                                       bias, MDNO_AGGR_MEAN, /*relu=*/1, nxt, fw, status, s));
                 float* t = cur; cur = nxt; nxt = t;
             }
         }
@@ -210,7 +210,7 @@ extern "C" size_t mdno_kernelnn_workspace_bytes(const mdno_kernelnn_params* p, i
 extern "C" int mdno_kernelnn_fwd(const mdno_kernelnn_params* p, const float* frames, int M, int W, int N,
                                  const int64_t* x_aminoacid, int aa_per_member, const int32_t* row_ptr,
                                  const int32_t* src, const int32_t* dst, const int32_t* num_edges,
-                                 int64_t edge_cap, const float* edge_pos, const float* edge_attr,
+                                 int64_t edge_cap, int max_degree, const float* edge_pos, const float* edge_attr,
                                  const int32_t* perm, float* out, float* latent, void* workspace,
                                  size_t workspace_bytes, int32_t* status, void* stream) {
     MDNO_TRY(validate_params(p));
@@ -221,8 +221,8 @@ extern "C" int mdno_kernelnn_fwd(const mdno_kernelnn_params* p, const float* fra
     MDNO_REQUIRE(workspace_bytes >= ws.total, MDNO_EWORKSPACE, "mdno_kernelnn_fwd: workspace %zu < %zu",
                  workspace_bytes, ws.total);
     return forward_impl(p, frames, 0, nullptr, M, W, N, (const long long*)x_aminoacid, aa_per_member, row_ptr, src,
-                        dst, num_edges, (long long)edge_cap, edge_pos, 0, edge_attr, perm, out, 0, latent, ws, status,
-                        static_cast<hipStream_t>(stream));
+                        dst, num_edges, (long long)edge_cap, max_degree, edge_pos, 0, edge_attr, perm, out, 0, latent, ws,
+                        status, static_cast<hipStream_t>(stream));
 }
 
 extern "C" size_t mdno_rollout_workspace_bytes(const mdno_kernelnn_params* p, int M, int N, int64_t edge_cap) {
@@ -244,6 +244,7 @@ struct mdno_rollout_plan {
     int aa_per_member;
     double threshold;
     long long edge_cap;
+    int max_degree;
     RolloutWs r;
     FwdWs fw;
     int* edges_per_step;
@@ -259,8 +260,8 @@ static int plan_enqueue_step(mdno_rollout_plan* pl, hipStream_t s) {
     MDNO_TRY(radius_graph(pl->traj, W - 1, pl->r.t_dev, pl->M, pl->N, pl->threshold, pl->r.row_ptr, pl->r.src,
                           pl->r.dst, pl->edge_cap, pl->r.num_edges, pl->status, s));
     MDNO_TRY(forward_impl(&pl->p, pl->traj, 0, pl->r.t_dev, pl->M, W, pl->N, pl->aa, pl->aa_per_member, pl->r.row_ptr,
-                          pl->r.src, pl->r.dst, pl->r.num_edges, pl->edge_cap, pl->traj, W - 1, nullptr, nullptr,
-                          pl->traj, W, nullptr, pl->fw, pl->status, s));
+                          pl->r.src, pl->r.dst, pl->r.num_edges, pl->edge_cap, pl->max_degree, pl->traj, W - 1, nullptr,
+                          nullptr, pl->traj, W, nullptr, pl->fw, pl->status, s));
     hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(1), 0, s, pl->r.t_dev, (const int*)pl->r.num_edges,
                        pl->edges_per_step);
     return check_launch("advance_step");
@@ -268,8 +269,9 @@ static int plan_enqueue_step(mdno_rollout_plan* pl, hipStream_t s) {
 
 extern "C" int mdno_rollout_plan_create(mdno_rollout_plan** plan, const mdno_kernelnn_params* p, float* traj, int M,
                                         int W, int N, int max_steps, const int64_t* x_aminoacid, int aa_per_member,
-                                        double threshold, int64_t edge_cap, void* workspace, size_t workspace_bytes,
-                                        int32_t* edges_per_step, int32_t* status, int use_graph, void* stream) {
+                                        double threshold, int64_t edge_cap, int max_degree, void* workspace,
+                                        size_t workspace_bytes, int32_t* edges_per_step, int32_t* status,
+                                        int use_graph, void* stream) {
     MDNO_REQUIRE(plan != nullptr, MDNO_EINVAL, "mdno_rollout_plan_create: null plan pointer");
     *plan = nullptr;
     MDNO_TRY(validate_params(p));
@@ -289,6 +291,7 @@ extern "C" int mdno_rollout_plan_create(mdno_rollout_plan** plan, const mdno_ker
     pl->aa_per_member = aa_per_member;
     pl->threshold = threshold;
     pl->edge_cap = (long long)edge_cap;
+    pl->max_degree = max_degree;
     pl->r = r;
     pl->fw = carve_fwd(r.fwd, p, M, N, (long long)edge_cap);
     pl->edges_per_step = edges_per_step;
@@ -407,7 +410,8 @@ extern "C" int mdno_rollout(const mdno_kernelnn_params* p, float* traj, int M, i
     if (steps == 0) return MDNO_OK;
     mdno_rollout_plan* pl = nullptr;
     MDNO_TRY(mdno_rollout_plan_create(&pl, p, traj, M, W, N, steps, x_aminoacid, aa_per_member, threshold, edge_cap,
-                                      workspace, workspace_bytes, edges_per_step, status, use_graph, stream));
+                                      /*max_degree=*/0, workspace, workspace_bytes, edges_per_step, status, use_graph,
+                                      stream));
     int rc = mdno_rollout_plan_run(pl, 0, steps, stream);
     if (pl->exec) {
         // The executable graph must outlive its enqueued launches; this convenience call has no

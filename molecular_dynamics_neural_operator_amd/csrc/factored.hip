@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256, 4) void gemm_per_source_kernel(const float* __
                                                                  const float* __restrict__ b3,
                                                                  const int* __restrict__ row_ptr,
                                                                  float* __restrict__ Mp, long long part_stride,
-                                                                 int K) {
+                                                                 int K, int* __restrict__ status) {
     __shared__ __attribute__((aligned(16))) float As[128 * LD];
     __shared__ __attribute__((aligned(16))) float Bs[64 * LD];
     // source j is the fastest grid dimension: workgroups are dealt round-robin over the 8 XCDs by
@@ -176,6 +176,8 @@ __global__ __launch_bounds__(256, 4) void gemm_per_source_kernel(const float* __
     const int j = blockIdx.x, slice = blockIdx.z;
     const int beg = row_ptr[j], end = row_ptr[j + 1];
     const int r0 = beg + blockIdx.y * 128;
+    if (blockIdx.y == gridDim.y - 1 && slice == 0 && threadIdx.x == 0 && end - beg > (int)gridDim.y * 128 && status)
+        atomicOr(status, MDNO_STATUS_DEGREE_OVERFLOW);   // max_degree bound too small: edges would be dropped
     if (r0 >= end) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
@@ -381,7 +383,7 @@ int factored_prepare_graph(const int* row_ptr, const int* col, const int* rowid,
 
 int factored_conv(const float* x, const float* h2, const int* row_ptr, int num_rows, int max_degree, int ker_width,
                   const float* b3, const float* root, const float* bias, int aggr, int relu, float* y,
-                  const FactoredWs& f, hipStream_t s) {
+                  const FactoredWs& f, int* status, hipStream_t s) {
     static bool attr_set = false;
     const size_t lds1 = sizeof(float) * 2 * 256 * LD;   // 73,728 B
     if (!attr_set) {
@@ -398,7 +400,7 @@ int factored_conv(const float* x, const float* h2, const int* row_ptr, int num_r
     {
         TimedSection ts(KID_NNCONV, s);
         hipLaunchKernelGGL(gemm_per_source_kernel, dim3(num_rows, (max_degree + 127) / 128, KS), dim3(256), 0, s, h2,
-                           (const float*)f.y, x, b3, row_ptr, f.m, f.part_stride, ker_width);
+                           (const float*)f.y, x, b3, row_ptr, f.m, f.part_stride, ker_width, status);
     }
     {
         TimedSection ts(KID_NNCONV_COMBINE, s);

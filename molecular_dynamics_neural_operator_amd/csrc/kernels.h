@@ -67,7 +67,7 @@ int factored_prepare_graph(const int* row_ptr, const int* col, const int* rowid,
                            const FactoredWs& f, int* status, hipStream_t s);
 int factored_conv(const float* x, const float* h2, const int* row_ptr, int num_rows, int max_degree, int ker_width,
                   const float* b3, const float* root, const float* bias, int aggr, int relu, float* y,
-                  const FactoredWs& f, hipStream_t s);
+                  const FactoredWs& f, int* status, hipStream_t s);
 
 int nnconv(const float* x, const int* row_ptr, const int* src, int num_rows, const float* w_e, const float* root,
            const float* bias, int Cin, int Cout, int aggr, int relu, float* y, hipStream_t s);

@@ -23,6 +23,7 @@ class CSRGraph:
     edge_cap: int
     perm: Optional[torch.Tensor] = None   # i32 [E]: CSR position p holds input edge perm[p]
     status: Optional[torch.Tensor] = None
+    max_degree: int = 0                   # bound on any node's degree for the factored conv (0 = N)
 
     def edge_count(self) -> int:
         return int(self.num_edges.item())
@@ -215,7 +216,8 @@ def kernelnn_forward(pack: ParamPack, frames: torch.Tensor, x_aminoacid: torch.T
         raise MdnoError("conv_mode='factored' needs a radius graph with position-derived attributes "
                         "(edge_pos); explicit edge_attr runs with conv_mode='materialized'")
     check(lib.mdno_kernelnn_fwd(pack.ref, ptr(frames), M, W, N, ptr(aa), aa_pm, ptr(graph.row_ptr), ptr(graph.src),
-                                ptr(graph.dst), ptr(graph.num_edges), graph.edge_cap, ptr(ep), ptr(ea),
+                                ptr(graph.dst), ptr(graph.num_edges), graph.edge_cap, int(graph.max_degree), ptr(ep),
+                                ptr(ea),
                                 ptr(graph.perm) if ea is not None else None, ptr(out), ptr(latent), ptr(workspace),
                                 workspace.numel(), ptr(status), stream_ptr(dev)), "mdno_kernelnn_fwd")
     return out, latent

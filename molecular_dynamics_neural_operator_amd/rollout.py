@@ -19,8 +19,8 @@ from typing import List, Optional, Tuple
 import torch
 
 from . import _lib, ops
-from ._lib import (MdnoError, STATUS_ASYMMETRIC_GRAPH, STATUS_BAD_AMINOACID, STATUS_EDGE_OVERFLOW, check, f32, ptr,
-                   require_gpu)
+from ._lib import (MdnoError, STATUS_ASYMMETRIC_GRAPH, STATUS_BAD_AMINOACID, STATUS_DEGREE_OVERFLOW,
+                   STATUS_EDGE_OVERFLOW, check, f32, ptr, require_gpu)
 
 
 def default_edge_cap(members: int, n_atoms: int, threshold: float, density: float = 0.1, slack: float = 1.6) -> int:
@@ -36,7 +36,8 @@ class RolloutEngine:
     """Owns the trajectory buffer [W+max_steps, M, N, 3], the workspace and the captured step."""
 
     def __init__(self, model, members: int, n_atoms: int, window: int, threshold: float = 8.0,
-                 max_steps: int = 1000, edge_cap: Optional[int] = None, device=None, use_graph: bool = True):
+                 max_steps: int = 1000, edge_cap: Optional[int] = None, device=None, use_graph: bool = True,
+                 max_degree: int = 0):
         self.lib = _lib.load()
         self.device = require_gpu(device if device not in (None, "cuda") else None)
         self.model = model
@@ -45,6 +46,7 @@ class RolloutEngine:
         self.max_steps = int(max_steps)
         self.edge_cap = int(edge_cap) if edge_cap is not None else self.M * self.N * self.N
         self.edge_cap = max(self.edge_cap, self.M * self.N)
+        self.max_degree = int(max_degree)      # factored conv grid bound; 0 = n_atoms (always safe)
         self.pack = model.param_pack(self.device) if hasattr(model, "param_pack") else model
         if not isinstance(self.pack, ops.ParamPack):
             raise MdnoError("model must be a KernelNN (or an ops.ParamPack)")
@@ -68,7 +70,8 @@ class RolloutEngine:
         aa_pm = int(self.aa.numel() == self.M * self.N and self.M > 1)
         check(self.lib.mdno_rollout_plan_create(
             C.byref(self.plan), self.pack.ref, ptr(self.traj), self.M, self.W, self.N, self.max_steps,
-            ptr(self.aa), aa_pm, self.threshold, self.edge_cap, ptr(self.workspace), self.workspace.numel(),
+            ptr(self.aa), aa_pm, self.threshold, self.edge_cap, self.max_degree, ptr(self.workspace),
+            self.workspace.numel(),
             ptr(self.edges_per_step), ptr(self.status), int(self.use_graph), self.stream.cuda_stream),
             "mdno_rollout_plan_create")
 
@@ -153,6 +156,8 @@ class RolloutEngine:
             raise MdnoError(f"radius graph exceeded edge_cap={self.edge_cap}; construct the engine with a larger cap")
         if st & STATUS_BAD_AMINOACID:
             raise MdnoError("x_aminoacid outside [0, num_embeddings)")
+        if st & STATUS_DEGREE_OVERFLOW:
+            raise MdnoError(f"a node has more than max_degree={self.max_degree} edges; raise the bound (0 = n_atoms)")
         if st & STATUS_ASYMMETRIC_GRAPH:
             raise MdnoError("factored conv met an edge without a reverse edge (graph not symmetric)")
 

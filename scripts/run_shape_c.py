@@ -1,0 +1,101 @@
+"""BASELINE.json configs[4] (SURVEY.md §8 shape C): synthetic 50k-atom box, 10 A cutoff, 1 GPU.
+
+  python scripts/run_shape_c.py [--atoms 50000] [--steps 2]
+
+(1) one full-model forward step (graph build on the device + factored conv; the materialised W_e
+    would be 298 GB in fp32 and does not fit) with per-kernel HIP-event times;
+(2) the materialised conv kernel alone on the first rows of the same graph holding ~2M edges with
+    fp32 W_e (33 GB) — the HBM-roofline stress of the gather/scatter kernel.
+"""
+import argparse
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from molecular_dynamics_neural_operator_amd import _lib, ops, synthetic as syn  # noqa: E402
+from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN  # noqa: E402
+from molecular_dynamics_neural_operator_amd.rollout import RolloutEngine  # noqa: E402
+from molecular_dynamics_neural_operator_amd.weights import near_identity_state_dict  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--atoms", type=int, default=50000)
+ap.add_argument("--cutoff", type=float, default=10.0)
+ap.add_argument("--steps", type=int, default=2)
+ap.add_argument("--max-degree", type=int, default=768)
+ap.add_argument("--slice-edges", type=int, default=2_000_000)
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+lib = _lib.load()
+N, W = a.atoms, 10
+frame = syn.box_frame(N, seed=3)
+win = syn.jitter_window(frame, W, sigma=0.01, seed=3)
+aa = torch.from_numpy(syn.amino_acids(N, seed=3))
+
+g = ops.radius_graph(torch.from_numpy(frame).to(dev), N, a.cutoff, edge_cap=int(N * 500))
+E = g.edge_count()
+deg = (g.row_ptr[1:] - g.row_ptr[:-1])
+print(f"N={N} r={a.cutoff}: E={E} mean degree {E / N:.1f} min {int(deg.min())} max {int(deg.max())}", flush=True)
+out = {"atoms": N, "cutoff": a.cutoff, "edges": E, "max_degree": int(deg.max())}
+
+# ---- (2) materialised conv kernel on a ~2M-edge slice
+rows = int(torch.searchsorted(g.row_ptr.long(), a.slice_edges).item())
+Es = int(g.row_ptr[rows].item())
+x = torch.randn(N, 64, device=dev)
+w_e = torch.randn(Es, 4096, device=dev) * 0.02
+root = torch.randn(64, 64, device=dev) * 0.1
+bias = torch.randn(64, device=dev)
+y = torch.empty(rows, 64, device=dev)
+s = torch.cuda.current_stream().cuda_stream
+
+
+def conv():
+    _lib.check(lib.mdno_nnconv_fwd(x.data_ptr(), g.row_ptr.data_ptr(), g.src.data_ptr(), rows, w_e.data_ptr(),
+                                   root.data_ptr(), bias.data_ptr(), 64, 64, 1, 1, y.data_ptr(), s))
+
+
+for _ in range(3):
+    conv()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10):
+    conv()
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 10
+byts = Es * 16388 + 516 * rows + 4
+out["conv_slice"] = {"rows": rows, "edges": Es, "ms": ms, "GBps": byts / ms / 1e6, "frac_of_8TBps": byts / ms / 1e6 / 8000}
+print("materialised conv slice:", out["conv_slice"], flush=True)
+del w_e, y
+torch.cuda.empty_cache()
+
+# ---- (1) full-model rollout steps, factored conv
+sd = near_identity_state_dict(64, 1024, seed=0, kernel_gain=1e-3, feature_gain=0.1)
+model = KernelNN(64, 1024, 6, 6, 7, 3, 20, 4)
+model.load_state_dict(sd)
+model.eval().to(dev)
+model.conv_mode = "factored"
+eng = RolloutEngine(model, 1, N, W, a.cutoff, max_steps=a.steps + 1, edge_cap=int(E * 1.05), device=dev,
+                    max_degree=a.max_degree)
+print(f"workspace {eng.workspace.numel() / 2**30:.1f} GiB", flush=True)
+eng.reset(torch.from_numpy(win), aa)
+eng.step(1)
+eng.synchronize()
+eng.attach_timer(a.steps * 2000)
+t0 = torch.cuda.Event(enable_timing=True)
+t1 = torch.cuda.Event(enable_timing=True)
+t0.record(eng.stream)
+eng.step(a.steps)
+t1.record(eng.stream)
+tm = eng.read_timer()
+eng.synchronize()
+ms_step = t0.elapsed_time(t1) / a.steps
+out["step_ms"] = ms_step
+out["frames_per_s"] = 1e3 / ms_step
+out["kernels_ms_per_step"] = {k: v[0] / a.steps for k, v in tm.items() if v[1]}
+out["edges_per_step"] = eng.edges_per_step[:a.steps + 1].tolist()
+print(json.dumps(out))

@@ -485,8 +485,17 @@ def test_factored_conv_matches_materialized_and_reference(dev):
         res[mode] = (eng.run(tm, aa, steps).clone(), eng.edges_per_step.clone())
     assert torch.equal(res["materialized"][1], res["factored"][1])
     close(res["factored"][0], res["materialized"][0])
-    # explicit edge_attr + factored pack is refused, not silently rerouted
+    # a max_degree bound that is too small is flagged, not silently truncated
+    # (the bound is honoured in 128-edge tiles: 200 atoms in a 12.6 A box have ~150 neighbours each)
+    small.conv_mode = "factored"
     from molecular_dynamics_neural_operator_amd import MdnoError
+    big = syn.jitter_window(syn.box_frame(200, seed=8), W, seed=8)
+    eng = RolloutEngine(small, 1, 200, W, 8.0, max_steps=2, device=dev, max_degree=64)
+    with pytest.raises(MdnoError, match="max_degree"):
+        eng.run(torch.from_numpy(big), torch.from_numpy(syn.amino_acids(200, seed=8)), 2)
+    eng = RolloutEngine(small, 1, 200, W, 8.0, max_steps=2, device=dev, max_degree=200)
+    eng.run(torch.from_numpy(big), torch.from_numpy(syn.amino_acids(200, seed=8)), 2)
+    # explicit edge_attr + factored pack is refused, not silently rerouted
     with pytest.raises(MdnoError):
         ops.kernelnn_forward(model.param_pack(dev, conv_mode="factored"), frames.unsqueeze(1), t(z["x_aminoacid"]), g,
                              edge_attr=torch.zeros(g.edge_count(), 6, device=dev))

@@ -229,6 +229,47 @@ int mdno_rollout_plan_timer_attach(mdno_rollout_plan* plan, int max_records);
 int mdno_rollout_plan_timer_read(mdno_rollout_plan* plan, int kernel_id, double* total_ms, int64_t* count);
 int mdno_rollout_plan_timer_detach(mdno_rollout_plan* plan);
 
+/* ------------------------------------------------------------------------------------------
+ * Training ops (BASELINE configs[3]) — the backward of the kernel-integral block that autograd +
+ * torch_geometric provide to train() (graph_kernel.py:445-474) for the path :299-302 / :194-209 /
+ * :239-242.  All fp32; row/edge reductions use fixed-order partial sums (bitwise reproducible).
+ * With gz = g * (x_out > 0) and gs[t] = gz[t] / max(deg_t,1) (mean) or gz[t] (add):
+ *   mdno_linear_fwd       C = act(A . W^T + b)       A [rows,k], W [n,k] (torch Linear layout)
+ *   mdno_gemm_atb         C (+)= A^T . B             A [rows,n1], B [rows,n2] -> C [n1,n2] (weight grads)
+ *   mdno_colsum           out (+)= column sums of A [rows,n]                       (bias grads)
+ *   mdno_relu_bwd         out = g * (y > 0) [* row_scale[row]]
+ *   mdno_transpose        At [cols,rows] = A [rows,cols]^T
+ *   mdno_inv_degree       inv[r] = 1/max(deg_r,1) (mean) or 1 (add)
+ *   mdno_nnconv_bwd_x     g_prev[r] = gz[r].root^T + sum_{e: src e = r} W_e . gs[dst e]; edges grouped by
+ *                         source: row_ptr_s [R+1], eid_s [E] (position of the edge in the dst-sorted
+ *                         arrays / in W_e), dst_s [E]   (mdno_coo_to_csr on the swapped edge list)
+ *   mdno_nnconv_bwd_root  d_root (+)= sum_rows x^T gz, d_bias (+)= colsum(gz); x, gz [rows,64] (layers stacked)
+ *   mdno_nnconv_bwd_we    d_we[p] (+)= sum_l x_l[src p] (x) gs_l[dst p]; x, gs [layers, R, 64] (layer_stride floats)
+ * Workspaces: mdno_reduce_workspace_bytes(n1, n2) for gemm_atb / colsum (n2 = 1),
+ * mdno_nnconv_bwd_root_workspace_bytes(rows).
+ * ---------------------------------------------------------------------------------------- */
+int mdno_linear_fwd(const float* a, const float* w, const float* bias, int64_t rows, int n, int k, int relu,
+                    float* c, void* stream);
+size_t mdno_reduce_workspace_bytes(int n1, int n2);
+int mdno_gemm_atb(const float* a, const float* b, int64_t rows, int n1, int n2, float* c, int accumulate,
+                  void* workspace, size_t workspace_bytes, void* stream);
+int mdno_colsum(const float* a, int64_t rows, int n, float* out, int accumulate,
+                void* workspace, size_t workspace_bytes, void* stream);
+int mdno_relu_bwd(const float* g, const float* y, const float* row_scale, int64_t rows, int n, float* out,
+                  void* stream);
+int mdno_transpose(const float* a, int rows, int cols, float* at, void* stream);
+int mdno_inv_degree(const int32_t* row_ptr, int rows, int aggr, float* inv, void* stream);
+int mdno_nnconv_bwd_x(const float* gz, const float* gs, const int32_t* row_ptr_s, const int32_t* eid_s,
+                      const int32_t* dst_s, int num_rows, const float* w_e, const float* root,
+                      int Cin, int Cout, float* g_prev, void* stream);
+size_t mdno_nnconv_bwd_root_workspace_bytes(int64_t rows);
+int mdno_nnconv_bwd_root(const float* x, const float* gz, int64_t rows, int Cin, int Cout,
+                         float* d_root, float* d_bias, int accumulate,
+                         void* workspace, size_t workspace_bytes, void* stream);
+int mdno_nnconv_bwd_we(const float* x, const float* gs, const int32_t* src, const int32_t* dst, int64_t E,
+                       int layers, int64_t layer_stride, int Cin, int Cout, float* d_we, int accumulate,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,8 +16,9 @@ Differences from the reference, all explicit:
     ([W,N,3]) instead of a module-global ``args`` (graph_kernel.py:279) and never calls ``.cuda()``.
   * one sample per ``forward`` (B=1 semantics); several independent samples go
     through ``rollout.RolloutEngine`` / ``ops.kernelnn_forward`` as a block-diagonal batch.
-  * inference only this round: ``forward`` in training mode with autograd enabled raises rather
-    than returning tensors without a graph.
+  * ``KernelNN.forward`` in training mode with autograd enabled runs the differentiable path of
+    ``training.py`` (HIP forward + backward of the kernel-integral block, fp32); stand-alone
+    ``NNConv_old`` / ``DenseNet`` forwards are inference-only and raise in that situation.
 """
 from __future__ import annotations
 
@@ -219,7 +220,12 @@ class KernelNN(nn.Module):
         return self._pack
 
     def forward(self, data: PairData, return_latent: bool = False, single_example: bool = False):
-        _no_training(self)
+        if self.training and torch.is_grad_enabled():
+            # differentiable path (training.py): HIP forward + backward of the kernel-integral block
+            from .training import train_forward
+            if return_latent:
+                raise NotImplementedError("return_latent is an inference-time option")
+            return train_forward(self, data)
         x_position = data.x_position
         if x_position.dim() == 2:  # notebook-era single-frame sample [N,3]
             x_position = x_position.unsqueeze(0)

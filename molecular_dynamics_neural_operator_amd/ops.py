@@ -221,3 +221,117 @@ def kernelnn_forward(pack: ParamPack, frames: torch.Tensor, x_aminoacid: torch.T
                                 ptr(graph.perm) if ea is not None else None, ptr(out), ptr(latent), ptr(workspace),
                                 workspace.numel(), ptr(status), stream_ptr(dev)), "mdno_kernelnn_fwd")
     return out, latent
+
+
+# ------------------------------------------------------------------------------------------------
+# Training ops (include/mdno.h "Training ops"): thin wrappers, torch only allocates the outputs.
+def _ws(nbytes: int, dev) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
+
+
+def linear(a: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], relu: bool = False) -> torch.Tensor:
+    """act(a . w^T + b): a [rows,k], w [n,k] (torch Linear layout)."""
+    lib = _lib.load()
+    a, w = f32(a), f32(w)
+    rows, k = a.shape
+    n = w.shape[0]
+    c = torch.empty((rows, n), dtype=torch.float32, device=a.device)
+    bb = f32(b) if b is not None else None
+    check(lib.mdno_linear_fwd(ptr(a), ptr(w), ptr(bb), rows, n, k, int(relu), ptr(c), stream_ptr(a.device)),
+          "mdno_linear_fwd")
+    return c
+
+
+def gemm_atb(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a^T . b over rows: a [rows,n1], b [rows,n2] -> [n1,n2] (fixed-order partial sums)."""
+    lib = _lib.load()
+    a, b = f32(a), f32(b)
+    rows, n1 = a.shape
+    n2 = b.shape[1]
+    c = torch.empty((n1, n2), dtype=torch.float32, device=a.device)
+    nb = lib.mdno_reduce_workspace_bytes(n1, n2)
+    ws = _ws(nb, a.device)
+    check(lib.mdno_gemm_atb(ptr(a), ptr(b), rows, n1, n2, ptr(c), 0, ptr(ws), ws.numel(), stream_ptr(a.device)),
+          "mdno_gemm_atb")
+    return c
+
+
+def colsum(a: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    a = f32(a)
+    rows, n = a.shape
+    out = torch.empty(n, dtype=torch.float32, device=a.device)
+    ws = _ws(lib.mdno_reduce_workspace_bytes(n, 1), a.device)
+    check(lib.mdno_colsum(ptr(a), rows, n, ptr(out), 0, ptr(ws), ws.numel(), stream_ptr(a.device)), "mdno_colsum")
+    return out
+
+
+def relu_bwd(g: torch.Tensor, y: torch.Tensor, row_scale: Optional[torch.Tensor] = None,
+             out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = _lib.load()
+    g, y = f32(g), f32(y)
+    rows, n = g.shape
+    if out is None:
+        out = torch.empty_like(g)
+    check(lib.mdno_relu_bwd(ptr(g), ptr(y), ptr(row_scale), rows, n, ptr(out), stream_ptr(g.device)), "mdno_relu_bwd")
+    return out
+
+
+def transpose(a: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    a = f32(a)
+    r, c = a.shape
+    at = torch.empty((c, r), dtype=torch.float32, device=a.device)
+    check(lib.mdno_transpose(ptr(a), r, c, ptr(at), stream_ptr(a.device)), "mdno_transpose")
+    return at
+
+
+def inv_degree(graph: CSRGraph, aggr: str = "mean") -> torch.Tensor:
+    lib = _lib.load()
+    rows = graph.row_ptr.numel() - 1
+    inv = torch.empty(rows, dtype=torch.float32, device=graph.row_ptr.device)
+    check(lib.mdno_inv_degree(ptr(graph.row_ptr), rows, AGGR[aggr], ptr(inv), stream_ptr(inv.device)), "mdno_inv_degree")
+    return inv
+
+
+def source_sorted(graph: CSRGraph, num_nodes: int) -> CSRGraph:
+    """The same edges grouped by SOURCE: row_ptr over sources, `src` field = destination of each
+    out-edge, `perm` = the edge's position in the destination-sorted arrays (and in W_e)."""
+    e = graph.edge_count()
+    swapped = torch.stack([graph.dst[:e], graph.src[:e]]).to(torch.long)   # "target" := source
+    return coo_to_csr(swapped, num_nodes)
+
+
+def nnconv_bwd_x(gz: torch.Tensor, gs: torch.Tensor, by_src: CSRGraph, w_e: torch.Tensor,
+                 root: Optional[torch.Tensor]) -> torch.Tensor:
+    lib = _lib.load()
+    rows = gz.shape[0]
+    g_prev = torch.empty_like(gz)
+    check(lib.mdno_nnconv_bwd_x(ptr(gz), ptr(gs), ptr(by_src.row_ptr), ptr(by_src.perm), ptr(by_src.src), rows,
+                                ptr(w_e), ptr(f32(root)) if root is not None else None, 64, 64, ptr(g_prev),
+                                stream_ptr(gz.device)), "mdno_nnconv_bwd_x")
+    return g_prev
+
+
+def nnconv_bwd_root(x: torch.Tensor, gz: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """x, gz [rows,64] (layers stacked along rows) -> (d_root [64,64], d_bias [64])."""
+    lib = _lib.load()
+    x, gz = f32(x), f32(gz)
+    rows = x.shape[0]
+    d_root = torch.empty((64, 64), dtype=torch.float32, device=x.device)
+    d_bias = torch.empty(64, dtype=torch.float32, device=x.device)
+    ws = _ws(lib.mdno_nnconv_bwd_root_workspace_bytes(rows), x.device)
+    check(lib.mdno_nnconv_bwd_root(ptr(x), ptr(gz), rows, 64, 64, ptr(d_root), ptr(d_bias), 0, ptr(ws), ws.numel(),
+                                   stream_ptr(x.device)), "mdno_nnconv_bwd_root")
+    return d_root, d_bias
+
+
+def nnconv_bwd_we(x_layers: torch.Tensor, gs_layers: torch.Tensor, graph: CSRGraph) -> torch.Tensor:
+    """x_layers, gs_layers [L,R,64] -> d_we [E,4096]."""
+    lib = _lib.load()
+    L, R, _ = x_layers.shape
+    e = graph.edge_count()
+    d_we = torch.empty((e, 4096), dtype=torch.float32, device=x_layers.device)
+    check(lib.mdno_nnconv_bwd_we(ptr(x_layers), ptr(gs_layers), ptr(graph.src), ptr(graph.dst), e, L, R * 64, 64, 64,
+                                 ptr(d_we), 0, stream_ptr(d_we.device)), "mdno_nnconv_bwd_we")
+    return d_we

@@ -1,0 +1,141 @@
+"""Training path (BASELINE.json configs[3]): the kernel-integral block — the
+shared edge-MLP and the 2*depth conv applications, i.e. all but ~1e3 flop/atom of the model — runs
+forward AND backward in libmdno's HIP kernels behind one `torch.autograd.Function`; the per-atom
+ends (LSTM(3,3), lstm_fc, Embedding, fc1, fc2: graph_kernel.py:279-298, :305) stay torch modules so
+autograd differentiates them ("one small fused kernel (or stay in torch)").
+
+Replaces what autograd + torch_geometric do in `train()` (graph_kernel.py:445-474).  Members of a
+batch are independent B=1 problems (block-diagonal graph); the reference's batched mode threads one
+LSTM state through the batch axis and is not reproduced.  fp32 throughout.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from ._lib import MdnoError
+from .dataset import PairData
+
+
+class KernelIntegralBlock(torch.autograd.Function):
+    """x_L = conv2^depth(conv1^depth(x_0)) with W_e = net(edge_attr) shared by every application
+    (graph_kernel.py:271-273, :299-302), materialised formulation, fp32 MFMA GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x0, edge_attr, graph, depth, w0, b0, w1, b1, w2, b2, root1, bias1, root2, bias2):
+        R = x0.shape[0]
+        E = graph.edge_count()
+        ea = ops.f32(edge_attr)[graph.perm[:E].long()] if graph.perm is not None else ops.f32(edge_attr)
+        ea = ea.contiguous()
+        h1 = ops.linear(ea, w0, b0, relu=True)
+        h2 = ops.linear(h1, w1, b1, relu=True)
+        w_e = ops.linear(h2, w2, b2, relu=False)
+        L = 2 * depth
+        X = torch.empty((L + 1, R, 64), dtype=torch.float32, device=x0.device)
+        X[0].copy_(x0)
+        for a in range(1, L + 1):
+            root, bias = (root1, bias1) if a <= depth else (root2, bias2)
+            X[a].copy_(ops.nnconv(X[a - 1], graph, w_e, root, bias, "mean", relu=True))
+        ctx.graph, ctx.depth = graph, depth
+        ctx.save_for_backward(ea, h1, h2, w_e, X, w0, w1, w2, root1, root2)
+        return X[L].clone()
+
+    @staticmethod
+    def backward(ctx, g_out):
+        ea, h1, h2, w_e, X, w0, w1, w2, root1, root2 = ctx.saved_tensors
+        graph, depth = ctx.graph, ctx.depth
+        L, R = 2 * depth, X.shape[1]
+        by_src = ops.source_sorted(graph, R)
+        inv = ops.inv_degree(graph, "mean")
+        GZ = torch.empty((L, R, 64), dtype=torch.float32, device=X.device)
+        GS = torch.empty((L, R, 64), dtype=torch.float32, device=X.device)
+        g = ops.f32(g_out)
+        for a in range(L, 0, -1):
+            ops.relu_bwd(g, X[a], None, out=GZ[a - 1])
+            ops.relu_bwd(g, X[a], inv, out=GS[a - 1])
+            g = ops.nnconv_bwd_x(GZ[a - 1], GS[a - 1], by_src, w_e, root1 if a <= depth else root2)
+        d_root1, d_bias1 = ops.nnconv_bwd_root(X[0:depth].reshape(-1, 64), GZ[0:depth].reshape(-1, 64))
+        d_root2, d_bias2 = ops.nnconv_bwd_root(X[depth:L].reshape(-1, 64), GZ[depth:L].reshape(-1, 64))
+        d_we = ops.nnconv_bwd_we(X[0:L], GS, graph)
+        del GZ, GS
+        # edge-MLP backward
+        d_b2 = ops.colsum(d_we)
+        d_w2 = ops.gemm_atb(d_we, h2)
+        gz2 = ops.relu_bwd(ops.linear(d_we, ops.transpose(w2), None), h2)
+        del d_we
+        d_b1 = ops.colsum(gz2)
+        d_w1 = ops.gemm_atb(gz2, h1)
+        gz1 = ops.relu_bwd(ops.linear(gz2, ops.transpose(w1), None), h1)
+        d_b0 = ops.colsum(gz1)
+        d_w0 = ops.gemm_atb(gz1, ea)
+        return (g, None, None, None, d_w0, d_b0, d_w1, d_b1, d_w2, d_b2, d_root1, d_bias1, d_root2, d_bias2)
+
+
+def collate(samples: Sequence[PairData]) -> PairData:
+    """Block-diagonal batch; x_position stacked time-major [W, B*N, 3]."""
+    if isinstance(samples, PairData):
+        return samples
+    b = PairData.collate(samples)
+    W = samples[0].x_position.shape[0]
+    b.x_position = torch.cat([s.x_position for s in samples], dim=1) if samples[0].x_position.dim() == 3 else \
+        torch.cat([s.x_position.unsqueeze(0) for s in samples], dim=1)
+    assert b.x_position.shape[0] == W or samples[0].x_position.dim() == 2
+    return b
+
+
+def train_forward(model, data) -> torch.Tensor:
+    """Differentiable forward of `KernelNN` for one sample or a list/batch of samples -> [B*N, out]."""
+    batch = collate(data) if not isinstance(data, PairData) else data
+    dev = next(model.parameters()).device
+    if dev.type != "cuda":
+        raise MdnoError("training needs the model on the GPU (model.to('cuda')); no CPU fallback")
+    xp = batch.x_position.to(dev, torch.float32)
+    if xp.dim() == 2:
+        xp = xp.unsqueeze(0)
+    W, R, _ = xp.shape
+    aa = batch.x_aminoacid.to(dev)
+    if model.conv1.net is not model.conv2.net:
+        raise NotImplementedError("training assumes the reference's single shared edge-MLP (graph_kernel.py:271-273)")
+    # per-atom prologue (torch, differentiable): graph_kernel.py:279-298 with B=1 semantics per sample
+    if hasattr(model, "lstm"):
+        hidden = (torch.zeros(1, R, 3, device=dev), torch.zeros(1, R, 3, device=dev))
+        out = None
+        for t in range(W):
+            out, hidden = model.lstm(xp[t].unsqueeze(0), hidden)
+        feat = model.lstm_fc(out.reshape(R, 3))
+    else:
+        feat = xp[-1]
+    x0 = F.relu(model.fc1(torch.cat((model.emb(aa), feat), dim=1)))
+    graph = ops.coo_to_csr(batch.edge_index.to(dev), R)
+    net = model.conv1.net
+    w0, b0, w1, b1, w2, b2 = net.hip_weights()
+    conv2 = getattr(model, "conv2", None)
+    depth = model.depth if conv2 is not None else model.depth // 2
+    if conv2 is None and model.depth % 2:
+        raise NotImplementedError("notebook-era variant: training needs an even depth")
+    c2 = conv2 if conv2 is not None else model.conv1
+    x = KernelIntegralBlock.apply(x0, batch.edge_attr.to(dev), graph, depth, w0, b0, w1, b1, w2, b2,
+                                  model.conv1.root, model.conv1.bias, c2.root, c2.bias)
+    return model.fc2(x)
+
+
+def train_epoch(model, batches, optimizer, loss_fn, batch_size: Optional[int] = None):
+    """One pass over `batches` (an iterable of lists of PairData, as the reference's DataListLoader
+    yields): returns (avg relative-L2 loss, avg MSE) like train() (graph_kernel.py:445-474)."""
+    model.train()
+    tot, tot_mse, n = 0.0, 0.0, 0
+    for batch in batches:
+        B = len(batch) if not isinstance(batch, PairData) else (batch_size or 1)
+        optimizer.zero_grad()
+        out = train_forward(model, batch)
+        y = torch.cat([s.y for s in batch]).to(out.device) if not isinstance(batch, PairData) else batch.y.to(out.device)
+        l2 = loss_fn(out.view(B, -1), y.view(B, -1))
+        l2.backward()
+        optimizer.step()
+        tot += float(l2.item())
+        tot_mse += float(F.mse_loss(out.detach(), y).item())
+        n += 1
+    return tot / max(n, 1), tot_mse / max(n, 1)

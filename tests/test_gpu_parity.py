@@ -509,8 +509,8 @@ def test_errors_are_loud(dev):
     z = load_golden("kernelnn_small.npz")
     model = KernelNN(*[int(v) for v in z["ctor"]]).to(dev)
     pd = PairData(t(z["x_aminoacid"]), t(z["x_position"]), None, t(z["edge_attr"]), t(z["edge_index"]))
-    with pytest.raises(NotImplementedError):       # training mode + autograd: no silent graph-less output
-        model(pd.to(dev))
+    with pytest.raises(NotImplementedError):       # stand-alone conv in training mode: no silent graph-less output
+        model.conv1(torch.zeros(28, 8, device=dev), pd.edge_index.to(dev), pd.edge_attr.to(dev))
     model.eval()
     with pytest.raises(MdnoError):                 # CPU sample: no CPU fallback
         model(PairData(t(z["x_aminoacid"]), t(z["x_position"]), None, t(z["edge_attr"]), t(z["edge_index"])))

@@ -1,0 +1,178 @@
+"""Training path (cfg4): every backward op against torch autograd of the oracle's formulas, and the
+whole differentiable forward+backward against an fp64 CPU replica of the model built from the
+oracle's ops.  Runs the HIP kernels through the C ABI on cuda:0."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from molecular_dynamics_neural_operator_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import graph_kernel_oracle
+    return graph_kernel_oracle
+
+
+def test_linear_atb_colsum_transpose_relu(dev):
+    from molecular_dynamics_neural_operator_amd import ops
+    g = torch.Generator().manual_seed(0)
+    for rows, n, k in ((300, 128, 64), (517, 256, 1024), (100, 24, 6), (77, 6, 40)):
+        a, w, b = torch.randn(rows, k, generator=g), torch.randn(n, k, generator=g), torch.randn(n, generator=g)
+        for relu in (False, True):
+            want = F.linear(a.double(), w.double(), b.double())
+            want = want.relu() if relu else want
+            assert rel_err(ops.linear(a.to(dev), w.to(dev), b.to(dev), relu), want) < 2e-6
+        assert rel_err(ops.linear(a.to(dev), w.to(dev), None), F.linear(a.double(), w.double())) < 2e-6
+    for rows, n1, n2 in ((5000, 128, 256), (333, 1024, 128), (4097, 256, 6), (50, 7, 3)):
+        a, b = torch.randn(rows, n1, generator=g), torch.randn(rows, n2, generator=g)
+        got = ops.gemm_atb(a.to(dev), b.to(dev))
+        assert rel_err(got, a.double().t() @ b.double()) < 2e-6
+        assert torch.equal(got, ops.gemm_atb(a.to(dev), b.to(dev)))          # fixed-order partials: reproducible
+        assert rel_err(ops.colsum(a.to(dev)), a.double().sum(0)) < 2e-6
+    a = torch.randn(70, 45, generator=g)
+    assert torch.equal(ops.transpose(a.to(dev)).cpu(), a.t().contiguous())
+    gq, y, sc = torch.randn(40, 64, generator=g), torch.randn(40, 64, generator=g), torch.rand(40, generator=g)
+    assert torch.equal(ops.relu_bwd(gq.to(dev), y.to(dev)).cpu(), gq * (y > 0))
+    torch.testing.assert_close(ops.relu_bwd(gq.to(dev), y.to(dev), sc.to(dev)).cpu(), gq * (y > 0) * sc[:, None])
+
+
+def test_nnconv_backward_ops_vs_autograd(dev, O):
+    """One conv application on an irregular graph (hub, isolated node, duplicate edges): input, root,
+    bias and per-edge-weight gradients of mean(x_j . W_e) + x.root + bias vs torch autograd (fp64)."""
+    from molecular_dynamics_neural_operator_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    n, E = 90, 1500
+    ei = torch.randint(0, n, (2, E), generator=gen)
+    ei[1, :220] = 11
+    ei[1, ei[1] == 30] = 31
+    x = torch.randn(n, 64, generator=gen).double().requires_grad_()
+    w_e = (torch.randn(E, 4096, generator=gen) * 0.1).double().requires_grad_()
+    root = (torch.randn(64, 64, generator=gen) * 0.1).double().requires_grad_()
+    bias = torch.randn(64, generator=gen).double().requires_grad_()
+    y = torch.relu(O.nnconv_apply(x, ei, w_e, root, bias, "mean"))
+    gy = torch.randn(n, 64, generator=gen).double()
+    y.backward(gy)
+    g = ops.coo_to_csr(ei.to(dev), n)
+    perm = g.perm[:E].long()
+    w_csr = w_e.detach().float().to(dev)[perm].contiguous()
+    xd = x.detach().float().to(dev)
+    yd = ops.nnconv(xd, g, w_csr, root.detach().float().to(dev), bias.detach().float().to(dev), "mean", relu=True)
+    inv = ops.inv_degree(g, "mean")
+    gz = ops.relu_bwd(gy.float().to(dev), yd)
+    gs = ops.relu_bwd(gy.float().to(dev), yd, inv)
+    by_src = ops.source_sorted(g, n)
+    gx = ops.nnconv_bwd_x(gz, gs, by_src, w_csr, root.detach().float().to(dev))
+    assert rel_err(gx, x.grad) < 1e-5
+    d_root, d_bias = ops.nnconv_bwd_root(xd, gz)
+    assert rel_err(d_root, root.grad) < 1e-5 and rel_err(d_bias, bias.grad) < 1e-5
+    d_we = ops.nnconv_bwd_we(xd.unsqueeze(0), gs.unsqueeze(0), g)
+    want = w_e.grad[perm.cpu()]
+    assert rel_err(d_we, want) < 1e-5
+
+
+def _replica_loss(model, O, batch, B):
+    """fp64 CPU replica: the model's own torch ends + the oracle's conv / edge-MLP formulas."""
+    from molecular_dynamics_neural_operator_amd.graph_kernel import LpLoss
+    ref = copy.deepcopy(model).cpu().double()
+    sd = dict(ref.named_parameters())
+    xp = batch.x_position.double()
+    W, R, _ = xp.shape
+    hidden = (torch.zeros(1, R, 3, dtype=torch.double), torch.zeros(1, R, 3, dtype=torch.double))
+    out = None
+    for t in range(W):
+        out, hidden = ref.lstm(xp[t].unsqueeze(0), hidden)
+    feat = ref.lstm_fc(out.reshape(R, 3))
+    x = F.relu(ref.fc1(torch.cat((ref.emb(batch.x_aminoacid), feat), dim=1)))
+    w_e = O.edge_mlp(batch.edge_attr.double(), sd, "conv1.net.")
+    for conv in ("conv1", "conv2"):
+        for _ in range(ref.depth):
+            x = F.relu(O.nnconv_apply(x, batch.edge_index, w_e, sd[conv + ".root"], sd[conv + ".bias"], "mean"))
+    y = ref.fc2(x)
+    loss = LpLoss(size_average=False)(y.view(B, -1), batch.y.double().view(B, -1))
+    loss.backward()
+    return float(loss), y.detach(), {k: v.grad for k, v in sd.items()}
+
+
+def test_model_gradients_vs_fp64_replica(dev, O, tmp_path):
+    """Batch of 3 dataset samples (N=28, W=10), width 64, k=128, depth 2: loss, outputs and every
+    parameter gradient of the HIP training path vs the fp64 replica."""
+    from molecular_dynamics_neural_operator_amd.dataset import ContactMapDataset
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN, LpLoss
+    from molecular_dynamics_neural_operator_amd.training import collate, train_forward
+    z = load_golden("rollout_20.npz")
+    path = tmp_path / "traj.npz"
+    np.savez(path, contact_map=z["contact_map"], point_cloud=z["point_cloud"], rmsd=z["rmsd"],
+             amino_acids=z["amino_acids"])
+    dset = ContactMapDataset(str(path), window_size=int(z["window"]), horizon=1)
+    samples = [dset[i] for i in (0, 7, 19)]
+    B = len(samples)
+    torch.manual_seed(3)
+    model = KernelNN(64, 128, 2, 6, 7, 3, 20, 4)
+    with torch.no_grad():                      # keep activations O(1) through 4 random-init layers
+        for p_ in model.conv1.net.layers[4].parameters():
+            p_.mul_(0.2)
+    model.to(dev).train()
+    out = model(samples)                       # training mode + autograd -> differentiable HIP path
+    assert out.requires_grad and out.shape == (B * 28, 3)
+    y = torch.cat([s.y for s in samples]).to(dev)
+    loss = LpLoss(size_average=False)(out.view(B, -1), y.view(B, -1))
+    loss.backward()
+    want_loss, want_out, want_grads = _replica_loss(model, O, collate(samples), B)
+    assert abs(float(loss) - want_loss) < 1e-4 * abs(want_loss)
+    assert rel_err(out, want_out) < 1e-4
+    for name, p_ in model.named_parameters():
+        assert p_.grad is not None, name
+        assert rel_err(p_.grad, want_grads[name]) < 2e-3, (name, rel_err(p_.grad, want_grads[name]))
+    # a second identical pass gives bitwise identical gradients (no float atomics anywhere)
+    g1 = {n: p_.grad.clone() for n, p_ in model.named_parameters()}
+    model.zero_grad()
+    out2 = train_forward(model, samples)
+    LpLoss(size_average=False)(out2.view(B, -1), y.view(B, -1)).backward()
+    for n, p_ in model.named_parameters():
+        if not n.startswith(("lstm", "emb", "fc1", "fc2", "lstm_fc")):     # torch's own ends may use atomics
+            assert torch.equal(p_.grad, g1[n]), n
+
+
+def test_training_reduces_loss(dev, tmp_path):
+    """A few Adam steps on a tiny synthetic trajectory: the loss goes down (graph_kernel.py:541-547)."""
+    from molecular_dynamics_neural_operator_amd import synthetic as syn
+    from molecular_dynamics_neural_operator_amd.dataset import ContactMapDataset, write_trajectory_npz
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN, LpLoss
+    from molecular_dynamics_neural_operator_amd.training import train_epoch
+    from oracle import graph_kernel_oracle as O
+    base = syn.chain_frame(28, seed=0)
+    traj = syn.ou_trajectory(base, 60, sigma=0.15, theta=0.2, seed=2)
+    cms = [O.radius_graph_coo(f, 8.0).reshape(-1) for f in traj]
+    path = tmp_path / "t.npz"
+    write_trajectory_npz(path, traj, cms, syn.amino_acids(28, seed=0))
+    dset = ContactMapDataset(str(path), window_size=10, horizon=1)
+    torch.manual_seed(0)
+    model = KernelNN(64, 128, 2, 6, 7, 3, 20, 4)
+    with torch.no_grad():
+        for p_ in model.conv1.net.layers[4].parameters():
+            p_.mul_(0.2)
+    model.to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-4)
+    batches = [[dset[i] for i in range(s, s + 8)] for s in range(0, 40, 8)]
+    first, _ = train_epoch(model, batches, opt, LpLoss(size_average=False))
+    for _ in range(5):
+        last, _ = train_epoch(model, batches, opt, LpLoss(size_average=False))
+    assert last < 0.8 * first, (first, last)

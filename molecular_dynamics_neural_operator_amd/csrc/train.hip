@@ -414,7 +414,8 @@ __global__ __launch_bounds__(256) void nnconv_bwd_we_kernel(const float* __restr
     for (int r = 0; r < 16; ++r) *reinterpret_cast<float4*>(out + r * 64) = acc[r];
 }
 
-constexpr int kSlices = 16;   // fixed K-split of the row reductions (partials added in slice order)
+constexpr int kSlices = 16;      // fixed K-split of the A^T.B reductions (partials added in slice order)
+constexpr int kColSlices = 128;  // column sums: many more slices (the reduction is a pure stream)
 
 }  // namespace
 }  // namespace mdno
@@ -449,7 +450,8 @@ extern "C" int mdno_linear_fwd(const float* a, const float* w, const float* bias
 }
 
 extern "C" size_t mdno_reduce_workspace_bytes(int n1, int n2) {
-    return align_up((size_t)kSlices * (size_t)n1 * (size_t)(n2 > 0 ? n2 : 1) * sizeof(float), 256);
+    if (n2 <= 1) return align_up((size_t)kColSlices * (size_t)n1 * sizeof(float), 256);
+    return align_up((size_t)kSlices * (size_t)n1 * (size_t)n2 * sizeof(float), 256);
 }
 
 extern "C" int mdno_gemm_atb(const float* a, const float* b, int64_t rows, int n1, int n2, float* c, int accumulate,
@@ -480,9 +482,10 @@ extern "C" int mdno_colsum(const float* a, int64_t rows, int n, float* out, int 
     MDNO_REQUIRE(workspace_bytes >= mdno_reduce_workspace_bytes(n, 1), MDNO_EWORKSPACE, "mdno_colsum: workspace");
     hipStream_t s = static_cast<hipStream_t>(stream);
     float* part = static_cast<float*>(workspace);
-    const long long kslice = (rows + kSlices - 1) / kSlices;
-    hipLaunchKernelGGL(colsum_kernel, dim3((n + 255) / 256, kSlices), dim3(256), 0, s, a, part, (long long)rows, n, kslice);
-    hipLaunchKernelGGL(reduce_slices_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const float*)part, kSlices,
+    const long long kslice = (rows + kColSlices - 1) / kColSlices;
+    hipLaunchKernelGGL(colsum_kernel, dim3((n + 255) / 256, kColSlices), dim3(256), 0, s, a, part, (long long)rows, n,
+                       kslice);
+    hipLaunchKernelGGL(reduce_slices_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const float*)part, kColSlices,
                        (long long)n, out, accumulate);
     return check_launch("mdno_colsum");
 }

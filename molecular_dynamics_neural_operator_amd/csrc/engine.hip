@@ -93,7 +93,8 @@ FwdWs carve_fwd(void* ws, const mdno_kernelnn_params* p, int M, int N, long long
     f.factored = use_factored(p);
     if (f.factored) {
         // no W_e at all: the last hidden activation H [edge_cap, k] plus the per-node Y and per-edge M
-        f.h2 = cv.take<float>((size_t)edge_cap * p->ker_width);
+        // k-tiled [e/128][k/32][128][32]: whole 128-row tiles, so the row count is rounded up
+        f.h2 = cv.take<float>((size_t)((edge_cap + 127) / 128 * 128) * p->ker_width);
         f.fact = cv.take<char>(factored_workspace_bytes((int)R, p->ker_width, edge_cap));
         f.mlp_bytes = mdno_edge_mlp_workspace_bytes(p->ker_width, p->ker_width, edge_cap, p->gemm_mode);
     } else {

@@ -501,6 +501,62 @@ def test_factored_conv_matches_materialized_and_reference(dev):
                              edge_attr=torch.zeros(g.edge_count(), 6, device=dev))
 
 
+def test_edge_cases_single_atom_window1_zero_steps_and_c_rollout(dev, O):
+    """Degenerate sizes: one atom (a single self-loop), window 1, zero steps; stepping past the plan's
+    capacity is refused; the one-shot C entry point mdno_rollout matches the plan API."""
+    import ctypes as C
+    from molecular_dynamics_neural_operator_amd import MdnoError, _lib, ops, synthetic as syn
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN, construct_pairdata
+    from molecular_dynamics_neural_operator_amd.rollout import RolloutEngine
+    from molecular_dynamics_neural_operator_amd.weights import near_identity_state_dict
+    sd = near_identity_state_dict(64, 128, seed=1, kernel_gain=1e-2, feature_gain=0.1, kernel_to_coords=1.0)
+    model = KernelNN(64, 128, 2, 6, 7, 3, 20, 4)
+    model.load_state_dict(sd)
+    model.eval().to(dev)
+    # N = 1, W = 1
+    one = np.array([[[1.0, -2.0, 3.0]]], dtype=np.float32)
+    aa1 = torch.tensor([7])
+    pd = construct_pairdata(one, aa1, 8.0)
+    assert pd.edge_index.tolist() == [[0], [0]]
+    with torch.no_grad():
+        out = model(pd)
+    ref_pd = O.construct_pairdata(one, aa1, 8.0)
+    want = O.kernelnn_forward(sd, ref_pd["x_position"], aa1, ref_pd["edge_index"], ref_pd["edge_attr"], 2)
+    close(out, want)
+    for mode in ("factored", "materialized"):
+        model.conv_mode = mode
+        eng = RolloutEngine(model, 1, 1, 1, 8.0, max_steps=2, device=dev)
+        assert eng.run(torch.from_numpy(one), aa1, 0).shape == (0, 1, 1, 3)       # zero steps
+        tr = eng.run(torch.from_numpy(one), aa1, 2)
+        close(tr[0, 0], want)
+        with pytest.raises(MdnoError):
+            eng.step(1)                                                           # past max_steps
+    # one-shot C entry point == plan API
+    N, W, steps = 28, 10, 3
+    win = syn.jitter_window(syn.chain_frame(N, seed=2), W, seed=2)
+    aa = torch.from_numpy(syn.amino_acids(N, seed=2))
+    model.conv_mode = "factored"
+    eng = RolloutEngine(model, 1, N, W, 8.0, max_steps=steps, device=dev)
+    want_traj = eng.run(torch.from_numpy(win), aa, steps).clone()
+    lib = _lib.load()
+    pack = model.param_pack(dev)
+    traj = torch.zeros((W + steps, 1, N, 3), device=dev)
+    traj[:W, 0] = torch.from_numpy(win).to(dev)
+    cap = N * N
+    nb = lib.mdno_rollout_workspace_bytes(pack.ref, 1, N, cap)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    eps = torch.zeros(steps, dtype=torch.int32, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    aad = aa.to(dev)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    _lib.check(lib.mdno_rollout(pack.ref, traj.data_ptr(), 1, W, N, steps, aad.data_ptr(), 0, 8.0, cap, ws.data_ptr(), nb,
+                                eps.data_ptr(), status.data_ptr(), 1, stream.cuda_stream))
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0 and torch.equal(traj[W:], want_traj)
+    assert torch.equal(eps, eng.edges_per_step[:steps])
+
+
 # ------------------------------------------------------------------------------- error behaviour
 def test_errors_are_loud(dev):
     from molecular_dynamics_neural_operator_amd import MdnoError, ops

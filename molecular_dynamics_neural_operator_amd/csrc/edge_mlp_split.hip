@@ -87,6 +87,32 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
         *reinterpret_cast<uint4*>(planes + tiled_off(row, k0, nkt, p)) = *reinterpret_cast<const uint4*>(o[p]);
 }
 
+// ---------------------------------------------------------------- x [rows,64] -> planes, + q = x . B
+// Block = 4 rows x 64 threads; thread (row, o) accumulates q[row][o] = sum_i x[row][i] * b[i*64 + o]
+// (i ascending, fmaf), threads o < 8 also split the row's 8-float chunk o.
+__global__ __launch_bounds__(256) void split_bias64_kernel(const float* __restrict__ x, const float* __restrict__ b,
+                                                           int rows, unsigned char* __restrict__ planes,
+                                                           float* __restrict__ q) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), o = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * 64;
+    float acc = 0.f;
+#pragma unroll 16
+    for (int i = 0; i < 64; ++i) acc = fmaf(xr[i], b[i * 64 + o], acc);
+    q[(size_t)row * 64 + o] = acc;
+    if (o < 8) {
+        const float4 v0 = *reinterpret_cast<const float4*>(xr + 8 * o);
+        const float4 v1 = *reinterpret_cast<const float4*>(xr + 8 * o + 4);
+        const float xv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        __bf16 pl[3][8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) split3(xv[j], pl[0][j], pl[1][j], pl[2][j]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            *reinterpret_cast<uint4*>(planes + tiled_off(row, 8 * o, 4, p)) = *reinterpret_cast<const uint4*>(pl[p]);
+    }
+}
+
 // ---------------------------------------------------------------- layer 0 (+ attr gather) -> planes
 // Block = 256 threads, EB edges.  Thread = one 16-B chunk (8 hidden units) of one edge at a time:
 // k/8 threads cover an edge, the block walks its edges in groups of 256/(k/8).
@@ -156,10 +182,11 @@ struct SplitGemmArgs {
     const float* bias;         // [N]
     float* C;                  // fp32 [rows][N] row-major            (OUT_PLANES = false)
     unsigned char* Cp;         // tiled planes [rows/128][N/32][3][8 KiB], ReLU applied (OUT_PLANES = true)
-    const int* num_edges;
-    long long row_begin;
+    const int* num_edges;      // device count of valid rows (rows past it are neither computed nor stored) ...
+    long long row_begin;       // ... relative to this first row; NULL: rows_valid below is used instead
     int rows, N, K;
     int tiles_n, tiles_m;
+    int rows_valid;
 };
 
 // One stage (k-step of 16) for a wave: (2x2 tiles) x 6 plane products = 24 MFMAs, 12 fragment reads.
@@ -197,7 +224,7 @@ __global__ __launch_bounds__(TM * 2, 2) void gemm_split_bf16_kernel(SplitGemmArg
     constexpr int A_PIECES = PIECES - 12;
     constexpr int PPW = (PIECES + WAVES - 1) / WAVES;    // pieces per wave: 6 or 5
 
-    long long valid = (long long)(*g.num_edges) - g.row_begin;
+    long long valid = g.num_edges ? (long long)(*g.num_edges) - g.row_begin : (long long)g.rows_valid;
     if (valid > g.rows) valid = g.rows;
     if (valid <= 0) return;
     // XCD-aware tile order over the tiles that hold valid rows: workgroups b, b+8, ... share an XCD
@@ -326,6 +353,35 @@ int launch_split_gemm(const SplitGemmArgs& g, int kid, hipStream_t s) {
 
 }  // namespace
 
+// ---------------------------------------------------------------- generic pieces (factored.hip step (1))
+size_t split_planes_bytes(long long rows, int K) {
+    return (size_t)3 * ((rows + 255) / 256 * 256) * K * sizeof(__bf16);   // whole 256-row GEMM tiles
+}
+
+int split_planes(const float* a, int rows, int K, void* planes, hipStream_t s) {
+    MDNO_REQUIRE(K % 16 == 0 && (reinterpret_cast<uintptr_t>(a) & 15) == 0, MDNO_EINVAL, "split_planes: K=%d", K);
+    const long long chunks = (long long)rows * (K / 8);
+    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, s, a, rows, K,
+                       static_cast<unsigned char*>(planes));
+    return check_launch("split_planes_kernel");
+}
+
+int split_planes_bias64(const float* x, int rows, const float* b, float* q, void* planes, hipStream_t s) {
+    MDNO_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && b && q, MDNO_EINVAL, "split_planes_bias64: bad arguments");
+    hipLaunchKernelGGL(split_bias64_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, b, rows,
+                       static_cast<unsigned char*>(planes), q);
+    return check_launch("split_bias64_kernel");
+}
+
+// C[rows, N] (fp32 row-major) = A . Bt^T from tiled planes of A [rows, K] and Bt [N, K]
+int split_gemm_rows(const void* a_planes, const void* b_planes, int rows, int N, int K, float* C, hipStream_t s) {
+    MDNO_REQUIRE(K % 32 == 0 && N % TN == 0 && rows > 0, MDNO_EUNSUPPORTED, "split_gemm_rows: rows=%d N=%d K=%d", rows, N, K);
+    SplitGemmArgs g{static_cast<const unsigned char*>(a_planes), static_cast<const unsigned char*>(b_planes), nullptr, C,
+                    nullptr, nullptr, 0, (rows + 255) / 256 * 256, N, K, 0, 0, rows};
+    // 256-row tiles also here: with 128-row tiles the B planes are fetched twice as often (61 vs 50 us at R=504)
+    return N >= 2048 ? launch_split_gemm_tm<256, 0>(g, s) : launch_split_gemm_tm<128, 0>(g, s);
+}
+
 bool edge_mlp_split_supported(int ker_width, int out_dim) {
     return ker_width % 32 == 0 && ker_width % TN == 0 && out_dim % TN == 0;
 }
@@ -370,10 +426,10 @@ int edge_mlp_split(const float* frames, int frame, const int* t_dev, int rows_pe
                                h1p);
         }
         MDNO_TRY(check_launch("edge_l0_split_kernel"));
-        SplitGemmArgs g1{h1p, w1p, w.b1, nullptr, h2p, num_edges, e0, (int)chunk, k, k, 0, 0};
+        SplitGemmArgs g1{h1p, w1p, w.b1, nullptr, h2p, num_edges, e0, (int)chunk, k, k, 0, 0, 0};
         MDNO_TRY(launch_split_gemm<1>(g1, KID_GEMM_L1, s));
         SplitGemmArgs g2{h2p, w2p, w.b2, w_e + (size_t)e0 * out_dim, nullptr, num_edges, e0, (int)chunk, out_dim, k,
-                         0, 0};
+                         0, 0, 0};
         MDNO_TRY(launch_split_gemm<0>(g2, KID_GEMM_L2, s));
     }
     return MDNO_OK;
@@ -407,7 +463,7 @@ int edge_mlp_split_hidden(const float* frames, int frame, const int* t_dev, int 
                                h1p);
         }
         MDNO_TRY(check_launch("edge_l0_split_kernel"));
-        SplitGemmArgs g1{h1p, w1p, w.b1, h_out + (size_t)e0 * k, nullptr, num_edges, e0, (int)chunk, k, k, 0, 0};
+        SplitGemmArgs g1{h1p, w1p, w.b1, h_out + (size_t)e0 * k, nullptr, num_edges, e0, (int)chunk, k, k, 0, 0, 0};
         MDNO_TRY(launch_split_gemm<2>(g1, KID_GEMM_L1, s));   // chunk % 128 == 0: tile index continues across chunks
     }
     return MDNO_OK;

@@ -134,13 +134,14 @@ int forward_impl(const mdno_kernelnn_params* p, const float* frames, int t0, con
                 MDNO_TRY(edge_mlp_hidden(edge_frames, edge_frame, t_dev, R, /*src=*/dst, /*dst=*/src, nullptr, nullptr,
                                          num_edges, edge_cap, p->ker_in, p->ker_width, p->gemm_mode, w, ws.h2, ws.mlp,
                                          ws.mlp_bytes, s));
-                MDNO_TRY(factored_prepare_weights(w.w2, p->ker_width, fw, s));
+                MDNO_TRY(factored_prepare_weights(w.w2, p->ker_width, p->gemm_mode, fw, s));
             }
             const float* b3 = (block == 1 && separate_conv2_kernel(p)) ? p->k2_b2 : p->k_b2;
             const float* root = block == 0 ? p->conv1_root : p->conv2_root;
             const float* bias = block == 0 ? p->conv1_bias : p->conv2_bias;
             for (int d = 0; d < p->depth; ++d) {
-                MDNO_TRY(factored_conv(cur, ws.h2, row_ptr, R, max_degree > 0 ? max_degree : N, p->ker_width, b3, root,
+                MDNO_TRY(factored_conv(cur, ws.h2, row_ptr, R, max_degree > 0 ? max_degree : N, p->ker_width,
+                                       p->gemm_mode, b3, root,
                                        bias, MDNO_AGGR_MEAN, /*relu=*/1, nxt, fw, status, s));
                 float* t = cur; cur = nxt; nxt = t;
             }

@@ -73,6 +73,19 @@ __global__ __launch_bounds__(256) void w3_transpose_kernel(const float* __restri
     w3t[id] = w3[((size_t)i * C + o) * k + kt * 32 + cc];
 }
 
+// q[r][o] = sum_i x[r][i] * b3[i*64 + o]: the last MLP layer's bias seen through x_j (added to every
+// message of source j by step (2)).  Thread = (row, o); used when the fused split+q kernel is not.
+__global__ __launch_bounds__(256) void node_bias_kernel(const float* __restrict__ x, const float* __restrict__ b3,
+                                                        int rows, float* __restrict__ q) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), o = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * 64;
+    float acc = 0.f;
+#pragma unroll 16
+    for (int i = 0; i < 64; ++i) acc = fmaf(xr[i], b3[i * 64 + o], acc);
+    q[(size_t)row * 64 + o] = acc;
+}
+
 // ---------------------------------------------------------------- (1) Y = X . W3T^T, rows guarded
 // C[m][n] = sum_kk A[m][kk] * Bt[n][kk];  A [rows, K], Bt [N, K], C [rows, N]; N % 128 == 0, K % 32 == 0.
 // 128x128x32 tile, 4 waves (2x2 of 64x64), register staging, double-buffered LDS (as edge_mlp.hip).
@@ -163,8 +176,7 @@ constexpr int KS = 2;
 
 __global__ __launch_bounds__(256, 4) void gemm_per_source_kernel(const float* __restrict__ Hm,
                                                                  const float* __restrict__ Y,
-                                                                 const float* __restrict__ x,
-                                                                 const float* __restrict__ b3,
+                                                                 const float* __restrict__ Q,
                                                                  const int* __restrict__ row_ptr,
                                                                  float* __restrict__ Mp, long long part_stride,
                                                                  int K, int* __restrict__ status) {
@@ -233,16 +245,167 @@ __global__ __launch_bounds__(256, 4) void gemm_per_source_kernel(const float* __
     if (rows_live) mma_32x64(acc0, acc1, a_rd, b_rd);
 #undef MDNO_LOAD
 #undef MDNO_STORE
-    // q_j[o] = sum_i x_j[i] * b3[i*64 + o] for this lane's two columns (bias of the last MLP layer)
+    // q_j (bias of the last MLP layer seen through x_j) rides on the first k-slice
     float q0 = 0.f, q1 = 0.f;
     if (slice == 0) {
-        const float* xj = x + (size_t)j * 64;
-#pragma unroll 16
-        for (int i = 0; i < 64; ++i) {
-            const float xi = xj[i];
-            q0 = fmaf(xi, b3[i * 64 + l31], q0);
-            q1 = fmaf(xi, b3[i * 64 + 32 + l31], q1);
+        q0 = Q[(size_t)j * 64 + l31];
+        q1 = Q[(size_t)j * 64 + 32 + l31];
+    }
+    float* Mo = Mp + (size_t)slice * part_stride;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int m = r0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (m < end) {
+            Mo[(size_t)m * 64 + l31] = acc0[e] + q0;
+            Mo[(size_t)m * 64 + 32 + l31] = acc1[e] + q1;
         }
+    }
+}
+
+// ---------------------------------------------------------------- (2) on the bf16 matrix pipe
+// Same workgroup shape and the same fp32 operands in HBM as gemm_per_source_kernel, but each staged
+// K-tile is split on the fly into three bf16 planes (x = hi + mid + lo exactly, edge_mlp_split.hip)
+// and multiplied as the six leading plane products with fp32 accumulation: 12 cycles of matrix pipe
+// per k instead of 32, for ~6 VALU ops per staged element.  That moves the kernel off the fp32 MFMA
+// rate (where it sat at 40 %, next to its HBM time) and leaves the H/Y stream as the one bound.
+// LDS: plane p of A = 128 rows x 64 B (32 k), of B = 64 rows x 64 B; the four 16-B chunks of a row
+// are XOR-swizzled with (row>>2)&3, which makes both the ds_write_b64 of the staging threads and the
+// ds_read_b128 fragment reads conflict-free without padding (36 KiB, 4 workgroups per CU).
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SPL_A_PLANE = 128 * 64, SPL_B_PLANE = 64 * 64, SPL_B_BASE = 3 * SPL_A_PLANE;
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// (a, b) -> packed bf16 pair (one v_cvt_pk_bf16_f32) and the pair's values back in fp32 (shift / mask)
+__device__ __forceinline__ unsigned pack_bf16(float a, float b, float& fa, float& fb) {
+    const f32x2 v = {a, b};
+    const bf16x2 p = __builtin_convertvector(v, bf16x2);
+    const unsigned u = __builtin_bit_cast(unsigned, p);
+    fa = __builtin_bit_cast(float, u << 16);
+    fb = __builtin_bit_cast(float, u & 0xffff0000u);
+    return u;
+}
+
+__device__ __forceinline__ void split_store4(const float4 v, unsigned char* dst, int plane_bytes) {
+    float h0, h1, h2, h3, m0, m1, m2, m3, t0, t1;
+    uint2 hi, mid, lo;
+    hi.x = pack_bf16(v.x, v.y, h0, h1);
+    hi.y = pack_bf16(v.z, v.w, h2, h3);
+    const float r0 = v.x - h0, r1 = v.y - h1, r2 = v.z - h2, r3 = v.w - h3;
+    mid.x = pack_bf16(r0, r1, m0, m1);
+    mid.y = pack_bf16(r2, r3, m2, m3);
+    lo.x = pack_bf16(r0 - m0, r1 - m1, t0, t1);
+    lo.y = pack_bf16(r2 - m2, r3 - m3, t0, t1);
+    *reinterpret_cast<uint2*>(dst) = hi;
+    *reinterpret_cast<uint2*>(dst + plane_bytes) = mid;
+    *reinterpret_cast<uint2*>(dst + 2 * plane_bytes) = lo;
+}
+
+__global__ __launch_bounds__(256, 4) void gemm_per_source_split_kernel(const float* __restrict__ Hm,
+                                                                       const float* __restrict__ Y,
+                                                                       const float* __restrict__ Q,
+                                                                       const int* __restrict__ row_ptr,
+                                                                       float* __restrict__ Mp, long long part_stride,
+                                                                       int K, int* __restrict__ status) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * SPL_A_PLANE + 3 * SPL_B_PLANE];
+    const int j = blockIdx.x, slice = blockIdx.z;
+    const int beg = row_ptr[j], end = row_ptr[j + 1];
+    const int r0 = beg + blockIdx.y * 128;
+    if (blockIdx.y == gridDim.y - 1 && slice == 0 && threadIdx.x == 0 && end - beg > (int)gridDim.y * 128 && status)
+        atomicOr(status, MDNO_STATUS_DEGREE_OVERFLOW);
+    if (r0 >= end) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int srow = tid >> 3, scol = (tid & 7) * 4;
+    const int nkt = K / BK, nk = nkt / KS, kt0 = slice * nk;
+    // 32-row groups that hold at least one of this source's rows: the others are neither loaded nor
+    // split nor multiplied (their LDS rows feed only the wave that skips its MFMAs)
+    const int live = (end - r0 + 31) >> 5;
+    auto aptr = [&](int r) {
+        const int rr = r0 + r, e = rr < end ? rr : end - 1;
+        return Hm + ((size_t)(e >> 7) * nkt + kt0) * 4096 + (e & 127) * 32 + scol;
+    };
+    const float* A0 = aptr(srow);
+    const float* A1 = aptr(srow + 32);
+    const float* A2 = aptr(srow + 64);
+    const float* A3 = aptr(srow + 96);
+    const float* Bg = Y + (size_t)j * 64 * K + (size_t)kt0 * 2048 + srow * 32 + scol;
+    float4 ra0, ra1 = make_float4(0.f, 0.f, 0.f, 0.f), ra2 = ra1, ra3 = ra1, rb0, rb1;
+#define MDNO_LOAD(KT)                                                                       \
+    ra0 = *reinterpret_cast<const float4*>(A0 + (size_t)(KT) * 4096);                       \
+    if (live > 1) ra1 = *reinterpret_cast<const float4*>(A1 + (size_t)(KT) * 4096);         \
+    if (live > 2) ra2 = *reinterpret_cast<const float4*>(A2 + (size_t)(KT) * 4096);         \
+    if (live > 3) ra3 = *reinterpret_cast<const float4*>(A3 + (size_t)(KT) * 4096);         \
+    rb0 = *reinterpret_cast<const float4*>(Bg + (size_t)(KT) * 2048);                       \
+    rb1 = *reinterpret_cast<const float4*>(Bg + (size_t)(KT) * 2048 + 1024);
+    // staging thread (row, 4 k at scol): 8 bytes of chunk (scol>>3) of the row, swizzled
+    auto st_off = [&](int row) { return row * 64 + ((((tid & 7) >> 1) ^ ((row >> 2) & 3)) << 4) + (tid & 1) * 8; };
+    unsigned char* a_st0 = lds + st_off(srow);
+    unsigned char* a_st1 = lds + st_off(srow + 32);
+    unsigned char* a_st2 = lds + st_off(srow + 64);
+    unsigned char* a_st3 = lds + st_off(srow + 96);
+    unsigned char* b_st0 = lds + SPL_B_BASE + st_off(srow);
+    unsigned char* b_st1 = lds + SPL_B_BASE + st_off(srow + 32);
+#define MDNO_STORE()                                              \
+    split_store4(ra0, a_st0, SPL_A_PLANE);                        \
+    if (live > 1) split_store4(ra1, a_st1, SPL_A_PLANE);          \
+    if (live > 2) split_store4(ra2, a_st2, SPL_A_PLANE);          \
+    if (live > 3) split_store4(ra3, a_st3, SPL_A_PLANE);          \
+    split_store4(rb0, b_st0, SPL_B_PLANE);                        \
+    split_store4(rb1, b_st1, SPL_B_PLANE);
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+    // fragment reads: row r, k-step s (16 k), half h -> chunk 2s+h, swizzled
+    const int arow = wave * 32 + l31, brow0 = l31, brow1 = 32 + l31;
+    const int a_sw = (arow >> 2) & 3, b_sw0 = (brow0 >> 2) & 3, b_sw1 = (brow1 >> 2) & 3;
+    const unsigned char* a_rd = lds + arow * 64;
+    const unsigned char* b_rd0 = lds + SPL_B_BASE + brow0 * 64;
+    const unsigned char* b_rd1 = lds + SPL_B_BASE + brow1 * 64;
+#define MDNO_MMA6(A, B, ACC)                                                        \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], B[1], ACC, 0, 0, 0);        \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2], B[0], ACC, 0, 0, 0);        \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[2], ACC, 0, 0, 0);        \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], B[0], ACC, 0, 0, 0);        \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[1], ACC, 0, 0, 0);        \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[0], ACC, 0, 0, 0);
+#define MDNO_MMA_TILE()                                                                                  \
+    _Pragma("unroll") for (int st = 0; st < 2; ++st) {                                                   \
+        bf16x8 a[3], b0[3], b1[3];                                                                       \
+        _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                  \
+            a[p] = *reinterpret_cast<const bf16x8*>(a_rd + p * SPL_A_PLANE + (((2 * st + h) ^ a_sw) << 4));   \
+            b0[p] = *reinterpret_cast<const bf16x8*>(b_rd0 + p * SPL_B_PLANE + (((2 * st + h) ^ b_sw0) << 4)); \
+            b1[p] = *reinterpret_cast<const bf16x8*>(b_rd1 + p * SPL_B_PLANE + (((2 * st + h) ^ b_sw1) << 4)); \
+        }                                                                                                \
+        MDNO_MMA6(a, b0, acc0) MDNO_MMA6(a, b1, acc1)                                                    \
+    }
+    MDNO_LOAD(0)
+    MDNO_STORE()
+    __syncthreads();
+    const bool rows_live = wave < live;
+    for (int kt = 0; kt < nk - 1; ++kt) {
+        MDNO_LOAD(kt + 1)
+        __builtin_amdgcn_sched_barrier(0);      // keep the prefetch above the MFMAs
+        if (rows_live) { MDNO_MMA_TILE() }
+        __syncthreads();
+        MDNO_STORE()
+        __syncthreads();
+    }
+    if (rows_live) { MDNO_MMA_TILE() }
+#undef MDNO_LOAD
+#undef MDNO_STORE
+#undef MDNO_MMA_TILE
+#undef MDNO_MMA6
+    // q_j (bias of the last MLP layer seen through x_j) rides on the first k-slice
+    float q0 = 0.f, q1 = 0.f;
+    if (slice == 0) {
+        q0 = Q[(size_t)j * 64 + l31];
+        q1 = Q[(size_t)j * 64 + 32 + l31];
     }
     float* Mo = Mp + (size_t)slice * part_stride;
 #pragma unroll
@@ -280,11 +443,14 @@ __global__ __launch_bounds__(256) void reverse_edges_kernel(const int* __restric
 }
 
 // ---------------------------------------------------------------- (3) aggregate + root + bias + act
-// One wave per destination row; lane = (es, q): four in-edges are gathered per step (es = lane>>4),
-// 16 B of the 64-float message per lane (q = lane&15).  Each es-chain adds its edges in row order
-// (and an edge's KS k-slice partials in slice order); the four chains are combined by two xor
-// shuffles at the end — a fixed order, so the result is deterministic.  The root term x_t.root is
-// accumulated the same way (es picks 16 of the 64 input channels).
+// One workgroup (4 waves) per destination row; thread = (es, q): sixteen in-edges are gathered per
+// step (es = tid>>4), 16 B of the 64-float message per thread (q = tid&15), two steps in flight.
+// The rows gathered are 256 B each at random positions of M, so the kernel is bound by how many
+// loads are outstanding, not by bytes: one wave per row (4 chains) took 35 us per application,
+// this shape 3x less.  Each es-chain adds its edges in row order (and an edge's KS k-slice partials
+// in slice order); the sixteen chains are then added in es order through LDS — a fixed order, so the
+// result is deterministic.  The root term x_t.root is accumulated the same way (es picks 4 of the
+// 64 input channels).
 __global__ __launch_bounds__(256) void aggregate_rev_kernel(const float* __restrict__ Mp, long long part_stride,
                                                             const int* __restrict__ rev,
                                                             const int* __restrict__ row_ptr,
@@ -292,13 +458,12 @@ __global__ __launch_bounds__(256) void aggregate_rev_kernel(const float* __restr
                                                             const float* __restrict__ root,
                                                             const float* __restrict__ bias, float* __restrict__ y,
                                                             int num_rows, int aggr, int relu) {
-    const int lane = threadIdx.x & 63, es = lane >> 4, q = lane & 15;
-    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= num_rows) return;
+    __shared__ float4 part[16][16];
+    const int tid = threadIdx.x, es = tid >> 4, q = tid & 15;
+    const int t = blockIdx.x;
     const int beg = row_ptr[t], end = row_ptr[t + 1];
     const int deg = end - beg;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int p = beg + es; p < end; p += 4) {
+    auto message = [&](int p) {
         const float* m = Mp + (size_t)rev[p] * 64 + 4 * q;
         float4 e = *reinterpret_cast<const float4*>(m);
 #pragma unroll
@@ -306,32 +471,58 @@ __global__ __launch_bounds__(256) void aggregate_rev_kernel(const float* __restr
             const float4 v = *reinterpret_cast<const float4*>(m + (size_t)k * part_stride);
             e.x += v.x; e.y += v.y; e.z += v.z; e.w += v.w;
         }
-        acc.x += e.x; acc.y += e.y; acc.z += e.z; acc.w += e.w;
+        return e;
+    };
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int p = beg + es;
+    for (; p + 16 < end; p += 32) {
+        const float4 e0 = message(p), e1 = message(p + 16);
+        acc.x += e0.x; acc.y += e0.y; acc.z += e0.z; acc.w += e0.w;
+        acc.x += e1.x; acc.y += e1.y; acc.z += e1.z; acc.w += e1.w;
     }
-    float4 racc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (root != nullptr) {
-        const float* xr = x + (size_t)t * 64 + 16 * es;
-        const float* rp = root + (16 * es) * 64 + 4 * q;
+    if (p < end) {
+        const float4 e0 = message(p);
+        acc.x += e0.x; acc.y += e0.y; acc.z += e0.z; acc.w += e0.w;
+    }
+    part[es][q] = acc;
+    __syncthreads();
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (es == 0) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int c = 0; c < 16; ++c) {
+            const float4 v = part[c][q];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        if (aggr == MDNO_AGGR_MEAN) {
+            const float inv = (float)(deg > 1 ? deg : 1);
+            s.x /= inv; s.y /= inv; s.z /= inv; s.w /= inv;
+        }
+    }
+    if (root != nullptr) {
+        __syncthreads();
+        float4 racc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* xr = x + (size_t)t * 64 + 4 * es;
+        const float* rp = root + (4 * es) * 64 + 4 * q;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
             const float xi = xr[i];
             const float4 w = *reinterpret_cast<const float4*>(rp + i * 64);
             racc.x = fmaf(xi, w.x, racc.x); racc.y = fmaf(xi, w.y, racc.y);
             racc.z = fmaf(xi, w.z, racc.z); racc.w = fmaf(xi, w.w, racc.w);
         }
-    }
+        part[es][q] = racc;
+        __syncthreads();
+        if (es == 0) {
+            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int o = 16; o <= 32; o <<= 1) {
-        acc.x += __shfl_xor(acc.x, o); acc.y += __shfl_xor(acc.y, o);
-        acc.z += __shfl_xor(acc.z, o); acc.w += __shfl_xor(acc.w, o);
-        racc.x += __shfl_xor(racc.x, o); racc.y += __shfl_xor(racc.y, o);
-        racc.z += __shfl_xor(racc.z, o); racc.w += __shfl_xor(racc.w, o);
+            for (int c = 0; c < 16; ++c) {
+                const float4 v = part[c][q];
+                r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w;
+            }
+            s.x += r.x; s.y += r.y; s.z += r.z; s.w += r.w;
+        }
     }
     if (es == 0) {
-        const float inv = (float)(deg > 1 ? deg : 1);
-        float4 s = acc;
-        if (aggr == MDNO_AGGR_MEAN) { s.x /= inv; s.y /= inv; s.z /= inv; s.w /= inv; }
-        s.x += racc.x; s.y += racc.y; s.z += racc.z; s.w += racc.w;
         if (bias != nullptr) {
             const float4 b = *reinterpret_cast<const float4*>(bias + 4 * q);
             s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
@@ -350,8 +541,11 @@ size_t factored_workspace_bytes(int num_rows, int ker_width, long long edge_cap)
     Carver cv(nullptr);
     cv.take<float>((size_t)64 * ker_width * 64);               // W3T
     cv.take<float>((size_t)num_rows * 64 * ker_width);         // Y
+    cv.take<float>((size_t)num_rows * 64);                     // q
     cv.take<float>((size_t)KS * edge_cap * 64);                // M: KS k-slice partials
     cv.take<int>((size_t)edge_cap);                            // rev
+    cv.take<char>(split_planes_bytes((long long)64 * ker_width, 64));   // W3T as bf16 planes
+    cv.take<char>(split_planes_bytes(num_rows, 64));                    // X as bf16 planes
     return cv.used();
 }
 
@@ -360,17 +554,22 @@ FactoredWs factored_carve(void* ws, int num_rows, int ker_width, long long edge_
     Carver cv(ws);
     f.w3t = cv.take<float>((size_t)64 * ker_width * 64);
     f.y = cv.take<float>((size_t)num_rows * 64 * ker_width);
+    f.q = cv.take<float>((size_t)num_rows * 64);
     f.m = cv.take<float>((size_t)KS * edge_cap * 64);
     f.part_stride = (long long)edge_cap * 64;
     f.rev = cv.take<int>((size_t)edge_cap);
+    f.w3tp = cv.take<char>(split_planes_bytes((long long)64 * ker_width, 64));
+    f.xp = cv.take<char>(split_planes_bytes(num_rows, 64));
     return f;
 }
 
-int factored_prepare_weights(const float* w3, int ker_width, const FactoredWs& f, hipStream_t s) {
+int factored_prepare_weights(const float* w3, int ker_width, int gemm_mode, const FactoredWs& f, hipStream_t s) {
     const long long total = (long long)64 * ker_width * 64;
     hipLaunchKernelGGL(w3_transpose_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w3, 64, ker_width,
                        f.w3t);
-    return check_launch("w3_transpose_kernel");
+    MDNO_TRY(check_launch("w3_transpose_kernel"));
+    if (gemm_mode == MDNO_GEMM_SPLIT_BF16) MDNO_TRY(split_planes(f.w3t, 64 * ker_width, 64, f.w3tp, s));
+    return MDNO_OK;
 }
 
 int factored_prepare_graph(const int* row_ptr, const int* col, const int* rowid, int num_rows, long long edge_cap,
@@ -382,7 +581,7 @@ int factored_prepare_graph(const int* row_ptr, const int* col, const int* rowid,
 }
 
 int factored_conv(const float* x, const float* h2, const int* row_ptr, int num_rows, int max_degree, int ker_width,
-                  const float* b3, const float* root, const float* bias, int aggr, int relu, float* y,
+                  int gemm_mode, const float* b3, const float* root, const float* bias, int aggr, int relu, float* y,
                   const FactoredWs& f, int* status, hipStream_t s) {
     static bool attr_set = false;
     const size_t lds1 = sizeof(float) * 2 * 256 * LD;   // 73,728 B
@@ -392,19 +591,31 @@ int factored_conv(const float* x, const float* h2, const int* row_ptr, int num_r
         attr_set = true;
     }
     const int ncols = 64 * ker_width;
-    {
+    if (gemm_mode == MDNO_GEMM_SPLIT_BF16) {
+        // 6 bf16 plane products (fp32-level accuracy, edge_mlp_split.hip): the matrix work drops under
+        // the 132 MB store of Y, which is what bounds this step
         TimedSection ts(KID_FACT_Y, s);
+        MDNO_TRY(split_planes_bias64(x, num_rows, b3, f.q, f.xp, s));   // X -> planes, and q = X . B3
+        MDNO_TRY(split_gemm_rows(f.xp, f.w3tp, num_rows, ncols, 64, f.y, s));
+    } else {
+        TimedSection ts(KID_FACT_Y, s);
+        hipLaunchKernelGGL(node_bias_kernel, dim3((num_rows + 3) / 4), dim3(256), 0, s, x, b3, num_rows, f.q);
         hipLaunchKernelGGL(gemm_rows_guarded_kernel, dim3(ncols / 128, (num_rows + 127) / 128), dim3(256), lds1, s, x,
                            (const float*)f.w3t, f.y, num_rows, ncols, 64);
     }
     {
         TimedSection ts(KID_NNCONV, s);
-        hipLaunchKernelGGL(gemm_per_source_kernel, dim3(num_rows, (max_degree + 127) / 128, KS), dim3(256), 0, s, h2,
-                           (const float*)f.y, x, b3, row_ptr, f.m, f.part_stride, ker_width, status);
+        const dim3 grid(num_rows, (max_degree + 127) / 128, KS);
+        if (gemm_mode == MDNO_GEMM_SPLIT_BF16)
+            hipLaunchKernelGGL(gemm_per_source_split_kernel, grid, dim3(256), 0, s, h2, (const float*)f.y,
+                               (const float*)f.q, row_ptr, f.m, f.part_stride, ker_width, status);
+        else
+            hipLaunchKernelGGL(gemm_per_source_kernel, grid, dim3(256), 0, s, h2, (const float*)f.y, (const float*)f.q,
+                               row_ptr, f.m, f.part_stride, ker_width, status);
     }
     {
         TimedSection ts(KID_NNCONV_COMBINE, s);
-        hipLaunchKernelGGL(aggregate_rev_kernel, dim3((num_rows + 3) / 4), dim3(256), 0, s, (const float*)f.m,
+        hipLaunchKernelGGL(aggregate_rev_kernel, dim3(num_rows), dim3(256), 0, s, (const float*)f.m,
                            f.part_stride, (const int*)f.rev, row_ptr, x, root, bias, y, num_rows, aggr, relu);
     }
     return check_launch("factored_conv");

@@ -53,20 +53,29 @@ int edge_mlp_split_hidden(const float* frames, int frame, const int* t_dev, int 
                           long long edge_cap, long long chunk, int ker_in, int ker_width, const EdgeMlpWeights& w,
                           float* h_out, void* workspace, hipStream_t s);
 
+// Pieces of the split-bf16 GEMM usable on their own (edge_mlp_split.hip): fp32 [rows,K] -> tiled bf16
+// planes (buffer of split_planes_bytes), and C[rows,N] = A . Bt^T (fp32 row-major) from two such images.
+size_t split_planes_bytes(long long rows, int K);
+int split_planes(const float* a, int rows, int K, void* planes, hipStream_t s);
+// K = 64 only: the same split of x [rows,64], fused with q[r][o] = sum_i x[r][i] * b[i*64 + o] (fp32 [rows,64])
+int split_planes_bias64(const float* x, int rows, const float* b, float* q, void* planes, hipStream_t s);
+int split_gemm_rows(const void* a_planes, const void* b_planes, int rows, int N, int K, float* C, hipStream_t s);
+
 // Factored conv (factored.hip): see the file header.
 struct FactoredWs {
-    float *w3t, *y, *m;
+    float *w3t, *y, *m, *q;
+    void *w3tp, *xp;          // split-bf16 images of W3T and of the current node features
     int* rev;
     long long part_stride;
 };
 bool factored_supported(int width, int ker_width);
 size_t factored_workspace_bytes(int num_rows, int ker_width, long long edge_cap);
 FactoredWs factored_carve(void* ws, int num_rows, int ker_width, long long edge_cap);
-int factored_prepare_weights(const float* w3, int ker_width, const FactoredWs& f, hipStream_t s);
+int factored_prepare_weights(const float* w3, int ker_width, int gemm_mode, const FactoredWs& f, hipStream_t s);
 int factored_prepare_graph(const int* row_ptr, const int* col, const int* rowid, int num_rows, long long edge_cap,
                            const FactoredWs& f, int* status, hipStream_t s);
 int factored_conv(const float* x, const float* h2, const int* row_ptr, int num_rows, int max_degree, int ker_width,
-                  const float* b3, const float* root, const float* bias, int aggr, int relu, float* y,
+                  int gemm_mode, const float* b3, const float* root, const float* bias, int aggr, int relu, float* y,
                   const FactoredWs& f, int* status, hipStream_t s);
 
 int nnconv(const float* x, const int* row_ptr, const int* src, int num_rows, const float* w_e, const float* root,

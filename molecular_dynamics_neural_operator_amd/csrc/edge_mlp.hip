@@ -284,7 +284,8 @@ extern "C" size_t mdno_edge_mlp_workspace_bytes(int ker_width, int out_dim, int6
 int mdno::edge_mlp(const float* frames, int frame, const int* t_dev, int rows_per_frame, const int* src,
                    const int* dst, const float* edge_attr, const int* perm, const int* num_edges,
                    long long edge_cap, int ker_in, int ker_width, int out_dim, int gemm_mode,
-                   const EdgeMlpWeights& w, float* w_e, void* workspace, size_t workspace_bytes, hipStream_t s) {
+                   const EdgeMlpWeights& w, float* w_e, void* workspace, size_t workspace_bytes, hipStream_t s,
+                   int phase) {
     MDNO_REQUIRE(num_edges && w.w0 && w.b0 && w.w1 && w.b1 && w.w2 && w.b2 && w_e && workspace, MDNO_EINVAL,
                  "edge_mlp: null pointer");
     MDNO_REQUIRE((frames && src && dst) || edge_attr, MDNO_EINVAL, "edge_mlp: need (edge_pos, src, dst) or edge_attr");
@@ -298,7 +299,8 @@ int mdno::edge_mlp(const float* frames, int frame, const int* t_dev, int rows_pe
     const long long chunk = chunk_rows_for(edge_cap);
     if (gemm_mode == MDNO_GEMM_SPLIT_BF16 && edge_mlp_split_supported(ker_width, out_dim))
         return edge_mlp_split(frames, frame, t_dev, rows_per_frame, src, dst, edge_attr, perm, num_edges, edge_cap,
-                              chunk, ker_in, ker_width, out_dim, w, w_e, workspace, s);
+                              chunk, ker_in, ker_width, out_dim, w, w_e, workspace, s, phase);
+    if (phase == WP_PREPARE_ONLY) return MDNO_OK;   // the fp32 GEMMs read the weights as they are
     Carver cv(workspace);
     float* h1 = cv.take<float>((size_t)chunk * ker_width);
     float* h2 = cv.take<float>((size_t)chunk * ker_width);
@@ -324,7 +326,7 @@ int mdno::edge_mlp(const float* frames, int frame, const int* t_dev, int rows_pe
 int mdno::edge_mlp_hidden(const float* frames, int frame, const int* t_dev, int rows_per_frame, const int* src,
                           const int* dst, const float* edge_attr, const int* perm, const int* num_edges,
                           long long edge_cap, int ker_in, int ker_width, int gemm_mode, const EdgeMlpWeights& w,
-                          float* h_out, void* workspace, size_t workspace_bytes, hipStream_t s) {
+                          float* h_out, void* workspace, size_t workspace_bytes, hipStream_t s, int phase) {
     MDNO_REQUIRE(num_edges && w.w0 && w.b0 && w.w1 && w.b1 && h_out && workspace, MDNO_EINVAL,
                  "edge_mlp_hidden: null pointer");
     MDNO_REQUIRE((frames && src && dst) || edge_attr, MDNO_EINVAL, "edge_mlp_hidden: need positions+CSR or edge_attr");
@@ -335,7 +337,8 @@ int mdno::edge_mlp_hidden(const float* frames, int frame, const int* t_dev, int 
     const long long chunk = chunk_rows_for(edge_cap);
     if (gemm_mode == MDNO_GEMM_SPLIT_BF16 && edge_mlp_split_supported(ker_width, ker_width))
         return edge_mlp_split_hidden(frames, frame, t_dev, rows_per_frame, src, dst, edge_attr, perm, num_edges,
-                                     edge_cap, chunk, ker_in, ker_width, w, h_out, workspace, s);
+                                     edge_cap, chunk, ker_in, ker_width, w, h_out, workspace, s, phase);
+    if (phase == WP_PREPARE_ONLY) return MDNO_OK;
     MDNO_REQUIRE(ker_width % BN == 0 && (reinterpret_cast<uintptr_t>(w.w1) & 15) == 0, MDNO_EUNSUPPORTED,
                  "edge_mlp_hidden: ker_width=%d must be a multiple of %d", ker_width, BN);
     Carver cv(workspace);

@@ -398,7 +398,7 @@ size_t edge_mlp_split_workspace_bytes(int ker_width, int out_dim, long long chun
 int edge_mlp_split(const float* frames, int frame, const int* t_dev, int rows_per_frame, const int* src,
                    const int* dst, const float* edge_attr, const int* perm, const int* num_edges,
                    long long edge_cap, long long chunk, int ker_in, int ker_width, int out_dim,
-                   const EdgeMlpWeights& w, float* w_e, void* workspace, hipStream_t s) {
+                   const EdgeMlpWeights& w, float* w_e, void* workspace, hipStream_t s, int phase) {
     MDNO_REQUIRE(ker_in > 0 && ker_in <= MAX_F, MDNO_EUNSUPPORTED, "edge_mlp: ker_in=%d (1..%d)", ker_in, MAX_F);
     MDNO_REQUIRE(((reinterpret_cast<uintptr_t>(w.w1) | reinterpret_cast<uintptr_t>(w.w2)) & 15) == 0, MDNO_EINVAL,
                  "edge_mlp: weight pointers must be 16-byte aligned");
@@ -408,7 +408,7 @@ int edge_mlp_split(const float* frames, int frame, const int* t_dev, int rows_pe
     unsigned char* h2p = reinterpret_cast<unsigned char*>(cv.take<__bf16>(3 * (size_t)chunk * k));
     unsigned char* w1p = reinterpret_cast<unsigned char*>(cv.take<__bf16>(3 * (size_t)k * k));
     unsigned char* w2p = reinterpret_cast<unsigned char*>(cv.take<__bf16>(3 * (size_t)out_dim * k));
-    {
+    if (phase != WP_RUN_ONLY) {
         TimedSection ts(KID_EDGE_L0, s);
         const long long c1 = (long long)k * (k / 8), c2 = (long long)out_dim * (k / 8);
         hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((c1 + 255) / 256)), dim3(256), 0, s, w.w1, k, k, w1p);
@@ -416,6 +416,7 @@ int edge_mlp_split(const float* frames, int frame, const int* t_dev, int rows_pe
                            w2p);
     }
     MDNO_TRY(check_launch("split_planes_kernel"));
+    if (phase == WP_PREPARE_ONLY) return MDNO_OK;
     const float* pos_mode = edge_attr ? nullptr : frames;
     for (long long e0 = 0; e0 < edge_cap; e0 += chunk) {
         const int cnt = (int)((edge_cap - e0) < chunk ? (edge_cap - e0) : chunk);
@@ -438,7 +439,7 @@ int edge_mlp_split(const float* frames, int frame, const int* t_dev, int rows_pe
 int edge_mlp_split_hidden(const float* frames, int frame, const int* t_dev, int rows_per_frame, const int* src,
                           const int* dst, const float* edge_attr, const int* perm, const int* num_edges,
                           long long edge_cap, long long chunk, int ker_in, int ker_width, const EdgeMlpWeights& w,
-                          float* h_out, void* workspace, hipStream_t s) {
+                          float* h_out, void* workspace, hipStream_t s, int phase) {
     MDNO_REQUIRE(ker_in > 0 && ker_in <= MAX_F, MDNO_EUNSUPPORTED, "edge_mlp: ker_in=%d (1..%d)", ker_in, MAX_F);
     MDNO_REQUIRE((reinterpret_cast<uintptr_t>(w.w1) & 15) == 0, MDNO_EINVAL,
                  "edge_mlp: weight pointers must be 16-byte aligned");
@@ -447,12 +448,13 @@ int edge_mlp_split_hidden(const float* frames, int frame, const int* t_dev, int 
     unsigned char* h1p = reinterpret_cast<unsigned char*>(cv.take<__bf16>(3 * (size_t)chunk * k));
     cv.take<__bf16>(3 * (size_t)chunk * k);   // (layout shared with the full MLP: second activation buffer unused)
     unsigned char* w1p = reinterpret_cast<unsigned char*>(cv.take<__bf16>(3 * (size_t)k * k));
-    {
+    if (phase != WP_RUN_ONLY) {
         TimedSection ts(KID_EDGE_L0, s);
         const long long c1 = (long long)k * (k / 8);
         hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((c1 + 255) / 256)), dim3(256), 0, s, w.w1, k, k, w1p);
     }
     MDNO_TRY(check_launch("split_planes_kernel"));
+    if (phase == WP_PREPARE_ONLY) return MDNO_OK;
     const float* pos_mode = edge_attr ? nullptr : frames;
     for (long long e0 = 0; e0 < edge_cap; e0 += chunk) {
         const int cnt = (int)((edge_cap - e0) < chunk ? (edge_cap - e0) : chunk);

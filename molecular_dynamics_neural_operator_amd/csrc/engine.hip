@@ -112,9 +112,11 @@ int forward_impl(const mdno_kernelnn_params* p, const float* frames, int t0, con
                  const long long* aa, int aa_per_member, const int* row_ptr, const int* src, const int* dst,
                  const int* num_edges, long long edge_cap, int max_degree, const float* edge_frames, int edge_frame,
                  const float* edge_attr, const int* perm, float* out_frames, int t_out, float* latent,
-                 const FwdWs& ws, int* status, hipStream_t s) {
+                 const FwdWs& ws, int* status, hipStream_t s, int phase = WP_BOTH) {
     const int R = M * N, C = p->width;
-    MDNO_TRY(node_prologue(p, frames, t0, t_dev, M, W, N, aa, aa_per_member, ws.xa, status, s));
+    // WP_PREPARE_ONLY: just the weight-derived operands of the (single, shared) edge-MLP
+    const bool prep_only = phase == WP_PREPARE_ONLY;
+    if (!prep_only) MDNO_TRY(node_prologue(p, frames, t0, t_dev, M, W, N, aa, aa_per_member, ws.xa, status, s));
     float* cur = ws.xa;
     float* nxt = ws.xb;
     const int blocks = p->conv2_root ? 2 : 1;   // notebook-era model: conv1 only (lstm_* NULL as well)
@@ -124,7 +126,7 @@ int forward_impl(const mdno_kernelnn_params* p, const float* frames, int t0, con
         MDNO_REQUIRE(edge_frames && !edge_attr && dst, MDNO_EINVAL,
                      "factored conv needs a position-derived radius graph (edge_pos, dst)");
         const FactoredWs fw = factored_carve(ws.fact, R, p->ker_width, edge_cap);
-        MDNO_TRY(factored_prepare_graph(row_ptr, src, dst, R, edge_cap, fw, status, s));
+        if (!prep_only) MDNO_TRY(factored_prepare_graph(row_ptr, src, dst, R, edge_cap, fw, status, s));
         for (int block = 0; block < blocks; ++block) {
             const bool own = block == 1 && separate_conv2_kernel(p);
             if (block == 0 || own) {
@@ -133,9 +135,10 @@ int forward_impl(const mdno_kernelnn_params* p, const float* frames, int t0, con
                 // attr = [pos[source], pos[destination]] = [pos[row], pos[col]]: pass (dst, src) swapped
                 MDNO_TRY(edge_mlp_hidden(edge_frames, edge_frame, t_dev, R, /*src=*/dst, /*dst=*/src, nullptr, nullptr,
                                          num_edges, edge_cap, p->ker_in, p->ker_width, p->gemm_mode, w, ws.h2, ws.mlp,
-                                         ws.mlp_bytes, s));
-                MDNO_TRY(factored_prepare_weights(w.w2, p->ker_width, p->gemm_mode, fw, s));
+                                         ws.mlp_bytes, s, phase));
+                if (phase != WP_RUN_ONLY) MDNO_TRY(factored_prepare_weights(w.w2, p->ker_width, p->gemm_mode, fw, s));
             }
+            if (prep_only) return MDNO_OK;
             const float* b3 = (block == 1 && separate_conv2_kernel(p)) ? p->k2_b2 : p->k_b2;
             const float* root = block == 0 ? p->conv1_root : p->conv2_root;
             const float* bias = block == 0 ? p->conv1_bias : p->conv2_bias;
@@ -153,8 +156,10 @@ int forward_impl(const mdno_kernelnn_params* p, const float* frames, int t0, con
                                        ? EdgeMlpWeights{p->k_w0, p->k_b0, p->k_w1, p->k_b1, p->k_w2, p->k_b2}
                                        : EdgeMlpWeights{p->k2_w0, p->k2_b0, p->k2_w1, p->k2_b1, p->k2_w2, p->k2_b2};
                 MDNO_TRY(edge_mlp(edge_frames, edge_frame, t_dev, R, src, dst, edge_attr, perm, num_edges, edge_cap,
-                                  p->ker_in, p->ker_width, C * C, p->gemm_mode, w, ws.w_e, ws.mlp, ws.mlp_bytes, s));
+                                  p->ker_in, p->ker_width, C * C, p->gemm_mode, w, ws.w_e, ws.mlp, ws.mlp_bytes, s,
+                                  phase));
             }
+            if (prep_only) return MDNO_OK;
             const float* root = block == 0 ? p->conv1_root : p->conv2_root;
             const float* bias = block == 0 ? p->conv1_bias : p->conv2_bias;
             for (int d = 0; d < p->depth; ++d) {
@@ -254,7 +259,17 @@ struct mdno_rollout_plan {
     hipGraph_t graph;
     hipGraphExec_t exec;
     Timer* timer;
+    bool weights_cached;   // weight-derived operands are rebuilt per plan_run call, not per step
 };
+
+// The bf16 plane images of W1 (/W2) and W3T depend on the weights only: one workspace slot each, so
+// they can be kept across steps when conv1 and conv2 share one edge-MLP (always, for KernelNN).
+static int plan_prepare_weights(mdno_rollout_plan* pl, hipStream_t s) {
+    const int W = pl->W;
+    return forward_impl(&pl->p, pl->traj, 0, pl->r.t_dev, pl->M, W, pl->N, pl->aa, pl->aa_per_member, pl->r.row_ptr,
+                        pl->r.src, pl->r.dst, pl->r.num_edges, pl->edge_cap, pl->max_degree, pl->traj, W - 1, nullptr,
+                        nullptr, pl->traj, W, nullptr, pl->fw, pl->status, s, WP_PREPARE_ONLY);
+}
 
 static int plan_enqueue_step(mdno_rollout_plan* pl, hipStream_t s) {
     const int W = pl->W;
@@ -263,7 +278,8 @@ static int plan_enqueue_step(mdno_rollout_plan* pl, hipStream_t s) {
                           pl->r.dst, pl->edge_cap, pl->r.num_edges, pl->status, s));
     MDNO_TRY(forward_impl(&pl->p, pl->traj, 0, pl->r.t_dev, pl->M, W, pl->N, pl->aa, pl->aa_per_member, pl->r.row_ptr,
                           pl->r.src, pl->r.dst, pl->r.num_edges, pl->edge_cap, pl->max_degree, pl->traj, W - 1, nullptr,
-                          nullptr, pl->traj, W, nullptr, pl->fw, pl->status, s));
+                          nullptr, pl->traj, W, nullptr, pl->fw, pl->status, s,
+                          pl->weights_cached ? WP_RUN_ONLY : WP_BOTH));
     hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(1), 0, s, pl->r.t_dev, (const int*)pl->r.num_edges,
                        pl->edges_per_step);
     return check_launch("advance_step");
@@ -298,6 +314,7 @@ extern "C" int mdno_rollout_plan_create(mdno_rollout_plan** plan, const mdno_ker
     pl->fw = carve_fwd(r.fwd, p, M, N, (long long)edge_cap);
     pl->edges_per_step = edges_per_step;
     pl->status = status;
+    pl->weights_cached = !separate_conv2_kernel(p);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (use_graph && s != nullptr) {
         hipError_t eb = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
@@ -334,6 +351,8 @@ extern "C" int mdno_rollout_plan_run(mdno_rollout_plan* pl, int start_step, int 
     if (steps == 0) return MDNO_OK;
     hipLaunchKernelGGL(set_step_kernel, dim3(1), dim3(1), 0, s, pl->r.t_dev, start_step);
     MDNO_TRY(check_launch("set_step"));
+    // the weights may have been updated in place since the last call: refresh their images once
+    if (pl->weights_cached) MDNO_TRY(plan_prepare_weights(pl, s));
     for (int t = 0; t < steps; ++t) {
         if (pl->exec && !pl->timer) {
             hipError_t el = hipGraphLaunch(pl->exec, s);

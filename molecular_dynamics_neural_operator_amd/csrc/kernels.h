@@ -29,29 +29,34 @@ struct EdgeMlpWeights {
     const float *w0, *b0, *w1, *b1, *w2, *b2;
 };
 
+// Weight-derived operands (bf16 plane images, W3T) live in the caller's workspace.  A rollout plan
+// builds them once per mdno_rollout_plan_run (WP_PREPARE_ONLY) and its steps reuse them (WP_RUN_ONLY);
+// one-off calls do both (WP_BOTH).
+enum WeightPhase { WP_BOTH = 0, WP_PREPARE_ONLY = 1, WP_RUN_ONLY = 2 };
+
 // gemm_mode: MDNO_GEMM_SPLIT_BF16 (default; falls back to exact fp32 when the shape is not tileable)
 // or MDNO_GEMM_F32.
 int edge_mlp(const float* frames, int frame, const int* t_dev, int rows_per_frame, const int* src, const int* dst,
              const float* edge_attr, const int* perm, const int* num_edges, long long edge_cap, int ker_in,
              int ker_width, int out_dim, int gemm_mode, const EdgeMlpWeights& w, float* w_e, void* workspace,
-             size_t workspace_bytes, hipStream_t s);
+             size_t workspace_bytes, hipStream_t s, int phase = WP_BOTH);
 bool edge_mlp_split_supported(int ker_width, int out_dim);
 size_t edge_mlp_split_workspace_bytes(int ker_width, int out_dim, long long chunk);
 int edge_mlp_split(const float* frames, int frame, const int* t_dev, int rows_per_frame, const int* src,
                    const int* dst, const float* edge_attr, const int* perm, const int* num_edges,
                    long long edge_cap, long long chunk, int ker_in, int ker_width, int out_dim,
-                   const EdgeMlpWeights& w, float* w_e, void* workspace, hipStream_t s);
+                   const EdgeMlpWeights& w, float* w_e, void* workspace, hipStream_t s, int phase = WP_BOTH);
 
 // Edge-MLP up to its last hidden activation: H = relu(L1(relu(L0(attr)))) as fp32 [edge_cap, ker_width]
 // row-major (what the factored conv consumes); same attr modes and gemm_mode as edge_mlp.
 int edge_mlp_hidden(const float* frames, int frame, const int* t_dev, int rows_per_frame, const int* src,
                     const int* dst, const float* edge_attr, const int* perm, const int* num_edges,
                     long long edge_cap, int ker_in, int ker_width, int gemm_mode, const EdgeMlpWeights& w,
-                    float* h_out, void* workspace, size_t workspace_bytes, hipStream_t s);
+                    float* h_out, void* workspace, size_t workspace_bytes, hipStream_t s, int phase = WP_BOTH);
 int edge_mlp_split_hidden(const float* frames, int frame, const int* t_dev, int rows_per_frame, const int* src,
                           const int* dst, const float* edge_attr, const int* perm, const int* num_edges,
                           long long edge_cap, long long chunk, int ker_in, int ker_width, const EdgeMlpWeights& w,
-                          float* h_out, void* workspace, hipStream_t s);
+                          float* h_out, void* workspace, hipStream_t s, int phase = WP_BOTH);
 
 // Pieces of the split-bf16 GEMM usable on their own (edge_mlp_split.hip): fp32 [rows,K] -> tiled bf16
 // planes (buffer of split_planes_bytes), and C[rows,N] = A . Bt^T (fp32 row-major) from two such images.

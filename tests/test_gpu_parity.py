@@ -558,6 +558,34 @@ def test_edge_cases_single_atom_window1_zero_steps_and_c_rollout(dev, O):
 
 
 # ------------------------------------------------------------------------------- error behaviour
+@pytest.mark.parametrize("conv_mode", ["factored", "materialized"])
+def test_rollout_plan_sees_in_place_weight_updates(dev, conv_mode):
+    """A plan keeps the weight-derived operands (bf16 plane images, W3T) across the steps of one run;
+    they are rebuilt at the start of every run, so weights updated in place between runs (an
+    optimiser step) are picked up by an existing engine."""
+    from molecular_dynamics_neural_operator_amd import synthetic as syn
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN
+    from molecular_dynamics_neural_operator_amd.rollout import RolloutEngine
+    from molecular_dynamics_neural_operator_amd.weights import near_identity_state_dict
+    N, W, steps = 40, 4, 3
+    sd = near_identity_state_dict(64, 128, seed=4, kernel_gain=1e-2, feature_gain=0.1, kernel_to_coords=1.0)
+    model = KernelNN(64, 128, 2, 6, 7, 3, 20, 4)
+    model.load_state_dict(sd)
+    model.eval().to(dev)
+    model.conv_mode = conv_mode
+    win = torch.from_numpy(syn.jitter_window(syn.chain_frame(N, seed=5), W, seed=5))
+    aa = torch.from_numpy(syn.amino_acids(N, seed=5))
+    eng = RolloutEngine(model, 1, N, W, 8.0, max_steps=steps, device=dev)
+    before = eng.run(win, aa, steps).clone()
+    with torch.no_grad():
+        for prm in model.conv1.net.parameters():
+            prm.mul_(1.25)
+    after = eng.run(win, aa, steps).clone()
+    fresh = RolloutEngine(model, 1, N, W, 8.0, max_steps=steps, device=dev).run(win, aa, steps)
+    assert float((after - before).abs().max()) > 1e-4        # the update matters ...
+    assert torch.equal(after, fresh)                          # ... and the old engine sees all of it
+
+
 def test_errors_are_loud(dev):
     from molecular_dynamics_neural_operator_amd import MdnoError, ops
     from molecular_dynamics_neural_operator_amd.dataset import PairData

@@ -187,6 +187,7 @@ struct SplitGemmArgs {
     int rows, N, K;
     int tiles_n, tiles_m;
     int rows_valid;
+    int m_fastest;             // tile order: 0 = n fastest (neighbours share the A row-panel), 1 = m fastest (share B)
 };
 
 // One stage (k-step of 16) for a wave: (2x2 tiles) x 6 plane products = 24 MFMAs, 12 fragment reads.
@@ -216,6 +217,7 @@ __device__ __forceinline__ void mma_split_stage(f32x16 (&acc)[2][2], const unsig
 // OUT: 0 = fp32 row-major (W_e), 1 = tiled bf16 planes after ReLU (next GEMM's operand),
 //      2 = fp32 k-tiled [rows/128][N/32][128][32] after ReLU (the hidden activation the factored conv streams)
 template <int TM, int OUT>
+// (second launch bound = waves per SIMD, not workgroups per CU; the LDS footprint decides the latter)
 __global__ __launch_bounds__(TM * 2, 2) void gemm_split_bf16_kernel(SplitGemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int WAVES = TM / 32;                       // (TM/64) x 2 waves of 64x64
@@ -234,8 +236,9 @@ __global__ __launch_bounds__(TM * 2, 2) void gemm_split_bf16_kernel(SplitGemmArg
     if (orig >= nwg) return;
     const int xcd = orig & 7, q = nwg >> 3, r8 = nwg & 7;
     const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
-    const int bm = (tile / g.tiles_n) * TM;
-    const int bn = (tile % g.tiles_n) * TN;
+    const int tiles_mv = nwg / g.tiles_n;
+    const int bm = (g.m_fastest ? tile % tiles_mv : tile / g.tiles_n) * TM;
+    const int bn = (g.m_fastest ? tile / tiles_mv : tile % g.tiles_n) * TN;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
@@ -377,8 +380,9 @@ int split_planes_bias64(const float* x, int rows, const float* b, float* q, void
 int split_gemm_rows(const void* a_planes, const void* b_planes, int rows, int N, int K, float* C, hipStream_t s) {
     MDNO_REQUIRE(K % 32 == 0 && N % TN == 0 && rows > 0, MDNO_EUNSUPPORTED, "split_gemm_rows: rows=%d N=%d K=%d", rows, N, K);
     SplitGemmArgs g{static_cast<const unsigned char*>(a_planes), static_cast<const unsigned char*>(b_planes), nullptr, C,
-                    nullptr, nullptr, 0, (rows + 255) / 256 * 256, N, K, 0, 0, rows};
-    // 256-row tiles also here: with 128-row tiles the B planes are fetched twice as often (61 vs 50 us at R=504)
+                    nullptr, nullptr, 0, (rows + 255) / 256 * 256, N, K, 0, 0, rows, 1};
+    // m-fastest tile order: the tiles of one B panel run back to back on one XCD.  256-row tiles also
+    // here: 128-row ones measured 57 vs 49 us at R=504, N=65536
     return N >= 2048 ? launch_split_gemm_tm<256, 0>(g, s) : launch_split_gemm_tm<128, 0>(g, s);
 }
 
@@ -427,10 +431,10 @@ int edge_mlp_split(const float* frames, int frame, const int* t_dev, int rows_pe
                                h1p);
         }
         MDNO_TRY(check_launch("edge_l0_split_kernel"));
-        SplitGemmArgs g1{h1p, w1p, w.b1, nullptr, h2p, num_edges, e0, (int)chunk, k, k, 0, 0, 0};
+        SplitGemmArgs g1{h1p, w1p, w.b1, nullptr, h2p, num_edges, e0, (int)chunk, k, k, 0, 0, 0, 0};
         MDNO_TRY(launch_split_gemm<1>(g1, KID_GEMM_L1, s));
         SplitGemmArgs g2{h2p, w2p, w.b2, w_e + (size_t)e0 * out_dim, nullptr, num_edges, e0, (int)chunk, out_dim, k,
-                         0, 0, 0};
+                         0, 0, 0, 0};
         MDNO_TRY(launch_split_gemm<0>(g2, KID_GEMM_L2, s));
     }
     return MDNO_OK;
@@ -465,7 +469,7 @@ int edge_mlp_split_hidden(const float* frames, int frame, const int* t_dev, int 
                                h1p);
         }
         MDNO_TRY(check_launch("edge_l0_split_kernel"));
-        SplitGemmArgs g1{h1p, w1p, w.b1, h_out + (size_t)e0 * k, nullptr, num_edges, e0, (int)chunk, k, k, 0, 0, 0};
+        SplitGemmArgs g1{h1p, w1p, w.b1, h_out + (size_t)e0 * k, nullptr, num_edges, e0, (int)chunk, k, k, 0, 0, 0, 0};
         MDNO_TRY(launch_split_gemm<2>(g1, KID_GEMM_L1, s));   // chunk % 128 == 0: tile index continues across chunks
     }
     return MDNO_OK;

@@ -190,11 +190,19 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_mfma_kernel(GemmArgs g) {
 #undef MDNO_LOAD_TILE
 #undef MDNO_STORE_TILE
 
-    // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+    // The bias values are loaded once and pinned (see edge_mlp_split.hip: sunk into the predicated
+    // store blocks, the load puts an s_waitcnt vmcnt(0) in front of every store).
+    float bv0 = 0.f, bv1 = 0.f;
+    if (g.bias) {
+        bv0 = g.bias[bn + wn * 64 + l31];
+        bv1 = g.bias[bn + wn * 64 + 32 + l31];
+    }
+    asm volatile("" : "+v"(bv0), "+v"(bv1));
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = bn + wn * 64 + j * 32 + l31;
-        const float bv = g.bias ? g.bias[n] : 0.f;
+        const float bv = j ? bv1 : bv0;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll

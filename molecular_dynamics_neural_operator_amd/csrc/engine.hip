@@ -143,9 +143,14 @@ int forward_impl(const mdno_kernelnn_params* p, const float* frames, int t0, con
             const float* root = block == 0 ? p->conv1_root : p->conv2_root;
             const float* bias = block == 0 ? p->conv1_bias : p->conv2_bias;
             for (int d = 0; d < p->depth; ++d) {
+                // each application leaves the next one's operands (bf16 image of its output, q) behind
+                const bool first = block == 0 && d == 0;
+                const float* next_b3 = d + 1 < p->depth ? b3
+                                       : block + 1 < blocks ? (separate_conv2_kernel(p) ? p->k2_b2 : p->k_b2)
+                                                            : nullptr;
                 MDNO_TRY(factored_conv(cur, ws.h2, row_ptr, R, max_degree > 0 ? max_degree : N, p->ker_width,
-                                       p->gemm_mode, b3, root,
-                                       bias, MDNO_AGGR_MEAN, /*relu=*/1, nxt, fw, status, s));
+                                       p->gemm_mode, b3, root, bias, MDNO_AGGR_MEAN, /*relu=*/1, nxt, fw, status, s,
+                                       /*x_prepared=*/!first, next_b3));
                 float* t = cur; cur = nxt; nxt = t;
             }
         }

@@ -20,6 +20,7 @@
 // All three steps use exact fp32 arithmetic (v_mfma_f32_32x32x2_f32); they are small next to the
 // k x k hidden GEMM that remains in the edge-MLP.
 #include "kernels.h"
+#include "split_layout.h"
 
 namespace mdno {
 namespace {
@@ -226,6 +227,15 @@ __global__ __launch_bounds__(256, 4) void gemm_per_source_kernel(const float* __
     f32x16 acc0, acc1;
 #pragma unroll
     for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+    // q_j (bias of the last MLP layer seen through x_j) rides on the first k-slice.  Loaded before
+    // the K loop and pinned: sunk into the predicated store blocks of the epilogue, the load would put
+    // an s_waitcnt vmcnt(0) — a full store round trip — in front of every store.
+    float q0 = 0.f, q1 = 0.f;
+    if (slice == 0) {
+        q0 = Q[(size_t)j * 64 + l31];
+        q1 = Q[(size_t)j * 64 + 32 + l31];
+    }
+    asm volatile("" : "+v"(q0), "+v"(q1));
     const float* a_rd = As + (wave * 32 + l31) * LD + 4 * h;
     const float* b_rd = Bs + l31 * LD + 4 * h;
     MDNO_LOAD(0)
@@ -245,12 +255,6 @@ __global__ __launch_bounds__(256, 4) void gemm_per_source_kernel(const float* __
     if (rows_live) mma_32x64(acc0, acc1, a_rd, b_rd);
 #undef MDNO_LOAD
 #undef MDNO_STORE
-    // q_j (bias of the last MLP layer seen through x_j) rides on the first k-slice
-    float q0 = 0.f, q1 = 0.f;
-    if (slice == 0) {
-        q0 = Q[(size_t)j * 64 + l31];
-        q1 = Q[(size_t)j * 64 + 32 + l31];
-    }
     float* Mo = Mp + (size_t)slice * part_stride;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -361,6 +365,15 @@ __global__ __launch_bounds__(256, 4) void gemm_per_source_split_kernel(const flo
     f32x16 acc0, acc1;
 #pragma unroll
     for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+    // q_j (bias of the last MLP layer seen through x_j) rides on the first k-slice.  Loaded before
+    // the K loop and pinned: sunk into the predicated store blocks of the epilogue, the load would put
+    // an s_waitcnt vmcnt(0) — a full store round trip — in front of every store.
+    float q0 = 0.f, q1 = 0.f;
+    if (slice == 0) {
+        q0 = Q[(size_t)j * 64 + l31];
+        q1 = Q[(size_t)j * 64 + 32 + l31];
+    }
+    asm volatile("" : "+v"(q0), "+v"(q1));
     // fragment reads: row r, k-step s (16 k), half h -> chunk 2s+h, swizzled
     const int arow = wave * 32 + l31, brow0 = l31, brow1 = 32 + l31;
     const int a_sw = (arow >> 2) & 3, b_sw0 = (brow0 >> 2) & 3, b_sw1 = (brow1 >> 2) & 3;
@@ -401,12 +414,6 @@ __global__ __launch_bounds__(256, 4) void gemm_per_source_split_kernel(const flo
 #undef MDNO_STORE
 #undef MDNO_MMA_TILE
 #undef MDNO_MMA6
-    // q_j (bias of the last MLP layer seen through x_j) rides on the first k-slice
-    float q0 = 0.f, q1 = 0.f;
-    if (slice == 0) {
-        q0 = Q[(size_t)j * 64 + l31];
-        q1 = Q[(size_t)j * 64 + 32 + l31];
-    }
     float* Mo = Mp + (size_t)slice * part_stride;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -457,7 +464,10 @@ __global__ __launch_bounds__(256) void aggregate_rev_kernel(const float* __restr
                                                             const float* __restrict__ x,
                                                             const float* __restrict__ root,
                                                             const float* __restrict__ bias, float* __restrict__ y,
-                                                            int num_rows, int aggr, int relu) {
+                                                            int num_rows, int aggr, int relu,
+                                                            const float* __restrict__ next_b3,
+                                                            float* __restrict__ next_q,
+                                                            unsigned char* __restrict__ next_xp) {
     __shared__ float4 part[16][16];
     const int tid = threadIdx.x, es = tid >> 4, q = tid & 15;
     const int t = blockIdx.x;
@@ -530,6 +540,29 @@ __global__ __launch_bounds__(256) void aggregate_rev_kernel(const float* __restr
         if (relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
         *reinterpret_cast<float4*>(y + (size_t)t * 64 + 4 * q) = s;
     }
+    // What the NEXT conv application needs from this row, while it is at hand (saves a launch per
+    // application): q = y_t . B3 (bias of the last MLP layer seen through the node) and the bf16
+    // plane image of y_t (operand of the Y GEMM).  Same arithmetic as split_bias64_kernel.
+    if (next_b3 != nullptr) {
+        __syncthreads();
+        if (es == 0) part[0][q] = s;
+        __syncthreads();
+        const float* row = reinterpret_cast<const float*>(&part[0][0]);
+        if (tid < 64) {
+            float acc2 = 0.f;
+#pragma unroll 16
+            for (int i = 0; i < 64; ++i) acc2 = fmaf(row[i], next_b3[i * 64 + tid], acc2);
+            next_q[(size_t)t * 64 + tid] = acc2;
+        } else if (tid < 72) {
+            const int c = tid - 64;
+            __bf16 pl[3][8];
+#pragma unroll
+            for (int j2 = 0; j2 < 8; ++j2) split3(row[8 * c + j2], pl[0][j2], pl[1][j2], pl[2][j2]);
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                *reinterpret_cast<uint4*>(next_xp + tiled_off(t, 8 * c, 4, p)) = *reinterpret_cast<const uint4*>(pl[p]);
+        }
+    }
 }
 
 }  // namespace
@@ -582,7 +615,7 @@ int factored_prepare_graph(const int* row_ptr, const int* col, const int* rowid,
 
 int factored_conv(const float* x, const float* h2, const int* row_ptr, int num_rows, int max_degree, int ker_width,
                   int gemm_mode, const float* b3, const float* root, const float* bias, int aggr, int relu, float* y,
-                  const FactoredWs& f, int* status, hipStream_t s) {
+                  const FactoredWs& f, int* status, hipStream_t s, bool x_prepared, const float* next_b3) {
     static bool attr_set = false;
     const size_t lds1 = sizeof(float) * 2 * 256 * LD;   // 73,728 B
     if (!attr_set) {
@@ -595,7 +628,8 @@ int factored_conv(const float* x, const float* h2, const int* row_ptr, int num_r
         // 6 bf16 plane products (fp32-level accuracy, edge_mlp_split.hip): the matrix work drops under
         // the 132 MB store of Y, which is what bounds this step
         TimedSection ts(KID_FACT_Y, s);
-        MDNO_TRY(split_planes_bias64(x, num_rows, b3, f.q, f.xp, s));   // X -> planes, and q = X . B3
+        // X -> planes and q = X . B3: done by the previous application's aggregation when x_prepared
+        if (!x_prepared) MDNO_TRY(split_planes_bias64(x, num_rows, b3, f.q, f.xp, s));
         MDNO_TRY(split_gemm_rows(f.xp, f.w3tp, num_rows, ncols, 64, f.y, s));
     } else {
         TimedSection ts(KID_FACT_Y, s);
@@ -613,10 +647,12 @@ int factored_conv(const float* x, const float* h2, const int* row_ptr, int num_r
             hipLaunchKernelGGL(gemm_per_source_kernel, grid, dim3(256), 0, s, h2, (const float*)f.y, (const float*)f.q,
                                row_ptr, f.m, f.part_stride, ker_width, status);
     }
+    const bool split_next = gemm_mode == MDNO_GEMM_SPLIT_BF16 && next_b3 != nullptr;
     {
         TimedSection ts(KID_NNCONV_COMBINE, s);
         hipLaunchKernelGGL(aggregate_rev_kernel, dim3(num_rows), dim3(256), 0, s, (const float*)f.m,
-                           f.part_stride, (const int*)f.rev, row_ptr, x, root, bias, y, num_rows, aggr, relu);
+                           f.part_stride, (const int*)f.rev, row_ptr, x, root, bias, y, num_rows, aggr, relu,
+                           split_next ? next_b3 : nullptr, f.q, static_cast<unsigned char*>(f.xp));
     }
     return check_launch("factored_conv");
 }

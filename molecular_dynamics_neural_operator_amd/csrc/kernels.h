@@ -81,7 +81,9 @@ int factored_prepare_graph(const int* row_ptr, const int* col, const int* rowid,
                            const FactoredWs& f, int* status, hipStream_t s);
 int factored_conv(const float* x, const float* h2, const int* row_ptr, int num_rows, int max_degree, int ker_width,
                   int gemm_mode, const float* b3, const float* root, const float* bias, int aggr, int relu, float* y,
-                  const FactoredWs& f, int* status, hipStream_t s);
+                  const FactoredWs& f, int* status, hipStream_t s, bool x_prepared, const float* next_b3);
+// x_prepared: the bf16 image of x and q = x.B3 are already in f.xp / f.q (left there by the previous
+// application, which was given this application's b3 as next_b3); next_b3 NULL: nothing follows.
 
 int nnconv(const float* x, const int* row_ptr, const int* src, int num_rows, const float* w_e, const float* root,
            const float* bias, int Cin, int Cout, int aggr, int relu, float* y, hipStream_t s);

@@ -1,0 +1,25 @@
+// Shared by the kernels that produce or consume the split-bf16 operand images (edge_mlp_split.hip
+// owns the layout; factored.hip's aggregation writes the node features of the next layer in it).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mdno {
+
+__device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
+    h = (__bf16)x;
+    const float r1 = x - (float)h;
+    m = (__bf16)r1;
+    const float r2 = r1 - (float)m;
+    l = (__bf16)r2;
+}
+
+// Byte offset of element (row, kcol) of plane p in the tiled layout; nkt = K/16.  A plane tile is
+// 128 rows of 32 B (16 k); the two 16-B halves of a row are swapped when (row>>3)&1, which spreads
+// the ds_read_b128 fragment reads of a 16-lane group over all 16 slots of a 256-B bank row.
+__device__ __forceinline__ size_t tiled_off(long long row, int kcol, int nkt, int p) {
+    const long long rt = row >> 7;
+    const int r = (int)(row & 127), kt = kcol >> 4, c = (kcol >> 3) & 1, e = kcol & 7;
+    return ((size_t)((rt * nkt + kt) * 3 + p) << 12) + r * 32 + ((c ^ ((r >> 3) & 1)) << 4) + e * 2;
+}
+
+}  // namespace mdno

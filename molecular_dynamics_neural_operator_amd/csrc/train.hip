@@ -101,10 +101,17 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(const float* __rest
     mma_64x64(acc, a_rd + ((nk - 1) & 1) * 128 * LD, b_rd + ((nk - 1) & 1) * 128 * LD);
 #undef MDNO_LOAD
 #undef MDNO_STORE
+    // bias loaded once and pinned (sunk into the predicated store blocks it serialises the stores)
+    float bv0 = 0.f, bv1 = 0.f;
+    if (bias) {
+        bv0 = bias[bn + wn * 64 + l31];
+        bv1 = bias[bn + wn * 64 + 32 + l31];
+    }
+    asm volatile("" : "+v"(bv0), "+v"(bv1));
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = bn + wn * 64 + j * 32 + l31;
-        const float bv = bias ? bias[n] : 0.f;
+        const float bv = j ? bv1 : bv0;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll

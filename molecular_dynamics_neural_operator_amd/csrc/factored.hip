@@ -340,11 +340,18 @@ __global__ __launch_bounds__(256, 4) void gemm_per_source_split_kernel(const flo
     const float* A3 = aptr(srow + 96);
     const float* Bg = Y + (size_t)j * 64 * K + (size_t)kt0 * 2048 + srow * 32 + scol;
     float4 ra0, ra1 = make_float4(0.f, 0.f, 0.f, 0.f), ra2 = ra1, ra3 = ra1, rb0, rb1;
+    // H is streamed once per application: non-temporal loads (global_load ... nt) leave the caches to
+    // Y_j and the partial sums (-4.5 % kernel time)
+#define MDNO_NT(DST, P)                                                                             \
+    {                                                                                               \
+        const f32x4 t_ = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(P));             \
+        DST = make_float4(t_.x, t_.y, t_.z, t_.w);                                                  \
+    }
 #define MDNO_LOAD(KT)                                                                       \
-    ra0 = *reinterpret_cast<const float4*>(A0 + (size_t)(KT) * 4096);                       \
-    if (live > 1) ra1 = *reinterpret_cast<const float4*>(A1 + (size_t)(KT) * 4096);         \
-    if (live > 2) ra2 = *reinterpret_cast<const float4*>(A2 + (size_t)(KT) * 4096);         \
-    if (live > 3) ra3 = *reinterpret_cast<const float4*>(A3 + (size_t)(KT) * 4096);         \
+    MDNO_NT(ra0, A0 + (size_t)(KT) * 4096)                                                  \
+    if (live > 1) MDNO_NT(ra1, A1 + (size_t)(KT) * 4096)                                    \
+    if (live > 2) MDNO_NT(ra2, A2 + (size_t)(KT) * 4096)                                    \
+    if (live > 3) MDNO_NT(ra3, A3 + (size_t)(KT) * 4096)                                    \
     rb0 = *reinterpret_cast<const float4*>(Bg + (size_t)(KT) * 2048);                       \
     rb1 = *reinterpret_cast<const float4*>(Bg + (size_t)(KT) * 2048 + 1024);
     // staging thread (row, 4 k at scol): 8 bytes of chunk (scol>>3) of the row, swizzled
@@ -411,6 +418,7 @@ __global__ __launch_bounds__(256, 4) void gemm_per_source_split_kernel(const flo
     }
     if (rows_live) { MDNO_MMA_TILE() }
 #undef MDNO_LOAD
+#undef MDNO_NT
 #undef MDNO_STORE
 #undef MDNO_MMA_TILE
 #undef MDNO_MMA6

@@ -28,6 +28,12 @@ namespace mdno {
 namespace {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// W_e is read exactly once per application: stream it past the caches (global_load ... nt)
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4_stream(const float* p) {
+    const f32x4_t t = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p));
+    return make_float4(t.x, t.y, t.z, t.w);
+}
 
 __device__ __forceinline__ void fma4(float4& a, float s, const float4& w) {
     a.x = fmaf(s, w.x, a.x);
@@ -44,7 +50,7 @@ __device__ __forceinline__ void edge_accumulate64(float4& acc, const float* __re
     const float* wp = wmat + (16 * g) * 64 + 4 * q;
     float4 w[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) w[r] = ld4(wp + r * 64);
+    for (int r = 0; r < 16; ++r) w[r] = ld4_stream(wp + r * 64);
     fma4(acc, x0.x, w[0]);  fma4(acc, x0.y, w[1]);  fma4(acc, x0.z, w[2]);  fma4(acc, x0.w, w[3]);
     fma4(acc, x1.x, w[4]);  fma4(acc, x1.y, w[5]);  fma4(acc, x1.z, w[6]);  fma4(acc, x1.w, w[7]);
     fma4(acc, x2.x, w[8]);  fma4(acc, x2.y, w[9]);  fma4(acc, x2.z, w[10]); fma4(acc, x2.w, w[11]);

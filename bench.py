@@ -245,22 +245,27 @@ def main():
     def per_source_roofline(ks, e):   # factored path: M_j = H_j . Y_j^T, one launch per conv application
         avg_s = ks["nnconv"]["avg_ms"] * 1e-3
         alg = e * KW * 4 + R * C * KW * 4 + 2 * e * C * 4 + (R + 1) * 4        # H once + Y once + 2 k-slice partials out
-        flops = 2.0 * e * KW * C
-        t_hbm, t_mfma = alg / (HBM_PEAK_GBS * 1e9), flops / (MFMA_F32_PEAK_TFLOPS * 1e12)
-        r = {"kernel": "gemm_per_source_kernel", "conv_mode": "factored", "avg_launch_ms": avg_s * 1e3,
+        flops = 2.0 * e * KW * C                                                # fp32-equivalent
+        split = a.gemm_mode == "split_bf16"
+        # matrix-pipe work as executed: 6 bf16 plane products per fp32 product, or the fp32 MFMA itself
+        mfma_exec, mfma_peak = (6.0 * flops, MFMA_BF16_PEAK_TFLOPS) if split else (flops, MFMA_F32_PEAK_TFLOPS)
+        t_hbm, t_mfma = alg / (HBM_PEAK_GBS * 1e9), mfma_exec / (mfma_peak * 1e12)
+        name = "gemm_per_source_split_kernel" if split else "gemm_per_source_kernel"
+        r = {"kernel": name, "conv_mode": "factored", "avg_launch_ms": avg_s * 1e3,
              "algorithmic_bytes_per_launch": alg, "flops_per_launch": flops, "traffic": None,
              "hbm_GBps": alg / avg_s / 1e9, "hbm_frac": alg / avg_s / 1e9 / HBM_PEAK_GBS,
-             "mfma_TFLOPs": flops / avg_s / 1e12, "mfma_frac": flops / avg_s / 1e12 / MFMA_F32_PEAK_TFLOPS}
+             "frac_of_measured_copy_peak": alg / avg_s / 1e9 / HBM_COPY_GBS,
+             "mfma_TFLOPs": mfma_exec / avg_s / 1e12, "mfma_frac": mfma_exec / avg_s / 1e12 / mfma_peak}
         tf = REPO / "profiles" / "roofline_traffic.json"
         if tf.exists():
             try:
-                r["traffic"] = json.loads(tf.read_text()).get("per_source_gemm_hbm_bytes_per_launch")
+                r["traffic"] = json.loads(tf.read_text()).get(name + "_hbm_bytes_per_launch")
             except Exception:
                 pass
         if t_hbm >= t_mfma:
             r.update(bound="hbm", achieved=r["hbm_GBps"], peak=HBM_PEAK_GBS, unit="GB/s", frac=r["hbm_frac"])
         else:
-            r.update(bound="mfma", achieved=r["mfma_TFLOPs"], peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=r["mfma_frac"])
+            r.update(bound="mfma", achieved=r["mfma_TFLOPs"], peak=mfma_peak, unit="TFLOP/s", frac=r["mfma_frac"])
         return r
 
     if not a.skip_roofline:

@@ -62,7 +62,8 @@ if pmc:
 
     traffic = {"source": f"profiles/{tag}_pmc.json",
                "nnconv_hbm_bytes_per_launch": corrected("nnconv64_row_kernel"),
-               "per_source_gemm_hbm_bytes_per_launch": corrected("gemm_per_source_kernel"),
+               "gemm_per_source_split_kernel_hbm_bytes_per_launch": corrected("gemm_per_source_split_kernel"),
+               "gemm_per_source_kernel_hbm_bytes_per_launch": corrected("gemm_per_source_kernel"),
                "note": "2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 read-side correction), separate --pmc passes"}
     (out / "roofline_traffic.json").write_text(json.dumps(traffic, indent=1))
     print("wrote profiles/roofline_traffic.json")

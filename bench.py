@@ -65,7 +65,7 @@ def parse():
     ap.add_argument("--gemm-mode", choices=["split_bf16", "f32"], default="split_bf16",
                     help="edge-MLP GEMMs: exact 3-way bf16 split (6 products, fp32 accumulate) or fp32-input MFMA")
     ap.add_argument("--single-mode", action="store_true", help="skip the comparison leg in the other conv mode")
-    ap.add_argument("--conv-mode", choices=["materialized", "factored"], default="factored",
+    ap.add_argument("--conv-mode", choices=["auto", "materialized", "factored"], default="auto",
                     help="materialized = W_e written once and streamed by every conv application (the reference's "
                          "formulation); factored = same sums reassociated per node, W_e never formed")
     ap.add_argument("--variant", choices=["intree", "notebook"], default="intree",
@@ -164,6 +164,7 @@ def main():
     eng = RolloutEngine(model, M, N, W, a.threshold, max_steps=max_steps, edge_cap=cap, device=dev,
                         use_graph=not a.no_graph)
     eng.reset(torch.from_numpy(wins), aa)
+    mode = eng.conv_mode            # what "auto" resolved to at this edge capacity
 
     # ---- warm-up (untimed): also captures nothing new — the step graph was captured in reset()
     eng.step(a.warmup)
@@ -270,7 +271,7 @@ def main():
 
     if not a.skip_roofline:
         kernels, e2 = timed_leg(eng, a.warmup + a.steps)
-        if a.conv_mode == "materialized":
+        if mode == "materialized":
             roofs["conv_materialized"] = conv_roofline(kernels, e2)
             roofs["edge_mlp_last_gemm"] = gemm_roofline(kernels, e2, "edge_mlp_gemm2", C * C)
         else:
@@ -279,7 +280,7 @@ def main():
         # ---- the other conv formulation on the same start window: frames/s and, for the materialised
         # one, the HBM roofline of the gather/matvec/scatter kernel BASELINE.json's target is stated on
         if a.variant == "intree" and not a.single_mode:
-            om = "materialized" if a.conv_mode == "factored" else "factored"
+            om = "materialized" if mode == "factored" else "factored"
             model.conv_mode = om
             eng2 = RolloutEngine(model, M, N, W, a.threshold, max_steps=a.warmup + 2 * a.steps, edge_cap=cap, device=dev,
                                  use_graph=not a.no_graph)
@@ -305,7 +306,7 @@ def main():
     dominant = None
     if kernels:
         name = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
-        dominant = {"nnconv": roofs.get("conv_materialized" if a.conv_mode == "materialized"
+        dominant = {"nnconv": roofs.get("conv_materialized" if mode == "materialized"
                                         else "conv_factored_per_source_gemm"),
                     "edge_mlp_gemm2": roofs.get("edge_mlp_last_gemm"),
                     "edge_mlp_gemm1": roofs.get("edge_mlp_hidden_gemm")}.get(name)
@@ -327,7 +328,7 @@ def main():
                        "edges_first_last": [int(eps[0].item()), int(eps[-1].item())], "edge_cap": cap,
                        "parallelism": f"ensemble-sharded x{world}, one all-gather of trajectories",
                        "launch": "plain" if a.no_graph else "hipGraph replay", "edge_mlp_gemm": a.gemm_mode,
-                       "variant": a.variant, "conv_mode": a.conv_mode},
+                       "variant": a.variant, "conv_mode": mode, "conv_mode_requested": a.conv_mode},
             "roofline": dominant, "rooflines": roofs, "other_conv_mode": other_mode, "cpu_baseline": cpu,
             "kernels": kernels,
         }

@@ -61,6 +61,10 @@ extern "C" {
  *                 else runs MATERIALIZED. */
 #define MDNO_CONV_MATERIALIZED 0
 #define MDNO_CONV_FACTORED     1
+/*   AUTO          FACTORED where it applies and the graph is large enough to pay for its fixed cost
+ *                 per application (the Y GEMM and a 16-iteration pipeline per source: edge_cap >=
+ *                 24,576), MATERIALIZED otherwise (small graphs: 2x faster at N=28..120). */
+#define MDNO_CONV_AUTO         2
 
 /* status word bits written by device code (read back by the caller after synchronising) */
 #define MDNO_STATUS_EDGE_OVERFLOW 1   /* radius graph found more than edge_cap edges; list truncated */
@@ -181,6 +185,9 @@ int mdno_fc_out_fwd(const float* x, const float* w, const float* b, int rows, in
  * Workspace: mdno_kernelnn_workspace_bytes(p, M, N, edge_cap).
  * ---------------------------------------------------------------------------------------- */
 size_t mdno_kernelnn_workspace_bytes(const mdno_kernelnn_params* p, int M, int N, int64_t edge_cap);
+/* The formulation (MDNO_CONV_MATERIALIZED / MDNO_CONV_FACTORED) a forward or rollout with these
+ * parameters and this edge capacity runs on a position-derived radius graph (resolves AUTO). */
+int mdno_resolve_conv_mode(const mdno_kernelnn_params* p, int64_t edge_cap);
 int mdno_kernelnn_fwd(const mdno_kernelnn_params* p, const float* frames, int M, int W, int N,
                       const int64_t* x_aminoacid, int aa_per_member,
                       const int32_t* row_ptr, const int32_t* src, const int32_t* dst,

@@ -16,7 +16,7 @@ AGGR = {"add": 0, "mean": 1}
 STATUS_EDGE_OVERFLOW, STATUS_BAD_AMINOACID = 1, 2
 ABI_VERSION = 4
 GEMM_MODES = {"split_bf16": 0, "f32": 1}
-CONV_MODES = {"materialized": 0, "factored": 1}
+CONV_MODES = {"materialized": 0, "factored": 1, "auto": 2}
 STATUS_ASYMMETRIC_GRAPH = 4
 STATUS_DEGREE_OVERFLOW = 8
 
@@ -56,6 +56,7 @@ SIGNATURES = {
     "mdno_node_prologue_fwd": (_I, [C.POINTER(KernelNNParams), _P, _I, _I, _I, _P, _I, _P, _P, _P]),
     "mdno_fc_out_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
     "mdno_kernelnn_workspace_bytes": (_SZ, [C.POINTER(KernelNNParams), _I, _I, _L]),
+    "mdno_resolve_conv_mode": (_I, [C.POINTER(KernelNNParams), _L]),
     "mdno_kernelnn_fwd": (_I, [C.POINTER(KernelNNParams), _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _L, _I,
                                _P, _P, _P, _P, _P, _P, _SZ, _P, _P]),
     "mdno_rollout_workspace_bytes": (_SZ, [C.POINTER(KernelNNParams), _I, _I, _L]),

@@ -377,7 +377,7 @@ int split_gemm_rows(const void* a_planes, const void* b_planes, int rows, int N,
                     nullptr, nullptr, 0, (rows + 255) / 256 * 256, N, K, 0, 0, rows, 1};
     // m-fastest tile order: the tiles of one B panel run back to back on one XCD.  256-row tiles also
     // here: 128-row ones measured 57 vs 49 us at R=504, N=65536
-    return N >= 2048 ? launch_split_gemm_tm<256, 0>(g, s) : launch_split_gemm_tm<128, 0>(g, s);
+    return (N >= 2048 && rows > 128) ? launch_split_gemm_tm<256, 0>(g, s) : launch_split_gemm_tm<128, 0>(g, s);
 }
 
 bool edge_mlp_split_supported(int ker_width, int out_dim) {

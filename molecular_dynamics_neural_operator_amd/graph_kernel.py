@@ -202,11 +202,13 @@ class KernelNN(nn.Module):
         # "f32" = fp32-input MFMA, bit-for-bit an fmaf chain
         self.gemm_mode = "split_bf16"
         # how conv applications run inside the on-device rollout / position-graph forward
-        # (include/mdno.h MDNO_CONV_*): "factored" (default) = the reference's sums reassociated per
-        # node, W_e never formed (csrc/factored.hip; needs width 64 and a radius graph built by the
-        # library, otherwise the library itself runs materialized); "materialized" = the reference's
-        # W_e formulation.  forward(data) with an explicit edge_index/edge_attr always runs materialized.
-        self.conv_mode = "factored"
+        # (include/mdno.h MDNO_CONV_*): "factored" = the reference's sums reassociated per node, W_e
+        # never formed (csrc/factored.hip; needs width 64 and a radius graph built by the library,
+        # otherwise the library itself runs materialized); "materialized" = the reference's W_e
+        # formulation; "auto" (default) = factored once the graph is large enough to pay for its fixed
+        # cost per application (edge capacity >= 24,576), materialized below.  forward(data) with an
+        # explicit edge_index/edge_attr always runs materialized.
+        self.conv_mode = "auto"
 
     # -- parameter pack (device pointers) cached until a parameter changes
     def param_pack(self, device=None, conv_mode: Optional[str] = None) -> ops.ParamPack:
@@ -269,11 +271,13 @@ class KernelNNNotebook(KernelNN):
         self._pack_key = None
         self.gemm_mode = "split_bf16"
         # how conv applications run inside the on-device rollout / position-graph forward
-        # (include/mdno.h MDNO_CONV_*): "factored" (default) = the reference's sums reassociated per
-        # node, W_e never formed (csrc/factored.hip; needs width 64 and a radius graph built by the
-        # library, otherwise the library itself runs materialized); "materialized" = the reference's
-        # W_e formulation.  forward(data) with an explicit edge_index/edge_attr always runs materialized.
-        self.conv_mode = "factored"
+        # (include/mdno.h MDNO_CONV_*): "factored" = the reference's sums reassociated per node, W_e
+        # never formed (csrc/factored.hip; needs width 64 and a radius graph built by the library,
+        # otherwise the library itself runs materialized); "materialized" = the reference's W_e
+        # formulation; "auto" (default) = factored once the graph is large enough to pay for its fixed
+        # cost per application (edge capacity >= 24,576), materialized below.  forward(data) with an
+        # explicit edge_index/edge_attr always runs materialized.
+        self.conv_mode = "auto"
 
 
 # --------------------------------------------------------------------------- graph construction

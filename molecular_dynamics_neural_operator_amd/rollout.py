@@ -51,6 +51,9 @@ class RolloutEngine:
         if not isinstance(self.pack, ops.ParamPack):
             raise MdnoError("model must be a KernelNN (or an ops.ParamPack)")
         dev = self.device
+        # what conv_mode "auto" resolves to at this capacity (include/mdno.h MDNO_CONV_AUTO)
+        self.conv_mode = {v: k for k, v in _lib.CONV_MODES.items()}[
+            int(self.lib.mdno_resolve_conv_mode(self.pack.ref, self.edge_cap))]
         self.traj = torch.zeros((self.W + self.max_steps, self.M, self.N, 3), dtype=torch.float32, device=dev)
         nbytes = self.lib.mdno_rollout_workspace_bytes(self.pack.ref, self.M, self.N, self.edge_cap)
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)

@@ -401,6 +401,7 @@ def test_rollout_graph_replay_equals_eager_and_members_are_independent(dev):
     model = KernelNN(64, 128, 2, 6, 7, 3, 20, 4)
     model.load_state_dict(near_identity_state_dict(64, 128, seed=5, kernel_gain=3e-2, feature_gain=0.3, kernel_to_coords=1.0))
     model.eval().to(dev)
+    model.conv_mode = "factored"      # ("auto" would pick materialized at this size)
     base = syn.jitter_window(syn.box_frame(N, seed=3), W, seed=3)
     wins = syn.ensemble_windows(base, M, sigma=0.3)                  # [M,W,N,3]
     tm = torch.from_numpy(np.ascontiguousarray(wins.transpose(1, 0, 2, 3)))   # [W,M,N,3]
@@ -584,6 +585,30 @@ def test_rollout_plan_sees_in_place_weight_updates(dev, conv_mode):
     fresh = RolloutEngine(model, 1, N, W, 8.0, max_steps=steps, device=dev).run(win, aa, steps)
     assert float((after - before).abs().max()) > 1e-4        # the update matters ...
     assert torch.equal(after, fresh)                          # ... and the old engine sees all of it
+
+
+def test_conv_mode_auto_resolves_by_edge_capacity(dev):
+    """conv_mode="auto" (the default): materialized for small graphs, factored from edge_cap 24,576 on
+    (include/mdno.h MDNO_CONV_AUTO); both give the same trajectory to fp32 rounding."""
+    from molecular_dynamics_neural_operator_amd import synthetic as syn
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN
+    from molecular_dynamics_neural_operator_amd.rollout import RolloutEngine
+    from molecular_dynamics_neural_operator_amd.weights import near_identity_state_dict
+    N, W, steps = 120, 4, 3
+    model = KernelNN(64, 128, 2, 6, 7, 3, 20, 4)
+    model.load_state_dict(near_identity_state_dict(64, 128, seed=6, kernel_gain=1e-2, feature_gain=0.1, kernel_to_coords=1.0))
+    model.eval().to(dev)
+    assert model.conv_mode == "auto"
+    win = torch.from_numpy(syn.jitter_window(syn.box_frame(N, seed=6), W, seed=6))
+    aa = torch.from_numpy(syn.amino_acids(N, seed=6))
+    small = RolloutEngine(model, 1, N, W, 8.0, max_steps=steps, device=dev)                    # cap = N^2 = 14,400
+    big = RolloutEngine(model, 1, N, W, 8.0, max_steps=steps, device=dev, edge_cap=32768)
+    assert (small.conv_mode, big.conv_mode) == ("materialized", "factored")
+    close(big.run(win, aa, steps), small.run(win, aa, steps))
+    model.conv_mode = "factored"
+    forced = RolloutEngine(model, 1, N, W, 8.0, max_steps=steps, device=dev)
+    assert forced.conv_mode == "factored"
+    assert torch.equal(forced.run(win, aa, steps), big.frames())
 
 
 def test_errors_are_loud(dev):

@@ -98,65 +98,84 @@ __global__ __launch_bounds__(256) void split_bias64_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------- layer 0 (+ attr gather) -> planes
-// Block = 256 threads, EB edges.  Thread = one 16-B chunk (8 hidden units) of one edge at a time:
-// k/8 threads cover an edge, the block walks its edges in groups of 256/(k/8).
-constexpr int EB = 32;
+// Workgroup = one 128-row tile of the chunk x 128 hidden units (8 k-steps of the tiled image).  Lanes
+// run over ROWS: lane = (row = lane>>1 within the wave's 32 rows, half = lane&1), so every wave store
+// is one contiguous KiB of a plane tile (32 rows x 32 B) and the workgroup fills whole 4 KiB plane
+// tiles.  (The first version ran lanes over the hidden units of one edge: each store instruction
+// scattered 32-B pieces 12 KiB apart and the kernel wrote its 372 MB at 3.8 TB/s; this shape reaches
+// the ~6 TB/s the chip stores at.)  The edge's attributes stay in registers; the block's slice of W0
+// and b0 (3.5 KiB) sits in LDS and is read as broadcasts.
 constexpr int MAX_F = 8;
+constexpr int L0_ROWS = 128, L0_UNITS = 128;
 
+template <int FT>   // FT = compile-time ker_in (6 for position-derived attributes), 0 = run-time F
 __global__ __launch_bounds__(256) void edge_l0_split_kernel(
     const float* __restrict__ frames, int frame, const int* __restrict__ t_dev, int rows_per_frame,
     const int* __restrict__ src, const int* __restrict__ dst, const float* __restrict__ edge_attr,
     const int* __restrict__ perm, const int* __restrict__ num_edges, long long e_begin, int e_count, int F, int k,
     const float* __restrict__ w0, const float* __restrict__ b0, unsigned char* __restrict__ hp) {
-    __shared__ float attr[EB][MAX_F];
+    __shared__ __attribute__((aligned(16))) float wsh[L0_UNITS * MAX_F];
+    __shared__ __attribute__((aligned(16))) float bsh[L0_UNITS];
+    const int Fn = FT ? FT : F;
     const long long E = *num_edges;
-    const long long e0 = e_begin + (long long)blockIdx.x * EB;
-    if (e0 >= E || (long long)blockIdx.x * EB >= e_count) return;
-    const int tid = threadIdx.x;
-    {
-        const int le = tid / MAX_F, f = tid % MAX_F;   // 256 threads = 32 edges x 8 features
-        const long long e = e0 + le;
-        float v = 0.f;
-        if (e < E && f < F) {
-            if (frames != nullptr) {  // attr = [pos[src], pos[dst]]   (graph_kernel.py:372-379)
-                const float* edge_pos = frames + (size_t)(frame + (t_dev ? *t_dev : 0)) * rows_per_frame * 3;
-                const int node = (f < 3) ? src[e] : dst[e];
-                v = edge_pos[(size_t)node * 3 + (f % 3)];
-            } else {
-                const long long pe = perm ? (long long)perm[e] : e;
-                v = edge_attr[pe * F + f];
-            }
+    const long long tile0 = (long long)blockIdx.x * L0_ROWS;   // first row of this tile inside the chunk
+    if (e_begin + tile0 >= E || tile0 >= e_count) return;
+    const int u0 = blockIdx.y * L0_UNITS, tid = threadIdx.x;
+    for (int i = tid; i < L0_UNITS * Fn; i += 256) wsh[i] = w0[(size_t)u0 * Fn + i];
+    if (tid < L0_UNITS) bsh[tid] = b0[u0 + tid];
+    const int lane = tid & 63, r = (tid >> 6) * 32 + (lane >> 1), half = lane & 1;
+    const long long le = tile0 + r, e = e_begin + le;
+    const bool valid = e < E && le < e_count;
+    float attr[MAX_F];
+#pragma unroll
+    for (int f = 0; f < MAX_F; ++f) attr[f] = 0.f;
+    if (valid) {
+        if (frames != nullptr) {  // attr = [pos[src], pos[dst]]   (graph_kernel.py:372-379)
+            const float* edge_pos = frames + (size_t)(frame + (t_dev ? *t_dev : 0)) * rows_per_frame * 3;
+            const float* ps = edge_pos + (size_t)src[e] * 3;
+            const float* pd = edge_pos + (size_t)dst[e] * 3;
+            attr[0] = ps[0]; attr[1] = ps[1]; attr[2] = ps[2];
+            attr[3] = pd[0]; attr[4] = pd[1]; attr[5] = pd[2];
+        } else {
+            const long long pe = perm ? (long long)perm[e] : e;
+#pragma unroll
+            for (int f = 0; f < MAX_F; ++f)
+                if (f < Fn) attr[f] = edge_attr[pe * Fn + f];
         }
-        attr[le][f] = v;
     }
     __syncthreads();
-    const int cpr = k >> 3;                 // chunks per edge row
+    if (!valid) return;
     const int nkt = k >> 4;
-    for (int c0 = (tid % cpr) * 8, le0 = tid / cpr; c0 < k; c0 += 256 * 8) {   // one pass when k/8 <= 256
-        float w[8][MAX_F], bc[8];
+#pragma unroll 2
+    for (int t = 0; t < L0_UNITS / 16; ++t) {
+        const int c = t * 16 + half * 8;       // this thread's 8 hidden units, relative to u0
+        __bf16 o[3][8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
+            float sum = 0.f;
 #pragma unroll
-            for (int f = 0; f < MAX_F; ++f) w[j][f] = (f < F) ? w0[(size_t)(c0 + j) * F + f] : 0.f;
-            bc[j] = b0[c0 + j];
+            for (int f = 0; f < MAX_F; ++f)
+                if (f < Fn) sum = fmaf(attr[f], wsh[(c + j) * Fn + f], sum);
+            split3(fmaxf(sum + bsh[c + j], 0.f), o[0][j], o[1][j], o[2][j]);
         }
-        const int estep = (cpr >= 256) ? 1 : 256 / cpr;
-        for (int le = le0; le < EB; le += estep) {
-            const long long e = e0 + le;
-            if (e >= E || e - e_begin >= e_count) break;
-            __bf16 o[3][8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float s = 0.f;
-#pragma unroll
-                for (int f = 0; f < MAX_F; ++f) s = fmaf(attr[le][f], w[j][f], s);
-                split3(fmaxf(s + bc[j], 0.f), o[0][j], o[1][j], o[2][j]);
-            }
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-                *reinterpret_cast<uint4*>(hp + tiled_off(e - e_begin, c0, nkt, p)) = *reinterpret_cast<const uint4*>(o[p]);
-        }
+        for (int p = 0; p < 3; ++p)
+            *reinterpret_cast<uint4*>(hp + tiled_off(le, u0 + c, nkt, p)) = *reinterpret_cast<const uint4*>(o[p]);
     }
+}
+
+static int launch_edge_l0_split(const float* pos_mode, int frame, const int* t_dev, int rows_per_frame, const int* src,
+                                const int* dst, const float* edge_attr, const int* perm, const int* num_edges,
+                                long long e0, int cnt, int F, int k, const float* w0, const float* b0,
+                                unsigned char* hp, hipStream_t s) {
+    const dim3 grid((cnt + L0_ROWS - 1) / L0_ROWS, k / L0_UNITS);
+    if (F == 6)
+        hipLaunchKernelGGL(edge_l0_split_kernel<6>, grid, dim3(256), 0, s, pos_mode, frame, t_dev, rows_per_frame, src,
+                           dst, edge_attr, perm, num_edges, e0, cnt, F, k, w0, b0, hp);
+    else
+        hipLaunchKernelGGL(edge_l0_split_kernel<0>, grid, dim3(256), 0, s, pos_mode, frame, t_dev, rows_per_frame, src,
+                           dst, edge_attr, perm, num_edges, e0, cnt, F, k, w0, b0, hp);
+    return check_launch("edge_l0_split_kernel");
 }
 
 // ---------------------------------------------------------------- split-bf16 GEMM
@@ -420,11 +439,9 @@ int edge_mlp_split(const float* frames, int frame, const int* t_dev, int rows_pe
         const int cnt = (int)((edge_cap - e0) < chunk ? (edge_cap - e0) : chunk);
         {
             TimedSection ts(KID_EDGE_L0, s);
-            hipLaunchKernelGGL(edge_l0_split_kernel, dim3((cnt + EB - 1) / EB), dim3(256), 0, s, pos_mode, frame, t_dev,
-                               rows_per_frame, src, dst, edge_attr, perm, num_edges, e0, cnt, ker_in, k, w.w0, w.b0,
-                               h1p);
+            MDNO_TRY(launch_edge_l0_split(pos_mode, frame, t_dev, rows_per_frame, src, dst, edge_attr, perm, num_edges,
+                                          e0, cnt, ker_in, k, w.w0, w.b0, h1p, s));
         }
-        MDNO_TRY(check_launch("edge_l0_split_kernel"));
         SplitGemmArgs g1{h1p, w1p, w.b1, nullptr, h2p, num_edges, e0, (int)chunk, k, k, 0, 0, 0, 0};
         MDNO_TRY(launch_split_gemm<1>(g1, KID_GEMM_L1, s));
         SplitGemmArgs g2{h2p, w2p, w.b2, w_e + (size_t)e0 * out_dim, nullptr, num_edges, e0, (int)chunk, out_dim, k,
@@ -458,11 +475,9 @@ int edge_mlp_split_hidden(const float* frames, int frame, const int* t_dev, int 
         const int cnt = (int)((edge_cap - e0) < chunk ? (edge_cap - e0) : chunk);
         {
             TimedSection ts(KID_EDGE_L0, s);
-            hipLaunchKernelGGL(edge_l0_split_kernel, dim3((cnt + EB - 1) / EB), dim3(256), 0, s, pos_mode, frame, t_dev,
-                               rows_per_frame, src, dst, edge_attr, perm, num_edges, e0, cnt, ker_in, k, w.w0, w.b0,
-                               h1p);
+            MDNO_TRY(launch_edge_l0_split(pos_mode, frame, t_dev, rows_per_frame, src, dst, edge_attr, perm, num_edges,
+                                          e0, cnt, ker_in, k, w.w0, w.b0, h1p, s));
         }
-        MDNO_TRY(check_launch("edge_l0_split_kernel"));
         SplitGemmArgs g1{h1p, w1p, w.b1, h_out + (size_t)e0 * k, nullptr, num_edges, e0, (int)chunk, k, k, 0, 0, 0, 0};
         MDNO_TRY(launch_split_gemm<2>(g1, KID_GEMM_L1, s));   // chunk % 128 == 0: tile index continues across chunks
     }

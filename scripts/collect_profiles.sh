@@ -12,3 +12,6 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROO
 echo "fetch done"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-graph --skip-cpu-baseline > $OUT/pmc_write.json 2> $OUT/pmc_write.err
 echo "write done"
+# training step (cfg4 stand-in): kernel trace only
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train_trace -- python3 $ROOT/scripts/train_synthetic.py > $OUT/train.json 2> $OUT/train.err
+echo "train trace done"

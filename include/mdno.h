@@ -242,6 +242,10 @@ int mdno_rollout_plan_timer_detach(mdno_rollout_plan* plan);
  * :239-242.  All fp32; row/edge reductions use fixed-order partial sums (bitwise reproducible).
  * With gz = g * (x_out > 0) and gs[t] = gz[t] / max(deg_t,1) (mean) or gz[t] (add):
  *   mdno_linear_fwd       C = act(A . W^T + b)       A [rows,k], W [n,k] (torch Linear layout)
+ *   mdno_linear_split_fwd the same on the bf16 matrix pipe: both operands split exactly into three
+ *                         bf16 planes on the way in, 6 plane products, fp32 accumulation (the
+ *                         MDNO_GEMM_SPLIT_BF16 arithmetic; needs k % 32 == 0, n % 128 == 0 and a
+ *                         workspace of mdno_linear_split_workspace_bytes(rows, n, k))
  *   mdno_gemm_atb         C (+)= A^T . B             A [rows,n1], B [rows,n2] -> C [n1,n2] (weight grads)
  *   mdno_colsum           out (+)= column sums of A [rows,n]                       (bias grads)
  *   mdno_relu_bwd         out = g * (y > 0) [* row_scale[row]]
@@ -257,6 +261,9 @@ int mdno_rollout_plan_timer_detach(mdno_rollout_plan* plan);
  * ---------------------------------------------------------------------------------------- */
 int mdno_linear_fwd(const float* a, const float* w, const float* bias, int64_t rows, int n, int k, int relu,
                     float* c, void* stream);
+size_t mdno_linear_split_workspace_bytes(int64_t rows, int n, int k);
+int mdno_linear_split_fwd(const float* a, const float* w, const float* bias, int64_t rows, int n, int k, int relu,
+                          float* c, void* workspace, size_t workspace_bytes, void* stream);
 size_t mdno_reduce_workspace_bytes(int n1, int n2);
 int mdno_gemm_atb(const float* a, const float* b, int64_t rows, int n1, int n2, float* c, int accumulate,
                   void* workspace, size_t workspace_bytes, void* stream);

@@ -69,6 +69,8 @@ SIGNATURES = {
     "mdno_rollout_plan_timer_read": (_I, [_P, _I, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "mdno_rollout_plan_timer_detach": (_I, [_P]),
     "mdno_linear_fwd": (_I, [_P, _P, _P, _L, _I, _I, _I, _P, _P]),
+    "mdno_linear_split_workspace_bytes": (_SZ, [_L, _I, _I]),
+    "mdno_linear_split_fwd": (_I, [_P, _P, _P, _L, _I, _I, _I, _P, _P, _SZ, _P]),
     "mdno_reduce_workspace_bytes": (_SZ, [_I, _I]),
     "mdno_gemm_atb": (_I, [_P, _P, _L, _I, _I, _P, _I, _P, _SZ, _P]),
     "mdno_colsum": (_I, [_P, _L, _I, _P, _I, _P, _SZ, _P]),

@@ -219,6 +219,7 @@ __device__ __forceinline__ void mma_split_stage(f32x16 (&acc)[2][2], const unsig
 
 // OUT: 0 = fp32 row-major (W_e), 1 = tiled bf16 planes after ReLU (next GEMM's operand),
 //      2 = fp32 k-tiled [rows/128][N/32][128][32] after ReLU (the hidden activation the factored conv streams)
+//      3 = fp32 row-major after ReLU (training: mdno_linear_split_fwd)
 template <int TM, int OUT>
 // (second launch bound = waves per SIMD, not workgroups per CU; the LDS footprint decides the latter)
 __global__ __launch_bounds__(TM * 2, 2) void gemm_split_bf16_kernel(SplitGemmArgs g) {
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(TM * 2, 2) void gemm_split_bf16_kernel(SplitGemmArg
                         *reinterpret_cast<__bf16*>(g.Cp + o + PLANE_BYTES) = pm;
                         *reinterpret_cast<__bf16*>(g.Cp + o + 2 * PLANE_BYTES) = pl;
                     } else {
-                        g.C[(size_t)m * g.N + n] = v;
+                        g.C[(size_t)m * g.N + n] = OUT == 3 ? fmaxf(v, 0.f) : v;
                     }
                 }
             }
@@ -397,6 +398,27 @@ int split_gemm_rows(const void* a_planes, const void* b_planes, int rows, int N,
     // m-fastest tile order: the tiles of one B panel run back to back on one XCD.  256-row tiles also
     // here: 128-row ones measured 57 vs 49 us at R=504, N=65536
     return (N >= 2048 && rows > 128) ? launch_split_gemm_tm<256, 0>(g, s) : launch_split_gemm_tm<128, 0>(g, s);
+}
+
+// act(A . W^T + b) for the training ops: A [rows,K] and W [N,K] are split here, every call
+size_t split_linear_workspace_bytes(long long rows, int N, int K) {
+    return align_up(split_planes_bytes(rows, K), 256) + align_up(split_planes_bytes(N, K), 256);
+}
+
+bool split_linear_supported(long long rows, int N, int K) {
+    return K % 32 == 0 && N % TN == 0 && rows > 0 && rows < (1ll << 31) - 256;
+}
+
+int split_linear(const float* a, const float* w, const float* bias, long long rows, int N, int K, int relu, float* c,
+                 void* workspace, hipStream_t s) {
+    Carver cv(workspace);
+    unsigned char* ap = reinterpret_cast<unsigned char*>(cv.take<char>(split_planes_bytes(rows, K)));
+    unsigned char* wp = reinterpret_cast<unsigned char*>(cv.take<char>(split_planes_bytes(N, K)));
+    MDNO_TRY(split_planes(a, (int)rows, K, ap, s));
+    MDNO_TRY(split_planes(w, N, K, wp, s));
+    SplitGemmArgs g{ap, wp, bias, c, nullptr, nullptr, 0, (int)((rows + 255) / 256 * 256), N, K, 0, 0, (int)rows, 0};
+    if (relu) return N >= 2048 ? launch_split_gemm_tm<256, 3>(g, s) : launch_split_gemm_tm<128, 3>(g, s);
+    return N >= 2048 ? launch_split_gemm_tm<256, 0>(g, s) : launch_split_gemm_tm<128, 0>(g, s);
 }
 
 bool edge_mlp_split_supported(int ker_width, int out_dim) {

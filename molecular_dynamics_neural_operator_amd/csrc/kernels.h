@@ -65,6 +65,11 @@ int split_planes(const float* a, int rows, int K, void* planes, hipStream_t s);
 // K = 64 only: the same split of x [rows,64], fused with q[r][o] = sum_i x[r][i] * b[i*64 + o] (fp32 [rows,64])
 int split_planes_bias64(const float* x, int rows, const float* b, float* q, void* planes, hipStream_t s);
 int split_gemm_rows(const void* a_planes, const void* b_planes, int rows, int N, int K, float* C, hipStream_t s);
+// C = act(A . W^T + b) with both operands split on the way in (training ops)
+size_t split_linear_workspace_bytes(long long rows, int N, int K);
+bool split_linear_supported(long long rows, int N, int K);
+int split_linear(const float* a, const float* w, const float* bias, long long rows, int N, int K, int relu, float* c,
+                 void* workspace, hipStream_t s);
 
 // Factored conv (factored.hip): see the file header.
 struct FactoredWs {

@@ -22,31 +22,34 @@ from .dataset import PairData
 
 class KernelIntegralBlock(torch.autograd.Function):
     """x_L = conv2^depth(conv1^depth(x_0)) with W_e = net(edge_attr) shared by every application
-    (graph_kernel.py:271-273, :299-302), materialised formulation, fp32 MFMA GEMMs."""
+    (graph_kernel.py:271-273, :299-302), materialised formulation.  gemm_mode as for inference:
+    "split_bf16" runs the four wide C = A.W^T products (two forward, two backward) on the bf16 matrix
+    pipe with the exact 3-way split, "f32" on the fp32 MFMA; the weight-gradient products A^T.B are
+    fp32 either way."""
 
     @staticmethod
-    def forward(ctx, x0, edge_attr, graph, depth, w0, b0, w1, b1, w2, b2, root1, bias1, root2, bias2):
+    def forward(ctx, x0, edge_attr, graph, depth, gemm_mode, w0, b0, w1, b1, w2, b2, root1, bias1, root2, bias2):
         R = x0.shape[0]
         E = graph.edge_count()
         ea = ops.f32(edge_attr)[graph.perm[:E].long()] if graph.perm is not None else ops.f32(edge_attr)
         ea = ea.contiguous()
         h1 = ops.linear(ea, w0, b0, relu=True)
-        h2 = ops.linear(h1, w1, b1, relu=True)
-        w_e = ops.linear(h2, w2, b2, relu=False)
+        h2 = ops.linear(h1, w1, b1, relu=True, gemm_mode=gemm_mode)
+        w_e = ops.linear(h2, w2, b2, relu=False, gemm_mode=gemm_mode)
         L = 2 * depth
         X = torch.empty((L + 1, R, 64), dtype=torch.float32, device=x0.device)
         X[0].copy_(x0)
         for a in range(1, L + 1):
             root, bias = (root1, bias1) if a <= depth else (root2, bias2)
             X[a].copy_(ops.nnconv(X[a - 1], graph, w_e, root, bias, "mean", relu=True))
-        ctx.graph, ctx.depth = graph, depth
+        ctx.graph, ctx.depth, ctx.gemm_mode = graph, depth, gemm_mode
         ctx.save_for_backward(ea, h1, h2, w_e, X, w0, w1, w2, root1, root2)
         return X[L].clone()
 
     @staticmethod
     def backward(ctx, g_out):
         ea, h1, h2, w_e, X, w0, w1, w2, root1, root2 = ctx.saved_tensors
-        graph, depth = ctx.graph, ctx.depth
+        graph, depth, gemm_mode = ctx.graph, ctx.depth, ctx.gemm_mode
         L, R = 2 * depth, X.shape[1]
         by_src = ops.source_sorted(graph, R)
         inv = ops.inv_degree(graph, "mean")
@@ -64,14 +67,14 @@ class KernelIntegralBlock(torch.autograd.Function):
         # edge-MLP backward
         d_b2 = ops.colsum(d_we)
         d_w2 = ops.gemm_atb(d_we, h2)
-        gz2 = ops.relu_bwd(ops.linear(d_we, ops.transpose(w2), None), h2)
+        gz2 = ops.relu_bwd(ops.linear(d_we, ops.transpose(w2), None, gemm_mode=gemm_mode), h2)
         del d_we
         d_b1 = ops.colsum(gz2)
         d_w1 = ops.gemm_atb(gz2, h1)
-        gz1 = ops.relu_bwd(ops.linear(gz2, ops.transpose(w1), None), h1)
+        gz1 = ops.relu_bwd(ops.linear(gz2, ops.transpose(w1), None, gemm_mode=gemm_mode), h1)
         d_b0 = ops.colsum(gz1)
         d_w0 = ops.gemm_atb(gz1, ea)
-        return (g, None, None, None, d_w0, d_b0, d_w1, d_b1, d_w2, d_b2, d_root1, d_bias1, d_root2, d_bias2)
+        return (g, None, None, None, None, d_w0, d_b0, d_w1, d_b1, d_w2, d_b2, d_root1, d_bias1, d_root2, d_bias2)
 
 
 def collate(samples: Sequence[PairData]) -> PairData:
@@ -117,7 +120,8 @@ def train_forward(model, data) -> torch.Tensor:
     if conv2 is None and model.depth % 2:
         raise NotImplementedError("notebook-era variant: training needs an even depth")
     c2 = conv2 if conv2 is not None else model.conv1
-    x = KernelIntegralBlock.apply(x0, batch.edge_attr.to(dev), graph, depth, w0, b0, w1, b1, w2, b2,
+    x = KernelIntegralBlock.apply(x0, batch.edge_attr.to(dev), graph, depth, getattr(model, "gemm_mode", "f32"),
+                                  w0, b0, w1, b1, w2, b2,
                                   model.conv1.root, model.conv1.bias, c2.root, c2.bias)
     return model.fc2(x)
 

@@ -34,13 +34,14 @@ def O():
 def test_linear_atb_colsum_transpose_relu(dev):
     from molecular_dynamics_neural_operator_amd import ops
     g = torch.Generator().manual_seed(0)
-    for rows, n, k in ((300, 128, 64), (517, 256, 1024), (100, 24, 6), (77, 6, 40)):
+    for rows, n, k in ((300, 128, 64), (517, 256, 1024), (260, 4096, 128), (100, 24, 6), (77, 6, 40)):
         a, w, b = torch.randn(rows, k, generator=g), torch.randn(n, k, generator=g), torch.randn(n, generator=g)
-        for relu in (False, True):
-            want = F.linear(a.double(), w.double(), b.double())
-            want = want.relu() if relu else want
-            assert rel_err(ops.linear(a.to(dev), w.to(dev), b.to(dev), relu), want) < 2e-6
-        assert rel_err(ops.linear(a.to(dev), w.to(dev), None), F.linear(a.double(), w.double())) < 2e-6
+        for mode in ("f32", "split_bf16"):     # split_bf16: bf16 matrix pipe where (n, k) tile, fp32 kernels otherwise
+            for relu in (False, True):
+                want = F.linear(a.double(), w.double(), b.double())
+                want = want.relu() if relu else want
+                assert rel_err(ops.linear(a.to(dev), w.to(dev), b.to(dev), relu, gemm_mode=mode), want) < 2e-6
+            assert rel_err(ops.linear(a.to(dev), w.to(dev), None, gemm_mode=mode), F.linear(a.double(), w.double())) < 2e-6
     for rows, n1, n2 in ((5000, 128, 256), (333, 1024, 128), (4097, 256, 6), (50, 7, 3)):
         a, b = torch.randn(rows, n1, generator=g), torch.randn(rows, n2, generator=g)
         got = ops.gemm_atb(a.to(dev), b.to(dev))
@@ -111,9 +112,10 @@ def _replica_loss(model, O, batch, B):
     return float(loss), y.detach(), {k: v.grad for k, v in sd.items()}
 
 
-def test_model_gradients_vs_fp64_replica(dev, O, tmp_path):
+@pytest.mark.parametrize("gemm_mode", ["split_bf16", "f32"])
+def test_model_gradients_vs_fp64_replica(dev, O, tmp_path, gemm_mode):
     """Batch of 3 dataset samples (N=28, W=10), width 64, k=128, depth 2: loss, outputs and every
-    parameter gradient of the HIP training path vs the fp64 replica."""
+    parameter gradient of the HIP training path vs the fp64 replica, in both GEMM modes."""
     from molecular_dynamics_neural_operator_amd.dataset import ContactMapDataset
     from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN, LpLoss
     from molecular_dynamics_neural_operator_amd.training import collate, train_forward
@@ -130,6 +132,7 @@ def test_model_gradients_vs_fp64_replica(dev, O, tmp_path):
         for p_ in model.conv1.net.layers[4].parameters():
             p_.mul_(0.2)
     model.to(dev).train()
+    model.gemm_mode = gemm_mode
     out = model(samples)                       # training mode + autograd -> differentiable HIP path
     assert out.requires_grad and out.shape == (B * 28, 3)
     y = torch.cat([s.y for s in samples]).to(dev)

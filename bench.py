@@ -169,6 +169,9 @@ def main():
     # ---- warm-up (untimed): also captures nothing new — the step graph was captured in reset()
     eng.step(a.warmup)
     eng.synchronize()
+    if world > 1:    # the collective of the timed region, once, untimed: communicator set-up and buffers
+        gather_trajectories(torch.zeros((a.steps, M, N, 3), dtype=torch.float32, device=dev), total_members)
+        torch.cuda.synchronize()
 
     # ---- timed region: exactly K steps + trajectory collection
     if world > 1:

@@ -19,11 +19,15 @@ random-init weights collapse the cloud to one point, which would change E (the c
 one step.  The architecture, arithmetic and update rule (next frame = model output) are unchanged.
 
 Extra objects on the JSON line:
-  roofline      the conv (gather -> per-edge matvec -> scatter-mean) kernel against HBM: algorithmic
-                bytes per launch (16,388*E + 516*R + 4) / average launch duration,
-                measured with HIP events on the launching stream over K more steps of the same
-                rollout issued as plain launches (events cannot sit inside a hipGraph replay).
-  roofline_mfma the edge-MLP last-layer GEMM against the fp32 MFMA peak, same measurement.
+  roofline      the dominant kernel of the timed path against HBM — the per-source GEMM of the
+                factored conv (what conv_mode "auto" runs at this size; algorithmic bytes per launch
+                E*k*4 + R*C*k*4 + 2*E*C*4) or, in materialized mode, the conv (gather ->
+                per-edge matvec -> scatter-mean) kernel (16,388*E + 516*R + 4):
+                bytes / average launch duration, measured with HIP events on the launching stream over
+                K more steps of the same rollout issued as plain launches (events cannot sit inside a
+                hipGraph replay); traffic = PMC bytes per launch from profiles/roofline_traffic.json.
+  rooflines     the same for every leg: both conv formulations (the other one is run as a comparison
+                leg on the same start window) and the two wide split-bf16 GEMMs against the bf16 MFMA peak.
   cpu_baseline  the oracle (CPU restatement of the reference: edge-MLP re-evaluated in all 12 conv
                 applications + scipy graph rebuild per step) timed on this box's host cores on a
                 bounded sample; rank 0, N=1 only.  A reported baseline, not the target.

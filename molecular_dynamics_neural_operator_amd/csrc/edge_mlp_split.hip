@@ -17,11 +17,14 @@
 // 12 KiB copy per operand, done by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction,
 // no VGPRs, no ds_write), and a workgroup walks one contiguous run of K/16 * 12 KiB.  We own both producers and consumers of
 // these buffers, so nothing else ever sees the layout:
-//   weights      fp32 [N,K] --split_planes_kernel--> tiled planes            (once per forward, 30 MB)
+//   weights      fp32 [N,K] --split_planes_kernel--> tiled planes   (once per forward, or once per
+//                                                                        mdno_rollout_plan_run; 30 MB)
 //   layer 0      edge attrs -> relu(linear)  --split--> H1 tiled planes      (edge_l0_split_kernel)
 //   layer 1      H1 x W1 -> relu -> split  ---------> H2 tiled planes        (epilogue emits planes)
 //   layer 2      H2 x W2 + b  -> fp32 W_e[E, Cin*Cout]  (row-major, what the conv streams)
-// so no fp32 activation is ever stored.
+// so no fp32 activation is ever stored (materialized conv).  The factored conv stops after layer 1,
+// whose epilogue then writes H as k-tiled fp32 (OUT 2), and reuses the same GEMM for Y = X . W3T
+// (split_gemm_rows); the training ops use it through split_linear (OUT 0 / 3).
 //
 // GEMM kernel: 256x128 block tile, k-step 16 per stage, 8 waves (4x2), wave tile 64x64 = 2x2
 // v_mfma_f32_32x32x16_bf16 tiles, 24 MFMAs + 12 fragment reads per stage per wave.  Each staged

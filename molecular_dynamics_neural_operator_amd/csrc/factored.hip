@@ -17,8 +17,14 @@
 // r inside row col[p], binary search).  H (= the edge-MLP's last hidden activation, fp32 [E,k]) is
 // produced in this source-major order by evaluating the MLP on attr = [pos[row], pos[col]].
 //
-// All three steps use exact fp32 arithmetic (v_mfma_f32_32x32x2_f32); they are small next to the
-// k x k hidden GEMM that remains in the edge-MLP.
+// Two sets of kernels, chosen by gemm_mode (same sums, both fp32-accurate):
+//   SPLIT_BF16 (default)  (1) = the split-bf16 GEMM of edge_mlp_split.hip on bf16 plane images of x and
+//                         W3T; (2) = gemm_per_source_split_kernel, which splits the fp32 K-tiles of H
+//                         and Y_j into three bf16 planes on the fly and runs the six plane products on
+//                         the bf16 matrix pipe; (3) also prepares the next application's operands.
+//   F32                   (1) gemm_rows_guarded_kernel, (2) gemm_per_source_kernel: exact fp32 MFMA
+//                         (v_mfma_f32_32x32x2_f32), bit-for-bit an fmaf chain.
+// (2) is bound by the H / Y stream (4 KiB of H per edge per application), not by the matrix pipe.
 #include "kernels.h"
 #include "split_layout.h"
 
@@ -171,8 +177,10 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_guarded_kernel(const float* 
 // [e/128][k/32][128][32], Y_j as [k/32][64][32] — so a K-tile is one contiguous 16 KiB / 8 KiB run
 // (row-major H cost 128-B granules at a 4 KiB stride: 1.5 TB/s).  Tile 128 x 64 x 32, 4 waves, wave w owns rows
 // 32w..32w+31 and both 32-column halves.  The GEMM reads every H row and every Y_j once and needs
-// 32 flop per H byte, so it sits at the corner of HBM and the fp32 matrix rate: many small
-// workgroups (single LDS buffer, 27 KiB, 5 per CU; k split KS ways) keep enough loads in flight.
+// 32 flop per H byte, so with the exact fp32 MFMA it sits at the corner of HBM and the fp32 matrix
+// rate (123 us at shape B: 40 % of either): many small workgroups (single LDS buffer, 27 KiB, 5 per
+// CU; k split KS ways) keep enough loads in flight.  gemm_mode F32 only; the bf16 kernel below is the
+// default.
 constexpr int KS = 2;
 
 __global__ __launch_bounds__(256, 4) void gemm_per_source_kernel(const float* __restrict__ Hm,

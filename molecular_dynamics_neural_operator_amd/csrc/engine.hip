@@ -135,7 +135,7 @@ int forward_impl(const mdno_kernelnn_params* p, const float* frames, int t0, con
         MDNO_REQUIRE(edge_frames && !edge_attr && dst, MDNO_EINVAL,
                      "factored conv needs a position-derived radius graph (edge_pos, dst)");
         const FactoredWs fw = factored_carve(ws.fact, R, p->ker_width, edge_cap);
-        if (!prep_only) MDNO_TRY(factored_prepare_graph(row_ptr, src, dst, R, edge_cap, fw, status, s));
+        if (!prep_only) MDNO_TRY(factored_prepare_graph(row_ptr, src, dst, R, p->gemm_mode, edge_cap, fw, status, s));
         for (int block = 0; block < blocks; ++block) {
             const bool own = block == 1 && separate_conv2_kernel(p);
             if (block == 0 || own) {

@@ -182,6 +182,14 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_guarded_kernel(const float* 
 // CU; k split KS ways) keep enough loads in flight.  gemm_mode F32 only; the bf16 kernel below is the
 // default.
 constexpr int KS = 2;
+// The bf16 kernel cuts k 2 ways for a source's first 128-row tile and 4 ways for its later tiles:
+// those hold the few rows past 128 (a third of the sources at shape B), are dispatched last, and as
+// 16-iteration workgroups they formed a 43 %-full second round as long as the first (an iteration
+// costs 2.3-2.8 us whatever the number of live rows).  With 8 iterations the tail is half as long.
+// The number of partials an entry has depends only on its own position in its row, so the result does
+// not depend on what else is in the batch; the aggregation reads it from the top bits of rev[].
+constexpr int KS_TAIL = 4, MAX_PLANES = 4, REV_SHIFT = 28;
+constexpr int REV_MASK = (1 << REV_SHIFT) - 1;
 
 __global__ __launch_bounds__(256, 4) void gemm_per_source_kernel(const float* __restrict__ Hm,
                                                                  const float* __restrict__ Y,
@@ -324,17 +332,21 @@ __global__ __launch_bounds__(256, 4) void gemm_per_source_split_kernel(const flo
                                                                        float* __restrict__ Mp, long long part_stride,
                                                                        int K, int* __restrict__ status) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[3 * SPL_A_PLANE + 3 * SPL_B_PLANE];
-    const int j = blockIdx.x, slice = blockIdx.z;
+    // grid: x = source (fastest: XCD balance), y = [tile 0: slices 0..KS-1 | tile 1: slices 0..KS_TAIL-1 | tile 2 ...]
+    const int j = blockIdx.x;
+    const int mt = (int)blockIdx.y < KS ? 0 : 1 + ((int)blockIdx.y - KS) / KS_TAIL;
+    const int slice = (int)blockIdx.y < KS ? (int)blockIdx.y : ((int)blockIdx.y - KS) % KS_TAIL;
+    const int ks = mt == 0 ? KS : KS_TAIL;
     const int beg = row_ptr[j], end = row_ptr[j + 1];
-    const int r0 = beg + blockIdx.y * 128;
-    if (blockIdx.y == gridDim.y - 1 && slice == 0 && threadIdx.x == 0 && end - beg > (int)gridDim.y * 128 && status)
+    const int r0 = beg + mt * 128;
+    if (blockIdx.y == gridDim.y - 1 && threadIdx.x == 0 && end - beg > (mt + 1) * 128 && status)
         atomicOr(status, MDNO_STATUS_DEGREE_OVERFLOW);
     if (r0 >= end) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
     const int srow = tid >> 3, scol = (tid & 7) * 4;
-    const int nkt = K / BK, nk = nkt / KS, kt0 = slice * nk;
+    const int nkt = K / BK, nk = nkt / ks, kt0 = slice * nk;
     // 32-row groups that hold at least one of this source's rows: the others are neither loaded nor
     // split nor multiplied (their LDS rows feed only the wave that skips its MFMAs)
     const int live = (end - r0 + 31) >> 5;
@@ -447,22 +459,26 @@ __global__ __launch_bounds__(256, 4) void gemm_per_source_split_kernel(const flo
 __global__ __launch_bounds__(256) void reverse_edges_kernel(const int* __restrict__ row_ptr,
                                                             const int* __restrict__ col,
                                                             const int* __restrict__ rowid, int num_rows,
-                                                            int* __restrict__ rev, int* __restrict__ status) {
+                                                            int* __restrict__ rev, int* __restrict__ status,
+                                                            int tail_planes) {
     const int E = row_ptr[num_rows];
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= E) return;
     const int r = rowid[p], c = col[p];
-    int lo = row_ptr[c], hi = row_ptr[c + 1];
+    const int cbeg = row_ptr[c];
+    int lo = cbeg, hi = row_ptr[c + 1];
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
         if (col[mid] < r) lo = mid + 1; else hi = mid;
     }
-    if (lo < row_ptr[c + 1] && col[lo] == r) {
-        rev[p] = lo;
-    } else {
-        rev[p] = p;
+    int at = lo, abeg = cbeg;
+    if (!(lo < row_ptr[c + 1] && col[lo] == r)) {
+        at = p;
+        abeg = row_ptr[r];
         if (status) atomicOr(status, MDNO_STATUS_ASYMMETRIC_GRAPH);
     }
+    // top bits: how many k-slice partials step (2) writes for that entry (first tile of its row or later)
+    rev[p] = at | ((at - abeg < 128 ? KS : tail_planes) << REV_SHIFT);
 }
 
 // ---------------------------------------------------------------- (3) aggregate + root + bias + act
@@ -470,7 +486,7 @@ __global__ __launch_bounds__(256) void reverse_edges_kernel(const int* __restric
 // step (es = tid>>4), 16 B of the 64-float message per thread (q = tid&15), two steps in flight.
 // The rows gathered are 256 B each at random positions of M, so the kernel is bound by how many
 // loads are outstanding, not by bytes: one wave per row (4 chains) took 35 us per application,
-// this shape 3x less.  Each es-chain adds its edges in row order (and an edge's KS k-slice partials
+// this shape 3x less.  Each es-chain adds its edges in row order (and an edge's k-slice partials
 // in slice order); the sixteen chains are then added in es order through LDS — a fixed order, so the
 // result is deterministic.  The root term x_t.root is accumulated the same way (es picks 4 of the
 // 64 input channels).
@@ -489,25 +505,39 @@ __global__ __launch_bounds__(256) void aggregate_rev_kernel(const float* __restr
     const int t = blockIdx.x;
     const int beg = row_ptr[t], end = row_ptr[t + 1];
     const int deg = end - beg;
-    auto message = [&](int p) {
-        const float* m = Mp + (size_t)rev[p] * 64 + 4 * q;
-        float4 e = *reinterpret_cast<const float4*>(m);
+    // Every entry has KS partials; an entry in a later tile of its row has MAX_PLANES (top bits of
+    // rev[]; rare).  All loads of a step are issued before any is consumed — the extra planes under a
+    // predicate, zero when absent — so a step costs one memory round trip either way; partials are
+    // added in plane order.
+    struct Msg { float4 v[MAX_PLANES]; };
+    auto fetch = [&](int rp) {
+        Msg g;
+        const float* m = Mp + (size_t)(rp & REV_MASK) * 64 + 4 * q;
+        const bool tail = (rp >> REV_SHIFT) > KS;
 #pragma unroll
-        for (int k = 1; k < KS; ++k) {
-            const float4 v = *reinterpret_cast<const float4*>(m + (size_t)k * part_stride);
-            e.x += v.x; e.y += v.y; e.z += v.z; e.w += v.w;
+        for (int k = 0; k < MAX_PLANES; ++k) {
+            g.v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < KS || tail) g.v[k] = *reinterpret_cast<const float4*>(m + (size_t)k * part_stride);
         }
+        return g;
+    };
+    auto total = [](const Msg& g) {
+        float4 e = g.v[0];
+#pragma unroll
+        for (int k = 1; k < MAX_PLANES; ++k) { e.x += g.v[k].x; e.y += g.v[k].y; e.z += g.v[k].z; e.w += g.v[k].w; }
         return e;
     };
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     int p = beg + es;
     for (; p + 16 < end; p += 32) {
-        const float4 e0 = message(p), e1 = message(p + 16);
+        const int rp0 = rev[p], rp1 = rev[p + 16];
+        const Msg g0 = fetch(rp0), g1 = fetch(rp1);
+        const float4 e0 = total(g0), e1 = total(g1);
         acc.x += e0.x; acc.y += e0.y; acc.z += e0.z; acc.w += e0.w;
         acc.x += e1.x; acc.y += e1.y; acc.z += e1.z; acc.w += e1.w;
     }
     if (p < end) {
-        const float4 e0 = message(p);
+        const float4 e0 = total(fetch(rev[p]));
         acc.x += e0.x; acc.y += e0.y; acc.z += e0.z; acc.w += e0.w;
     }
     part[es][q] = acc;
@@ -584,14 +614,14 @@ __global__ __launch_bounds__(256) void aggregate_rev_kernel(const float* __restr
 }  // namespace
 
 // ---------------------------------------------------------------- host side
-bool factored_supported(int width, int ker_width) { return width == 64 && ker_width % (KS * BK) == 0; }
+bool factored_supported(int width, int ker_width) { return width == 64 && ker_width % (KS_TAIL * BK) == 0; }
 
 size_t factored_workspace_bytes(int num_rows, int ker_width, long long edge_cap) {
     Carver cv(nullptr);
     cv.take<float>((size_t)64 * ker_width * 64);               // W3T
     cv.take<float>((size_t)num_rows * 64 * ker_width);         // Y
     cv.take<float>((size_t)num_rows * 64);                     // q
-    cv.take<float>((size_t)KS * edge_cap * 64);                // M: KS k-slice partials
+    cv.take<float>((size_t)MAX_PLANES * edge_cap * 64);        // M: k-slice partials, one plane each
     cv.take<int>((size_t)edge_cap);                            // rev
     cv.take<char>(split_planes_bytes((long long)64 * ker_width, 64));   // W3T as bf16 planes
     cv.take<char>(split_planes_bytes(num_rows, 64));                    // X as bf16 planes
@@ -604,7 +634,7 @@ FactoredWs factored_carve(void* ws, int num_rows, int ker_width, long long edge_
     f.w3t = cv.take<float>((size_t)64 * ker_width * 64);
     f.y = cv.take<float>((size_t)num_rows * 64 * ker_width);
     f.q = cv.take<float>((size_t)num_rows * 64);
-    f.m = cv.take<float>((size_t)KS * edge_cap * 64);
+    f.m = cv.take<float>((size_t)MAX_PLANES * edge_cap * 64);
     f.part_stride = (long long)edge_cap * 64;
     f.rev = cv.take<int>((size_t)edge_cap);
     f.w3tp = cv.take<char>(split_planes_bytes((long long)64 * ker_width, 64));
@@ -621,11 +651,12 @@ int factored_prepare_weights(const float* w3, int ker_width, int gemm_mode, cons
     return MDNO_OK;
 }
 
-int factored_prepare_graph(const int* row_ptr, const int* col, const int* rowid, int num_rows, long long edge_cap,
-                           const FactoredWs& f, int* status, hipStream_t s) {
+int factored_prepare_graph(const int* row_ptr, const int* col, const int* rowid, int num_rows, int gemm_mode,
+                           long long edge_cap, const FactoredWs& f, int* status, hipStream_t s) {
+    MDNO_REQUIRE(edge_cap <= REV_MASK, MDNO_EUNSUPPORTED, "factored conv: edge_cap %lld exceeds %d", edge_cap, REV_MASK);
     TimedSection ts(KID_GRAPH, s);
     hipLaunchKernelGGL(reverse_edges_kernel, dim3((unsigned)((edge_cap + 255) / 256)), dim3(256), 0, s, row_ptr, col,
-                       rowid, num_rows, f.rev, status);
+                       rowid, num_rows, f.rev, status, gemm_mode == MDNO_GEMM_SPLIT_BF16 ? KS_TAIL : KS);
     return check_launch("reverse_edges_kernel");
 }
 
@@ -655,13 +686,14 @@ int factored_conv(const float* x, const float* h2, const int* row_ptr, int num_r
     }
     {
         TimedSection ts(KID_NNCONV, s);
-        const dim3 grid(num_rows, (max_degree + 127) / 128, KS);
+        const int mtiles = (max_degree + 127) / 128;
         if (gemm_mode == MDNO_GEMM_SPLIT_BF16)
-            hipLaunchKernelGGL(gemm_per_source_split_kernel, grid, dim3(256), 0, s, h2, (const float*)f.y,
-                               (const float*)f.q, row_ptr, f.m, f.part_stride, ker_width, status);
+            hipLaunchKernelGGL(gemm_per_source_split_kernel, dim3(num_rows, KS + (mtiles - 1) * KS_TAIL), dim3(256), 0,
+                               s, h2, (const float*)f.y, (const float*)f.q, row_ptr, f.m, f.part_stride, ker_width,
+                               status);
         else
-            hipLaunchKernelGGL(gemm_per_source_kernel, grid, dim3(256), 0, s, h2, (const float*)f.y, (const float*)f.q,
-                               row_ptr, f.m, f.part_stride, ker_width, status);
+            hipLaunchKernelGGL(gemm_per_source_kernel, dim3(num_rows, mtiles, KS), dim3(256), 0, s, h2,
+                               (const float*)f.y, (const float*)f.q, row_ptr, f.m, f.part_stride, ker_width, status);
     }
     const bool split_next = gemm_mode == MDNO_GEMM_SPLIT_BF16 && next_b3 != nullptr;
     {

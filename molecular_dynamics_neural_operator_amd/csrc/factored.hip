@@ -529,6 +529,15 @@ __global__ __launch_bounds__(256) void aggregate_rev_kernel(const float* __restr
     };
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     int p = beg + es;
+    for (; p + 48 < end; p += 64) {      // four messages (8+ loads) in flight per thread
+        const int rp0 = rev[p], rp1 = rev[p + 16], rp2 = rev[p + 32], rp3 = rev[p + 48];
+        const Msg g0 = fetch(rp0), g1 = fetch(rp1), g2 = fetch(rp2), g3 = fetch(rp3);
+        const float4 e0 = total(g0), e1 = total(g1), e2 = total(g2), e3 = total(g3);
+        acc.x += e0.x; acc.y += e0.y; acc.z += e0.z; acc.w += e0.w;
+        acc.x += e1.x; acc.y += e1.y; acc.z += e1.z; acc.w += e1.w;
+        acc.x += e2.x; acc.y += e2.y; acc.z += e2.z; acc.w += e2.w;
+        acc.x += e3.x; acc.y += e3.y; acc.z += e3.z; acc.w += e3.w;
+    }
     for (; p + 16 < end; p += 32) {
         const int rp0 = rev[p], rp1 = rev[p + 16];
         const Msg g0 = fetch(rp0), g1 = fetch(rp1);

@@ -188,6 +188,9 @@ constexpr int KS = 2;
 // costs 2.3-2.8 us whatever the number of live rows).  With 8 iterations the tail is half as long.
 // The number of partials an entry has depends only on its own position in its row, so the result does
 // not depend on what else is in the batch; the aggregation reads it from the top bits of rev[].
+// Only done for small members (N*KS <= 2048 workgroups in the first tiles: one or two rounds of the
+// chip), where the tail matters; a function of the member size alone, so batches stay bit-identical
+// to their members run alone.
 constexpr int KS_TAIL = 4, MAX_PLANES = 4, REV_SHIFT = 28;
 constexpr int REV_MASK = (1 << REV_SHIFT) - 1;
 
@@ -330,13 +333,13 @@ __global__ __launch_bounds__(256, 4) void gemm_per_source_split_kernel(const flo
                                                                        const float* __restrict__ Q,
                                                                        const int* __restrict__ row_ptr,
                                                                        float* __restrict__ Mp, long long part_stride,
-                                                                       int K, int* __restrict__ status) {
+                                                                       int K, int ks_tail, int* __restrict__ status) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[3 * SPL_A_PLANE + 3 * SPL_B_PLANE];
-    // grid: x = source (fastest: XCD balance), y = [tile 0: slices 0..KS-1 | tile 1: slices 0..KS_TAIL-1 | tile 2 ...]
+    // grid: x = source (fastest: XCD balance), y = [tile 0: slices 0..KS-1 | tile 1: slices 0..ks_tail-1 | tile 2 ...]
     const int j = blockIdx.x;
-    const int mt = (int)blockIdx.y < KS ? 0 : 1 + ((int)blockIdx.y - KS) / KS_TAIL;
-    const int slice = (int)blockIdx.y < KS ? (int)blockIdx.y : ((int)blockIdx.y - KS) % KS_TAIL;
-    const int ks = mt == 0 ? KS : KS_TAIL;
+    const int mt = (int)blockIdx.y < KS ? 0 : 1 + ((int)blockIdx.y - KS) / ks_tail;
+    const int slice = (int)blockIdx.y < KS ? (int)blockIdx.y : ((int)blockIdx.y - KS) % ks_tail;
+    const int ks = mt == 0 ? KS : ks_tail;
     const int beg = row_ptr[j], end = row_ptr[j + 1];
     const int r0 = beg + mt * 128;
     if (blockIdx.y == gridDim.y - 1 && threadIdx.x == 0 && end - beg > (mt + 1) * 128 && status)
@@ -660,16 +663,22 @@ int factored_prepare_weights(const float* w3, int ker_width, int gemm_mode, cons
     return MDNO_OK;
 }
 
-int factored_prepare_graph(const int* row_ptr, const int* col, const int* rowid, int num_rows, int gemm_mode,
-                           long long edge_cap, const FactoredWs& f, int* status, hipStream_t s) {
+// k slices of a source's second and later row tiles (see KS_TAIL)
+static int tail_slices(int gemm_mode, int rows_per_member) {
+    return gemm_mode == MDNO_GEMM_SPLIT_BF16 && (long long)rows_per_member * KS <= 2048 ? KS_TAIL : KS;
+}
+
+int factored_prepare_graph(const int* row_ptr, const int* col, const int* rowid, int num_rows, int rows_per_member,
+                           int gemm_mode, long long edge_cap, const FactoredWs& f, int* status, hipStream_t s) {
     MDNO_REQUIRE(edge_cap <= REV_MASK, MDNO_EUNSUPPORTED, "factored conv: edge_cap %lld exceeds %d", edge_cap, REV_MASK);
     TimedSection ts(KID_GRAPH, s);
     hipLaunchKernelGGL(reverse_edges_kernel, dim3((unsigned)((edge_cap + 255) / 256)), dim3(256), 0, s, row_ptr, col,
-                       rowid, num_rows, f.rev, status, gemm_mode == MDNO_GEMM_SPLIT_BF16 ? KS_TAIL : KS);
+                       rowid, num_rows, f.rev, status, tail_slices(gemm_mode, rows_per_member));
     return check_launch("reverse_edges_kernel");
 }
 
-int factored_conv(const float* x, const float* h2, const int* row_ptr, int num_rows, int max_degree, int ker_width,
+int factored_conv(const float* x, const float* h2, const int* row_ptr, int num_rows, int rows_per_member,
+                  int max_degree, int ker_width,
                   int gemm_mode, const float* b3, const float* root, const float* bias, int aggr, int relu, float* y,
                   const FactoredWs& f, int* status, hipStream_t s, bool x_prepared, const float* next_b3) {
     static bool attr_set = false;
@@ -696,9 +705,10 @@ int factored_conv(const float* x, const float* h2, const int* row_ptr, int num_r
     {
         TimedSection ts(KID_NNCONV, s);
         const int mtiles = (max_degree + 127) / 128;
+        const int kt = tail_slices(gemm_mode, rows_per_member);
         if (gemm_mode == MDNO_GEMM_SPLIT_BF16)
-            hipLaunchKernelGGL(gemm_per_source_split_kernel, dim3(num_rows, KS + (mtiles - 1) * KS_TAIL), dim3(256), 0,
-                               s, h2, (const float*)f.y, (const float*)f.q, row_ptr, f.m, f.part_stride, ker_width,
+            hipLaunchKernelGGL(gemm_per_source_split_kernel, dim3(num_rows, KS + (mtiles - 1) * kt), dim3(256), 0, s, h2,
+                               (const float*)f.y, (const float*)f.q, row_ptr, f.m, f.part_stride, ker_width, kt,
                                status);
         else
             hipLaunchKernelGGL(gemm_per_source_kernel, dim3(num_rows, mtiles, KS), dim3(256), 0, s, h2,

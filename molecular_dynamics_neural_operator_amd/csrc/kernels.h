@@ -82,9 +82,10 @@ bool factored_supported(int width, int ker_width);
 size_t factored_workspace_bytes(int num_rows, int ker_width, long long edge_cap);
 FactoredWs factored_carve(void* ws, int num_rows, int ker_width, long long edge_cap);
 int factored_prepare_weights(const float* w3, int ker_width, int gemm_mode, const FactoredWs& f, hipStream_t s);
-int factored_prepare_graph(const int* row_ptr, const int* col, const int* rowid, int num_rows, int gemm_mode,
-                           long long edge_cap, const FactoredWs& f, int* status, hipStream_t s);
-int factored_conv(const float* x, const float* h2, const int* row_ptr, int num_rows, int max_degree, int ker_width,
+int factored_prepare_graph(const int* row_ptr, const int* col, const int* rowid, int num_rows, int rows_per_member,
+                           int gemm_mode, long long edge_cap, const FactoredWs& f, int* status, hipStream_t s);
+int factored_conv(const float* x, const float* h2, const int* row_ptr, int num_rows, int rows_per_member,
+                  int max_degree, int ker_width,
                   int gemm_mode, const float* b3, const float* root, const float* bias, int aggr, int relu, float* y,
                   const FactoredWs& f, int* status, hipStream_t s, bool x_prepared, const float* next_b3);
 // x_prepared: the bf16 image of x and q = x.B3 are already in f.xp / f.q (left there by the previous

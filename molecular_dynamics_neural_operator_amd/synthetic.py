@@ -74,3 +74,13 @@ def min_threshold_gap(frame: np.ndarray, threshold: float) -> float:
     p = frame.astype(np.float64)
     d = np.sqrt(((p[:, None, :] - p[None, :, :]) ** 2).sum(-1))
     return float(np.abs(d - threshold).min())
+
+
+def contact_map(frame: np.ndarray, cutoff: float = 8.0) -> np.ndarray:
+    """Flat [rows..., cols...] contact map of one frame as the reference's data files store it
+    (dataset.py:114, 189): pairs with f64 distance < cutoff, self-pairs included, row-major order."""
+    d = frame.astype(np.float64)
+    dist = np.sqrt(((d[:, None, :] - d[None, :, :]) ** 2).sum(-1))
+    rows, cols = np.nonzero(dist < cutoff)
+    return np.concatenate([rows, cols]).astype(np.int64)
+

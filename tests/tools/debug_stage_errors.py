@@ -6,7 +6,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 from molecular_dynamics_neural_operator_amd import _lib, ops, synthetic as syn  # noqa: E402
 from molecular_dynamics_neural_operator_amd.weights import near_identity_state_dict  # noqa: E402
 from oracle import graph_kernel_oracle as O  # noqa: E402

@@ -587,6 +587,33 @@ def test_rollout_plan_sees_in_place_weight_updates(dev, conv_mode):
     assert torch.equal(after, fresh)                          # ... and the old engine sees all of it
 
 
+def test_factored_conv_many_row_tiles(dev):
+    """A dense cloud (degree ~300-400: three to four 128-row tiles per source, the later ones cut four
+    ways in k) — factored == materialized in both GEMM modes."""
+    from molecular_dynamics_neural_operator_amd import synthetic as syn
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN
+    from molecular_dynamics_neural_operator_amd.rollout import RolloutEngine
+    from molecular_dynamics_neural_operator_amd.weights import near_identity_state_dict
+    N, W, steps = 400, 3, 2
+    model = KernelNN(64, 128, 2, 6, 7, 3, 20, 4)
+    model.load_state_dict(near_identity_state_dict(64, 128, seed=9, kernel_gain=1e-2, feature_gain=0.1, kernel_to_coords=1.0))
+    model.eval().to(dev)
+    win = torch.from_numpy(syn.jitter_window(syn.box_frame(N, density=0.5, seed=9), W, seed=9))
+    aa = torch.from_numpy(syn.amino_acids(N, seed=9))
+    out = {}
+    for gemm in ("split_bf16", "f32"):
+        model.gemm_mode = gemm
+        for conv in ("materialized", "factored"):
+            model.conv_mode = conv
+            eng = RolloutEngine(model, 1, N, W, 8.0, max_steps=steps, device=dev)
+            out[gemm, conv] = eng.run(win, aa, steps).clone()
+            if conv == "factored":
+                deg = int(eng.edges_per_step[0]) / N
+                assert deg > 300, deg                                  # three tiles for most sources
+        close(out[gemm, "factored"], out[gemm, "materialized"])
+    close(out["split_bf16", "factored"], out["f32", "factored"])
+
+
 def test_conv_mode_auto_resolves_by_edge_capacity(dev):
     """conv_mode="auto" (the default): materialized for small graphs, factored from edge_cap 24,576 on
     (include/mdno.h MDNO_CONV_AUTO); both give the same trajectory to fp32 rounding."""

@@ -333,16 +333,25 @@ __global__ __launch_bounds__(256, 4) void gemm_per_source_split_kernel(const flo
                                                                        const float* __restrict__ Q,
                                                                        const int* __restrict__ row_ptr,
                                                                        float* __restrict__ Mp, long long part_stride,
-                                                                       int K, int ks_tail, int* __restrict__ status) {
+                                                                       int K, int ks_tail, int slots,
+                                                                       int* __restrict__ status) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[3 * SPL_A_PLANE + 3 * SPL_B_PLANE];
-    // grid: x = source (fastest: XCD balance), y = [tile 0: slices 0..KS-1 | tile 1: slices 0..ks_tail-1 | tile 2 ...]
-    const int j = blockIdx.x;
-    const int mt = (int)blockIdx.y < KS ? 0 : 1 + ((int)blockIdx.y - KS) / ks_tail;
-    const int slice = (int)blockIdx.y < KS ? (int)blockIdx.y : ((int)blockIdx.y - KS) % ks_tail;
+    // slots of a source: [tile 0: slices 0..KS-1 | tile 1: slices 0..ks_tail-1 | tile 2 ...].
+    // Small members: grid (source, slot), source fastest (XCD balance; first tiles before later ones).
+    // Large members (gridDim.y == 1, many rounds): source-major — a source's workgroups are dispatched
+    // together, so the second and third read of Y_j meet it in the Infinity Cache instead of HBM; the
+    // slot is rotated by the source index so that the heavy first-tile slots visit all eight XCDs.
+    int j = blockIdx.x, slot = blockIdx.y;
+    if (gridDim.y == 1) {
+        j = (int)(blockIdx.x / (unsigned)slots);
+        slot = (int)((blockIdx.x % (unsigned)slots + (unsigned)j) % (unsigned)slots);
+    }
+    const int mt = slot < KS ? 0 : 1 + (slot - KS) / ks_tail;
+    const int slice = slot < KS ? slot : (slot - KS) % ks_tail;
     const int ks = mt == 0 ? KS : ks_tail;
     const int beg = row_ptr[j], end = row_ptr[j + 1];
     const int r0 = beg + mt * 128;
-    if (blockIdx.y == gridDim.y - 1 && threadIdx.x == 0 && end - beg > (mt + 1) * 128 && status)
+    if (slot == slots - 1 && threadIdx.x == 0 && end - beg > (mt + 1) * 128 && status)
         atomicOr(status, MDNO_STATUS_DEGREE_OVERFLOW);
     if (r0 >= end) return;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -706,10 +715,14 @@ int factored_conv(const float* x, const float* h2, const int* row_ptr, int num_r
         TimedSection ts(KID_NNCONV, s);
         const int mtiles = (max_degree + 127) / 128;
         const int kt = tail_slices(gemm_mode, rows_per_member);
-        if (gemm_mode == MDNO_GEMM_SPLIT_BF16)
-            hipLaunchKernelGGL(gemm_per_source_split_kernel, dim3(num_rows, KS + (mtiles - 1) * kt), dim3(256), 0, s, h2,
-                               (const float*)f.y, (const float*)f.q, row_ptr, f.m, f.part_stride, ker_width, kt,
-                               status);
+        if (gemm_mode == MDNO_GEMM_SPLIT_BF16) {
+            const int slots = KS + (mtiles - 1) * kt;
+            const bool source_major = kt == KS && (long long)num_rows * slots < (1ll << 31);   // large members
+            hipLaunchKernelGGL(gemm_per_source_split_kernel,
+                               source_major ? dim3((unsigned)(num_rows * slots), 1) : dim3(num_rows, slots), dim3(256),
+                               0, s, h2, (const float*)f.y, (const float*)f.q, row_ptr, f.m, f.part_stride, ker_width,
+                               kt, slots, status);
+        }
         else
             hipLaunchKernelGGL(gemm_per_source_kernel, dim3(num_rows, mtiles, KS), dim3(256), 0, s, h2,
                                (const float*)f.y, (const float*)f.q, row_ptr, f.m, f.part_stride, ker_width, status);

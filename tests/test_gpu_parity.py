@@ -614,6 +614,29 @@ def test_factored_conv_many_row_tiles(dev):
     close(out["split_bf16", "factored"], out["f32", "factored"])
 
 
+def test_factored_conv_large_member_source_major_order(dev):
+    """Members with more than 1,024 atoms take the other launch shape of the per-source GEMM (uniform
+    2-way k split, source-major dispatch with rotated slots): factored == materialized at N = 1,100."""
+    from molecular_dynamics_neural_operator_amd import synthetic as syn
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN
+    from molecular_dynamics_neural_operator_amd.rollout import RolloutEngine, default_edge_cap
+    from molecular_dynamics_neural_operator_amd.weights import near_identity_state_dict
+    N, W, steps = 1100, 2, 2
+    model = KernelNN(64, 128, 2, 6, 7, 3, 20, 4)
+    model.load_state_dict(near_identity_state_dict(64, 128, seed=11, kernel_gain=1e-2, feature_gain=0.1, kernel_to_coords=1.0))
+    model.eval().to(dev)
+    win = torch.from_numpy(syn.jitter_window(syn.box_frame(N, seed=11), W, seed=11))
+    aa = torch.from_numpy(syn.amino_acids(N, seed=11))
+    out = {}
+    for conv in ("materialized", "factored"):
+        model.conv_mode = conv
+        eng = RolloutEngine(model, 1, N, W, 8.0, max_steps=steps, edge_cap=default_edge_cap(1, N, 8.0), device=dev,
+                            max_degree=384)
+        out[conv] = eng.run(win, aa, steps).clone()
+        assert int(eng.edges_per_step.max()) > 128 * N * 0.9          # most sources have a second tile
+    close(out["factored"], out["materialized"])
+
+
 def test_conv_mode_auto_resolves_by_edge_capacity(dev):
     """conv_mode="auto" (the default): materialized for small graphs, factored from edge_cap 24,576 on
     (include/mdno.h MDNO_CONV_AUTO); both give the same trajectory to fp32 rounding."""

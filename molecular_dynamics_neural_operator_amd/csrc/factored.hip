@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256, 4) void gemm_per_source_split_kernel(const flo
     __shared__ __attribute__((aligned(16))) unsigned char lds[3 * SPL_A_PLANE + 3 * SPL_B_PLANE];
     // slots of a source: [tile 0: slices 0..KS-1 | tile 1: slices 0..ks_tail-1 | tile 2 ...].
     // Small members: grid (source, slot), source fastest (XCD balance; first tiles before later ones).
-    // Large members (gridDim.y == 1, many rounds): source-major — a source's workgroups are dispatched
+    // Many rounds of workgroups (gridDim.y == 1: large members or many members): source-major — a source's workgroups are dispatched
     // together, so the second and third read of Y_j meet it in the Infinity Cache instead of HBM; the
     // slot is rotated by the source index so that the heavy first-tile slots visit all eight XCDs.
     int j = blockIdx.x, slot = blockIdx.y;
@@ -717,7 +717,9 @@ int factored_conv(const float* x, const float* h2, const int* row_ptr, int num_r
         const int kt = tail_slices(gemm_mode, rows_per_member);
         if (gemm_mode == MDNO_GEMM_SPLIT_BF16) {
             const int slots = KS + (mtiles - 1) * kt;
-            const bool source_major = kt == KS && (long long)num_rows * slots < (1ll << 31);   // large members
+            // many rounds of workgroups (large members, or many members): source-major
+            const long long nwg = (long long)num_rows * slots;
+            const bool source_major = nwg >= 8192 && nwg < (1ll << 31);
             hipLaunchKernelGGL(gemm_per_source_split_kernel,
                                source_major ? dim3((unsigned)(num_rows * slots), 1) : dim3(num_rows, slots), dim3(256),
                                0, s, h2, (const float*)f.y, (const float*)f.q, row_ptr, f.m, f.part_stride, ker_width,

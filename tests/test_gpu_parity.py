@@ -616,7 +616,8 @@ def test_factored_conv_many_row_tiles(dev):
 
 def test_factored_conv_large_member_source_major_order(dev):
     """Members with more than 1,024 atoms take the other launch shape of the per-source GEMM (uniform
-    2-way k split, source-major dispatch with rotated slots): factored == materialized at N = 1,100."""
+    2-way k split; with >= 8,192 workgroups also source-major dispatch with rotated slots):
+    factored == materialized at N = 1,100."""
     from molecular_dynamics_neural_operator_amd import synthetic as syn
     from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN
     from molecular_dynamics_neural_operator_amd.rollout import RolloutEngine, default_edge_cap

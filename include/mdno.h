@@ -15,7 +15,7 @@
  *   - `stream` is a hipStream_t passed as void*; work is enqueued asynchronously and not
  *     synchronised (one exception: mdno_rollout with use_graph != 0 waits for `stream` before it
  *     returns, to release the captured graph).  Entry points are re-entrant; there is no global
- *     state besides the per-thread error string.
+ *     state besides the per-thread error string (and per-device "attribute already raised" caches).
  *   - graphs are CSR over DESTINATION rows: row r (= member*N + atom) lists, in ascending order,
  *     the SOURCE nodes j of its in-edges (j -> r), self-loop included.  "Edge p" is position p of
  *     that list; per-edge tensors (W_e) are stored in this order, so every row's edges are one
@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDNO_ABI_VERSION 5
+#define MDNO_ABI_VERSION 6
 
 #define MDNO_OK            0
 #define MDNO_EINVAL       -1   /* bad argument (null pointer, non-positive size, unsupported dim) */
@@ -62,8 +62,8 @@ extern "C" {
 #define MDNO_CONV_MATERIALIZED 0
 #define MDNO_CONV_FACTORED     1
 /*   AUTO          FACTORED where it applies and the graph is large enough to pay for its fixed cost
- *                 per application (the Y GEMM and a 16-iteration pipeline per source: edge_cap >=
- *                 24,576), MATERIALIZED otherwise (small graphs: 2x faster at N=28..120). */
+ *                 per application (the Y GEMM and a 16-iteration pipeline per source: edge capacity
+ *                 per member >= 24,576), MATERIALIZED otherwise (small graphs: 2x faster at N=28..120). */
 #define MDNO_CONV_AUTO         2
 
 /* status word bits written by device code (read back by the caller after synchronising) */
@@ -71,6 +71,8 @@ extern "C" {
 #define MDNO_STATUS_BAD_AMINOACID 2   /* x_aminoacid outside [0, num_embeddings) */
 #define MDNO_STATUS_ASYMMETRIC_GRAPH 4 /* factored conv: an edge has no reverse edge */
 #define MDNO_STATUS_DEGREE_OVERFLOW  8 /* factored conv: a node has more edges than the max_degree bound */
+#define MDNO_STATUS_BAD_EDGE_INDEX  16 /* mdno_coo_to_csr: a node id outside [0, num_nodes) (clamped in bounds;
+                                          the reference's index_select / scatter raise IndexError there) */
 
 int         mdno_abi_version(void);
 const char* mdno_last_error(void);
@@ -118,10 +120,14 @@ int mdno_radius_graph_csr(const float* pos, int M, int N, double cutoff,
  * scatter over edge_index[1] implies (graph_kernel.py:198 -> MessagePassing.propagate).
  *   edge_index i64 [2,E] (row 0 = source, row 1 = target)
  *   row_ptr i32 [num_nodes+1], src i32 [E], dst i32 [E] (may be NULL), perm i32 [E]: CSR position
- *   p holds input edge perm[p].  Workspace size from mdno_coo_to_csr_workspace_bytes. */
+ *   p holds input edge perm[p].  Own counting sort (count, scan, slot, per-row rank sort of the
+ *   unique edge ids): deterministic, no vendor sort.  Node ids outside [0, num_nodes) — where the
+ *   reference's index_select / scatter raise — set MDNO_STATUS_BAD_EDGE_INDEX in `status`
+ *   (i32 [1] device, OR-ed; may be NULL) and are clamped so that nothing is read out of bounds.
+ *   Workspace size from mdno_coo_to_csr_workspace_bytes. */
 size_t mdno_coo_to_csr_workspace_bytes(int64_t E, int num_nodes);
 int mdno_coo_to_csr(const int64_t* edge_index, int64_t E, int num_nodes,
-                    int32_t* row_ptr, int32_t* src, int32_t* dst, int32_t* perm,
+                    int32_t* row_ptr, int32_t* src, int32_t* dst, int32_t* perm, int32_t* status,
                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -186,8 +192,9 @@ int mdno_fc_out_fwd(const float* x, const float* w, const float* b, int rows, in
  * ---------------------------------------------------------------------------------------- */
 size_t mdno_kernelnn_workspace_bytes(const mdno_kernelnn_params* p, int M, int N, int64_t edge_cap);
 /* The formulation (MDNO_CONV_MATERIALIZED / MDNO_CONV_FACTORED) a forward or rollout with these
- * parameters and this edge capacity runs on a position-derived radius graph (resolves AUTO). */
-int mdno_resolve_conv_mode(const mdno_kernelnn_params* p, int64_t edge_cap);
+ * parameters, M members and this total edge capacity runs on a position-derived radius graph
+ * (resolves AUTO; the rule is on edge_cap / M, so it does not depend on the batch a member is in). */
+int mdno_resolve_conv_mode(const mdno_kernelnn_params* p, int M, int64_t edge_cap);
 int mdno_kernelnn_fwd(const mdno_kernelnn_params* p, const float* frames, int M, int W, int N,
                       const int64_t* x_aminoacid, int aa_per_member,
                       const int32_t* row_ptr, const int32_t* src, const int32_t* dst,

@@ -14,15 +14,20 @@ LIB_PATH = Path(os.environ.get("MDNO_LIB", _HERE / "libmdno.so"))
 OK, EINVAL, ELAUNCH, EWORKSPACE, EUNSUPPORTED = 0, -1, -2, -3, -4
 AGGR = {"add": 0, "mean": 1}
 STATUS_EDGE_OVERFLOW, STATUS_BAD_AMINOACID = 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 GEMM_MODES = {"split_bf16": 0, "f32": 1}
 CONV_MODES = {"materialized": 0, "factored": 1, "auto": 2}
 STATUS_ASYMMETRIC_GRAPH = 4
 STATUS_DEGREE_OVERFLOW = 8
+STATUS_BAD_EDGE_INDEX = 16
 
 
 class MdnoError(RuntimeError):
     pass
+
+
+class MdnoIndexError(MdnoError, IndexError):
+    """An index the reference's nn.Embedding / index_select / scatter would reject with IndexError."""
 
 
 class KernelNNParams(C.Structure):
@@ -48,7 +53,7 @@ SIGNATURES = {
     "mdno_last_error": (C.c_char_p, []),
     "mdno_radius_graph_csr": (_I, [_P, _I, _I, _D, _P, _P, _P, _L, _P, _P, _P]),
     "mdno_coo_to_csr_workspace_bytes": (_SZ, [_L, _I]),
-    "mdno_coo_to_csr": (_I, [_P, _L, _I, _P, _P, _P, _P, _P, _SZ, _P]),
+    "mdno_coo_to_csr": (_I, [_P, _L, _I, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "mdno_edge_mlp_workspace_bytes": (_SZ, [_I, _I, _L, _I]),
     "mdno_edge_mlp_fwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _SZ,
                                _P]),
@@ -56,7 +61,7 @@ SIGNATURES = {
     "mdno_node_prologue_fwd": (_I, [C.POINTER(KernelNNParams), _P, _I, _I, _I, _P, _I, _P, _P, _P]),
     "mdno_fc_out_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
     "mdno_kernelnn_workspace_bytes": (_SZ, [C.POINTER(KernelNNParams), _I, _I, _L]),
-    "mdno_resolve_conv_mode": (_I, [C.POINTER(KernelNNParams), _L]),
+    "mdno_resolve_conv_mode": (_I, [C.POINTER(KernelNNParams), _I, _L]),
     "mdno_kernelnn_fwd": (_I, [C.POINTER(KernelNNParams), _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _L, _I,
                                _P, _P, _P, _P, _P, _P, _SZ, _P, _P]),
     "mdno_rollout_workspace_bytes": (_SZ, [C.POINTER(KernelNNParams), _I, _I, _L]),
@@ -138,3 +143,23 @@ def require_gpu(device=None) -> torch.device:
     if not torch.cuda.is_available():
         raise MdnoError("no HIP device visible: this package only runs on an MI355X-class GPU (no CPU fallback)")
     return torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+
+
+def raise_on_status(status_word: int, what: str = "") -> None:
+    """Turn the device status bits (include/mdno.h MDNO_STATUS_*) into the exception the reference
+    would have raised at that point (IndexError from nn.Embedding / index_select) or an MdnoError."""
+    st = int(status_word)
+    if not st:
+        return
+    pre = (what + ": ") if what else ""
+    if st & STATUS_BAD_AMINOACID:
+        raise MdnoIndexError(pre + "x_aminoacid outside [0, num_embeddings) (index out of range in self)")
+    if st & STATUS_BAD_EDGE_INDEX:
+        raise MdnoIndexError(pre + "edge_index holds a node id outside [0, num_nodes)")
+    if st & STATUS_EDGE_OVERFLOW:
+        raise MdnoError(pre + "radius graph exceeded edge_cap; use a larger capacity")
+    if st & STATUS_DEGREE_OVERFLOW:
+        raise MdnoError(pre + "a node has more edges than max_degree; raise the bound (0 = n_atoms)")
+    if st & STATUS_ASYMMETRIC_GRAPH:
+        raise MdnoError(pre + "factored conv met an edge without a reverse edge (graph not symmetric)")
+    raise MdnoError(pre + f"device status {st:#x}")

@@ -1,6 +1,7 @@
 // Internal helpers shared by the libmdno translation units (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -44,6 +45,28 @@ inline int check_launch(const char* what) {
     } while (0)
 
 constexpr int kWave = 64;  // CDNA4 wavefront
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: raise it once per
+// (call site, device).  `done` is that call site's device bitmask — a cache of "already raised", not
+// state a caller can observe; two threads racing on a first use both set the (idempotent) attribute.
+inline int raise_dynamic_lds(const void* kernel, int bytes, std::atomic<unsigned long long>& done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) {
+        set_error("hipGetDevice: %s", hipGetErrorString(e));
+        return MDNO_ELAUNCH;
+    }
+    const bool cached = dev >= 0 && dev < 64;
+    const unsigned long long bit = cached ? 1ull << dev : 0ull;
+    if (cached && (done.load(std::memory_order_acquire) & bit)) return MDNO_OK;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d): %s", bytes, hipGetErrorString(e));
+        return MDNO_ELAUNCH;
+    }
+    if (cached) done.fetch_or(bit, std::memory_order_release);
+    return MDNO_OK;
+}
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

@@ -254,12 +254,8 @@ int launch_gemm(const GemmArgs& g, hipStream_t s) {
                          ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.Bt)) & 15) == 0;
     if (mfma_ok) {
         const size_t lds = sizeof(float) * 2 * (BM + BN) * LDS_LD;  // 73,728 B
-        static bool attr_set[2] = {false, false};
-        if (!attr_set[RELU]) {
-            MDNO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_mfma_kernel<RELU>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set[RELU] = true;
-        }
+        static std::atomic<unsigned long long> lds_raised{0};   // one per <RELU> instantiation
+        MDNO_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(&gemm_tn_mfma_kernel<RELU>), (int)lds, lds_raised));
         dim3 grid(g.N / BN, g.rows / BM);
         hipLaunchKernelGGL(gemm_tn_mfma_kernel<RELU>, grid, dim3(256), lds, s, g);
     } else {

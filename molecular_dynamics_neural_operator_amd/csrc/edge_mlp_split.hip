@@ -306,16 +306,22 @@ __global__ __launch_bounds__(TM * 2, 2) void gemm_split_bf16_kernel(SplitGemmArg
     // Pipeline: stage kt+1 is in flight (DMA) while stage kt is multiplied.  __syncthreads() waits
     // for this wave's outstanding DMA (vmcnt(0)) and then for every wave: after it, stage kt is
     // complete in LDS and nobody still reads the buffer stage kt+1 is about to overwrite.
+    // The wait for this wave's own DMA is written out: a workgroup-scope barrier is not required by the
+    // memory model to imply vmcnt(0) (today's compiler emits it anyway; the explicit wait costs nothing).
+#define MDNO_DMA_BARRIER()                                 \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       \
+    __syncthreads();
     MDNO_DMA_STAGE(0, 0)
     for (int kt = 0; kt < nkt; kt += 2) {      // K is a multiple of 32: stages come in pairs
-        __syncthreads();
+        MDNO_DMA_BARRIER()
         MDNO_DMA_STAGE(kt + 1, 1)
         mma_split_stage(acc, lds, a_rd, b_rd);
-        __syncthreads();
+        MDNO_DMA_BARRIER()
         if (kt + 2 < nkt) MDNO_DMA_STAGE(kt + 2, 0)
         mma_split_stage(acc, lds + STAGE_BYTES, a_rd, b_rd);
     }
 #undef MDNO_DMA_STAGE
+#undef MDNO_DMA_BARRIER
 
     // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
@@ -350,12 +356,8 @@ __global__ __launch_bounds__(TM * 2, 2) void gemm_split_bf16_kernel(SplitGemmArg
 template <int TM, int OUT>
 int launch_split_gemm_tm(SplitGemmArgs g, hipStream_t s) {
     constexpr int lds_bytes = 2 * stage_bytes(TM);
-    static bool attr_set = false;
-    if (!attr_set) {
-        MDNO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_bf16_kernel<TM, OUT>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> lds_raised{0};   // one per <TM, OUT> instantiation
+    MDNO_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(&gemm_split_bf16_kernel<TM, OUT>), lds_bytes, lds_raised));
     g.tiles_n = g.N / TN;
     g.tiles_m = g.rows / TM;
     hipLaunchKernelGGL((gemm_split_bf16_kernel<TM, OUT>), dim3(g.tiles_n * g.tiles_m), dim3(TM * 2), lds_bytes,

@@ -84,13 +84,15 @@ struct FwdWs {
 // The factored conv applies to graphs the library builds itself (symmetric radius graphs) at width 64.
 // AUTO adds a size rule: below ~8-10k edges the factored form's fixed cost per application (Y GEMM
 // over 64*k columns whatever the row count, 16 pipeline iterations per source) loses to simply
-// materialising W_e (N=28: 0.25 vs 0.52 ms/step, N=120: 0.27 vs 0.58; N=504: 5.3 vs 2.4).
-constexpr long long kAutoFactoredMinEdgeCap = 24576;
+// materialising W_e (N=28: 0.25 vs 0.52 ms/step, N=120: 0.27 vs 0.58; N=504: 5.3 vs 2.4).  The rule
+// looks at the capacity PER MEMBER, so a member takes the same path — and gives the same bits —
+// alone, in a batch of 8 or in a shard of 64.
+constexpr long long kAutoFactoredMinEdgeCapPerMember = 24576;
 
-bool use_factored(const mdno_kernelnn_params* p, long long edge_cap, bool position_graph) {
+bool use_factored(const mdno_kernelnn_params* p, int M, long long edge_cap, bool position_graph) {
     if (p->conv_mode == MDNO_CONV_MATERIALIZED || !factored_supported(p->width, p->ker_width)) return false;
     if (p->conv_mode == MDNO_CONV_FACTORED) return true;   // (forward_impl insists on a position graph)
-    return position_graph && edge_cap >= kAutoFactoredMinEdgeCap;
+    return position_graph && edge_cap / (M > 0 ? M : 1) >= kAutoFactoredMinEdgeCapPerMember;
 }
 
 FwdWs carve_fwd(void* ws, const mdno_kernelnn_params* p, int M, int N, long long edge_cap, bool factored) {
@@ -208,7 +210,7 @@ RolloutWs carve_rollout(void* ws, const mdno_kernelnn_params* p, int M, int N, l
     r.dst = cv.take<int>((size_t)edge_cap);
     r.num_edges = cv.take<int>(64);   // counters on their own 256-B line
     r.t_dev = r.num_edges + 1;
-    r.fwd_bytes = carve_fwd(nullptr, p, M, N, edge_cap, use_factored(p, edge_cap, true)).total;
+    r.fwd_bytes = carve_fwd(nullptr, p, M, N, edge_cap, use_factored(p, M, edge_cap, true)).total;
     r.fwd = cv.take<char>(r.fwd_bytes);
     r.total = cv.used();
     return r;
@@ -226,13 +228,13 @@ extern "C" const char* mdno_last_error(void) { return g_last_error.c_str(); }
 extern "C" size_t mdno_kernelnn_workspace_bytes(const mdno_kernelnn_params* p, int M, int N, int64_t edge_cap) {
     if (!p || M <= 0 || N <= 0 || edge_cap <= 0) return 0;
     // AUTO resolves per call (explicit edge attributes always run materialised): room for either
-    const size_t a = carve_fwd(nullptr, p, M, N, (long long)edge_cap, use_factored(p, edge_cap, true)).total;
-    const size_t b = carve_fwd(nullptr, p, M, N, (long long)edge_cap, use_factored(p, edge_cap, false)).total;
+    const size_t a = carve_fwd(nullptr, p, M, N, (long long)edge_cap, use_factored(p, M, edge_cap, true)).total;
+    const size_t b = carve_fwd(nullptr, p, M, N, (long long)edge_cap, use_factored(p, M, edge_cap, false)).total;
     return a > b ? a : b;
 }
 
-extern "C" int mdno_resolve_conv_mode(const mdno_kernelnn_params* p, int64_t edge_cap) {
-    return p && use_factored(p, (long long)edge_cap, true) ? MDNO_CONV_FACTORED : MDNO_CONV_MATERIALIZED;
+extern "C" int mdno_resolve_conv_mode(const mdno_kernelnn_params* p, int M, int64_t edge_cap) {
+    return p && use_factored(p, M, (long long)edge_cap, true) ? MDNO_CONV_FACTORED : MDNO_CONV_MATERIALIZED;
 }
 
 extern "C" int mdno_kernelnn_fwd(const mdno_kernelnn_params* p, const float* frames, int M, int W, int N,
@@ -246,7 +248,7 @@ extern "C" int mdno_kernelnn_fwd(const mdno_kernelnn_params* p, const float* fra
                  "mdno_kernelnn_fwd: null pointer");
     MDNO_REQUIRE(M > 0 && W > 0 && N > 0 && edge_cap > 0, MDNO_EINVAL, "mdno_kernelnn_fwd: M=%d W=%d N=%d", M, W, N);
     FwdWs ws = carve_fwd(workspace, p, M, N, (long long)edge_cap,
-                         use_factored(p, (long long)edge_cap, edge_pos && !edge_attr && dst));
+                         use_factored(p, M, (long long)edge_cap, edge_pos && !edge_attr && dst));
     MDNO_REQUIRE(workspace_bytes >= ws.total, MDNO_EWORKSPACE, "mdno_kernelnn_fwd: workspace %zu < %zu",
                  workspace_bytes, ws.total);
     return forward_impl(p, frames, 0, nullptr, M, W, N, (const long long*)x_aminoacid, aa_per_member, row_ptr, src,
@@ -333,7 +335,7 @@ extern "C" int mdno_rollout_plan_create(mdno_rollout_plan** plan, const mdno_ker
     pl->edge_cap = (long long)edge_cap;
     pl->max_degree = max_degree;
     pl->r = r;
-    pl->fw = carve_fwd(r.fwd, p, M, N, (long long)edge_cap, use_factored(p, (long long)edge_cap, true));
+    pl->fw = carve_fwd(r.fwd, p, M, N, (long long)edge_cap, use_factored(p, M, (long long)edge_cap, true));
     pl->edges_per_step = edges_per_step;
     pl->status = status;
     pl->weights_cached = !separate_conv2_kernel(p);

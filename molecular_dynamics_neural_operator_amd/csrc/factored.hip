@@ -690,13 +690,7 @@ int factored_conv(const float* x, const float* h2, const int* row_ptr, int num_r
                   int max_degree, int ker_width,
                   int gemm_mode, const float* b3, const float* root, const float* bias, int aggr, int relu, float* y,
                   const FactoredWs& f, int* status, hipStream_t s, bool x_prepared, const float* next_b3) {
-    static bool attr_set = false;
     const size_t lds1 = sizeof(float) * 2 * 256 * LD;   // 73,728 B
-    if (!attr_set) {
-        MDNO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rows_guarded_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-        attr_set = true;
-    }
     const int ncols = 64 * ker_width;
     if (gemm_mode == MDNO_GEMM_SPLIT_BF16) {
         // 6 bf16 plane products (fp32-level accuracy, edge_mlp_split.hip): the matrix work drops under
@@ -706,6 +700,8 @@ int factored_conv(const float* x, const float* h2, const int* row_ptr, int num_r
         if (!x_prepared) MDNO_TRY(split_planes_bias64(x, num_rows, b3, f.q, f.xp, s));
         MDNO_TRY(split_gemm_rows(f.xp, f.w3tp, num_rows, ncols, 64, f.y, s));
     } else {
+        static std::atomic<unsigned long long> lds_raised{0};
+        MDNO_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(&gemm_rows_guarded_kernel), (int)lds1, lds_raised));
         TimedSection ts(KID_FACT_Y, s);
         hipLaunchKernelGGL(node_bias_kernel, dim3((num_rows + 3) / 4), dim3(256), 0, s, x, b3, num_rows, f.q);
         hipLaunchKernelGGL(gemm_rows_guarded_kernel, dim3(ncols / 128, (num_rows + 127) / 128), dim3(256), lds1, s, x,

@@ -9,8 +9,6 @@
 // contraction cannot change the sum), correctly rounded f64 sqrt, strict `<` against the f64 cutoff.
 #include "kernels.h"
 
-#include <hipcub/hipcub.hpp>
-
 namespace mdno {
 
 namespace {
@@ -115,55 +113,108 @@ __global__ __launch_bounds__(256) void radius_fill_kernel(const float* __restric
     }
 }
 
-// ---- COO -> CSR helpers
-__global__ void coo_keys_kernel(const long long* __restrict__ edge_index, long long E, int* __restrict__ keys,
-                                int* __restrict__ vals) {
-    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < E) {
-        keys[e] = (int)edge_index[E + e];  // row 1 = target
-        vals[e] = (int)e;
+// ---- COO -> CSR: counting sort by destination (keys are node ids < num_nodes)
+//   count   in-degree of every node (integer atomics: the counts are deterministic); node ids outside
+//           [0, num_nodes) set a status bit and are clamped so that every later access stays in bounds
+//   scan    row_ptr (scan_rows_kernel above)
+//   slot    every edge takes a slot of its destination's row through an atomic cursor — any order
+//   sort    each row's edge ids are put in ascending order: ids are unique, so the result is THE stable
+//           order by destination whatever order the slots were handed out in, and the sort is
+//           run-to-run deterministic.  Rank sort: rows are short (a contact-map row has ~10^2
+//           entries); rows above kBigRow entries take a whole workgroup each.
+constexpr int kBigRow = 2048;
+
+__device__ __forceinline__ int clamp_node(long long v, int num_nodes, bool& bad) {
+    if (v < 0 || v >= num_nodes) {
+        bad = true;
+        return v < 0 ? 0 : num_nodes - 1;
+    }
+    return (int)v;
+}
+
+__global__ __launch_bounds__(256) void coo_count_kernel(const long long* __restrict__ edge_index, long long E,
+                                                        int num_nodes, int* __restrict__ deg,
+                                                        int* __restrict__ status) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    bool bad = false;
+    (void)clamp_node(edge_index[e], num_nodes, bad);
+    const int d = clamp_node(edge_index[E + e], num_nodes, bad);
+    if (bad && status) atomicOr(status, MDNO_STATUS_BAD_EDGE_INDEX);
+    atomicAdd(&deg[d], 1);
+}
+
+__global__ __launch_bounds__(256) void coo_slot_kernel(const long long* __restrict__ edge_index, long long E,
+                                                       int num_nodes, const int* __restrict__ row_ptr,
+                                                       int* __restrict__ cursor, int* __restrict__ ids) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    bool bad = false;
+    const int d = clamp_node(edge_index[E + e], num_nodes, bad);
+    ids[row_ptr[d] + atomicAdd(&cursor[d], 1)] = (int)e;
+}
+
+// rank of an id = number of smaller ids in its row; `ids` is read-only here, results go to perm/src/dst
+__device__ __forceinline__ void coo_place(const long long* __restrict__ edge_index, int num_nodes, int row, int beg,
+                                          int rank, int id, int* __restrict__ perm, int* __restrict__ src,
+                                          int* __restrict__ dst) {
+    bool bad = false;
+    perm[beg + rank] = id;
+    src[beg + rank] = clamp_node(edge_index[id], num_nodes, bad);
+    if (dst) dst[beg + rank] = row;
+}
+
+__global__ __launch_bounds__(256) void coo_row_sort_kernel(const long long* __restrict__ edge_index, int num_nodes,
+                                                           const int* __restrict__ row_ptr,
+                                                           const int* __restrict__ ids, int* __restrict__ perm,
+                                                           int* __restrict__ src, int* __restrict__ dst) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= num_nodes) return;
+    const int beg = row_ptr[row], deg = row_ptr[row + 1] - beg;
+    if (deg > kBigRow) return;                      // coo_big_row_sort_kernel
+    for (int i = lane; i < deg; i += 64) {
+        const int id = ids[beg + i];
+        int rank = 0;
+        for (int j = 0; j < deg; ++j) rank += ids[beg + j] < id;   // same address in every lane: one broadcast load
+        coo_place(edge_index, num_nodes, row, beg, rank, id, perm, src, dst);
     }
 }
 
-__global__ void coo_gather_kernel(const long long* __restrict__ edge_index, long long E,
-                                  const int* __restrict__ keys_sorted, const int* __restrict__ perm,
-                                  int* __restrict__ src, int* __restrict__ dst) {
-    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < E) {
-        src[p] = (int)edge_index[perm[p]];  // row 0 = source
-        if (dst) dst[p] = keys_sorted[p];
+__global__ __launch_bounds__(1024) void coo_big_row_sort_kernel(const long long* __restrict__ edge_index,
+                                                                int num_nodes, const int* __restrict__ row_ptr,
+                                                                const int* __restrict__ ids, int* __restrict__ perm,
+                                                                int* __restrict__ src, int* __restrict__ dst) {
+    __shared__ int tile[1024];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const int beg = row_ptr[row], deg = row_ptr[row + 1] - beg;
+    if (deg <= kBigRow) return;
+    for (int i0 = 0; i0 < deg; i0 += 1024) {        // uniform trip counts: the barriers below are reached by all
+        const int i = i0 + tid;
+        const int id = i < deg ? ids[beg + i] : 0x7fffffff;
+        int rank = 0;
+        for (int j0 = 0; j0 < deg; j0 += 1024) {
+            __syncthreads();
+            tile[tid] = j0 + tid < deg ? ids[beg + j0 + tid] : 0x7fffffff;
+            __syncthreads();
+            const int n = deg - j0 < 1024 ? deg - j0 : 1024;
+            for (int j = 0; j < n; ++j) rank += tile[j] < id;
+        }
+        if (i < deg) coo_place(edge_index, num_nodes, row, beg, rank, id, perm, src, dst);
     }
-}
-
-__global__ void row_ptr_lower_bound_kernel(const int* __restrict__ keys_sorted, long long E, int num_nodes,
-                                           int* __restrict__ row_ptr) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r > num_nodes) return;
-    long long lo = 0, hi = E;  // first position with key >= r
-    while (lo < hi) {
-        const long long mid = (lo + hi) >> 1;
-        if (keys_sorted[mid] < r) lo = mid + 1; else hi = mid;
-    }
-    row_ptr[r] = (int)lo;
 }
 
 struct CooWs {
-    int *keys_in, *keys_out, *vals_in;
-    void* cub;
-    size_t cub_bytes, total;
+    int *deg, *cursor, *ids, *scratch;
+    size_t total;
 };
 
-CooWs carve_coo(void* ws, long long E) {
+CooWs carve_coo(void* ws, long long E, int num_nodes) {
     CooWs c{};
-    size_t cub_bytes = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, cub_bytes, (const int*)nullptr, (int*)nullptr,
-                                       (const int*)nullptr, (int*)nullptr, (int)E);
     Carver cv(ws);
-    c.keys_in = cv.take<int>(E);
-    c.keys_out = cv.take<int>(E);
-    c.vals_in = cv.take<int>(E);
-    c.cub = cv.take<char>(cub_bytes);
-    c.cub_bytes = cub_bytes;
+    c.deg = cv.take<int>((size_t)2 * num_nodes);   // deg | cursor: one memset
+    c.cursor = c.deg ? c.deg + num_nodes : nullptr;
+    c.ids = cv.take<int>((size_t)E);
+    c.scratch = cv.take<int>(64);
     c.total = cv.used();
     return c;
 }
@@ -201,13 +252,12 @@ extern "C" int mdno_radius_graph_csr(const float* pos, int M, int N, double cuto
 }
 
 extern "C" size_t mdno_coo_to_csr_workspace_bytes(int64_t E, int num_nodes) {
-    (void)num_nodes;
-    if (E <= 0) return 256;
-    return carve_coo(nullptr, E).total;
+    if (E <= 0 || num_nodes <= 0) return 256;
+    return carve_coo(nullptr, E, num_nodes).total;
 }
 
 extern "C" int mdno_coo_to_csr(const int64_t* edge_index, int64_t E, int num_nodes, int32_t* row_ptr,
-                               int32_t* src, int32_t* dst, int32_t* perm, void* workspace,
+                               int32_t* src, int32_t* dst, int32_t* perm, int32_t* status, void* workspace,
                                size_t workspace_bytes, void* stream) {
     MDNO_REQUIRE(row_ptr && num_nodes > 0 && E >= 0, MDNO_EINVAL, "mdno_coo_to_csr: bad arguments");
     MDNO_REQUIRE(E < (1ll << 31) - 1, MDNO_EUNSUPPORTED, "mdno_coo_to_csr: E exceeds int32 indexing");
@@ -217,21 +267,22 @@ extern "C" int mdno_coo_to_csr(const int64_t* edge_index, int64_t E, int num_nod
         return MDNO_OK;
     }
     MDNO_REQUIRE(edge_index && src && perm && workspace, MDNO_EINVAL, "mdno_coo_to_csr: null pointer");
-    CooWs c = carve_coo(workspace, E);
+    CooWs c = carve_coo(workspace, E, num_nodes);
     MDNO_REQUIRE(workspace_bytes >= c.total, MDNO_EWORKSPACE, "mdno_coo_to_csr: workspace %zu < %zu",
                  workspace_bytes, c.total);
-    const int tb = 256;
-    const int nb = (int)((E + tb - 1) / tb);
-    hipLaunchKernelGGL(coo_keys_kernel, dim3(nb), dim3(tb), 0, s, (const long long*)edge_index, (long long)E,
-                       c.keys_in, c.vals_in);
-    int end_bit = 1;
-    while ((1ll << end_bit) < (long long)num_nodes && end_bit < 31) ++end_bit;
-    size_t cub_bytes = c.cub_bytes;
-    MDNO_HIP(hipcub::DeviceRadixSort::SortPairs(c.cub, cub_bytes, (const int*)c.keys_in, c.keys_out,
-                                                (const int*)c.vals_in, perm, (int)E, 0, end_bit, s));
-    hipLaunchKernelGGL(coo_gather_kernel, dim3(nb), dim3(tb), 0, s, (const long long*)edge_index, (long long)E,
-                       (const int*)c.keys_out, (const int*)perm, src, dst);
-    hipLaunchKernelGGL(row_ptr_lower_bound_kernel, dim3((num_nodes + 1 + tb - 1) / tb), dim3(tb), 0, s,
-                       (const int*)c.keys_out, (long long)E, num_nodes, row_ptr);
+    const long long* ei = (const long long*)edge_index;
+    const unsigned nb = (unsigned)((E + 255) / 256);
+    MDNO_HIP(hipMemsetAsync(c.deg, 0, sizeof(int) * 2 * (size_t)num_nodes, s));
+    hipLaunchKernelGGL(coo_count_kernel, dim3(nb), dim3(256), 0, s, ei, (long long)E, num_nodes, c.deg, status);
+    hipLaunchKernelGGL(scan_rows_kernel, dim3(1), dim3(1024), 0, s, (const int*)c.deg, num_nodes, (long long)E,
+                       row_ptr, c.scratch, (int*)nullptr);
+    hipLaunchKernelGGL(coo_slot_kernel, dim3(nb), dim3(256), 0, s, ei, (long long)E, num_nodes, (const int*)row_ptr,
+                       c.cursor, c.ids);
+    hipLaunchKernelGGL(coo_row_sort_kernel, dim3((num_nodes + 3) / 4), dim3(256), 0, s, ei, num_nodes,
+                       (const int*)row_ptr, (const int*)c.ids, perm, src, dst);
+    // rows above kBigRow entries exist only if E does
+    if (E > kBigRow)
+        hipLaunchKernelGGL(coo_big_row_sort_kernel, dim3(num_nodes), dim3(1024), 0, s, ei, num_nodes,
+                           (const int*)row_ptr, (const int*)c.ids, perm, src, dst);
     return check_launch("mdno_coo_to_csr");
 }

@@ -10,7 +10,7 @@
 //
 // Layout / mapping (64x64 specialisation): edges are sorted by destination, so a row's W_e block
 // is ONE contiguous run of deg*16 KiB.  One workgroup owns one destination row; its 4 (many rows)
-// or 16 (few rows) waves take the row's edges round-robin.  Inside a wave, lane l = (g, q) with g = l>>4, q = l&15
+// or 16 (few rows) waves take the row's edges round-robin (16 summation chains either way).  Inside a wave, lane l = (g, q) with g = l>>4, q = l&15
 // accumulates output columns 4q..4q+3 over input rows 16g..16g+15: every wave-instruction is a
 // 16 B/lane load covering four whole 256-B rows of W_e[p] (fully coalesced), 16 such loads per
 // edge, 64 FMAs per lane.  Partial sums stay in registers across ALL edges of the row; the
@@ -68,12 +68,20 @@ __device__ __forceinline__ float4 reduce_over_g(float4 a) {
     return a;
 }
 
+// A row's edges are dealt to CHAINS = 16 summation chains (edge i of the row -> chain i % 16) whatever
+// the launch shape: with 16 waves a wave owns one chain, with 4 waves it owns chains w, w+4, w+8, w+12
+// (one accumulator each).  The chains are then added in chain order, so the 4- and the 16-wave launch
+// give the same bits and a row's result does not depend on how many rows it is batched with.
+constexpr int CHAINS = 16;
+
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void nnconv64_row_kernel(
     const float* __restrict__ x, const int* __restrict__ row_ptr, const int* __restrict__ src,
     const float* __restrict__ w_e, const float* __restrict__ root, const float* __restrict__ bias,
     float* __restrict__ y, int num_rows, int aggr, int relu) {
-    __shared__ float red[WAVES][2][64];
+    constexpr int CPW = CHAINS / WAVES;   // chains per wave
+    __shared__ float red[CHAINS][64];
+    __shared__ float rootred[64];
     const int row = blockIdx.x;
     if (row >= num_rows) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -81,30 +89,32 @@ __global__ __launch_bounds__(WAVES * 64) void nnconv64_row_kernel(
     const int beg = row_ptr[row], end = row_ptr[row + 1];
     const int deg = end - beg;
 
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int p = beg + wave; p < end; p += WAVES) {
-        const int j = src[p];
-        edge_accumulate64(acc, x + (size_t)j * 64, w_e + (size_t)p * 4096, g, q);
+    // one chain after the other (a single accumulator and one edge's 16 loads in flight per wave, as
+    // in the one-chain-per-wave shape; interleaving the chains made the compiler hoist the loads of
+    // all CPW edges: 198 VGPRs, 2 waves per SIMD)
+#pragma unroll
+    for (int u = 0; u < CPW; ++u) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int p = beg + wave + u * WAVES; p < end; p += CHAINS)
+            edge_accumulate64(acc, x + (size_t)src[p] * 64, w_e + (size_t)p * 4096, g, q);
+        acc = reduce_over_g(acc);
+        if (lane < 16) *reinterpret_cast<float4*>(&red[wave + u * WAVES][4 * lane]) = acc;
     }
+    // the root term x[r].root is one more "edge" with its own accumulator, taken by the wave that
+    // got the fewest edges
+    const bool root_wave = root != nullptr && wave == (deg % WAVES);
     float4 racc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (root != nullptr && wave == (deg % WAVES)) edge_accumulate64(racc, x + (size_t)row * 64, root, g, q);
+    if (root_wave) edge_accumulate64(racc, x + (size_t)row * 64, root, g, q);
 
-    acc = reduce_over_g(acc);
     racc = reduce_over_g(racc);
-    if (lane < 16) {
-        *reinterpret_cast<float4*>(&red[wave][0][4 * lane]) = acc;
-        *reinterpret_cast<float4*>(&red[wave][1][4 * lane]) = racc;
-    }
+    if (root_wave && lane < 16) *reinterpret_cast<float4*>(&rootred[4 * lane]) = racc;
     __syncthreads();
     if (tid < 64) {
-        float s = 0.f, rs = 0.f;
+        float s = 0.f;
 #pragma unroll
-        for (int w = 0; w < WAVES; ++w) {   // fixed order: bitwise reproducible
-            s += red[w][0][tid];
-            rs += red[w][1][tid];
-        }
+        for (int c = 0; c < CHAINS; ++c) s += red[c][tid];   // fixed order: bitwise reproducible
         if (aggr == MDNO_AGGR_MEAN) s = s / (float)(deg > 1 ? deg : 1);
-        s += rs;
+        if (root != nullptr) s += rootred[tid];
         if (bias != nullptr) s += bias[tid];
         if (relu) s = fmaxf(s, 0.f);
         y[(size_t)row * 64 + tid] = s;
@@ -161,8 +171,8 @@ int mdno::nnconv(const float* x, const int* row_ptr, const int* src, int num_row
     TimedSection ts(KID_NNCONV, s);
     if (Cin == 64 && Cout == 64 && aligned) {
         // waves per destination row: with only a few hundred rows (one ~500-atom trajectory) more
-        // waves per row keep enough loads in flight on every CU; the wave count is a function of the
-        // row count only, so a row's summation order never depends on what it is batched with
+        // waves per row keep enough loads in flight on every CU.  Both shapes add a row's edges in the
+        // same 16 chains, so the choice never changes a bit of the result
         if (num_rows >= 4096)
             hipLaunchKernelGGL(nnconv64_row_kernel<4>, dim3(num_rows), dim3(256), 0, s, x, row_ptr, src, w_e, root,
                                bias, y, num_rows, aggr, relu);

@@ -437,14 +437,9 @@ extern "C" int mdno_linear_fwd(const float* a, const float* w, const float* bias
                       ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(w)) & 15) == 0;
     if (mfma) {
         const size_t lds = sizeof(float) * 2 * 256 * LD;
-        static bool attr_set = false;
-        if (!attr_set) {
-            MDNO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_mfma_kernel<true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            MDNO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_mfma_kernel<false>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
-        }
+        static std::atomic<unsigned long long> raised_relu{0}, raised_plain{0};
+        MDNO_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(&linear_mfma_kernel<true>), (int)lds, raised_relu));
+        MDNO_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(&linear_mfma_kernel<false>), (int)lds, raised_plain));
         dim3 grid(n / 128, (unsigned)((rows + 127) / 128));
         if (relu) hipLaunchKernelGGL(linear_mfma_kernel<true>, grid, dim3(256), lds, s, a, w, bias, c, (int)rows, n, k);
         else hipLaunchKernelGGL(linear_mfma_kernel<false>, grid, dim3(256), lds, s, a, w, bias, c, (int)rows, n, k);

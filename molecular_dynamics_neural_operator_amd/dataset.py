@@ -6,8 +6,12 @@
 
 On-disk layout (dataset.py:112-127, 159): datasets `contact_map` (per-frame ragged flat COO
 `[rows..., cols...]`), `point_cloud` `[T,3,N]`, `rmsd` `[T]`, `amino_acids` `[N]`.  HDF5 files are
-read when `h5py` is importable; an `.npz` with the same dataset names is read everywhere (the image
-has no h5py).  Directory mode concatenates the sorted files (dataset.py:134-141).
+read when `h5py` is importable (the build image has none: that branch is unexecuted here, see
+tests/test_host_logic.py::test_hdf5_container); an `.npz` with the same dataset names is read
+everywhere.  In the `.npz` twin a ragged dataset is stored without pickling, as the concatenation of
+its rows under its own name plus `<name>_offsets` (int64 [T+1]); object arrays written by older
+versions are only read with `allow_pickle=True`.  Directory mode concatenates the sorted files
+(dataset.py:134-141).
 """
 from __future__ import annotations
 
@@ -83,15 +87,29 @@ class PairData:
         return out
 
 
-def _read_container(path: str, names: Sequence[str]):
+def _read_container(path: str, names: Sequence[str], allow_pickle: bool = False):
     """Return {name: array} for the datasets of `names` present in an .h5 (needs h5py) or .npz file."""
     p = str(path)
     out = {}
     if p.endswith(".npz"):
-        with np.load(p, allow_pickle=True) as z:
+        with np.load(p, allow_pickle=allow_pickle) as z:
             for n in names:
-                if n in z.files:
-                    out[n] = z[n]
+                if n not in z.files:
+                    continue
+                try:
+                    arr = z[n]
+                except ValueError as e:     # a pickled object array and allow_pickle is off
+                    raise ValueError(
+                        f"{p}: dataset {n!r} is a pickled object array; rewrite the file with "
+                        "write_trajectory_npz (flat rows + offsets) or pass allow_pickle=True for a file "
+                        "you trust") from e
+                if n + "_offsets" in z.files:       # ragged rows stored flat
+                    off = np.asarray(z[n + "_offsets"], dtype=np.int64)
+                    rows = np.empty(len(off) - 1, dtype=object)
+                    for t in range(len(off) - 1):
+                        rows[t] = arr[off[t]:off[t + 1]]
+                    arr = rows
+                out[n] = arr
         return out
     try:
         import h5py  # noqa: not in the build image; used when present
@@ -118,6 +136,7 @@ class ContactMapDataset(torch.utils.data.Dataset):
         window_size: int = 1,
         horizon: int = 1,
         node_feature_dset_path: Optional[str] = None,
+        allow_pickle: bool = False,
     ):
         self._constant_num_node_features = constant_num_node_features
         self.window_size = window_size
@@ -137,7 +156,7 @@ class ContactMapDataset(torch.utils.data.Dataset):
         rmsd: List[np.ndarray] = []
         node_features = None
         for fpath in files:
-            d = _read_container(fpath, names)
+            d = _read_container(fpath, names, allow_pickle)
             edge_indices.extend(list(d[edge_index_dset_name][:ntrain]))
             edge_attrs.append(np.asarray(d[edge_attr_dset_name][:ntrain]))
             if "rmsd" in d:
@@ -145,7 +164,7 @@ class ContactMapDataset(torch.utils.data.Dataset):
             if node_feature_dset_name is not None and names[-1] in d and node_features is None:
                 node_features = np.asarray(d[names[-1]])
         if node_feature_dset_name is not None and node_feature_dset_path is not None:
-            node_features = np.asarray(_read_container(node_feature_dset_path, (names[-1],))[names[-1]])
+            node_features = np.asarray(_read_container(node_feature_dset_path, (names[-1],), allow_pickle)[names[-1]])
         if node_feature_dset_name is not None and node_features is None:
             raise ValueError(f"dataset {names[-1]!r} not found (pass node_feature_dset_path)")
 
@@ -181,11 +200,13 @@ class ContactMapDataset(torch.utils.data.Dataset):
 
 def write_trajectory_npz(path, frames: np.ndarray, contact_maps: Sequence[np.ndarray], amino_acids: np.ndarray,
                          rmsd: Optional[np.ndarray] = None) -> None:
-    """Write frames `[T,N,3]` + per-frame flat COO in the on-disk layout above (npz container)."""
+    """Write frames `[T,N,3]` + per-frame flat COO in the on-disk layout above (npz container; the
+    ragged contact maps as one flat vector + offsets, so the file loads without pickle)."""
     frames = np.asarray(frames, dtype=np.float32)
-    cms = np.empty(len(contact_maps), dtype=object)
-    for t, c in enumerate(contact_maps):
-        cms[t] = np.asarray(c, dtype=np.int64).reshape(-1)
-    np.savez(path, contact_map=cms, point_cloud=np.ascontiguousarray(np.transpose(frames, (0, 2, 1))),
+    rows = [np.asarray(c, dtype=np.int64).reshape(-1) for c in contact_maps]
+    offsets = np.zeros(len(rows) + 1, dtype=np.int64)
+    np.cumsum([r.size for r in rows], out=offsets[1:])
+    flat = np.concatenate(rows) if rows else np.zeros(0, np.int64)
+    np.savez(path, contact_map=flat, contact_map_offsets=offsets, point_cloud=np.ascontiguousarray(np.transpose(frames, (0, 2, 1))),
              rmsd=(np.zeros(len(frames), np.float32) if rmsd is None else np.asarray(rmsd, np.float32)),
              amino_acids=np.asarray(amino_acids, dtype=np.int64))

@@ -57,8 +57,8 @@ def reset(value) -> None:
 def _no_training(module: nn.Module) -> None:
     if module.training and torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
         raise NotImplementedError(
-            "the HIP path is forward-only this round (SURVEY.md §8f row 2): call model.eval() or run "
-            "under torch.no_grad()")
+            "a stand-alone NNConv_old / DenseNet forward is inference-only (the differentiable HIP path is "
+            "KernelNN.forward in training mode, training.py): call .eval() or run under torch.no_grad()")
 
 
 # --------------------------------------------------------------------------- loss

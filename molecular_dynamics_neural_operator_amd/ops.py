@@ -10,7 +10,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import AGGR, KernelNNParams, MdnoError, check, f32, ptr, stream_ptr
+from ._lib import AGGR, KernelNNParams, MdnoError, check, f32, ptr, raise_on_status, stream_ptr
 
 
 @dataclass
@@ -56,8 +56,10 @@ def radius_graph(pos: torch.Tensor, n_atoms: int, cutoff: float = 8.0, edge_cap:
     return CSRGraph(row_ptr, src, dst, ne, cap, None, status)
 
 
-def coo_to_csr(edge_index: torch.Tensor, num_nodes: int) -> CSRGraph:
-    """edge_index i64 [2,E] (row 0 = source, row 1 = target) -> CSRGraph with `perm`."""
+def coo_to_csr(edge_index: torch.Tensor, num_nodes: int, validate: bool = True) -> CSRGraph:
+    """edge_index i64 [2,E] (row 0 = source, row 1 = target) -> CSRGraph with `perm`.  A node id
+    outside [0, num_nodes) raises (as the reference's gather / scatter do); `validate=False` defers
+    that check: the bit stays in `graph.status` for the caller to read after its own work."""
     lib = _lib.load()
     if edge_index.dim() != 2 or edge_index.shape[0] != 2:
         raise MdnoError(f"edge_index must be [2,E], got {tuple(edge_index.shape)}")
@@ -71,10 +73,13 @@ def coo_to_csr(edge_index: torch.Tensor, num_nodes: int) -> CSRGraph:
     perm = torch.empty(cap, dtype=torch.int32, device=dev)
     nbytes = lib.mdno_coo_to_csr_workspace_bytes(E, num_nodes)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    check(lib.mdno_coo_to_csr(ptr(ei), E, num_nodes, ptr(row_ptr), ptr(src), ptr(dst), ptr(perm), ptr(ws), nbytes,
-                              stream_ptr(dev)), "mdno_coo_to_csr")
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    check(lib.mdno_coo_to_csr(ptr(ei), E, num_nodes, ptr(row_ptr), ptr(src), ptr(dst), ptr(perm), ptr(status),
+                              ptr(ws), nbytes, stream_ptr(dev)), "mdno_coo_to_csr")
+    if validate:
+        raise_on_status(status.item(), "coo_to_csr")
     ne = torch.full((1,), E, dtype=torch.int32, device=dev)
-    return CSRGraph(row_ptr, src, dst, ne, cap, perm, None)
+    return CSRGraph(row_ptr, src, dst, ne, cap, perm, status)
 
 
 def edge_mlp(weights, ker_in: int, ker_width: int, out_dim: int, graph: CSRGraph,
@@ -190,9 +195,12 @@ class ParamPack:
 
 def kernelnn_forward(pack: ParamPack, frames: torch.Tensor, x_aminoacid: torch.Tensor, graph: CSRGraph,
                      edge_pos: Optional[torch.Tensor] = None, edge_attr: Optional[torch.Tensor] = None,
-                     return_latent: bool = False, workspace: Optional[torch.Tensor] = None
-                     ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
-    """frames f32 [W,M,N,3] (time-major) -> out [M*N,out_width] (+ latent [M*N,width])."""
+                     return_latent: bool = False, workspace: Optional[torch.Tensor] = None,
+                     check_status: bool = True) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """frames f32 [W,M,N,3] (time-major) -> out [M*N,out_width] (+ latent [M*N,width]).
+    The device status word (bad amino-acid id, edge overflow, asymmetric graph, ...) is read back and
+    raised after the call — the reference's nn.Embedding raises IndexError at that point; pass
+    `check_status=False` to keep the call asynchronous and read `graph.status` yourself."""
     lib = _lib.load()
     frames = f32(frames)
     if frames.dim() == 3:
@@ -209,7 +217,9 @@ def kernelnn_forward(pack: ParamPack, frames: torch.Tensor, x_aminoacid: torch.T
     nbytes = lib.mdno_kernelnn_workspace_bytes(pack.ref, M, N, graph.edge_cap)
     if workspace is None or workspace.numel() < nbytes:
         workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    status = graph.status if graph.status is not None else torch.zeros(1, dtype=torch.int32, device=dev)
+    if graph.status is None:
+        graph.status = torch.zeros(1, dtype=torch.int32, device=dev)
+    status = graph.status
     ea = f32(edge_attr) if edge_attr is not None else None
     ep = f32(edge_pos).reshape(-1, 3) if edge_pos is not None else None
     if pack.conv_mode == "factored" and (ea is not None or ep is None):
@@ -220,6 +230,8 @@ def kernelnn_forward(pack: ParamPack, frames: torch.Tensor, x_aminoacid: torch.T
                                 ptr(ea),
                                 ptr(graph.perm) if ea is not None else None, ptr(out), ptr(latent), ptr(workspace),
                                 workspace.numel(), ptr(status), stream_ptr(dev)), "mdno_kernelnn_fwd")
+    if check_status:
+        raise_on_status(status.item(), "kernelnn_forward")
     return out, latent
 
 

@@ -19,8 +19,8 @@ from typing import List, Optional, Tuple
 import torch
 
 from . import _lib, ops
-from ._lib import (MdnoError, STATUS_ASYMMETRIC_GRAPH, STATUS_BAD_AMINOACID, STATUS_DEGREE_OVERFLOW,
-                   STATUS_EDGE_OVERFLOW, check, f32, ptr, require_gpu)
+from ._lib import (MdnoError, STATUS_DEGREE_OVERFLOW, STATUS_EDGE_OVERFLOW, check, f32, ptr, raise_on_status,
+                   require_gpu)
 
 
 def default_edge_cap(members: int, n_atoms: int, threshold: float, density: float = 0.1, slack: float = 1.6) -> int:
@@ -53,7 +53,7 @@ class RolloutEngine:
         dev = self.device
         # what conv_mode "auto" resolves to at this capacity (include/mdno.h MDNO_CONV_AUTO)
         self.conv_mode = {v: k for k, v in _lib.CONV_MODES.items()}[
-            int(self.lib.mdno_resolve_conv_mode(self.pack.ref, self.edge_cap))]
+            int(self.lib.mdno_resolve_conv_mode(self.pack.ref, self.M, self.edge_cap))]
         self.traj = torch.zeros((self.W + self.max_steps, self.M, self.N, 3), dtype=torch.float32, device=dev)
         nbytes = self.lib.mdno_rollout_workspace_bytes(self.pack.ref, self.M, self.N, self.edge_cap)
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -157,12 +157,9 @@ class RolloutEngine:
         st = int(self.status.item())
         if st & STATUS_EDGE_OVERFLOW:
             raise MdnoError(f"radius graph exceeded edge_cap={self.edge_cap}; construct the engine with a larger cap")
-        if st & STATUS_BAD_AMINOACID:
-            raise MdnoError("x_aminoacid outside [0, num_embeddings)")
         if st & STATUS_DEGREE_OVERFLOW:
             raise MdnoError(f"a node has more than max_degree={self.max_degree} edges; raise the bound (0 = n_atoms)")
-        if st & STATUS_ASYMMETRIC_GRAPH:
-            raise MdnoError("factored conv met an edge without a reverse edge (graph not symmetric)")
+        raise_on_status(st, "rollout")
 
     def run(self, window: torch.Tensor, x_aminoacid: torch.Tensor, steps: int) -> torch.Tensor:
         """reset + step + synchronize; returns the produced frames f32 [steps, M, N, 3] (a view)."""

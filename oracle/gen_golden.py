@@ -14,7 +14,9 @@ Two things are patched at run time, nothing in the reference is edited:
 
 The reference itself never travels: only the data written here is committed.
 
-Usage:  python oracle/gen_golden.py [--out tests/golden] [--skip-large]
+Usage:  python oracle/gen_golden.py [--out tests/golden] [--skip-large] [--only NAME[,NAME]]
+        (sections: base, live504, checkpoint; every section seeds itself, so any subset
+        reproduces the same files)
 """
 from __future__ import annotations
 
@@ -57,16 +59,123 @@ def _checksums(sd):
     return np.array(names), sums, asums
 
 
+def _flat_contact_map(pd):
+    return np.concatenate([pd.edge_index[0].numpy(), pd.edge_index[1].numpy()]).astype(np.int64)
+
+
+def _cm_checksum(cm):
+    """Order-sensitive 64-bit checksum of a flat [rows..., cols...] contact map (wraps mod 2^64)."""
+    c = np.asarray(cm, dtype=np.uint64)
+    w = (np.arange(c.size, dtype=np.uint64) * np.uint64(2654435761) + np.uint64(1)) | np.uint64(1)
+    with np.errstate(over="ignore"):
+        return np.uint64((c * w).sum())
+
+
+def gen_live504(gk, ds, out: Path):
+    """Width-64 / k=1024 / depth-6 model at N=504 with bounded, live activations (the near-identity
+    weight set with a kernel integral strong enough to move atoms ~0.4 A per step): 5 teacher-forced
+    forwards on the reference's own ContactMapDataset samples and 5 free-running steps through the
+    reference's recursive_propagation (graph_kernel.py:396-413).  ~10 reference forwards at 7.6 TFLOP."""
+    from molecular_dynamics_neural_operator_amd import synthetic as syn
+    from molecular_dynamics_neural_operator_amd.weights import near_identity_state_dict
+    THR, N, W, NTF, NFREE = 8.0, 504, 10, 5, 5
+    T = W + NTF + 1
+    base = syn.box_frame(N, seed=1)
+    traj = syn.ou_trajectory(base, T, sigma=0.15, theta=0.2, seed=4)          # [T,N,3]
+    aa = torch.from_numpy(syn.amino_acids(N, seed=1))
+    gk.args = Namespace(window_size=W, num_residues=N, batch_size=1)
+    cms = np.empty(T, dtype=object)
+    for t in range(T):
+        cms[t] = _flat_contact_map(gk.construct_pairdata(traj[t:t + 1], aa, threshold=THR))
+    gains = dict(seed=0, kernel_gain=0.02, feature_gain=0.1, kernel_to_coords=1.0)
+    sd = near_identity_state_dict(64, 1024, **gains)
+    model = gk.KernelNN(64, 1024, 6, 6, 7, 3, 20, 4)
+    print("live504 load:", model.load_state_dict(sd))
+    model.eval()
+    names, sums, asums = _checksums(model.state_dict())
+    with tempfile.TemporaryDirectory() as td:
+        h5 = Path(td) / "synthetic504.h5"
+        with open(h5, "wb") as fh:
+            np.savez(fh, contact_map=cms, point_cloud=np.transpose(traj, (0, 2, 1)).copy(),
+                     rmsd=np.zeros(T, np.float32), amino_acids=aa.numpy())
+        dset = ds.ContactMapDataset(str(h5), window_size=W, horizon=1, node_feature_dset_path=str(h5))
+        tf_out, tf_lat0 = [], None
+        with torch.no_grad():
+            for i in range(NTF):
+                o, lat = model(dset[i], return_latent=True)
+                tf_out.append(o.numpy())
+                if i == 0:
+                    tf_lat0 = lat.numpy()
+                print(f"  live504 teacher-forced {i}: |out-y| mean {float((o - dset[i].y).norm(dim=1).mean()):.3f}", flush=True)
+        holder = Namespace(module=model, eval=lambda: None)
+        fc = gk.recursive_propagation(holder, dset, "cpu", num_steps=NFREE, starting_points=[0], threshold=THR)
+    free = np.stack([f.x_position[-1].numpy() for f in fc])
+    free_E = np.array([f.edge_index.shape[1] for f in fc])
+    free_gap = np.array([syn.min_threshold_gap(f.x_position[-1].numpy(), THR) for f in fc])
+    np.savez_compressed(
+        out / "kernelnn_live504.npz",
+        ctor=np.array([64, 1024, 6, 6, 7, 3, 20, 4]), threshold=THR, window=W,
+        weight_gains=np.array([gains["seed"], gains["kernel_gain"], gains["feature_gain"], gains["kernel_to_coords"]]),
+        param_names=names, param_sum=sums, param_abs_sum=asums,
+        frames=traj, amino_acids=aa.numpy(),
+        contact_map_len=np.array([c.size for c in cms]), contact_map_checksum=np.array([_cm_checksum(c) for c in cms]),
+        teacher_forced_out=np.stack(tf_out), teacher_forced_latent0=tf_lat0,
+        free_frames=free, free_num_edges=free_E, free_min_gap=free_gap,
+        free_edge_checksum_last=_cm_checksum(_flat_contact_map(fc[-1])),
+    )
+    zf = float((tf_lat0 == 0).mean())
+    print(f"kernelnn_live504: ok; E0 {cms[0].size // 2}, free-run E {free_E}, min gap {free_gap}, "
+          f"latent zeros {zf:.2f}, |latent| max {np.abs(tf_lat0).max():.2f}")
+
+
+def gen_checkpoint(gk, out: Path):
+    """A `best.pt`-shaped checkpoint (graph_kernel.py:630-639) written from the reference's own
+    KernelNN wrapped as `main` wraps it (DataParallel -> `module.` key prefix, :528), stored as
+    plain arrays, plus the reference forward it must reproduce once loaded."""
+    from molecular_dynamics_neural_operator_amd import synthetic as syn
+    THR, N, W = 8.0, 28, 10
+    win = syn.jitter_window(syn.chain_frame(N, seed=0), W, seed=0)
+    aa = torch.from_numpy(syn.amino_acids(N, seed=0))
+    gk.args = Namespace(window_size=W, num_residues=N, batch_size=1)
+    pd = gk.construct_pairdata(win, aa, threshold=THR)
+    torch.manual_seed(77)
+    model = gk.KernelNN(64, 32, 2, 6, 7, 3, 20, 4)
+    wrapped = torch.nn.DataParallel(model)               # CPU: only the `module.` prefix matters here
+    optimizer = torch.optim.Adam(wrapped.parameters(), lr=0.01, weight_decay=5e-4)      # :541-543
+    scheduler = torch.optim.lr_scheduler.StepLR(optimizer, step_size=50, gamma=0.8)     # :544-546
+    ckpt = {"epoch": 3, "model_state_dict": wrapped.state_dict(),
+            "optimizer_state_dict": optimizer.state_dict(), "scheduler_state_dict": scheduler.state_dict()}
+    assert all(k.startswith("module.") for k in ckpt["model_state_dict"])
+    model.eval()
+    with torch.no_grad():
+        out_ref = model(pd).numpy()
+    arrays = {"msd/" + k: v.detach().numpy() for k, v in ckpt["model_state_dict"].items()}
+    np.savez_compressed(
+        out / "checkpoint_best_pt.npz", epoch=ckpt["epoch"], ctor=np.array([64, 32, 2, 6, 7, 3, 20, 4]),
+        scheduler_step_size=50, scheduler_gamma=0.8, optimizer_lr=0.01, optimizer_weight_decay=5e-4,
+        x_position=win, x_aminoacid=aa.numpy(), edge_index=pd.edge_index.numpy(), edge_attr=pd.edge_attr.numpy(),
+        out=out_ref, **arrays)
+    print("checkpoint_best_pt: ok;", len(arrays), "tensors, |out| max", float(np.abs(out_ref).max()))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", type=Path, default=REPO / "tests" / "golden")
-    ap.add_argument("--skip-large", action="store_true", help="skip the N=504 full-size forward (~1-2 min CPU)")
+    ap.add_argument("--skip-large", action="store_true", help="skip the N=504 full-size forwards (minutes of CPU)")
+    ap.add_argument("--only", default="", help="comma-separated sections: base, live504, checkpoint (default: all)")
     a = ap.parse_args()
     a.out.mkdir(parents=True, exist_ok=True)
     torch.set_num_threads(8)
+    only = set(filter(None, a.only.split(",")))
 
     gk, ds = _import_reference()
     from molecular_dynamics_neural_operator_amd import synthetic as syn
+    if not only or "checkpoint" in only:
+        gen_checkpoint(gk, a.out)
+    if (not only and not a.skip_large) or "live504" in only:
+        gen_live504(gk, ds, a.out)
+    if only and "base" not in only:
+        return
 
     THR = 8.0
     N, W = 28, 10

@@ -41,3 +41,11 @@ def golden_state_dict(z, prefix="p."):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+def write_golden_trajectory(path, z):
+    """The golden rollout fixture's trajectory as an .npz twin of the reference's HDF5 layout
+    (flat contact maps + offsets: loads without pickle)."""
+    from molecular_dynamics_neural_operator_amd.dataset import write_trajectory_npz
+    frames = np.transpose(z["point_cloud"], (0, 2, 1))
+    write_trajectory_npz(path, frames, list(z["contact_map"]), z["amino_acids"], z["rmsd"])

@@ -50,7 +50,7 @@ def test_exports_are_c_linkage_only_mdno(lib):
 
 def test_abi_version_struct_layout_and_error_string(lib):
     from molecular_dynamics_neural_operator_amd import _lib
-    assert lib.mdno_abi_version() == 5
+    assert lib.mdno_abi_version() == _lib.ABI_VERSION == 6
     # 12 int32 + 27 pointers, no padding surprises
     assert ctypes.sizeof(_lib.KernelNNParams) == 12 * 4 + 27 * 8
     # argument validation happens before any device work: exercise it without a GPU
@@ -67,17 +67,20 @@ def test_abi_version_struct_layout_and_error_string(lib):
 
 def test_conv_mode_resolution_is_host_logic(lib):
     """mdno_resolve_conv_mode (include/mdno.h MDNO_CONV_AUTO): factored where it applies (width 64,
-    ker_width a multiple of 64) and, for auto, only from an edge capacity of 24,576 on."""
+    ker_width a multiple of 64) and, for auto, only from an edge capacity of 24,576 PER MEMBER on — a
+    member takes the same path alone and inside any batch."""
     from molecular_dynamics_neural_operator_amd import _lib
     M, F, A = (_lib.CONV_MODES[k] for k in ("materialized", "factored", "auto"))
 
-    def resolve(width, ker_width, mode, cap):
+    def resolve(width, ker_width, mode, cap, members=1):
         p = _lib.KernelNNParams()
         p.width, p.ker_width, p.depth, p.ker_in, p.out_width, p.conv_mode = width, ker_width, 6, 6, 3, mode
-        return lib.mdno_resolve_conv_mode(ctypes.byref(p), cap)
+        return lib.mdno_resolve_conv_mode(ctypes.byref(p), members, cap)
 
     assert resolve(64, 1024, A, 24575) == M and resolve(64, 1024, A, 24576) == F
     assert resolve(64, 1024, F, 100) == F and resolve(64, 1024, M, 10**6) == M
     assert resolve(32, 1024, A, 10**6) == M and resolve(32, 1024, F, 10**6) == M      # width != 64: never
     assert resolve(64, 1000, A, 10**6) == M                                            # untileable k
-    assert lib.mdno_resolve_conv_mode(None, 10**6) == M
+    assert resolve(64, 1024, A, 8 * 24576 - 8, members=8) == M and resolve(64, 1024, A, 8 * 24576, members=8) == F
+    assert resolve(64, 1024, A, 64 * 784, members=64) == M                            # 64 x N=28: materialized
+    assert lib.mdno_resolve_conv_mode(None, 1, 10**6) == M

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden_state_dict, load_golden
+from conftest import golden_state_dict, load_golden, write_golden_trajectory
 
 pytestmark = pytest.mark.gpu
 
@@ -373,8 +373,7 @@ def test_rollout_teacher_forced_and_free_golden(dev, tmp_path):
     z = load_golden("rollout_20.npz")
     W, thr = int(z["window"]), float(z["threshold"])
     path = tmp_path / "traj.npz"
-    np.savez(path, contact_map=z["contact_map"], point_cloud=z["point_cloud"], rmsd=z["rmsd"],
-             amino_acids=z["amino_acids"])
+    write_golden_trajectory(path, z)
     dset = ContactMapDataset(str(path), window_size=W, horizon=int(z["horizon"]))
     assert len(dset) == int(z["dataset_len"])
     # teacher forced: dataset samples carry the FIRST window frame's graph (dataset.py:189-201)

@@ -8,7 +8,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import load_golden
+from conftest import load_golden, write_golden_trajectory
 
 pytestmark = pytest.mark.gpu
 
@@ -121,8 +121,7 @@ def test_model_gradients_vs_fp64_replica(dev, O, tmp_path, gemm_mode):
     from molecular_dynamics_neural_operator_amd.training import collate, train_forward
     z = load_golden("rollout_20.npz")
     path = tmp_path / "traj.npz"
-    np.savez(path, contact_map=z["contact_map"], point_cloud=z["point_cloud"], rmsd=z["rmsd"],
-             amino_acids=z["amino_acids"])
+    write_golden_trajectory(path, z)
     dset = ContactMapDataset(str(path), window_size=int(z["window"]), horizon=1)
     samples = [dset[i] for i in (0, 7, 19)]
     B = len(samples)

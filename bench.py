@@ -1,18 +1,25 @@
 #!/usr/bin/env python3
 """Headline benchmark: rolled-out MD frames/sec (BASELINE.json), one process per GPU.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1: starts N fresh worker processes itself)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-         --master-port P bench.py --gpus N --steps K --warmup W
+         --master-port P bench.py --gpus N --steps K --warmup W        (or under an external launcher)
 
-Workload (BASELINE.json configs[1], SURVEY.md §8d shape B): BBA all-atom stand-in, N=504 atoms
-uniform at 0.1 atoms/A^3, 8 A cutoff (E ~ 60k directed edges incl. self-loops), window 10, the
-reference's CLI-default model (width 64, kernel_width 1024, depth 6 -> 12 conv applications), fp32,
-free-running autoregressive rollout entirely on the device.  One "step" = one new frame for every
-member on every rank (graph rebuild + forward + window slide).  Weak scaling: every rank runs
-`--members-per-gpu` independent trajectories (ensemble members, different perturbations of the
-start window); no collective while stepping, one RCCL all-gather of the produced frames at the end,
-inside the timed region.  value = frames produced by all ranks / max-over-ranks wall time.
+Workload.  N=504 atoms uniform at 0.1 atoms/A^3 (BBA all-atom stand-in), 8 A cutoff (E ~ 60k directed
+edges incl. self-loops per member), window 10, the reference's CLI-default model (width 64,
+kernel_width 1024, depth 6 -> 12 conv applications), fp32, free-running autoregressive rollout entirely
+on the device.  One "step" = one new frame for every ensemble member (graph rebuild + forward + window
+slide).
+  --gpus 1 (default)   BASELINE configs[1]: ONE trajectory, 1 GPU.
+  --gpus N > 1         BASELINE configs[2]: the 64-member ensemble (`--total-members`, default 64 when
+                       N > 1), member m on rank m mod N, no collective while stepping, one RCCL
+                       all-gather of the produced frames at the end, inside the timed region.  The total
+                       work is the same for every N > 1 ("scaling": "strong"); the like-for-like
+                       single-GPU figure (64 members on one GPU) is `python bench.py --gpus 1
+                       --total-members 64` and is also reported by the default N=1 run as
+                       `ensemble64_single_gpu`.
+  --members-per-gpu M  weak-scaling mode instead: every rank runs M members.
+value = frames produced by all ranks / max-over-ranks wall time of exactly K steps (+ the gather).
 
 Weights: synthetic near-identity set (weights.py) — no trained checkpoint exists offline and
 random-init weights collapse the cloud to one point, which would change E (the cost driver) after
@@ -25,7 +32,8 @@ Extra objects on the JSON line:
                 per-edge matvec -> scatter-mean) kernel (16,388*E + 516*R + 4):
                 bytes / average launch duration, measured with HIP events on the launching stream over
                 K more steps of the same rollout issued as plain launches (events cannot sit inside a
-                hipGraph replay); traffic = PMC bytes per launch from profiles/roofline_traffic.json.
+                hipGraph replay); traffic = PMC bytes per launch from profiles/roofline_traffic.json,
+                only when this run's (atoms, members, conv mode, GEMM mode) is the profiled one.
   rooflines     the same for every leg: both conv formulations (the other one is run as a comparison
                 leg on the same start window) and the two wide split-bf16 GEMMs against the bf16 MFMA peak.
   cpu_baseline  the oracle (CPU restatement of the reference: edge-MLP re-evaluated in all 12 conv
@@ -37,6 +45,9 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -51,14 +62,18 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s mea
 HBM_COPY_GBS = 6290.0
 MFMA_F32_PEAK_TFLOPS = 157.3  # fp32-input MFMA = vector fp32 peak
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (MI355X_MICROARCH.md)
+ENSEMBLE_MEMBERS = 64         # BASELINE.json configs[2]
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--members-per-gpu", type=int, default=1)
+    ap.add_argument("--total-members", type=int, default=None,
+                    help="ensemble size shared by all ranks (member m on rank m mod N); default 1 for --gpus 1, "
+                         f"{ENSEMBLE_MEMBERS} for --gpus > 1")
+    ap.add_argument("--members-per-gpu", type=int, default=None, help="weak scaling: every rank runs this many members")
     ap.add_argument("--atoms", type=int, default=504)
     ap.add_argument("--width", type=int, default=64)
     ap.add_argument("--kernel-width", type=int, default=1024)
@@ -78,24 +93,104 @@ def parse():
     ap.add_argument("--chain", action="store_true", help="random-walk C-alpha chain frame instead of the uniform box")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--skip-roofline", action="store_true")
-    ap.add_argument("--cpu-budget-s", type=float, default=45.0)
-    return ap.parse_args()
+    ap.add_argument("--skip-ensemble-leg", action="store_true",
+                    help="N=1 default run: skip the 64-member single-GPU leg (cfg3's like-for-like baseline)")
+    ap.add_argument("--cpu-budget-s", type=float, default=120.0,
+                    help="bound on the full reference-faithful CPU step; estimated first from one conv application")
+    return ap.parse_args(argv)
+
+
+# ----------------------------------------------------------------------------------------------- launcher
+def launch_workers(a) -> int:
+    """`python bench.py --gpus N` with no launcher around it: start N fresh worker processes (this
+    process has made no GPU call and makes none), relay rank 0's JSON line, return the worst exit code."""
+    n = a.gpus
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this driver (RCCL needs it)
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+    ndev = torch.cuda.device_count()                        # counts devices without initialising HIP
+    if ndev < n and "MDNO_BENCH_BACKEND" not in env:
+        print(f"bench.py: {n} ranks on {ndev} visible GPU(s): ranks share cards, collective over gloo "
+              "(rehearsal only — RCCL needs one GPU per rank)", file=sys.stderr)
+        env["MDNO_BENCH_BACKEND"] = "gloo"
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=e,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno(), text=(r == 0)))
+    out0, _ = procs[0].communicate()
+    deadline = None
+    codes = [procs[0].returncode] + [None] * (n - 1)
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+        if any(c not in (None, 0) for c in codes) and deadline is None:
+            deadline = time.time() + 30.0                   # a rank failed: give the others 30 s, then stop them
+        if deadline is not None and time.time() > deadline:
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    p.kill()                                # exactly the children started above
+                    codes[i] = p.wait()
+        time.sleep(0.05)
+    sys.stdout.write(out0 or "")
+    sys.stdout.flush()
+    bad = [c for c in codes if c != 0]
+    return 0 if not bad else (max(bad) if max(bad) > 0 else 1)
+
+
+# ----------------------------------------------------------------------------------------------- CPU leg
+def note(msg: str) -> None:
+    """Progress line on stderr (the JSON line is the only thing on stdout)."""
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def _cores() -> int:
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota (a GPU box
+    shows all 256 host threads in the mask but grants 16 CPUs of quota — 256 torch threads on that
+    quota are throttled to a crawl)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()[:2]          # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read_text())             # cgroup v1
+            p = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+            if q > 0 and p > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return n
 
 
 def cpu_baseline(sd, depth, window, aa, threshold, budget_s):
-    """Reference-faithful CPU step on this host: forward with the edge-MLP evaluated in every conv
-    application (hoist=False) + scipy graph rebuild (graph_kernel.py:396-413)."""
+    """Reference-faithful CPU step on this host (graph_kernel.py:396-413): forward with the edge-MLP
+    evaluated in every conv application (hoist=False) + scipy graph rebuild.  Legs:
+      value      shape B (this workload), all host cores: ONE full rollout step, timed (estimated from one
+                 conv application only if that estimate exceeds the budget — stated in `sample`)
+      one_thread shape B at torch.set_num_threads(1) — the reference's own setting when
+                 num_data_workers == 0 (graph_kernel.py:501) — extrapolated from one conv application on an
+                 edge slice (labelled so)
+      shape_A    N=28 C-alpha chain (the reference's BBA), median of 20 steps, all cores, and of 5 steps
+                 at one thread"""
     from oracle import graph_kernel_oracle as O
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    from molecular_dynamics_neural_operator_amd import synthetic as syn
+    cores = _cores()
     torch.set_num_threads(cores)
+    note(f"cpu baseline: {cores} threads")
     sd_cpu = {k: v.detach().cpu() for k, v in sd.items()}
     aa = aa.cpu()
+    N = window.shape[1]
     t0 = time.perf_counter()
     s = O.construct_pairdata(window, aa, threshold)
     t_graph = time.perf_counter() - t0
     E = int(s["edge_index"].shape[1])
-    # one conv application (edge-MLP + gather/matvec/scatter) to size the sample
-    x = torch.randn(window.shape[1], sd_cpu["fc1.weight"].shape[0])
+    x = torch.randn(N, sd_cpu["fc1.weight"].shape[0])
     O.edge_mlp(s["edge_attr"][:2048], sd_cpu, "conv1.net.")  # warm the thread pool
     t0 = time.perf_counter()
     w_e = O.edge_mlp(s["edge_attr"], sd_cpu, "conv1.net.")
@@ -103,28 +198,90 @@ def cpu_baseline(sd, depth, window, aa, threshold, budget_s):
     t_conv = time.perf_counter() - t0
     del w_e
     est = 2 * depth * t_conv + t_graph
+    note(f"cpu baseline: one conv application {t_conv:.2f}s, graph {t_graph:.3f}s -> full step ~{est:.0f}s")
     if est <= budget_s:
         t0 = time.perf_counter()
         O.recursive_propagation(sd_cpu, depth, s, 1, threshold, hoist=False)
         t_step = time.perf_counter() - t0
-        sample = (f"1 full rollout step: forward with the edge-MLP evaluated {2 * depth}x as the reference does + "
-                  f"scipy graph rebuild, N={window.shape[1]}, E={E}")
+        sample = (f"1 full rollout step, timed: forward with the edge-MLP evaluated {2 * depth}x as the reference does "
+                  f"+ scipy graph rebuild, N={N}, E={E} ({cores} threads)")
+        measured = True
     else:
         t_step = est
-        sample = (f"1 of the {2 * depth} conv applications (edge-MLP + conv, {t_conv:.2f}s) x {2 * depth} + measured "
-                  f"scipy graph rebuild ({t_graph:.3f}s); full step estimated, N={window.shape[1]}, E={E}")
-    return {"value": 1.0 / t_step, "unit": "frames/s", "cores": cores, "kind": "port", "sample": sample,
-            "seconds_per_frame": t_step}
+        sample = (f"ESTIMATE (a full step would exceed --cpu-budget-s {budget_s:.0f}): 1 of the {2 * depth} conv "
+                  f"applications (edge-MLP + conv, {t_conv:.2f}s) x {2 * depth} + measured scipy graph rebuild "
+                  f"({t_graph:.3f}s), N={N}, E={E} ({cores} threads)")
+        measured = False
+    out = {"value": 1.0 / t_step, "unit": "frames/s", "cores": cores, "kind": "port", "sample": sample,
+           "seconds_per_frame": t_step, "full_step_measured": measured,
+           "one_conv_application_s": t_conv, "graph_rebuild_s": t_graph}
+
+    # ---- one thread, shape B: one conv application on an edge slice, scaled
+    note(f"cpu baseline: full step {t_step:.1f}s ({'timed' if measured else 'estimated'}); one-thread leg")
+    torch.set_num_threads(1)
+    e_slice = min(E, 3072)
+    ei, ea = s["edge_index"][:, :e_slice], s["edge_attr"][:e_slice]
+    t0 = time.perf_counter()
+    w_e = O.edge_mlp(ea, sd_cpu, "conv1.net.")
+    O.nnconv_apply(x, ei, w_e, sd_cpu["conv1.root"], sd_cpu["conv1.bias"], "mean")
+    t1 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    O.construct_pairdata(window, aa, threshold)
+    t_graph1 = time.perf_counter() - t0
+    t_step1 = 2 * depth * t1 * (E / e_slice) + t_graph1
+    out["one_thread"] = {"value": 1.0 / t_step1, "unit": "frames/s", "cores": 1, "seconds_per_frame": t_step1,
+                         "sample": f"EXTRAPOLATED: one conv application on the first {e_slice} of {E} edges ({t1:.2f}s) "
+                                   f"x {E / e_slice:.1f} x {2 * depth} + measured graph rebuild ({t_graph1:.3f}s); "
+                                   "torch.set_num_threads(1) as graph_kernel.py:501"}
+
+    # ---- shape A: N=28 chain, the reference's own BBA size (bba_analysis.ipynb:1034), timed steps
+    note(f"cpu baseline: one thread ~{t_step1:.0f}s/frame; shape A legs")
+    wa = syn.jitter_window(syn.chain_frame(28, seed=0), window.shape[0], seed=0)
+    aa_a = torch.from_numpy(syn.amino_acids(28, seed=0))
+
+    def steps_a(n):
+        sa = O.construct_pairdata(wa, aa_a, threshold)
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            sa = O.recursive_propagation(sd_cpu, depth, sa, 1, threshold, hoist=False)[0]
+            ts.append(time.perf_counter() - t0)
+        return ts
+
+    ta1 = steps_a(5)
+    note(f"cpu baseline: shape A one thread {statistics.median(ta1):.2f}s/frame; {cores} threads, 3 + 20 steps")
+    torch.set_num_threads(cores)
+    steps_a(3)
+    ta = steps_a(20)
+    out["shape_A"] = {"atoms": 28, "median_s_per_frame": statistics.median(ta), "frames_per_s": 1.0 / statistics.median(ta),
+                      "steps": 20, "warmup": 3, "cores": cores,
+                      "one_thread_median_s_per_frame": statistics.median(ta1), "one_thread_steps": 5}
+    return out
 
 
-def main():
-    a = parse()
+# ----------------------------------------------------------------------------------------------- worker
+def profiled_traffic(kernel: str, atoms: int, members: int, conv_mode: str, gemm_mode: str):
+    """PMC HBM bytes per launch from profiles/roofline_traffic.json — only for the configuration the
+    counters were collected on (anything else would print a number that belongs to another run)."""
+    tf = REPO / "profiles" / "roofline_traffic.json"
+    if not tf.exists():
+        return None
+    try:
+        for ent in json.loads(tf.read_text()).get("configs", []):
+            if (ent.get("kernel") == kernel and ent.get("atoms") == atoms and ent.get("members") == members
+                    and ent.get("conv_mode") == conv_mode and ent.get("gemm_mode") == gemm_mode):
+                return ent.get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+    return None
+
+
+def worker(a):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}")
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
@@ -141,11 +298,23 @@ def main():
 
     from molecular_dynamics_neural_operator_amd import synthetic as syn
     from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN, KernelNNNotebook
-    from molecular_dynamics_neural_operator_amd.rollout import RolloutEngine, default_edge_cap, gather_trajectories
+    from molecular_dynamics_neural_operator_amd.rollout import (RolloutEngine, default_edge_cap, gather_trajectories,
+                                                                 shard_members)
     from molecular_dynamics_neural_operator_amd.weights import near_identity_state_dict
 
-    N, W, M = a.atoms, a.window, a.members_per_gpu
-    total_members = M * world
+    N, W = a.atoms, a.window
+    if a.members_per_gpu is not None and a.total_members is not None:
+        raise SystemExit("give --total-members (strong scaling) or --members-per-gpu (weak scaling), not both")
+    if a.members_per_gpu is not None:
+        total_members, scaling = a.members_per_gpu * world, "weak"
+    elif a.total_members is not None:
+        total_members, scaling = a.total_members, "strong"
+    else:
+        total_members, scaling = (1, "weak") if world == 1 else (ENSEMBLE_MEMBERS, "strong")
+    my_members = shard_members(total_members, rank, world)
+    M = len(my_members)
+    if M == 0:
+        raise SystemExit(f"rank {rank}: no members ({total_members} members over {world} ranks)")
     sd = near_identity_state_dict(a.width, a.kernel_width, seed=0, kernel_gain=1e-3, feature_gain=0.1)
     if a.variant == "notebook":
         sd = {k: v for k, v in sd.items() if not k.startswith(("lstm", "conv2"))}
@@ -159,9 +328,14 @@ def main():
 
     frame0 = syn.chain_frame(N, seed=1) if a.chain else syn.box_frame(N, seed=1)
     base = syn.jitter_window(frame0, W, seed=1)                                    # [W,N,3]
-    wins = np.stack([base if (total_members == 1) else
-                     syn.ensemble_windows(base, 1, sigma=0.1, seed0=100 + rank + world * m)[0]
-                     for m in range(M)], axis=1)                                   # [W,M,N,3] member = rank + world*m
+
+    def member_windows(ids, perturbed):
+        """[W,len(ids),N,3]: member m = base window + N(0, 0.1^2), seed 100+m; a
+        one-member run uses the base window itself (cfg2)."""
+        return np.stack([syn.ensemble_windows(base, 1, sigma=0.1, seed0=100 + m)[0] if perturbed else base
+                         for m in ids], axis=1)
+
+    wins = member_windows(my_members, perturbed=total_members > 1)
     aa = torch.from_numpy(syn.amino_acids(N, seed=1))
     max_steps = a.warmup + a.steps + (0 if a.skip_roofline else a.steps)
     cap = default_edge_cap(M, N, a.threshold)
@@ -169,10 +343,13 @@ def main():
                         use_graph=not a.no_graph)
     eng.reset(torch.from_numpy(wins), aa)
     mode = eng.conv_mode            # what "auto" resolved to at this edge capacity
+    if rank == 0:
+        note(f"rank 0: {M} of {total_members} members, conv_mode {mode}, workspace {eng.workspace.numel() / 2**30:.1f} GiB")
 
-    # ---- warm-up (untimed): also captures nothing new — the step graph was captured in reset()
+    # ---- warm-up (untimed): the step graph was captured in reset()
     eng.step(a.warmup)
     eng.synchronize()
+    m_max = -(-total_members // world)
     if world > 1:    # the collective of the timed region, once, untimed: communicator set-up and buffers
         gather_trajectories(torch.zeros((a.steps, M, N, 3), dtype=torch.float32, device=dev), total_members)
         torch.cuda.synchronize()
@@ -203,16 +380,18 @@ def main():
     e_mean = float(eps.mean().item())
     frames = a.steps * total_members
     value = frames / elapsed
+    if rank == 0:
+        note(f"timed region: {value:.1f} frames/s ({elapsed / a.steps * 1e3:.3f} ms/step)")
 
     # ---- roofline leg: K more steps of the SAME rollout, plain launches bracketed by HIP events on
-    # the launch stream (events cannot sit inside a hipGraph replay)
+    # the launch stream (events cannot sit inside a hipGraph replay).  Rank 0 only.
     roofs = {}
     kernels = {}
     other_mode = None
     R, C, KW = M * N, a.width, a.kernel_width
 
-    def timed_leg(engine, first_step):
-        engine.attach_timer(a.steps * (6 * a.depth + 20))
+    def timed_leg(engine, first_step, members):
+        engine.attach_timer(a.steps * (6 * a.depth * max(1, members) + 20))
         engine.step(a.steps)
         tm = engine.read_timer()
         engine.detach_timer()
@@ -224,18 +403,12 @@ def main():
     def conv_roofline(ks, e):      # the metric's kernel: gather -> per-edge matvec -> scatter-mean, HBM-bound
         avg_s = ks["nnconv"]["avg_ms"] * 1e-3
         alg = e * (C * C * 4 + 4) + (R + 1) * 4 + 2 * R * C * 4
-        r = {"bound": "hbm", "kernel": "nnconv64_row_kernel", "conv_mode": "materialized", "achieved": alg / avg_s / 1e9,
-             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / avg_s / 1e9 / HBM_PEAK_GBS,
-             "frac_of_measured_copy_peak": alg / avg_s / 1e9 / HBM_COPY_GBS, "traffic": None,
-             "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_s * 1e3, "edges_per_launch": e,
-             "rows_per_launch": R}
-        tf = REPO / "profiles" / "roofline_traffic.json"
-        if tf.exists():
-            try:
-                r["traffic"] = json.loads(tf.read_text()).get("nnconv_hbm_bytes_per_launch")
-            except Exception:
-                pass
-        return r
+        return {"bound": "hbm", "kernel": "nnconv64_row_kernel", "conv_mode": "materialized", "achieved": alg / avg_s / 1e9,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / avg_s / 1e9 / HBM_PEAK_GBS,
+                "frac_of_measured_copy_peak": alg / avg_s / 1e9 / HBM_COPY_GBS,
+                "traffic": profiled_traffic("nnconv64_row_kernel", N, M, "materialized", a.gemm_mode),
+                "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_s * 1e3, "edges_per_launch": e,
+                "rows_per_launch": R}
 
     def gemm_roofline(ks, e, which, n_out):
         step_s = ks[which]["ms_per_step"] * 1e-3     # all launches of a step (capacity-sized chunks past E exit at once)
@@ -250,8 +423,9 @@ def main():
                 "ms_per_step": step_s * 1e3,
                 "note": "executed bf16 MFMA flops (6 plane products per fp32 product) vs dense bf16 peak"}
 
-    def per_source_roofline(ks, e):   # factored path: M_j = H_j . Y_j^T, one launch per conv application
-        avg_s = ks["nnconv"]["avg_ms"] * 1e-3
+    def per_source_roofline(ks, e):   # factored path: M_j = H_j . Y_j^T, all launches of one conv application
+        launches_per_app = max(1, round(ks["nnconv"]["launches"] / (a.steps * 2 * a.depth)))
+        avg_s = ks["nnconv"]["avg_ms"] * 1e-3 * launches_per_app      # one application over all R rows
         alg = e * KW * 4 + R * C * KW * 4 + 2 * e * C * 4 + (R + 1) * 4        # H once + Y once + 2 k-slice partials out
         flops = 2.0 * e * KW * C                                                # fp32-equivalent
         split = a.gemm_mode == "split_bf16"
@@ -259,25 +433,21 @@ def main():
         mfma_exec, mfma_peak = (6.0 * flops, MFMA_BF16_PEAK_TFLOPS) if split else (flops, MFMA_F32_PEAK_TFLOPS)
         t_hbm, t_mfma = alg / (HBM_PEAK_GBS * 1e9), mfma_exec / (mfma_peak * 1e12)
         name = "gemm_per_source_split_kernel" if split else "gemm_per_source_kernel"
-        r = {"kernel": name, "conv_mode": "factored", "avg_launch_ms": avg_s * 1e3,
-             "algorithmic_bytes_per_launch": alg, "flops_per_launch": flops, "traffic": None,
+        r = {"kernel": name, "conv_mode": "factored", "avg_launch_ms": avg_s * 1e3, "launches_per_application": launches_per_app,
+             "algorithmic_bytes_per_launch": alg, "flops_per_launch": flops,
+             "traffic": profiled_traffic(name, N, M, "factored", a.gemm_mode),
              "hbm_GBps": alg / avg_s / 1e9, "hbm_frac": alg / avg_s / 1e9 / HBM_PEAK_GBS,
              "frac_of_measured_copy_peak": alg / avg_s / 1e9 / HBM_COPY_GBS,
              "mfma_TFLOPs": mfma_exec / avg_s / 1e12, "mfma_frac": mfma_exec / avg_s / 1e12 / mfma_peak}
-        tf = REPO / "profiles" / "roofline_traffic.json"
-        if tf.exists():
-            try:
-                r["traffic"] = json.loads(tf.read_text()).get(name + "_hbm_bytes_per_launch")
-            except Exception:
-                pass
         if t_hbm >= t_mfma:
             r.update(bound="hbm", achieved=r["hbm_GBps"], peak=HBM_PEAK_GBS, unit="GB/s", frac=r["hbm_frac"])
         else:
             r.update(bound="mfma", achieved=r["mfma_TFLOPs"], peak=mfma_peak, unit="TFLOP/s", frac=r["mfma_frac"])
         return r
 
-    if not a.skip_roofline:
-        kernels, e2 = timed_leg(eng, a.warmup + a.steps)
+    # rank 0 only: the other ranks idle at the final barrier through the measurement legs
+    if not a.skip_roofline and rank == 0:
+        kernels, e2 = timed_leg(eng, a.warmup + a.steps, M)
         if mode == "materialized":
             roofs["conv_materialized"] = conv_roofline(kernels, e2)
             roofs["edge_mlp_last_gemm"] = gemm_roofline(kernels, e2, "edge_mlp_gemm2", C * C)
@@ -286,7 +456,7 @@ def main():
         roofs["edge_mlp_hidden_gemm"] = gemm_roofline(kernels, e2, "edge_mlp_gemm1", KW)
         # ---- the other conv formulation on the same start window: frames/s and, for the materialised
         # one, the HBM roofline of the gather/matvec/scatter kernel BASELINE.json's target is stated on
-        if a.variant == "intree" and not a.single_mode:
+        if a.variant == "intree" and not a.single_mode and world == 1 and M <= 8:
             om = "materialized" if mode == "factored" else "factored"
             model.conv_mode = om
             eng2 = RolloutEngine(model, M, N, W, a.threshold, max_steps=a.warmup + 2 * a.steps, edge_cap=cap, device=dev,
@@ -299,7 +469,8 @@ def main():
             eng2.step(a.steps)
             eng2.stream.synchronize()
             dt = time.perf_counter() - t0
-            k2, e3 = timed_leg(eng2, a.warmup + a.steps)
+            k2, e3 = timed_leg(eng2, a.warmup + a.steps, M)
+            note(f"comparison leg ({om}): {a.steps * M / dt:.1f} frames/s")
             other_mode = {"conv_mode": om, "frames_per_s_this_rank": a.steps * M / dt, "ms_per_step": dt / a.steps * 1e3,
                           "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in k2.items()}}
             if om == "materialized":
@@ -308,6 +479,7 @@ def main():
             else:
                 roofs["conv_factored_per_source_gemm"] = per_source_roofline(k2, e3)
             eng2.close()
+            del eng2
             model.conv_mode = a.conv_mode
     # "roofline" = the dominant kernel of the TIMED path
     dominant = None
@@ -318,31 +490,79 @@ def main():
                     "edge_mlp_gemm2": roofs.get("edge_mlp_last_gemm"),
                     "edge_mlp_gemm1": roofs.get("edge_mlp_hidden_gemm")}.get(name)
 
+    # ---- cfg3's like-for-like single-GPU figure: the SAME 64-member ensemble the N > 1 runs shard, on
+    # this one GPU (default N=1 run only; `--gpus 1 --total-members 64` makes it the headline instead)
+    ensemble_leg = None
+    default_single = (world == 1 and a.total_members is None and a.members_per_gpu is None
+                      and a.variant == "intree" and not a.chain)
+    if default_single and not a.skip_ensemble_leg:
+        eng.close()
+        del eng
+        torch.cuda.empty_cache()
+        me = ENSEMBLE_MEMBERS
+        es, ew = max(2, min(a.steps, 10)), 2
+        we = member_windows(list(range(me)), perturbed=True)     # seeds 100..163
+        note(f"ensemble leg: {me} members x {N} atoms")
+        enge = RolloutEngine(model, me, N, W, a.threshold, max_steps=ew + es, edge_cap=default_edge_cap(me, N, a.threshold),
+                             device=dev, use_graph=not a.no_graph)
+        enge.reset(torch.from_numpy(we), aa)
+        enge.step(ew)
+        enge.synchronize()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        enge.step(es)
+        enge.stream.synchronize()
+        dte = time.perf_counter() - t0
+        enge.synchronize()
+        note(f"ensemble leg: {me} members on this GPU, {es * me / dte:.1f} frames/s")
+        ensemble_leg = {"members": me, "steps": es, "warmup": ew, "frames_per_s": es * me / dte,
+                        "ms_per_step": dte / es * 1e3, "ms_per_member_step": dte / es / me * 1e3,
+                        "conv_mode": enge.conv_mode,
+                        "note": "BASELINE configs[2] (64-member ensemble) on ONE GPU: the 1-GPU point of the "
+                                "strong-scaling series that `--gpus N` (N > 1) runs"}
+        enge.close()
+        del enge
+        eng = None
+
     cpu = None
     if rank == 0 and world == 1 and not a.skip_cpu_baseline and a.variant == "intree":
         cpu = cpu_baseline(sd, a.depth, base, aa, a.threshold, a.cpu_budget_s)
 
     if rank == 0:
+        cfg = "configs[1]" if total_members == 1 else ("configs[2]" if total_members == ENSEMBLE_MEMBERS else "ensemble")
         line = {
             "metric": "rolled-out MD frames/sec", "value": value, "unit": "frames/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (uniform-box frames, seeded; near-identity synthetic weights, see weights.py)",
-            "config": {"workload": f"BBA all-atom stand-in N={N} r={a.threshold}A free-running autoregressive rollout "
-                                   f"(BASELINE configs[1]), {M} member(s) per GPU",
+            "config": {"workload": f"BBA all-atom stand-in N={N} r={a.threshold}A free-running autoregressive rollout, "
+                                   f"{total_members}-member ensemble (BASELINE {cfg}), member m on rank m mod {world}",
                        "atoms": N, "window": W, "width": a.width, "kernel_width": a.kernel_width, "depth": a.depth,
-                       "members_per_gpu": M, "total_members": total_members, "mean_edges_per_member": e_mean / M,
+                       "members_this_rank": M, "members_per_gpu_max": m_max, "total_members": total_members,
+                       "mean_edges_per_member": e_mean / M,
                        "edges_first_last": [int(eps[0].item()), int(eps[-1].item())], "edge_cap": cap,
-                       "parallelism": f"ensemble-sharded x{world}, one all-gather of trajectories",
+                       "parallelism": f"ensemble-sharded x{world}, no collective while stepping, one all-gather of "
+                                      f"trajectories ({backend if world > 1 else 'none'})",
                        "launch": "plain" if a.no_graph else "hipGraph replay", "edge_mlp_gemm": a.gemm_mode,
                        "variant": a.variant, "conv_mode": mode, "conv_mode_requested": a.conv_mode},
-            "roofline": dominant, "rooflines": roofs, "other_conv_mode": other_mode, "cpu_baseline": cpu,
-            "kernels": kernels,
+            "roofline": dominant, "rooflines": roofs, "other_conv_mode": other_mode,
+            "ensemble64_single_gpu": ensemble_leg, "cpu_baseline": cpu, "kernels": kernels,
         }
-        print(json.dumps(line))
-    eng.close()
+        print(json.dumps(line), flush=True)
+    if eng is not None:
+        eng.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        # no launcher around us: become one.  Nothing above has touched the GPU (torch is imported, HIP
+        # is not initialised), and this process never does.
+        sys.exit(launch_workers(a))
+    worker(a)
 
 
 if __name__ == "__main__":

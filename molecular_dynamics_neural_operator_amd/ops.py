@@ -193,6 +193,26 @@ class ParamPack:
         return C.byref(self.struct)
 
 
+def node_prologue(pack: ParamPack, frames: torch.Tensor, x_aminoacid: torch.Tensor) -> torch.Tensor:
+    """frames f32 [W,M,N,3] -> x0 f32 [M*N,width]: LSTM over the window, lstm_fc, Embedding, concat, fc1,
+    ReLU (graph_kernel.py:279-298).  Raises on an amino-acid id outside [0, num_embeddings)."""
+    lib = _lib.load()
+    frames = f32(frames)
+    if frames.dim() == 3:
+        frames = frames.unsqueeze(1)
+    W, M, N, _ = frames.shape
+    dev = frames.device
+    aa = x_aminoacid.to(device=dev, dtype=torch.long).contiguous()
+    if aa.numel() not in (N, M * N):
+        raise MdnoError(f"x_aminoacid has {aa.numel()} entries, expected {N} or {M * N}")
+    x0 = torch.empty((M * N, pack.struct.width), dtype=torch.float32, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    check(lib.mdno_node_prologue_fwd(pack.ref, ptr(frames), M, W, N, ptr(aa), int(aa.numel() == M * N and M > 1),
+                                     ptr(x0), ptr(status), stream_ptr(dev)), "mdno_node_prologue_fwd")
+    raise_on_status(status.item(), "node_prologue")
+    return x0
+
+
 def kernelnn_forward(pack: ParamPack, frames: torch.Tensor, x_aminoacid: torch.Tensor, graph: CSRGraph,
                      edge_pos: Optional[torch.Tensor] = None, edge_attr: Optional[torch.Tensor] = None,
                      return_latent: bool = False, workspace: Optional[torch.Tensor] = None,

@@ -1,0 +1,487 @@
+"""GPU tests at the BASELINE.json configuration sizes (cfg2 live fixture, cfg3 ensemble share, cfg4
+training step, cfg5 50k-atom box) plus the reference-shaped entry points that had no coverage
+(propogate, checkpoint loading on the device, index validation).  Everything runs through the C ABI.
+
+Floating point: rtol 1e-4, atol 1e-4*max|y| per element AND relative L2 <= 1e-5 (`close`, shared
+with test_gpu_parity.py); graphs, CSR and edge counts bit-exact.
+"""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, load_golden, write_golden_trajectory
+from test_gpu_parity import close, t
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from molecular_dynamics_neural_operator_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import graph_kernel_oracle
+    return graph_kernel_oracle
+
+
+def cm_checksum(cm):
+    c = np.asarray(cm, dtype=np.uint64)
+    w = (np.arange(c.size, dtype=np.uint64) * np.uint64(2654435761) + np.uint64(1)) | np.uint64(1)
+    with np.errstate(over="ignore"):
+        return np.uint64((c * w).sum())
+
+
+def near_threshold_atoms(frame, thr, eps):
+    """Atoms that are an endpoint of a pair whose f64 distance lies within eps of the cutoff."""
+    p = frame.astype(np.float64)
+    d = np.sqrt(((p[:, None, :] - p[None, :, :]) ** 2).sum(-1))
+    i, j = np.nonzero(np.abs(d - thr) < eps)
+    return np.unique(i), len(i) // 2
+
+
+# ------------------------------------------------------------------------------- cfg2, live fixture
+@pytest.fixture(scope="module")
+def live504(tmp_path_factory):
+    """The reference's own KernelNN (width 64, k=1024, depth 6) at N=504 with bounded, live
+    activations: 5 teacher-forced forwards + 5 free-running steps (oracle/gen_golden.py gen_live504)."""
+    from molecular_dynamics_neural_operator_amd import synthetic as syn
+    from molecular_dynamics_neural_operator_amd.dataset import ContactMapDataset, write_trajectory_npz
+    from molecular_dynamics_neural_operator_amd.weights import near_identity_state_dict
+    z = load_golden("kernelnn_live504.npz")
+    thr, W = float(z["threshold"]), int(z["window"])
+    frames = z["frames"]
+    cms = [syn.contact_map(f, thr) for f in frames]
+    assert [c.size for c in cms] == list(z["contact_map_len"])
+    assert [cm_checksum(c) for c in cms] == list(z["contact_map_checksum"])      # the reference's own contact maps
+    path = tmp_path_factory.mktemp("live504") / "traj.npz"
+    write_trajectory_npz(path, frames, cms, z["amino_acids"])
+    dset = ContactMapDataset(str(path), window_size=W, horizon=1)
+    seed, kg, fg, kc = z["weight_gains"]
+    sd = near_identity_state_dict(64, 1024, seed=int(seed), kernel_gain=float(kg), feature_gain=float(fg),
+                                  kernel_to_coords=float(kc))
+    for n, s_, a_ in zip([str(x) for x in z["param_names"]], z["param_sum"], z["param_abs_sum"]):
+        assert float(sd[n].double().sum()) == pytest.approx(float(s_), rel=1e-12, abs=1e-12), n
+        assert float(sd[n].double().abs().sum()) == pytest.approx(float(a_), rel=1e-12), n
+    return z, dset, sd
+
+
+@pytest.mark.parametrize("gemm_mode", ["split_bf16", "f32"])
+def test_live504_teacher_forced_reference_golden(dev, live504, gemm_mode):
+    """The 64x64 fast kernels against the REFERENCE on live activations: materialized (the sample's own
+    edge list) and factored (the same graph rebuilt on the device from the sample's first frame)."""
+    from molecular_dynamics_neural_operator_amd import ops
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN
+    z, dset, sd = live504
+    model = KernelNN(*[int(v) for v in z["ctor"]])
+    model.load_state_dict(sd)
+    model.eval().to(dev)
+    model.gemm_mode = gemm_mode
+    lat0 = z["teacher_forced_latent0"]
+    assert 0.3 < float((lat0 == 0).mean()) < 0.7 and float(np.abs(lat0).max()) < 50      # live, bounded
+    thr = float(z["threshold"])
+    for i in range(z["teacher_forced_out"].shape[0]):
+        s = dset[i].to(dev)
+        with torch.no_grad():
+            out, lat = model(s, return_latent=True)
+        close(out, z["teacher_forced_out"][i], name=f"tf{i} materialized {gemm_mode}")
+        if i == 0:
+            close(lat, lat0, name="latent0 materialized")
+        # factored: the sample's graph is the radius graph of its FIRST window frame (dataset.py:189-201)
+        first = s.x_position[0].contiguous()
+        g = ops.radius_graph(first, first.shape[0], thr)
+        assert torch.equal(g.to_edge_index(), s.edge_index)
+        of, lf = ops.kernelnn_forward(model.param_pack(dev, conv_mode="factored"), s.x_position.unsqueeze(1),
+                                      s.x_aminoacid, g, edge_pos=first, return_latent=True)
+        close(of, z["teacher_forced_out"][i], name=f"tf{i} factored {gemm_mode}")
+        if i == 0:
+            close(lf, lat0, name="latent0 factored")
+
+
+@pytest.mark.parametrize("conv_mode,gemm_mode", [("factored", "split_bf16"), ("materialized", "split_bf16"),
+                                                 ("factored", "f32"), ("materialized", "f32")])
+def test_live504_free_run_reference_golden(dev, live504, conv_mode, gemm_mode):
+    """5 free-running steps through recursive_propagation (on-device loop) against the reference's own
+    loop (graph_kernel.py:396-413).  A pair whose distance sits within 2e-4 A of the cutoff in the
+    reference's frame may fall on the other side for fp32-rounded positions (the reference's frames
+    here have pairs as close as 2e-6 A): its two atoms are then compared loosely from that step on."""
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN, recursive_propagation
+    z, dset, sd = live504
+    model = KernelNN(*[int(v) for v in z["ctor"]])
+    model.load_state_dict(sd)
+    model.eval().to(dev)
+    model.gemm_mode, model.conv_mode = gemm_mode, conv_mode
+    thr = float(z["threshold"])
+    want = z["free_frames"]
+    steps = want.shape[0]
+    fc = recursive_propagation(model, dset, dev, num_steps=steps, starting_points=[0], threshold=thr)
+    got = np.stack([f.x_position[-1].numpy() for f in fc])
+    loose = np.zeros(want.shape[1], dtype=bool)
+    risky_pairs = 0
+    for s in range(steps):
+        strict = ~loose
+        close(got[s][strict], want[s][strict], name=f"free step {s} {conv_mode}/{gemm_mode} ({int(strict.sum())} atoms)")
+        if loose.any():
+            assert float(np.abs(got[s][loose] - want[s][loose]).max()) < 5e-2
+        # the graph the NEXT step runs on is built from this frame
+        e_got, e_want = fc[s].edge_index.shape[1], int(z["free_num_edges"][s])
+        atoms, pairs = near_threshold_atoms(want[s], thr, 2e-4)
+        risky_pairs += pairs
+        assert abs(e_got - e_want) <= 2 * risky_pairs, (s, e_got, e_want)
+        loose[atoms] = True
+    assert int(loose.sum()) < 0.2 * loose.size
+
+
+# ------------------------------------------------------------------------------- propogate (nb:336-358)
+def test_propogate_notebook_loop_and_mse(dev, O, tmp_path):
+    """The notebook's rollout: window 1, start at dataset[0], per-step MSE against dataset[i+1]
+    (bba_analysis.ipynb:336-358), against the oracle's loop with the same bookkeeping."""
+    from molecular_dynamics_neural_operator_amd.dataset import ContactMapDataset
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNNNotebook, propogate
+    from molecular_dynamics_neural_operator_amd.weights import near_identity_state_dict
+    z = load_golden("rollout_20.npz")
+    thr = float(z["threshold"])
+    path = tmp_path / "traj.npz"
+    write_golden_trajectory(path, z)
+    dset = ContactMapDataset(str(path), window_size=1, horizon=1)
+    sd = {k: v for k, v in near_identity_state_dict(64, 128, seed=2, kernel_gain=2e-2, feature_gain=0.1,
+                                                    kernel_to_coords=1.0).items()
+          if not k.startswith(("lstm", "conv2"))}
+    model = KernelNNNotebook(64, 128, 4, 6, 7, 3, 20, 4)
+    model.load_state_dict(sd)
+    model.to(dev)
+    steps = 6
+    fc, metrics = propogate(model, dset, dev, steps, threshold=thr)
+    assert len(fc) == steps and list(metrics) == ["mse"] and len(metrics["mse"]) == steps
+    cur = O.dataset_sample(z["point_cloud"], z["contact_map"], z["amino_acids"], 0, 1, 1)
+    aa = cur["x_aminoacid"]
+    for i in range(steps):
+        out = O.kernelnn_notebook_forward(sd, cur["x_position"], aa, cur["edge_index"], cur["edge_attr"], 4)
+        truth = O.dataset_sample(z["point_cloud"], z["contact_map"], z["amino_acids"], i + 1, 1, 1)["x_position"]
+        want_mse = float(((out.numpy() - truth.numpy()) ** 2).mean())
+        close(fc[i].x_position[-1], out, name=f"propogate step {i}")
+        assert metrics["mse"][i] == pytest.approx(want_mse, rel=1e-4)
+        cur = O.construct_pairdata(out.numpy(), aa, thr)
+        assert fc[i].edge_index.shape[1] == cur["edge_index"].shape[1]
+        assert not fc[i].x_position.is_cuda
+
+
+# ------------------------------------------------------------------------------- cfg3: 8 members x 504
+def test_cfg3_eight_members_n504_full_model(dev):
+    """One GPU's share of the 64-member ensemble at 8 GPUs (BASELINE configs[2]): 8 x N=504, full model,
+    3 steps.  factored == materialized within tolerance; a member inside the batch of 8 == the member
+    alone, bitwise, in BOTH formulations (the materialized kernel changes its launch shape at 4,096 rows)."""
+    from molecular_dynamics_neural_operator_amd import synthetic as syn
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN
+    from molecular_dynamics_neural_operator_amd.rollout import RolloutEngine, default_edge_cap
+    from molecular_dynamics_neural_operator_amd.weights import near_identity_state_dict
+    N, W, M, steps = 504, 10, 8, 3
+    model = KernelNN(64, 1024, 6, 6, 7, 3, 20, 4)
+    model.load_state_dict(near_identity_state_dict(64, 1024, seed=0, kernel_gain=0.02, feature_gain=0.1, kernel_to_coords=1.0))
+    model.eval().to(dev)
+    base = syn.jitter_window(syn.box_frame(N, seed=1), W, seed=1)
+    wins = syn.ensemble_windows(base, M, sigma=0.1, seed0=100)                        # cfg3 seeds 100..
+    tm = torch.from_numpy(np.ascontiguousarray(wins.transpose(1, 0, 2, 3)))          # [W,M,N,3]
+    aa = torch.from_numpy(syn.amino_acids(N, seed=1))
+    res = {}
+    for conv in ("factored", "materialized"):
+        model.conv_mode = conv
+        eng = RolloutEngine(model, M, N, W, 8.0, max_steps=steps, edge_cap=default_edge_cap(M, N, 8.0), device=dev)
+        assert eng.conv_mode == conv
+        res[conv] = (eng.run(tm, aa, steps).clone(), eng.edges_per_step[:steps].clone())
+        eng.close()
+        solo = RolloutEngine(model, 1, N, W, 8.0, max_steps=steps, edge_cap=default_edge_cap(1, N, 8.0), device=dev)
+        for m in (0, 5):
+            alone = solo.run(tm[:, m:m + 1].contiguous(), aa, steps)
+            assert torch.equal(alone[:, 0], res[conv][0][:, m]), (conv, m)
+        solo.close()
+        del eng, solo
+        torch.cuda.empty_cache()
+    assert torch.equal(res["factored"][1], res["materialized"][1])
+    assert int(res["factored"][1].min()) > 8 * 55_000
+    close(res["factored"][0], res["materialized"][0], name="cfg3 factored vs materialized")
+    # "auto" takes the factored path for this share, as it does for one member
+    model.conv_mode = "auto"
+    eng = RolloutEngine(model, M, N, W, 8.0, max_steps=1, edge_cap=default_edge_cap(M, N, 8.0), device=dev)
+    assert eng.conv_mode == "factored"
+    eng.close()
+
+
+def test_materialized_conv_launch_shapes_agree_bitwise(dev):
+    """nnconv64_row_kernel<16> (fewer than 4,096 rows) and <4> (more) add a row's edges in the same 16
+    chains: the same rows give the same bits in either launch (batch invariance)."""
+    from molecular_dynamics_neural_operator_amd import ops
+    gen = torch.Generator().manual_seed(11)
+    n, E = 700, 30_000
+    ei = torch.randint(0, n, (2, E), generator=gen)
+    ei[1, :900] = 3                                   # a hub
+    x = torch.randn(n, 64, generator=gen).to(dev)
+    w_e = (torch.randn(E, 4096, generator=gen) * 0.05).to(dev)
+    root = (torch.randn(64, 64, generator=gen) * 0.1).to(dev)
+    bias = torch.randn(64, generator=gen).to(dev)
+    g = ops.coo_to_csr(ei.to(dev), n)
+    w_csr = w_e[g.perm[:E].long()].contiguous()
+    y16 = ops.nnconv(x, g, w_csr, root, bias, "mean", relu=True)
+    # the same graph padded with 4,000 isolated rows -> the 4-wave launch
+    big = 4700
+    g2 = ops.coo_to_csr(ei.to(dev), big)
+    x2 = torch.cat([x, torch.zeros(big - n, 64, device=dev)])
+    y4 = ops.nnconv(x2, g2, w_csr, root, bias, "mean", relu=True)
+    assert torch.equal(y4[:n], y16)
+
+
+# ------------------------------------------------------------------------------- cfg5: 50k atoms
+def test_cfg5_50k_atoms_one_factored_step(dev):
+    """BASELINE configs[4]: N=50,000 uniform box, r=10 A, full model, ONE factored step (W_e would be
+    298 GB).  Graph: bit-exact against f64 numpy on sampled rows, symmetric, E and degrees in the expected
+    range.  Conv: the factored forward of the whole box against the materialized formulation evaluated
+    on the first ~4k rows (edge-MLP + conv kernel on that row slice, same x), layer by layer."""
+    from molecular_dynamics_neural_operator_amd import _lib, ops, synthetic as syn
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN
+    from molecular_dynamics_neural_operator_amd.weights import near_identity_state_dict
+    N, W, thr = 50_000, 2, 10.0
+    frame = syn.box_frame(N, seed=3)
+    pos = torch.from_numpy(frame).to(dev)
+    g = ops.radius_graph(pos, N, thr, edge_cap=N * 420)
+    E = g.edge_count()
+    assert int(g.status.item()) == 0
+    rp = g.row_ptr.cpu().numpy().astype(np.int64)
+    deg = np.diff(rp)
+    assert 17_500_000 < E < 18_800_000 and 330 < E / N < 380              # E ~ 18.2M, mean degree ~364
+    assert 30 <= deg.min() and deg.max() < 768
+    src = g.src[:E].cpu().numpy()
+    rng = np.random.default_rng(0)
+    p64 = frame.astype(np.float64)
+    for r in np.concatenate([[0, N - 1], rng.integers(0, N, 300)]):
+        d = np.sqrt(((p64 - p64[r]) ** 2).sum(1))
+        assert np.array_equal(src[rp[r]:rp[r + 1]], np.nonzero(d < thr)[0]), r
+    # full model forward, factored (explicitly: nothing else fits)
+    # (coordinates reach +-40 A here, 4x the N=504 box: a 10x smaller kernel gain keeps the step ~1 A)
+    sd = near_identity_state_dict(64, 1024, seed=0, kernel_gain=2e-3, feature_gain=0.1, kernel_to_coords=1.0)
+    model = KernelNN(64, 1024, 6, 6, 7, 3, 20, 4)
+    model.load_state_dict(sd)
+    model.eval().to(dev)
+    g.max_degree = 768
+    win = torch.from_numpy(syn.jitter_window(frame, W, sigma=0.01, seed=3)).to(dev)
+    win[-1] = pos                                                          # the graph's frame is the last one
+    aa = torch.from_numpy(syn.amino_acids(N, seed=3)).to(dev)
+    out, lat = ops.kernelnn_forward(model.param_pack(dev, conv_mode="factored"), win.unsqueeze(1), aa, g, edge_pos=pos,
+                                    return_latent=True)
+    assert bool(torch.isfinite(out).all())
+    disp = (out - pos).norm(dim=1)
+    print(f"cfg5: E={E} mean degree {E / N:.1f} max {deg.max()}  mean displacement {float(disp.mean()):.3f} A")
+    assert 1e-3 < float(disp.mean()) < 5.0                                 # the kernel integral moves atoms, boundedly
+    del out, lat
+    # ONE conv application both ways: the notebook-era model at depth 1 is  fc1 -> relu(conv1) -> fc2,
+    # its latent is the conv's output and its conv input x0 comes from the node prologue.  Factored over
+    # the whole box vs the materialized formulation (edge-MLP -> W_e -> conv kernel) on the first rows
+    # holding ~1.4M edges (23 GB of fp32 W_e).
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNNNotebook
+    nb = KernelNNNotebook(64, 1024, 1, 6, 7, 3, 20, 4)
+    nb.load_state_dict({k: v for k, v in sd.items() if not k.startswith(("lstm", "conv2"))})
+    nb.eval().to(dev)
+    one = pos.reshape(1, 1, N, 3)
+    _, y_fac = ops.kernelnn_forward(nb.param_pack(dev, conv_mode="factored"), one, aa, g, edge_pos=pos,
+                                    return_latent=True)
+    x0 = ops.node_prologue(nb.param_pack(dev, conv_mode="materialized"), one, aa)
+    rows = int(np.searchsorted(rp, 1_400_000))
+    Es = int(rp[rows])
+    sl = ops.CSRGraph(g.row_ptr[:rows + 1].contiguous(), g.src[:Es].contiguous(), g.dst[:Es].contiguous(),
+                      torch.tensor([Es], dtype=torch.int32, device=dev), Es, None, None)
+    w_e = ops.edge_mlp(nb.conv1.net.hip_weights(), 6, 1024, 4096, sl, edge_pos=pos)
+    y_mat = torch.empty(rows, 64, device=dev)
+    lib = _lib.load()
+    _lib.check(lib.mdno_nnconv_fwd(x0.data_ptr(), sl.row_ptr.data_ptr(), sl.src.data_ptr(), rows, w_e.data_ptr(),
+                                   nb.conv1.root.data_ptr(), nb.conv1.bias.data_ptr(), 64, 64, 1, 1, y_mat.data_ptr(),
+                                   torch.cuda.current_stream().cuda_stream), "mdno_nnconv_fwd")
+    torch.cuda.synchronize()
+    close(y_fac[:rows], y_mat, name=f"cfg5 factored vs materialized conv, first {rows} rows / {Es} edges")
+
+
+# ------------------------------------------------------------------------------- cfg4: training step
+def test_cfg4_training_step_full_size(dev, O, tmp_path):
+    """BASELINE configs[3] at the reference's CLI sizes: k=1024, depth 6, batch 128 of N=28 samples.
+    The whole batch runs (finite loss, every gradient present); because samples are independent
+    problems, the first 4 outputs of the batch equal the 4-sample sub-batch's (to rounding: torch's own
+    LSTM / Linear kernels at the per-atom ends pick batch-size-dependent algorithms), and the sub-batch's
+    loss and gradients are checked against the fp64 replica."""
+    from test_gpu_training import _replica_loss, rel_err
+    from molecular_dynamics_neural_operator_amd import synthetic as syn
+    from molecular_dynamics_neural_operator_amd.dataset import ContactMapDataset, write_trajectory_npz
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN, LpLoss
+    from molecular_dynamics_neural_operator_amd.training import collate
+    base = syn.chain_frame(28, seed=0)
+    traj = syn.ou_trajectory(base, 150, sigma=0.15, theta=0.2, seed=2)
+    cms = [syn.contact_map(f, 8.0) for f in traj]
+    path = tmp_path / "t.npz"
+    write_trajectory_npz(path, traj, cms, syn.amino_acids(28, seed=0))
+    dset = ContactMapDataset(str(path), window_size=10, horizon=1)
+    B = 128
+    batch = [dset[i] for i in range(B)]
+    torch.manual_seed(3)
+    model = KernelNN(64, 1024, 6, 6, 7, 3, 20, 4)
+    with torch.no_grad():                      # keep activations O(1) through 12 random-init layers
+        for p_ in model.conv1.net.layers[4].parameters():
+            p_.mul_(0.2)
+    model.to(dev).train()
+    out = model(batch)
+    assert out.shape == (B * 28, 3)
+    y = torch.cat([s.y for s in batch]).to(dev)
+    loss = LpLoss(size_average=False)(out.view(B, -1), y.view(B, -1))
+    loss.backward()
+    assert bool(torch.isfinite(loss)) and all(p_.grad is not None and bool(torch.isfinite(p_.grad).all())
+                                               for p_ in model.parameters())
+    full_out = out.detach().clone()
+    model.zero_grad()
+    sub = batch[:4]
+    out4 = model(sub)
+    close(out4, full_out[:4 * 28], name="cfg4 sub-batch of 4 vs the same samples inside the batch of 128")
+    loss4 = LpLoss(size_average=False)(out4.view(4, -1), y[:4 * 28].view(4, -1))
+    loss4.backward()
+    want_loss, want_out, want_grads = _replica_loss(model, O, collate(sub), 4)
+    assert abs(float(loss4) - want_loss) < 1e-4 * abs(want_loss)
+    assert rel_err(out4, want_out) < 1e-4
+    worst = {}
+    for name, p_ in model.named_parameters():
+        worst[name] = rel_err(p_.grad, want_grads[name])
+    print("cfg4 gradient rel errors:", {k: f"{v:.1e}" for k, v in worst.items()})
+    for name, e in worst.items():
+        assert e < 3e-3, (name, e)
+
+
+# ------------------------------------------------------------------------------- loader / validation
+def test_reference_checkpoint_forward_on_device(dev, tmp_path):
+    """A best.pt-shaped checkpoint written by the reference's own (DataParallel-wrapped) KernelNN loads
+    through load_reference_checkpoint and reproduces the reference's forward."""
+    from molecular_dynamics_neural_operator_amd import load_reference_checkpoint
+    from molecular_dynamics_neural_operator_amd.dataset import PairData
+    z = load_golden("checkpoint_best_pt.npz")
+    msd = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("msd/")}
+    ckpt = {"epoch": int(z["epoch"]), "model_state_dict": msd, "optimizer_state_dict": {}, "scheduler_state_dict": {}}
+    p = tmp_path / "best.pt"
+    torch.save(ckpt, p)
+    model, meta = load_reference_checkpoint(p, depth=int(z["ctor"][2]))
+    assert meta["epoch"] == 3 and meta["variant"] == "intree"
+    model.eval().to(dev)
+    pd = PairData(t(z["x_aminoacid"]), t(z["x_position"]), None, t(z["edge_attr"]), t(z["edge_index"])).to(dev)
+    with torch.no_grad():
+        close(model(pd), z["out"], name="checkpoint forward")
+
+
+def test_bad_indices_raise_like_the_reference(dev):
+    """An amino-acid id == num_embeddings (1-indexed labels) and an edge to a node that does not exist:
+    the reference's nn.Embedding / index_select raise IndexError; so does the HIP path."""
+    from molecular_dynamics_neural_operator_amd import MdnoError, ops
+    from molecular_dynamics_neural_operator_amd.dataset import PairData
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN
+    z = load_golden("kernelnn_small.npz")
+    model = KernelNN(*[int(v) for v in z["ctor"]]).eval().to(dev)
+    aa = t(z["x_aminoacid"]).clone()
+    aa[5] = 20                                                     # == num_embeddings
+    pd = PairData(aa, t(z["x_position"]), None, t(z["edge_attr"]), t(z["edge_index"])).to(dev)
+    with pytest.raises(IndexError):
+        with torch.no_grad():
+            model(pd)
+    ei = t(z["edge_index"]).clone()
+    ei[0, 7] = 28                                                  # source == num_nodes
+    with pytest.raises(IndexError):
+        ops.coo_to_csr(ei.to(dev), 28)
+    ei = t(z["edge_index"]).clone()
+    ei[1, 3] = -1
+    with pytest.raises(MdnoError):
+        ops.coo_to_csr(ei.to(dev), 28)
+    g = ops.coo_to_csr(ei.to(dev), 28, validate=False)             # deferred check: flagged, in bounds
+    assert int(g.status.item()) != 0 and int(g.src.max()) < 28 and int(g.row_ptr[-1]) == ei.shape[1]
+    pd = PairData(t(z["x_aminoacid"]), t(z["x_position"]), None, t(z["edge_attr"]), ei).to(dev)
+    with pytest.raises(IndexError):
+        with torch.no_grad():
+            model(pd)
+
+
+def test_coo_to_csr_big_rows_and_determinism(dev):
+    """Rows above the per-wave limit (2,048 entries) take the workgroup-per-row rank sort; the result
+    is the stable order by destination whatever order the atomic slots were handed out in."""
+    from molecular_dynamics_neural_operator_amd import ops
+    gen = torch.Generator().manual_seed(9)
+    n, E = 300, 40_000
+    ei = torch.randint(0, n, (2, E), generator=gen)
+    ei[1, :9000] = 17                                  # 9,000+ in-edges: big-row kernel
+    ei[1, 9000:12000] = 250                            # 3,000+: big-row kernel, one partial tile
+    g = ops.coo_to_csr(ei.to(dev), n)
+    order = torch.sort(ei[1], stable=True).indices
+    assert torch.equal(g.perm[:E].cpu().long(), order)
+    assert torch.equal(g.src[:E].cpu().long(), ei[0][order])
+    g2 = ops.coo_to_csr(ei.to(dev), n)
+    assert torch.equal(g.perm, g2.perm)
+
+
+# ------------------------------------------------------------------------------- multi-process
+def _run_bench(args, timeout=600):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, str(REPO / "bench.py")] + args, capture_output=True, text=True, env=env,
+                       timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_bench_launches_its_own_ranks(dev):
+    """`python bench.py --gpus 2` typed as the driver types it: the parent starts two fresh workers,
+    relays rank 0's line and exits 0.  On a one-GPU box the ranks share the card and the collective
+    runs over gloo (rehearsal); with two GPUs the same command runs RCCL."""
+    line = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--total-members", "4", "--skip-roofline",
+                       "--skip-cpu-baseline"])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
+    assert line["config"]["total_members"] == 4 and line["config"]["members_this_rank"] == 2
+
+
+NCCL_CHILD = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["MDNO_REPO"])
+from molecular_dynamics_neural_operator_amd.rollout import gather_trajectories, shard_members
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(rank)
+dev = torch.device("cuda", rank)
+dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+total, T, N = 5, 3, 7                                   # uneven: rank 0 holds 3 members, rank 1 holds 2
+full = torch.arange(T * total * N * 3, dtype=torch.float32).reshape(T, total, N, 3)
+mine = full[:, shard_members(total, rank, world)].contiguous().to(dev)
+out = gather_trajectories(mine, total)
+torch.cuda.synchronize()
+assert out.is_cuda and torch.equal(out.cpu(), full), "gathered trajectories differ"
+dist.barrier()
+dist.destroy_process_group()
+print("ok", rank)
+"""
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL wants one device per rank)")
+def test_gather_trajectories_over_rccl_two_gpus(tmp_path):
+    """gather_trajectories over the nccl (= RCCL) backend in two spawned children, one GPU each,
+    against the single-process result."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    script = tmp_path / "child.py"
+    script.write_text(NCCL_CHILD)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), MDNO_REPO=str(REPO))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        out, err = p.communicate(timeout=300)
+        assert p.returncode == 0 and "ok" in out, err[-2000:]

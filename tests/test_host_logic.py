@@ -131,3 +131,94 @@ def test_synthetic_shapes():
     assert 55_000 < e < 66_000                              # SURVEY.md §8 shape B: E ~ 59.7k
     w = syn.ensemble_windows(syn.jitter_window(b, 10), 4)
     assert w.shape == (4, 10, 504, 3) and not np.array_equal(w[0], w[1])
+
+
+def _golden_checkpoint():
+    z = load_golden("checkpoint_best_pt.npz")
+    msd = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("msd/")}
+    return z, {"epoch": int(z["epoch"]), "model_state_dict": msd, "optimizer_state_dict": {"state": {}},
+               "scheduler_state_dict": {"step_size": int(z["scheduler_step_size"])}}
+
+
+def test_load_reference_checkpoint_variants(tmp_path):
+    """best.pt dict / bare state_dict, with and without `module.`, in-tree and notebook-era key sets
+    (graph_kernel.py:630-639; bba_analysis.ipynb:80-111, 123-128)."""
+    from molecular_dynamics_neural_operator_amd import MdnoError, load_reference_checkpoint
+    from molecular_dynamics_neural_operator_amd.checkpoint import infer_constructor_args, read_checkpoint
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNNNotebook
+    z, ckpt = _golden_checkpoint()
+    ctor = [int(v) for v in z["ctor"]]
+    sd, meta = read_checkpoint(ckpt)
+    assert not any(k.startswith("module.") for k in sd) and meta["epoch"] == 3
+    assert infer_constructor_args(sd) == dict(width=ctor[0], ker_width=ctor[1], ker_in=ctor[3], in_width=ctor[4],
+                                              out_width=ctor[5], num_embeddings=ctor[6], embedding_dim=ctor[7])
+    # (1) the dict as saved, into an existing model
+    m = KernelNN(*ctor)
+    m2, meta = load_reference_checkpoint(ckpt, m)
+    assert m2 is m and meta["variant"] == "intree" and not meta["load_result"].missing_keys
+    for k, v in sd.items():
+        assert torch.equal(m.state_dict()[k], v), k
+    assert m.conv1.net is m.conv2.net                              # the shared edge-MLP stays shared
+    # (2) from a file on disk, model built from the shapes; (3) bare state_dict without the prefix
+    p = tmp_path / "best.pt"
+    torch.save(ckpt, p)
+    m3, _ = load_reference_checkpoint(str(p), depth=ctor[2])
+    m4, _ = load_reference_checkpoint(sd, depth=ctor[2])
+    for k in sd:
+        assert torch.equal(m3.state_dict()[k], sd[k]) and torch.equal(m4.state_dict()[k], sd[k])
+    with pytest.raises(MdnoError):
+        load_reference_checkpoint(sd)                              # depth is not recorded anywhere
+    # (4) notebook-era key set (emb, fc1, conv1.*, fc2), DataParallel prefix kept
+    nb_sd = {"module." + k: v for k, v in sd.items() if k.startswith(("emb.", "fc1.", "conv1.", "fc2."))}
+    nb, meta = load_reference_checkpoint({"model_state_dict": nb_sd}, depth=ctor[2])
+    assert isinstance(nb, KernelNNNotebook) and meta["variant"] == "notebook"
+    assert torch.equal(nb.conv1.root, sd["conv1.root"])
+    with pytest.raises(MdnoError):
+        load_reference_checkpoint(nb_sd, KernelNN(*ctor))          # notebook checkpoint into the in-tree model
+    with pytest.raises(MdnoError):
+        load_reference_checkpoint(ckpt, KernelNNNotebook(*ctor[:8]))
+    with pytest.raises(MdnoError):
+        load_reference_checkpoint({"model_state_dict": {}})
+    # a plain nn.Module.load_state_dict on the prefixed keys is what fails without the loader
+    with pytest.raises(RuntimeError):
+        KernelNN(*ctor).load_state_dict(ckpt["model_state_dict"])
+
+
+def test_npz_trajectory_is_pickle_free_and_pickled_files_are_refused(tmp_path):
+    fr = syn.ou_trajectory(syn.chain_frame(9, seed=1), 5, seed=1)
+    cms = [O.radius_graph_coo(f, 8.0).reshape(-1) for f in fr]
+    p = tmp_path / "flat.npz"
+    write_trajectory_npz(p, fr, cms, syn.amino_acids(9, seed=1))
+    with np.load(p, allow_pickle=False) as zf:                     # loads without pickle
+        assert zf["contact_map"].dtype == np.int64 and zf["contact_map_offsets"].shape == (6,)
+    d = ContactMapDataset(str(p), window_size=2, horizon=1)
+    assert np.array_equal(d[1].edge_index.numpy().reshape(-1), cms[1])
+    legacy = tmp_path / "legacy.npz"
+    obj = np.empty(5, dtype=object)
+    for i, c in enumerate(cms):
+        obj[i] = c
+    np.savez(legacy, contact_map=obj, point_cloud=np.transpose(fr, (0, 2, 1)), rmsd=np.zeros(5, np.float32),
+             amino_acids=syn.amino_acids(9, seed=1))
+    with pytest.raises(ValueError, match="pickled"):
+        ContactMapDataset(str(legacy), window_size=2, horizon=1)
+    d2 = ContactMapDataset(str(legacy), window_size=2, horizon=1, allow_pickle=True)
+    assert torch.equal(d2[1].edge_index, d[1].edge_index)
+
+
+def test_hdf5_container(tmp_path):
+    """The reference's real container (dataset.py:112-127).  h5py is not in the build image, so this
+    test is skipped there and the .h5 branch of `_read_container` is unexecuted."""
+    h5py = pytest.importorskip("h5py")
+    fr = syn.ou_trajectory(syn.chain_frame(9, seed=1), 5, seed=1)
+    cms = [O.radius_graph_coo(f, 8.0).reshape(-1) for f in fr]
+    p = tmp_path / "t.h5"
+    with h5py.File(p, "w") as f:
+        dt = h5py.vlen_dtype(np.dtype("int64"))
+        ds = f.create_dataset("contact_map", (len(cms),), dtype=dt)
+        for i, c in enumerate(cms):
+            ds[i] = c
+        f.create_dataset("point_cloud", data=np.transpose(fr, (0, 2, 1)))
+        f.create_dataset("rmsd", data=np.zeros(5, np.float32))
+        f.create_dataset("amino_acids", data=syn.amino_acids(9, seed=1))
+    d = ContactMapDataset(str(p), window_size=2, horizon=1)
+    assert np.array_equal(d[1].edge_index.numpy().reshape(-1), cms[1])

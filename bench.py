@@ -81,8 +81,10 @@ def parse(argv=None):
     ap.add_argument("--window", type=int, default=10)
     ap.add_argument("--threshold", type=float, default=8.0)
     ap.add_argument("--no-graph", action="store_true", help="plain launches instead of hipGraph replay")
-    ap.add_argument("--gemm-mode", choices=["split_bf16", "f32"], default="split_bf16",
-                    help="edge-MLP GEMMs: exact 3-way bf16 split (6 products, fp32 accumulate) or fp32-input MFMA")
+    ap.add_argument("--gemm-mode", choices=["split_bf16", "split_f16", "f32"], default="split_bf16",
+                    help="edge-MLP GEMMs: exact 3-way bf16 split (6 products, fp32 accumulate); split_f16 = the same "
+                         "with the hidden layer of the factored path on 2 fp16 planes (3 products, device-side "
+                         "fallback to bf16 out of fp16 range); f32 = fp32-input MFMA")
     ap.add_argument("--single-mode", action="store_true", help="skip the comparison leg in the other conv mode")
     ap.add_argument("--conv-mode", choices=["auto", "materialized", "factored"], default="auto",
                     help="materialized = W_e written once and streamed by every conv application (the reference's "
@@ -417,18 +419,21 @@ def worker(a):
             return {"bound": "mfma", "kernel": "gemm_tn_mfma_kernel", "achieved": flops32 / step_s / 1e12,
                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops32 / step_s / 1e12 / MFMA_F32_PEAK_TFLOPS,
                     "ms_per_step": step_s * 1e3}
-        ach = 6.0 * flops32 / step_s / 1e12           # 6 bf16 plane products executed per fp32 product
-        return {"bound": "mfma", "kernel": "gemm_split_bf16_kernel", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "fp32_equivalent_tflops": flops32 / step_s / 1e12,
-                "ms_per_step": step_s * 1e3,
-                "note": "executed bf16 MFMA flops (6 plane products per fp32 product) vs dense bf16 peak"}
+        f16 = a.gemm_mode == "split_f16" and which == "edge_mlp_gemm1" and mode == "factored"
+        products = 3.0 if f16 else 6.0                # plane products executed per fp32 product
+        ach = products * flops32 / step_s / 1e12
+        return {"bound": "mfma", "kernel": "gemm_split_f16_kernel" if f16 else "gemm_split_bf16_kernel", "achieved": ach,
+                "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
+                "fp32_equivalent_tflops": flops32 / step_s / 1e12, "ms_per_step": step_s * 1e3,
+                "note": f"executed 16-bit MFMA flops ({products:.0f} plane products per fp32 product) vs the dense "
+                        "bf16/fp16 peak"}
 
     def per_source_roofline(ks, e):   # factored path: M_j = H_j . Y_j^T, all launches of one conv application
         launches_per_app = max(1, round(ks["nnconv"]["launches"] / (a.steps * 2 * a.depth)))
         avg_s = ks["nnconv"]["avg_ms"] * 1e-3 * launches_per_app      # one application over all R rows
         alg = e * KW * 4 + R * C * KW * 4 + 2 * e * C * 4 + (R + 1) * 4        # H once + Y once + 2 k-slice partials out
         flops = 2.0 * e * KW * C                                                # fp32-equivalent
-        split = a.gemm_mode == "split_bf16"
+        split = a.gemm_mode != "f32"
         # matrix-pipe work as executed: 6 bf16 plane products per fp32 product, or the fp32 MFMA itself
         mfma_exec, mfma_peak = (6.0 * flops, MFMA_BF16_PEAK_TFLOPS) if split else (flops, MFMA_F32_PEAK_TFLOPS)
         t_hbm, t_mfma = alg / (HBM_PEAK_GBS * 1e9), mfma_exec / (mfma_peak * 1e12)

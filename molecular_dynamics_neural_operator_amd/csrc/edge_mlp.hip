@@ -280,7 +280,7 @@ using namespace mdno;
 extern "C" size_t mdno_edge_mlp_workspace_bytes(int ker_width, int out_dim, int64_t edge_cap, int gemm_mode) {
     if (ker_width <= 0 || out_dim <= 0 || edge_cap <= 0) return 0;
     const long long chunk = chunk_rows_for(edge_cap);
-    if (gemm_mode == MDNO_GEMM_SPLIT_BF16 && edge_mlp_split_supported(ker_width, out_dim))
+    if (gemm_mode != MDNO_GEMM_F32 && edge_mlp_split_supported(ker_width, out_dim))
         return edge_mlp_split_workspace_bytes(ker_width, out_dim, chunk);
     return align_up(2 * (size_t)chunk * (size_t)ker_width * sizeof(float) + 512, 256);
 }
@@ -296,12 +296,12 @@ int mdno::edge_mlp(const float* frames, int frame, const int* t_dev, int rows_pe
     MDNO_REQUIRE(edge_cap > 0 && ker_width > 0 && out_dim > 0, MDNO_EINVAL, "edge_mlp: bad sizes");
     MDNO_REQUIRE(ker_in > 0 && ker_in <= MAX_F, MDNO_EUNSUPPORTED, "edge_mlp: ker_in=%d (1..%d)", ker_in, MAX_F);
     MDNO_REQUIRE(edge_attr || ker_in == 6, MDNO_EINVAL, "edge_mlp: position-derived attributes need ker_in == 6");
-    MDNO_REQUIRE(gemm_mode == MDNO_GEMM_SPLIT_BF16 || gemm_mode == MDNO_GEMM_F32, MDNO_EINVAL,
-                 "edge_mlp: gemm_mode=%d", gemm_mode);
+    MDNO_REQUIRE(gemm_mode == MDNO_GEMM_SPLIT_BF16 || gemm_mode == MDNO_GEMM_F32 || gemm_mode == MDNO_GEMM_SPLIT_F16,
+                 MDNO_EINVAL, "edge_mlp: gemm_mode=%d", gemm_mode);
     const size_t need = mdno_edge_mlp_workspace_bytes(ker_width, out_dim, edge_cap, gemm_mode);
     MDNO_REQUIRE(workspace_bytes >= need, MDNO_EWORKSPACE, "edge_mlp: workspace %zu < %zu", workspace_bytes, need);
     const long long chunk = chunk_rows_for(edge_cap);
-    if (gemm_mode == MDNO_GEMM_SPLIT_BF16 && edge_mlp_split_supported(ker_width, out_dim))
+    if (gemm_mode != MDNO_GEMM_F32 && edge_mlp_split_supported(ker_width, out_dim))   // (SPLIT_F16: bf16 kernels here)
         return edge_mlp_split(frames, frame, t_dev, rows_per_frame, src, dst, edge_attr, perm, num_edges, edge_cap,
                               chunk, ker_in, ker_width, out_dim, w, w_e, workspace, s, phase);
     if (phase == WP_PREPARE_ONLY) return MDNO_OK;   // the fp32 GEMMs read the weights as they are
@@ -339,9 +339,10 @@ int mdno::edge_mlp_hidden(const float* frames, int frame, const int* t_dev, int 
     const size_t need = mdno_edge_mlp_workspace_bytes(ker_width, ker_width, edge_cap, gemm_mode);
     MDNO_REQUIRE(workspace_bytes >= need, MDNO_EWORKSPACE, "edge_mlp_hidden: workspace %zu < %zu", workspace_bytes, need);
     const long long chunk = chunk_rows_for(edge_cap);
-    if (gemm_mode == MDNO_GEMM_SPLIT_BF16 && edge_mlp_split_supported(ker_width, ker_width))
+    if (gemm_mode != MDNO_GEMM_F32 && edge_mlp_split_supported(ker_width, ker_width))
         return edge_mlp_split_hidden(frames, frame, t_dev, rows_per_frame, src, dst, edge_attr, perm, num_edges,
-                                     edge_cap, chunk, ker_in, ker_width, w, h_out, workspace, s, phase);
+                                     edge_cap, chunk, ker_in, ker_width, w, h_out, workspace, s, phase,
+                                     gemm_mode == MDNO_GEMM_SPLIT_F16);
     if (phase == WP_PREPARE_ONLY) return MDNO_OK;
     MDNO_REQUIRE(ker_width % BN == 0 && (reinterpret_cast<uintptr_t>(w.w1) & 15) == 0, MDNO_EUNSUPPORTED,
                  "edge_mlp_hidden: ker_width=%d must be a multiple of %d", ker_width, BN);

@@ -36,6 +36,18 @@
 // fragment reads bank-conflict-free.  Workgroups are numbered so that each
 // XCD owns a contiguous range of tiles (neighbouring tiles share the A row-panel through that
 // XCD's L2).
+//
+// SPLIT_F16 (gemm_mode 2) runs the k x k hidden layer with TWO fp16 planes instead:
+//     x = x_hi + 2^-11 x_lo',   x_hi = fp16(x),  x_lo' = fp16((x - x_hi) * 2^11)      (22-23 mantissa bits)
+//     a.b ~= a_hi b_hi + 2^-11 (a_hi b_lo' + a_lo' b_hi)                               (dropped: 2^-22 a_lo' b_lo')
+// — three fp16 x fp16 MFMAs (exact products, fp32 accumulation, the cross terms in their own
+// accumulator so that the 2^-11 is applied once, exactly) instead of six bf16 ones: half the matrix
+// work and two thirds of the staged bytes for an error vs fp64 still below a plain fp32 GEMM's
+// (rel. rms 7e-8 before accumulation error vs 2.4e-7; tests/test_gpu_parity.py).  fp16 has a 5-bit
+// exponent: the scheme is exact only while |x| < 65504, so the producers of the planes raise a device
+// flag when a value is out of range, the fp16 GEMM then exits at once and the bf16 kernels — launched
+// right behind it, and exiting at once when the flag is clear — redo the chunk.  Values below 2^-14
+// lose relative, never absolute, accuracy (x_hi goes subnormal, x_lo' still carries 11 more bits).
 #include "kernels.h"
 #include "split_layout.h"
 
@@ -44,6 +56,28 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr float F16_LO_SCALE = 2048.f, F16_LO_UNSCALE = 1.f / 2048.f, F16_MAX = 65504.f;
+
+__device__ __forceinline__ void split2h(float x, _Float16& h, _Float16& l) {
+    h = (_Float16)x;
+    l = (_Float16)((x - (float)h) * F16_LO_SCALE);
+}
+
+// Byte offset of element (row, kcol) of plane p in the two-plane image (same 4 KiB plane tiles and
+// swizzle as tiled_off, two planes per k-step instead of three).
+__device__ __forceinline__ size_t tiled_off2(long long row, int kcol, int nkt, int p) {
+    const long long rt = row >> 7;
+    const int r = (int)(row & 127), kt = kcol >> 4, c = (kcol >> 3) & 1, e = kcol & 7;
+    return ((size_t)((rt * nkt + kt) * 2 + p) << 12) + r * 32 + ((c ^ ((r >> 3) & 1)) << 4) + e * 2;
+}
+
+// flags[0]: a weight is out of fp16 range (set when the weight planes are built);
+// flags[1]: an activation of the current forward is.  Either one sends the chunk down the bf16 path.
+__device__ __forceinline__ bool f16_blocked(const int* __restrict__ flags) {
+    return (__builtin_nontemporal_load(flags) | __builtin_nontemporal_load(flags + 1)) != 0;
+}
 
 constexpr int TN = 128, TK = 16;               // block tile is TM x 128 (TM = 128 or 256); one MFMA k-step per stage
 constexpr int PLANE_BYTES = 128 * TK * 2;      // 4 KiB per (128-row) operand plane tile
@@ -72,6 +106,30 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
 #pragma unroll
     for (int p = 0; p < 3; ++p)
         *reinterpret_cast<uint4*>(planes + tiled_off(row, k0, nkt, p)) = *reinterpret_cast<const uint4*>(o[p]);
+}
+
+__global__ __launch_bounds__(256) void split_planes_f16_kernel(const float* __restrict__ w, int rows, int K,
+                                                               unsigned char* __restrict__ planes,
+                                                               int* __restrict__ range_flag) {
+    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int chunks_per_row = K >> 3;
+    if (id >= (long long)rows * chunks_per_row) return;
+    const int row = (int)(id / chunks_per_row), k0 = (int)(id % chunks_per_row) * 8;
+    const float4 v0 = *reinterpret_cast<const float4*>(w + (size_t)row * K + k0);
+    const float4 v1 = *reinterpret_cast<const float4*>(w + (size_t)row * K + k0 + 4);
+    const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    _Float16 o[2][8];
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        bad |= !(fabsf(x[j]) < F16_MAX);
+        split2h(x[j], o[0][j], o[1][j]);
+    }
+    if (bad) atomicOr(range_flag, 1);
+    const int nkt = K >> 4;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+        *reinterpret_cast<uint4*>(planes + tiled_off2(row, k0, nkt, p)) = *reinterpret_cast<const uint4*>(o[p]);
 }
 
 // ---------------------------------------------------------------- x [rows,64] -> planes, + q = x . B
@@ -111,14 +169,18 @@ __global__ __launch_bounds__(256) void split_bias64_kernel(const float* __restri
 constexpr int MAX_F = 8;
 constexpr int L0_ROWS = 128, L0_UNITS = 128;
 
-template <int FT>   // FT = compile-time ker_in (6 for position-derived attributes), 0 = run-time F
+// F16: emit the two fp16 planes (and raise f16_flags[1] on a value out of fp16 range) instead of the
+// three bf16 planes; the bf16 instantiation given f16_flags runs only when a flag is up (fallback).
+template <int FT, bool F16>   // FT = compile-time ker_in (6 for position-derived attributes), 0 = run-time F
 __global__ __launch_bounds__(256) void edge_l0_split_kernel(
     const float* __restrict__ frames, int frame, const int* __restrict__ t_dev, int rows_per_frame,
     const int* __restrict__ src, const int* __restrict__ dst, const float* __restrict__ edge_attr,
     const int* __restrict__ perm, const int* __restrict__ num_edges, long long e_begin, int e_count, int F, int k,
-    const float* __restrict__ w0, const float* __restrict__ b0, unsigned char* __restrict__ hp) {
+    const float* __restrict__ w0, const float* __restrict__ b0, unsigned char* __restrict__ hp,
+    int* __restrict__ f16_flags) {
     __shared__ __attribute__((aligned(16))) float wsh[L0_UNITS * MAX_F];
     __shared__ __attribute__((aligned(16))) float bsh[L0_UNITS];
+    if (!F16 && f16_flags != nullptr && !f16_blocked(f16_flags)) return;   // fallback launch, not needed
     const int Fn = FT ? FT : F;
     const long long E = *num_edges;
     const long long tile0 = (long long)blockIdx.x * L0_ROWS;   // first row of this tile inside the chunk
@@ -149,35 +211,51 @@ __global__ __launch_bounds__(256) void edge_l0_split_kernel(
     __syncthreads();
     if (!valid) return;
     const int nkt = k >> 4;
+    bool bad = false;
 #pragma unroll 2
     for (int t = 0; t < L0_UNITS / 16; ++t) {
         const int c = t * 16 + half * 8;       // this thread's 8 hidden units, relative to u0
         __bf16 o[3][8];
+        _Float16 oh[2][8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float sum = 0.f;
 #pragma unroll
             for (int f = 0; f < MAX_F; ++f)
                 if (f < Fn) sum = fmaf(attr[f], wsh[(c + j) * Fn + f], sum);
-            split3(fmaxf(sum + bsh[c + j], 0.f), o[0][j], o[1][j], o[2][j]);
+            const float v = fmaxf(sum + bsh[c + j], 0.f);
+            if (F16) {
+                bad |= !(v < F16_MAX);
+                split2h(v, oh[0][j], oh[1][j]);
+            } else {
+                split3(v, o[0][j], o[1][j], o[2][j]);
+            }
         }
+        if (F16) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
-            *reinterpret_cast<uint4*>(hp + tiled_off(le, u0 + c, nkt, p)) = *reinterpret_cast<const uint4*>(o[p]);
+            for (int p = 0; p < 2; ++p)
+                *reinterpret_cast<uint4*>(hp + tiled_off2(le, u0 + c, nkt, p)) = *reinterpret_cast<const uint4*>(oh[p]);
+        } else {
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                *reinterpret_cast<uint4*>(hp + tiled_off(le, u0 + c, nkt, p)) = *reinterpret_cast<const uint4*>(o[p]);
+        }
     }
+    if (F16 && bad) atomicOr(f16_flags + 1, 1);
 }
 
+// f16 = true: fp16 planes + range flag; f16 = false with flags: the bf16 fallback (runs if a flag is up)
 static int launch_edge_l0_split(const float* pos_mode, int frame, const int* t_dev, int rows_per_frame, const int* src,
                                 const int* dst, const float* edge_attr, const int* perm, const int* num_edges,
                                 long long e0, int cnt, int F, int k, const float* w0, const float* b0,
-                                unsigned char* hp, hipStream_t s) {
+                                unsigned char* hp, hipStream_t s, bool f16 = false, int* f16_flags = nullptr) {
     const dim3 grid((cnt + L0_ROWS - 1) / L0_ROWS, k / L0_UNITS);
-    if (F == 6)
-        hipLaunchKernelGGL(edge_l0_split_kernel<6>, grid, dim3(256), 0, s, pos_mode, frame, t_dev, rows_per_frame, src,
-                           dst, edge_attr, perm, num_edges, e0, cnt, F, k, w0, b0, hp);
-    else
-        hipLaunchKernelGGL(edge_l0_split_kernel<0>, grid, dim3(256), 0, s, pos_mode, frame, t_dev, rows_per_frame, src,
-                           dst, edge_attr, perm, num_edges, e0, cnt, F, k, w0, b0, hp);
+#define MDNO_L0(FT, H)                                                                                             \
+    hipLaunchKernelGGL((edge_l0_split_kernel<FT, H>), grid, dim3(256), 0, s, pos_mode, frame, t_dev, rows_per_frame, \
+                       src, dst, edge_attr, perm, num_edges, e0, cnt, F, k, w0, b0, hp, f16_flags)
+    if (F == 6) { if (f16) MDNO_L0(6, true); else MDNO_L0(6, false); }
+    else        { if (f16) MDNO_L0(0, true); else MDNO_L0(0, false); }
+#undef MDNO_L0
     return check_launch("edge_l0_split_kernel");
 }
 
@@ -194,6 +272,8 @@ struct SplitGemmArgs {
     int tiles_n, tiles_m;
     int rows_valid;
     int m_fastest;             // tile order: 0 = n fastest (neighbours share the A row-panel), 1 = m fastest (share B)
+    const int* f16_flags = nullptr;   // SPLIT_F16: the fp16 kernel runs while no flag is up, the bf16 one (given
+                                      // the flags) only when one is; NULL: unconditional
 };
 
 // One stage (k-step of 16) for a wave: (2x2 tiles) x 6 plane products = 24 MFMAs, 12 fragment reads.
@@ -233,6 +313,7 @@ __global__ __launch_bounds__(TM * 2, 2) void gemm_split_bf16_kernel(SplitGemmArg
     constexpr int A_PIECES = PIECES - 12;
     constexpr int PPW = (PIECES + WAVES - 1) / WAVES;    // pieces per wave: 6 or 5
 
+    if (g.f16_flags != nullptr && !f16_blocked(g.f16_flags)) return;   // bf16 fallback launch, not needed
     long long valid = g.num_edges ? (long long)(*g.num_edges) - g.row_begin : (long long)g.rows_valid;
     if (valid > g.rows) valid = g.rows;
     if (valid <= 0) return;
@@ -353,6 +434,158 @@ __global__ __launch_bounds__(TM * 2, 2) void gemm_split_bf16_kernel(SplitGemmArg
     }
 }
 
+
+// ---------------------------------------------------------------- two-plane fp16 GEMM (SPLIT_F16)
+// Same 256x128 block tile, wave tile, LDS image and tile order as gemm_split_bf16_kernel, with two
+// planes per operand and two accumulator sets (hi.hi, and the cross terms that carry the 2^-11).  The
+// second set costs 64 VGPRs (170 in all), which leaves one 8-wave workgroup per CU instead of two, so
+// the latency of the LDS-DMA can no longer hide behind a neighbour workgroup: stages are twice as long
+// (two k-steps = 32 k: 24 MFMAs + 16 fragment reads per wave, one barrier) and live in a ring of three
+// (3 x 48 KiB), two stages ahead of the MFMAs, with a COUNTED wait — `s_waitcnt vmcnt(6)` lets the
+// newest stage's six pieces stay in flight (loads return in order; the K loop issues no stores).
+__device__ __forceinline__ void mma_f16_kstep(f32x16 (&acc)[2][2], f32x16 (&accx)[2][2], const unsigned char* st,
+                                              int a_rd, int b_rd) {
+    f16x8 a[2][2], b[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            a[i][p] = *reinterpret_cast<const f16x8*>(st + p * PLANE_BYTES + a_rd + i * 32 * 32);
+            b[i][p] = *reinterpret_cast<const f16x8*>(st + p * PLANE_BYTES + b_rd + i * 32 * 32);
+        }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], accx[i][j], 0, 0, 0);
+            accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], accx[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+        }
+}
+
+constexpr int F16_TM = 256, F16_WAVES = 8, F16_RING = 3;
+constexpr int F16_TILE_BYTES = 2 * 2 * PLANE_BYTES;       // one 128-row tile: two k-steps x two planes = 16 KiB
+constexpr int F16_STAGE_BYTES = 3 * F16_TILE_BYTES;       // A tile 0 | A tile 1 | B = 48 KiB
+constexpr int F16_PPW = F16_STAGE_BYTES / 1024 / F16_WAVES;   // 6 one-KiB DMA pieces per wave per stage
+
+// OUT: 2 = fp32 k-tiled after ReLU (the factored conv's H), 0 = fp32 row-major, 3 = fp32 row-major after ReLU
+template <int OUT>
+__global__ __launch_bounds__(F16_TM * 2) void gemm_split_f16_kernel(SplitGemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int TM = F16_TM, WAVES = F16_WAVES, PPW = F16_PPW;
+    if (g.f16_flags != nullptr && f16_blocked(g.f16_flags)) return;   // out of fp16 range: the bf16 launch behind us runs
+    long long valid = g.num_edges ? (long long)(*g.num_edges) - g.row_begin : (long long)g.rows_valid;
+    if (valid > g.rows) valid = g.rows;
+    if (valid <= 0) return;
+    const int nwg = g.tiles_n * (int)((valid + TM - 1) / TM);
+    const int orig = blockIdx.x;
+    if (orig >= nwg) return;
+    const int xcd = orig & 7, q = nwg >> 3, r8 = nwg & 7;
+    const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
+    const int tiles_mv = nwg / g.tiles_n;
+    const int bm = (g.m_fastest ? tile % tiles_mv : tile / g.tiles_n) * TM;
+    const int bn = (g.m_fastest ? tile / tiles_mv : tile % g.tiles_n) * TN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+
+    // piece qq of a stage: block qq/16 (A row tile 0, A row tile 1, B), KiB qq%16 of that block's 16 KiB;
+    // in HBM a row tile's k-steps are contiguous (8 KiB each), so a stage is one 16 KiB run per block
+    const int nkt = g.K / TK, nst = g.K / 32;
+    const size_t a_tile_stride = (size_t)nkt * 2 << 12;
+    const unsigned char* a_base = g.Ap + (size_t)(bm >> 7) * a_tile_stride;
+    const unsigned char* b_base = g.Bp + (size_t)(bn >> 7) * a_tile_stride;
+    const unsigned char* psrc[PPW];
+#pragma unroll
+    for (int t = 0; t < PPW; ++t) {
+        const int qq = wave + t * WAVES, blk = qq >> 4;
+        psrc[t] = (blk < 2 ? a_base + (size_t)blk * a_tile_stride : b_base) + (qq & 15) * 1024 + lane * 16;
+    }
+    const int d0 = wave * 1024;
+#define MDNO_DMA_STAGE(ST, SLOT)                                                                       \
+    {                                                                                                  \
+        const size_t ko = (size_t)(ST) * F16_TILE_BYTES;                                               \
+        lds_u8* ldst = (lds_u8*)(lds + (SLOT) * F16_STAGE_BYTES + d0);                                 \
+        _Pragma("unroll") for (int t = 0; t < PPW; ++t)                                                \
+            __builtin_amdgcn_global_load_lds((glb_u8*)(psrc[t] + ko), ldst + t * WAVES * 1024, 16, 0, 0); \
+    }
+
+    const int hsw = (h ^ ((l31 >> 3) & 1)) << 4;
+    const int a_rd = (wm >> 1) * F16_TILE_BYTES + ((wm & 1) * 64 + l31) * 32 + hsw;
+    const int b_rd = 2 * F16_TILE_BYTES + (wn * 64 + l31) * 32 + hsw;
+
+    f32x16 acc[2][2], accx[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.f; accx[i][j][e] = 0.f; }
+    float bv0 = 0.f, bv1 = 0.f;      // fetched before the K loop and pinned (see gemm_split_bf16_kernel)
+    if (g.bias) {
+        bv0 = g.bias[bn + wn * 64 + l31];
+        bv1 = g.bias[bn + wn * 64 + 32 + l31];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bv0), "+v"(bv1));   // the counted waits below must see DMA pieces only
+
+    MDNO_DMA_STAGE(0, 0)
+    if (nst > 1) MDNO_DMA_STAGE(1, 1)
+    int slot = 0, slot_in = 2;       // slot being multiplied; slot the next DMA goes to
+    for (int st = 0; st < nst; ++st) {
+        // this wave's pieces of stage st have landed (the next stage's PPW pieces may still be in flight) ...
+        if (st + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ... and so have everybody's; nobody still reads the slot stage st+2 goes to (multiplied at st-1:
+        // a wave's fragment reads feed its MFMAs, so they have returned before it gets here).  The bare
+        // barrier instruction: __syncthreads() carries a fence that the compiler lowers to vmcnt(0),
+        // which would wait for the stage just put in flight
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (st + 2 < nst) MDNO_DMA_STAGE(st + 2, slot_in)
+        const unsigned char* sb = lds + slot * F16_STAGE_BYTES;
+        mma_f16_kstep(acc, accx, sb, a_rd, b_rd);
+        mma_f16_kstep(acc, accx, sb + 2 * PLANE_BYTES, a_rd, b_rd);
+        slot = slot == F16_RING - 1 ? 0 : slot + 1;
+        slot_in = slot_in == F16_RING - 1 ? 0 : slot_in + 1;
+    }
+#undef MDNO_DMA_STAGE
+
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = bn + wn * 64 + j * 32 + l31;
+        const float bv = j ? bv1 : bv0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = bm + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (m < valid) {
+                    const float v = (acc[i][j][e] + accx[i][j][e] * F16_LO_UNSCALE) + bv;
+                    if (OUT == 2)
+                        g.C[((size_t)(m >> 7) * (g.N >> 5) + (n >> 5)) * 4096 + (m & 127) * 32 + (n & 31)] = fmaxf(v, 0.f);
+                    else
+                        g.C[(size_t)m * g.N + n] = OUT == 3 ? fmaxf(v, 0.f) : v;
+                }
+            }
+        }
+    }
+}
+
+template <int OUT>
+int launch_split_f16_gemm(SplitGemmArgs g, hipStream_t s) {
+    constexpr int lds_bytes = F16_RING * F16_STAGE_BYTES;     // 147,456 B: one workgroup per CU
+    static std::atomic<unsigned long long> lds_raised{0};
+    MDNO_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(&gemm_split_f16_kernel<OUT>), lds_bytes, lds_raised));
+    MDNO_REQUIRE(g.K % 32 == 0 && g.N % TN == 0 && g.rows % F16_TM == 0, MDNO_EUNSUPPORTED,
+                 "split-f16 GEMM: rows=%d N=%d K=%d", g.rows, g.N, g.K);
+    g.tiles_n = g.N / TN;
+    g.tiles_m = g.rows / F16_TM;
+    hipLaunchKernelGGL((gemm_split_f16_kernel<OUT>), dim3(g.tiles_n * g.tiles_m), dim3(F16_TM * 2), lds_bytes, s, g);
+    return check_launch("split-f16 GEMM");
+}
+
 template <int TM, int OUT>
 int launch_split_gemm_tm(SplitGemmArgs g, hipStream_t s) {
     constexpr int lds_bytes = 2 * stage_bytes(TM);
@@ -430,13 +663,28 @@ bool edge_mlp_split_supported(int ker_width, int out_dim) {
     return ker_width % 32 == 0 && ker_width % TN == 0 && out_dim % TN == 0;
 }
 
+// One layout for both entry points: [h1 planes][h2 planes][W1 planes][W2 planes][W1 fp16 planes][flags]
+struct SplitWs {
+    unsigned char *h1p, *h2p, *w1p, *w2p, *w1h;
+    int* f16_flags;
+    size_t total;
+};
+
+static SplitWs carve_split(void* ws, int k, int out_dim, long long chunk) {
+    SplitWs w{};
+    Carver cv(ws);
+    w.h1p = reinterpret_cast<unsigned char*>(cv.take<__bf16>(3 * (size_t)chunk * k));
+    w.h2p = reinterpret_cast<unsigned char*>(cv.take<__bf16>(3 * (size_t)chunk * k));
+    w.w1p = reinterpret_cast<unsigned char*>(cv.take<__bf16>(3 * (size_t)k * k));
+    w.w2p = reinterpret_cast<unsigned char*>(cv.take<__bf16>(3 * (size_t)out_dim * k));
+    w.w1h = reinterpret_cast<unsigned char*>(cv.take<_Float16>(2 * (size_t)k * k));
+    w.f16_flags = cv.take<int>(64);
+    w.total = cv.used();
+    return w;
+}
+
 size_t edge_mlp_split_workspace_bytes(int ker_width, int out_dim, long long chunk) {
-    Carver cv(nullptr);
-    cv.take<__bf16>(3 * (size_t)chunk * ker_width);
-    cv.take<__bf16>(3 * (size_t)chunk * ker_width);
-    cv.take<__bf16>(3 * (size_t)ker_width * ker_width);
-    cv.take<__bf16>(3 * (size_t)out_dim * ker_width);
-    return cv.used();
+    return carve_split(nullptr, ker_width, out_dim, chunk).total;
 }
 
 int edge_mlp_split(const float* frames, int frame, const int* t_dev, int rows_per_frame, const int* src,
@@ -447,11 +695,8 @@ int edge_mlp_split(const float* frames, int frame, const int* t_dev, int rows_pe
     MDNO_REQUIRE(((reinterpret_cast<uintptr_t>(w.w1) | reinterpret_cast<uintptr_t>(w.w2)) & 15) == 0, MDNO_EINVAL,
                  "edge_mlp: weight pointers must be 16-byte aligned");
     const int k = ker_width;
-    Carver cv(workspace);
-    unsigned char* h1p = reinterpret_cast<unsigned char*>(cv.take<__bf16>(3 * (size_t)chunk * k));
-    unsigned char* h2p = reinterpret_cast<unsigned char*>(cv.take<__bf16>(3 * (size_t)chunk * k));
-    unsigned char* w1p = reinterpret_cast<unsigned char*>(cv.take<__bf16>(3 * (size_t)k * k));
-    unsigned char* w2p = reinterpret_cast<unsigned char*>(cv.take<__bf16>(3 * (size_t)out_dim * k));
+    const SplitWs sw = carve_split(workspace, k, out_dim, chunk);
+    unsigned char *h1p = sw.h1p, *h2p = sw.h2p, *w1p = sw.w1p, *w2p = sw.w2p;
     if (phase != WP_RUN_ONLY) {
         TimedSection ts(KID_EDGE_L0, s);
         const long long c1 = (long long)k * (k / 8), c2 = (long long)out_dim * (k / 8);
@@ -481,32 +726,53 @@ int edge_mlp_split(const float* frames, int frame, const int* t_dev, int rows_pe
 int edge_mlp_split_hidden(const float* frames, int frame, const int* t_dev, int rows_per_frame, const int* src,
                           const int* dst, const float* edge_attr, const int* perm, const int* num_edges,
                           long long edge_cap, long long chunk, int ker_in, int ker_width, const EdgeMlpWeights& w,
-                          float* h_out, void* workspace, hipStream_t s, int phase) {
+                          float* h_out, void* workspace, hipStream_t s, int phase, bool f16) {
     MDNO_REQUIRE(ker_in > 0 && ker_in <= MAX_F, MDNO_EUNSUPPORTED, "edge_mlp: ker_in=%d (1..%d)", ker_in, MAX_F);
     MDNO_REQUIRE((reinterpret_cast<uintptr_t>(w.w1) & 15) == 0, MDNO_EINVAL,
                  "edge_mlp: weight pointers must be 16-byte aligned");
     const int k = ker_width;
-    Carver cv(workspace);
-    unsigned char* h1p = reinterpret_cast<unsigned char*>(cv.take<__bf16>(3 * (size_t)chunk * k));
-    cv.take<__bf16>(3 * (size_t)chunk * k);   // (layout shared with the full MLP: second activation buffer unused)
-    unsigned char* w1p = reinterpret_cast<unsigned char*>(cv.take<__bf16>(3 * (size_t)k * k));
+    const SplitWs sw = carve_split(workspace, k, k, chunk);      // (same layout as the full MLP with out_dim = k)
+    unsigned char *h1p = sw.h1p, *w1p = sw.w1p;
     if (phase != WP_RUN_ONLY) {
         TimedSection ts(KID_EDGE_L0, s);
         const long long c1 = (long long)k * (k / 8);
         hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((c1 + 255) / 256)), dim3(256), 0, s, w.w1, k, k, w1p);
+        if (f16) {   // fp16 image of W1 + its range flag (flags[0]); the bf16 image above serves the fallback
+            MDNO_HIP(hipMemsetAsync(sw.f16_flags, 0, sizeof(int), s));
+            hipLaunchKernelGGL(split_planes_f16_kernel, dim3((unsigned)((c1 + 255) / 256)), dim3(256), 0, s, w.w1, k, k,
+                               sw.w1h, sw.f16_flags);
+        }
     }
     MDNO_TRY(check_launch("split_planes_kernel"));
     if (phase == WP_PREPARE_ONLY) return MDNO_OK;
     const float* pos_mode = edge_attr ? nullptr : frames;
+    if (f16) MDNO_HIP(hipMemsetAsync(sw.f16_flags + 1, 0, sizeof(int), s));   // activation flag of THIS forward
     for (long long e0 = 0; e0 < edge_cap; e0 += chunk) {
         const int cnt = (int)((edge_cap - e0) < chunk ? (edge_cap - e0) : chunk);
+        float* out = h_out + (size_t)e0 * k;      // chunk % 128 == 0: the k-tiled tile index continues across chunks
+        if (f16) {
+            {
+                TimedSection ts(KID_EDGE_L0, s);
+                MDNO_TRY(launch_edge_l0_split(pos_mode, frame, t_dev, rows_per_frame, src, dst, edge_attr, perm, num_edges,
+                                              e0, cnt, ker_in, k, w.w0, w.b0, h1p, s, true, sw.f16_flags));
+            }
+            TimedSection ts(KID_GEMM_L1, s);
+            SplitGemmArgs gh{h1p, sw.w1h, w.b1, out, nullptr, num_edges, e0, (int)chunk, k, k, 0, 0, 0, 0, sw.f16_flags};
+            MDNO_TRY(launch_split_f16_gemm<2>(gh, s));
+            // the same chunk on the bf16 kernels: both exit at their first instruction unless a range flag is up
+            MDNO_TRY(launch_edge_l0_split(pos_mode, frame, t_dev, rows_per_frame, src, dst, edge_attr, perm, num_edges,
+                                          e0, cnt, ker_in, k, w.w0, w.b0, h1p, s, false, sw.f16_flags));
+            SplitGemmArgs g1{h1p, w1p, w.b1, out, nullptr, num_edges, e0, (int)chunk, k, k, 0, 0, 0, 0, sw.f16_flags};
+            MDNO_TRY((launch_split_gemm_tm<128, 2>(g1, s)));
+            continue;
+        }
         {
             TimedSection ts(KID_EDGE_L0, s);
             MDNO_TRY(launch_edge_l0_split(pos_mode, frame, t_dev, rows_per_frame, src, dst, edge_attr, perm, num_edges,
                                           e0, cnt, ker_in, k, w.w0, w.b0, h1p, s));
         }
-        SplitGemmArgs g1{h1p, w1p, w.b1, h_out + (size_t)e0 * k, nullptr, num_edges, e0, (int)chunk, k, k, 0, 0, 0, 0};
-        MDNO_TRY(launch_split_gemm<2>(g1, KID_GEMM_L1, s));   // chunk % 128 == 0: tile index continues across chunks
+        SplitGemmArgs g1{h1p, w1p, w.b1, out, nullptr, num_edges, e0, (int)chunk, k, k, 0, 0, 0, 0};
+        MDNO_TRY(launch_split_gemm<2>(g1, KID_GEMM_L1, s));
     }
     return MDNO_OK;
 }

@@ -137,7 +137,8 @@ int forward_impl(const mdno_kernelnn_params* p, const float* frames, int t0, con
         MDNO_REQUIRE(edge_frames && !edge_attr && dst, MDNO_EINVAL,
                      "factored conv needs a position-derived radius graph (edge_pos, dst)");
         const FactoredWs fw = factored_carve(ws.fact, R, p->ker_width, edge_cap);
-        if (!prep_only) MDNO_TRY(factored_prepare_graph(row_ptr, src, dst, R, N, p->gemm_mode, edge_cap, fw, status, s));
+        const int cgm = conv_gemm_mode(p->gemm_mode);
+        if (!prep_only) MDNO_TRY(factored_prepare_graph(row_ptr, src, dst, R, N, cgm, edge_cap, fw, status, s));
         for (int block = 0; block < blocks; ++block) {
             const bool own = block == 1 && separate_conv2_kernel(p);
             if (block == 0 || own) {
@@ -147,7 +148,7 @@ int forward_impl(const mdno_kernelnn_params* p, const float* frames, int t0, con
                 MDNO_TRY(edge_mlp_hidden(edge_frames, edge_frame, t_dev, R, /*src=*/dst, /*dst=*/src, nullptr, nullptr,
                                          num_edges, edge_cap, p->ker_in, p->ker_width, p->gemm_mode, w, ws.h2, ws.mlp,
                                          ws.mlp_bytes, s, phase));
-                if (phase != WP_RUN_ONLY) MDNO_TRY(factored_prepare_weights(w.w2, p->ker_width, p->gemm_mode, fw, s));
+                if (phase != WP_RUN_ONLY) MDNO_TRY(factored_prepare_weights(w.w2, p->ker_width, cgm, fw, s));
             }
             if (prep_only) return MDNO_OK;
             const float* b3 = (block == 1 && separate_conv2_kernel(p)) ? p->k2_b2 : p->k_b2;
@@ -160,7 +161,7 @@ int forward_impl(const mdno_kernelnn_params* p, const float* frames, int t0, con
                                        : block + 1 < blocks ? (separate_conv2_kernel(p) ? p->k2_b2 : p->k_b2)
                                                             : nullptr;
                 MDNO_TRY(factored_conv(cur, ws.h2, row_ptr, R, N, max_degree > 0 ? max_degree : N, p->ker_width,
-                                       p->gemm_mode, b3, root, bias, MDNO_AGGR_MEAN, /*relu=*/1, nxt, fw, status, s,
+                                       cgm, b3, root, bias, MDNO_AGGR_MEAN, /*relu=*/1, nxt, fw, status, s,
                                        /*x_prepared=*/!first, next_b3));
                 float* t = cur; cur = nxt; nxt = t;
             }

@@ -56,7 +56,10 @@ int edge_mlp_hidden(const float* frames, int frame, const int* t_dev, int rows_p
 int edge_mlp_split_hidden(const float* frames, int frame, const int* t_dev, int rows_per_frame, const int* src,
                           const int* dst, const float* edge_attr, const int* perm, const int* num_edges,
                           long long edge_cap, long long chunk, int ker_in, int ker_width, const EdgeMlpWeights& w,
-                          float* h_out, void* workspace, hipStream_t s, int phase = WP_BOTH);
+                          float* h_out, void* workspace, hipStream_t s, int phase = WP_BOTH, bool f16 = false);
+// gemm_mode as the bf16-split kernels see it: SPLIT_F16 changes the k x k hidden GEMM of the factored
+// path only; every other product of that mode runs the SPLIT_BF16 kernels
+inline int conv_gemm_mode(int gemm_mode) { return gemm_mode == MDNO_GEMM_SPLIT_F16 ? MDNO_GEMM_SPLIT_BF16 : gemm_mode; }
 
 // Pieces of the split-bf16 GEMM usable on their own (edge_mlp_split.hip): fp32 [rows,K] -> tiled bf16
 // planes (buffer of split_planes_bytes), and C[rows,N] = A . Bt^T (fp32 row-major) from two such images.

@@ -272,7 +272,7 @@ def linear(a: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], relu: bo
     n = w.shape[0]
     c = torch.empty((rows, n), dtype=torch.float32, device=a.device)
     bb = f32(b) if b is not None else None
-    if gemm_mode == "split_bf16" and k % 32 == 0 and n % 128 == 0 and rows > 0:
+    if gemm_mode != "f32" and k % 32 == 0 and n % 128 == 0 and rows > 0:      # ("split_f16": bf16 planes here)
         ws = _ws(lib.mdno_linear_split_workspace_bytes(rows, n, k), a.device)
         check(lib.mdno_linear_split_fwd(ptr(a), ptr(w), ptr(bb), rows, n, k, int(relu), ptr(c), ptr(ws), ws.numel(),
                                         stream_ptr(a.device)), "mdno_linear_split_fwd")

@@ -75,7 +75,7 @@ def live504(tmp_path_factory):
     return z, dset, sd
 
 
-@pytest.mark.parametrize("gemm_mode", ["split_bf16", "f32"])
+@pytest.mark.parametrize("gemm_mode", ["split_bf16", "split_f16", "f32"])
 def test_live504_teacher_forced_reference_golden(dev, live504, gemm_mode):
     """The 64x64 fast kernels against the REFERENCE on live activations: materialized (the sample's own
     edge list) and factored (the same graph rebuilt on the device from the sample's first frame)."""
@@ -108,7 +108,8 @@ def test_live504_teacher_forced_reference_golden(dev, live504, gemm_mode):
 
 
 @pytest.mark.parametrize("conv_mode,gemm_mode", [("factored", "split_bf16"), ("materialized", "split_bf16"),
-                                                 ("factored", "f32"), ("materialized", "f32")])
+                                                 ("factored", "split_f16"), ("factored", "f32"),
+                                                 ("materialized", "f32")])
 def test_live504_free_run_reference_golden(dev, live504, conv_mode, gemm_mode):
     """5 free-running steps through recursive_propagation (on-device loop) against the reference's own
     loop (graph_kernel.py:396-413).  A pair whose distance sits within 2e-4 A of the cutoff in the
@@ -139,6 +140,43 @@ def test_live504_free_run_reference_golden(dev, live504, conv_mode, gemm_mode):
         assert abs(e_got - e_want) <= 2 * risky_pairs, (s, e_got, e_want)
         loose[atoms] = True
     assert int(loose.sum()) < 0.2 * loose.size
+
+
+def test_split_f16_hidden_gemm_accuracy_and_range_fallback(dev, live504):
+    """gemm_mode "split_f16": the factored path's hidden GEMM on two fp16 planes.  (1) its latent is as
+    close to the reference's as the bf16-split and exact-fp32 kernels'; (2) out of fp16 range — an
+    activation (coordinates scaled up) or a weight above 65504 — the device-side flag sends the chunk
+    through the bf16 kernels: the result is then bit-identical to gemm_mode "split_bf16"."""
+    from molecular_dynamics_neural_operator_amd import ops
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN
+    z, dset, sd = live504
+    model = KernelNN(*[int(v) for v in z["ctor"]])
+    model.load_state_dict(sd)
+    model.eval().to(dev)
+    s = dset[0].to(dev)
+    first = s.x_position[0].contiguous()
+    g = ops.radius_graph(first, first.shape[0], float(z["threshold"]))
+
+    def latent(mode, frames=s.x_position, pos=first, graph=g):
+        model.gemm_mode = mode
+        return ops.kernelnn_forward(model.param_pack(dev, conv_mode="factored"), frames.unsqueeze(1), s.x_aminoacid, graph,
+                                    edge_pos=pos, return_latent=True)[1]
+
+    want = torch.from_numpy(z["teacher_forced_latent0"]).double()
+    err = {m: float((latent(m).cpu().double() - want).norm() / want.norm()) for m in ("split_f16", "split_bf16", "f32")}
+    print("latent rel-L2 vs reference:", {k: f"{v:.2e}" for k, v in err.items()})
+    assert err["split_f16"] < 3 * max(err["split_bf16"], err["f32"]) and err["split_f16"] < 1e-6
+    assert not torch.equal(latent("split_f16"), latent("split_bf16"))            # (it IS a different kernel)
+    # (2a) activations out of range: the same cloud, coordinates x 3e5 (layer-0 activations reach ~1e6)
+    big_frames, big_pos = s.x_position * 3.0e5, first * 3.0e5
+    gb = ops.radius_graph(big_pos, first.shape[0], float(z["threshold"]) * 3.0e5)
+    a, b = latent("split_f16", big_frames, big_pos, gb), latent("split_bf16", big_frames, big_pos, gb)
+    assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
+    # (2b) one hidden-layer weight out of range
+    with torch.no_grad():
+        model.conv1.net.layers[2].weight[5, 7] = 1.0e5
+    a, b = latent("split_f16"), latent("split_bf16")
+    assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
 
 
 # ------------------------------------------------------------------------------- propogate (nb:336-358)

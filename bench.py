@@ -81,7 +81,7 @@ def parse(argv=None):
     ap.add_argument("--window", type=int, default=10)
     ap.add_argument("--threshold", type=float, default=8.0)
     ap.add_argument("--no-graph", action="store_true", help="plain launches instead of hipGraph replay")
-    ap.add_argument("--gemm-mode", choices=["split_bf16", "split_f16", "f32"], default="split_bf16",
+    ap.add_argument("--gemm-mode", choices=["split_bf16", "split_f16", "f32"], default="split_f16",
                     help="edge-MLP GEMMs: exact 3-way bf16 split (6 products, fp32 accumulate); split_f16 = the same "
                          "with the hidden layer of the factored path on 2 fp16 planes (3 products, device-side "
                          "fallback to bf16 out of fp16 range); f32 = fp32-input MFMA")

@@ -46,7 +46,7 @@ extern "C" {
 /* How the two wide edge-MLP GEMMs are evaluated (fp32 in, fp32 out either way):
  *   SPLIT_BF16  every fp32 operand is split exactly into 3 bf16 planes and the product accumulated
  *               in fp32 from the 6 leading plane products on the bf16 matrix pipe; error vs fp64 at
- *               the level of a plain fp32 GEMM (dropped terms <= 2^-24 |a b|).  Default.  Shapes the
+ *               the level of a plain fp32 GEMM (dropped terms <= 2^-24 |a b|).  Shapes the
  *               tiles do not divide (ker_width % 128, out_dim % 128) silently use F32.
  *   F32         v_mfma_f32_32x32x2_f32: bit-for-bit an fp32 fmaf chain. */
 #define MDNO_GEMM_SPLIT_BF16 0
@@ -56,7 +56,8 @@ extern "C" {
  *               with fp32 accumulation: half the matrix work, error vs fp64 still below a plain fp32
  *               GEMM's.  Exact only for |x| < 65504: producers raise a device flag on a value out of
  *               fp16 range and the chunk is then redone by the SPLIT_BF16 kernels inside the same
- *               forward (no host involvement), so results are fp32-accurate for any input. */
+ *               forward (no host involvement), so results are fp32-accurate for any input.  The Python
+ *               host side's default. */
 #define MDNO_GEMM_SPLIT_F16  2
 
 /* How a conv application is evaluated inside mdno_kernelnn_fwd / the rollout (same function either way):

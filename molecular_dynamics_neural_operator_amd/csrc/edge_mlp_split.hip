@@ -58,21 +58,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-constexpr float F16_LO_SCALE = 2048.f, F16_LO_UNSCALE = 1.f / 2048.f, F16_MAX = 65504.f;
-
-__device__ __forceinline__ void split2h(float x, _Float16& h, _Float16& l) {
-    h = (_Float16)x;
-    l = (_Float16)((x - (float)h) * F16_LO_SCALE);
-}
-
-// Byte offset of element (row, kcol) of plane p in the two-plane image (same 4 KiB plane tiles and
-// swizzle as tiled_off, two planes per k-step instead of three).
-__device__ __forceinline__ size_t tiled_off2(long long row, int kcol, int nkt, int p) {
-    const long long rt = row >> 7;
-    const int r = (int)(row & 127), kt = kcol >> 4, c = (kcol >> 3) & 1, e = kcol & 7;
-    return ((size_t)((rt * nkt + kt) * 2 + p) << 12) + r * 32 + ((c ^ ((r >> 3) & 1)) << 4) + e * 2;
-}
-
 // flags[0]: a weight is out of fp16 range (set when the weight planes are built);
 // flags[1]: an activation of the current forward is.  Either one sends the chunk down the bf16 path.
 __device__ __forceinline__ bool f16_blocked(const int* __restrict__ flags) {
@@ -137,7 +122,8 @@ __global__ __launch_bounds__(256) void split_planes_f16_kernel(const float* __re
 // (i ascending, fmaf), threads o < 8 also split the row's 8-float chunk o.
 __global__ __launch_bounds__(256) void split_bias64_kernel(const float* __restrict__ x, const float* __restrict__ b,
                                                            int rows, unsigned char* __restrict__ planes,
-                                                           float* __restrict__ q) {
+                                                           float* __restrict__ q, unsigned char* __restrict__ planes_h,
+                                                           int* __restrict__ range_flag) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), o = threadIdx.x & 63;
     if (row >= rows) return;
     const float* xr = x + (size_t)row * 64;
@@ -155,6 +141,19 @@ __global__ __launch_bounds__(256) void split_bias64_kernel(const float* __restri
 #pragma unroll
         for (int p = 0; p < 3; ++p)
             *reinterpret_cast<uint4*>(planes + tiled_off(row, 8 * o, 4, p)) = *reinterpret_cast<const uint4*>(pl[p]);
+        if (planes_h != nullptr) {
+            _Float16 ph[2][8];
+            bool bad = false;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                bad |= !(fabsf(xv[j]) < F16_MAX);
+                split2h(xv[j], ph[0][j], ph[1][j]);
+            }
+            if (bad) atomicOr(range_flag, 1);
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                *reinterpret_cast<uint4*>(planes_h + tiled_off2(row, 8 * o, 4, p)) = *reinterpret_cast<const uint4*>(ph[p]);
+        }
     }
 }
 
@@ -586,6 +585,91 @@ int launch_split_f16_gemm(SplitGemmArgs g, hipStream_t s) {
     return check_launch("split-f16 GEMM");
 }
 
+
+// ---------------------------------------------------------------- K = 64 GEMM on two fp16 planes
+// C [rows, N] = A . Bt^T for the factored conv's Y = X . W3T (factored.hip step (1)): 4.2 GFLOP for a
+// 132 MB result — a store with a little arithmetic in front.  K is four k-steps: a 128 x 128 tile's
+// whole operand set (32 KiB of A planes + 32 KiB of B planes, each ONE contiguous run of the tiled
+// images) is brought in by a single burst of LDS-DMA, waited for once, multiplied (48 MFMAs per wave)
+// and stored; 64 KiB of LDS: two workgroups per CU, so one's stores overlap the other's load + multiply
+// (37 -> 31 us per launch against the 256-row bf16 kernel with its four-stage pipeline).
+// Out of fp16 range (flag_w: a weight, flag_x: a node feature of this application — exploding
+// activations of an untrained net get there) the SAME launch multiplies the bf16 plane images instead,
+// in two halves of K through the same LDS: no second launch, bit-identical to gemm_split_bf16_kernel.
+constexpr int K64_LDS_BYTES = 2 * 4 * 2 * PLANE_BYTES;     // A | B, 4 k-steps x 2 planes x 4 KiB each
+
+__global__ __launch_bounds__(256) void gemm_k64_f16_kernel(const unsigned char* __restrict__ Ah,
+                                                           const unsigned char* __restrict__ Bh,
+                                                           const unsigned char* __restrict__ Ab,
+                                                           const unsigned char* __restrict__ Bb,
+                                                           const int* __restrict__ flag_w,
+                                                           const int* __restrict__ flag_x, float* __restrict__ C,
+                                                           int rows_valid, int N, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    // XCD-contiguous tile ranges, m fastest (the tiles of one B panel run back to back on one XCD)
+    const int nwg = tiles_m * tiles_n, orig = blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, r8 = nwg & 7;
+    const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
+    const int tm = tile % tiles_m, tn = tile / tiles_m;
+    const int bm = tm * 128, bn = tn * TN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
+    const bool blocked = (__builtin_nontemporal_load(flag_w) | __builtin_nontemporal_load(flag_x)) != 0;
+    f32x16 acc[2][2], accx[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.f; accx[i][j][e] = 0.f; }
+    const int hsw = (h ^ ((l31 >> 3) & 1)) << 4;
+    const int a_rd = (wm * 64 + l31) * 32 + hsw, b_rd = 32768 + (wn * 64 + l31) * 32 + hsw;
+    if (!blocked) {
+        const unsigned char* a_src = Ah + ((size_t)tm << 15) + lane * 16;      // 32 KiB per 128-row tile
+        const unsigned char* b_src = Bh + ((size_t)tn << 15) + lane * 16;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {       // wave w moves KiB w, w+4, ... of A and of B
+            const int piece = wave + 4 * t;
+            __builtin_amdgcn_global_load_lds((glb_u8*)(a_src + piece * 1024), (lds_u8*)(lds + piece * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_u8*)(b_src + piece * 1024), (lds_u8*)(lds + 32768 + piece * 1024), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) mma_f16_kstep(acc, accx, lds + ks * 2 * PLANE_BYTES, a_rd, b_rd);
+    } else {
+        // bf16 planes: 12 KiB per k-step per 128-row tile; two k-steps (24 KiB of A, 24 KiB of B) at a time
+        const unsigned char* a_src = Ab + (size_t)tm * 4 * 3 * PLANE_BYTES + lane * 16;
+        const unsigned char* b_src = Bb + (size_t)tn * 4 * 3 * PLANE_BYTES + lane * 16;
+        for (int half = 0; half < 2; ++half) {
+            if (half) __syncthreads();      // everyone is done reading the first half
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                const int piece = wave + 4 * t;       // 24 pieces of A, 24 of B
+                __builtin_amdgcn_global_load_lds((glb_u8*)(a_src + (half * 24 + piece) * 1024), (lds_u8*)(lds + piece * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_u8*)(b_src + (half * 24 + piece) * 1024), (lds_u8*)(lds + 32768 + piece * 1024), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) mma_split_stage(acc, lds + ks * 3 * PLANE_BYTES, a_rd, b_rd);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = bn + wn * 64 + j * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = bm + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                // (fallback: accx is all zero and the sum below is acc itself, bit for bit)
+                if (m < rows_valid) C[(size_t)m * N + n] = acc[i][j][e] + accx[i][j][e] * F16_LO_UNSCALE;
+            }
+    }
+}
+
 template <int TM, int OUT>
 int launch_split_gemm_tm(SplitGemmArgs g, hipStream_t s) {
     constexpr int lds_bytes = 2 * stage_bytes(TM);
@@ -608,6 +692,19 @@ int launch_split_gemm(const SplitGemmArgs& g, int kid, hipStream_t s) {
 
 }  // namespace
 
+namespace {
+__global__ void fill_ints_kernel(int* p, int n, int v) {
+    if ((int)threadIdx.x < n) p[threadIdx.x] = v;
+}
+}  // namespace
+
+// n <= 256 ints set by a kernel (not a memset node: a captured step stays a plain chain of kernel nodes)
+int fill_ints(int* p, int n, int value, hipStream_t s) {
+    MDNO_REQUIRE(p && n > 0 && n <= 256, MDNO_EINVAL, "fill_ints: n=%d", n);
+    hipLaunchKernelGGL(fill_ints_kernel, dim3(1), dim3(256), 0, s, p, n, value);
+    return check_launch("fill_ints_kernel");
+}
+
 // ---------------------------------------------------------------- generic pieces (factored.hip step (1))
 size_t split_planes_bytes(long long rows, int K) {
     return (size_t)3 * ((rows + 255) / 256 * 256) * K * sizeof(__bf16);   // whole 256-row GEMM tiles
@@ -621,11 +718,40 @@ int split_planes(const float* a, int rows, int K, void* planes, hipStream_t s) {
     return check_launch("split_planes_kernel");
 }
 
-int split_planes_bias64(const float* x, int rows, const float* b, float* q, void* planes, hipStream_t s) {
-    MDNO_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && b && q, MDNO_EINVAL, "split_planes_bias64: bad arguments");
+int split_planes_bias64(const float* x, int rows, const float* b, float* q, void* planes, hipStream_t s, void* planes_h,
+                        int* range_flag) {
+    MDNO_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && b && q && (!planes_h || range_flag), MDNO_EINVAL,
+                 "split_planes_bias64: bad arguments");
     hipLaunchKernelGGL(split_bias64_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, b, rows,
-                       static_cast<unsigned char*>(planes), q);
+                       static_cast<unsigned char*>(planes), q, static_cast<unsigned char*>(planes_h), range_flag);
     return check_launch("split_bias64_kernel");
+}
+
+size_t split_planes_f16_bytes(long long rows, int K) {
+    return (size_t)2 * ((rows + 255) / 256 * 256) * K * sizeof(_Float16);
+}
+
+int split_planes_f16(const float* a, int rows, int K, void* planes, int* range_flag, hipStream_t s) {
+    MDNO_REQUIRE(K % 16 == 0 && (reinterpret_cast<uintptr_t>(a) & 15) == 0 && range_flag, MDNO_EINVAL,
+                 "split_planes_f16: K=%d", K);
+    const long long chunks = (long long)rows * (K / 8);
+    hipLaunchKernelGGL(split_planes_f16_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, s, a, rows, K,
+                       static_cast<unsigned char*>(planes), range_flag);
+    return check_launch("split_planes_f16_kernel");
+}
+
+int split_gemm_rows_k64_f16(const void* a_planes, const void* b_planes, const void* a_bf16, const void* b_bf16,
+                            const int* flag_w, const int* flag_x, int rows, int N, float* C, hipStream_t s) {
+    MDNO_REQUIRE(N % TN == 0 && rows > 0 && a_bf16 && b_bf16 && flag_w && flag_x, MDNO_EUNSUPPORTED,
+                 "split_gemm_rows_k64_f16: rows=%d N=%d", rows, N);
+    static std::atomic<unsigned long long> lds_raised{0};
+    MDNO_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(&gemm_k64_f16_kernel), K64_LDS_BYTES, lds_raised));
+    const int tiles_m = (rows + 127) / 128, tiles_n = N / TN;
+    hipLaunchKernelGGL(gemm_k64_f16_kernel, dim3(tiles_m * tiles_n), dim3(256), K64_LDS_BYTES, s,
+                       static_cast<const unsigned char*>(a_planes), static_cast<const unsigned char*>(b_planes),
+                       static_cast<const unsigned char*>(a_bf16), static_cast<const unsigned char*>(b_bf16), flag_w, flag_x,
+                       C, rows, N, tiles_m, tiles_n);
+    return check_launch("gemm_k64_f16_kernel");
 }
 
 // C[rows, N] (fp32 row-major) = A . Bt^T from tiled planes of A [rows, K] and Bt [N, K]
@@ -738,7 +864,7 @@ int edge_mlp_split_hidden(const float* frames, int frame, const int* t_dev, int 
         const long long c1 = (long long)k * (k / 8);
         hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((c1 + 255) / 256)), dim3(256), 0, s, w.w1, k, k, w1p);
         if (f16) {   // fp16 image of W1 + its range flag (flags[0]); the bf16 image above serves the fallback
-            MDNO_HIP(hipMemsetAsync(sw.f16_flags, 0, sizeof(int), s));
+            MDNO_TRY(fill_ints(sw.f16_flags, 1, 0, s));
             hipLaunchKernelGGL(split_planes_f16_kernel, dim3((unsigned)((c1 + 255) / 256)), dim3(256), 0, s, w.w1, k, k,
                                sw.w1h, sw.f16_flags);
         }
@@ -746,7 +872,7 @@ int edge_mlp_split_hidden(const float* frames, int frame, const int* t_dev, int 
     MDNO_TRY(check_launch("split_planes_kernel"));
     if (phase == WP_PREPARE_ONLY) return MDNO_OK;
     const float* pos_mode = edge_attr ? nullptr : frames;
-    if (f16) MDNO_HIP(hipMemsetAsync(sw.f16_flags + 1, 0, sizeof(int), s));   // activation flag of THIS forward
+    if (f16) MDNO_TRY(fill_ints(sw.f16_flags + 1, 1, 0, s));   // activation flag of THIS forward
     for (long long e0 = 0; e0 < edge_cap; e0 += chunk) {
         const int cnt = (int)((edge_cap - e0) < chunk ? (edge_cap - e0) : chunk);
         float* out = h_out + (size_t)e0 * k;      // chunk % 128 == 0: the k-tiled tile index continues across chunks

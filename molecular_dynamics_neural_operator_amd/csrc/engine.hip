@@ -162,7 +162,8 @@ int forward_impl(const mdno_kernelnn_params* p, const float* frames, int t0, con
                                                             : nullptr;
                 MDNO_TRY(factored_conv(cur, ws.h2, row_ptr, R, N, max_degree > 0 ? max_degree : N, p->ker_width,
                                        cgm, b3, root, bias, MDNO_AGGR_MEAN, /*relu=*/1, nxt, fw, status, s,
-                                       /*x_prepared=*/!first, next_b3));
+                                       /*x_prepared=*/!first, next_b3,
+                                       p->gemm_mode == MDNO_GEMM_SPLIT_F16 ? block * p->depth + d : -1));
                 float* t = cur; cur = nxt; nxt = t;
             }
         }

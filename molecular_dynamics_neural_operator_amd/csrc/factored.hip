@@ -199,13 +199,13 @@ __global__ __launch_bounds__(256, 4) void gemm_per_source_kernel(const float* __
                                                                  const float* __restrict__ Q,
                                                                  const int* __restrict__ row_ptr,
                                                                  float* __restrict__ Mp, long long part_stride,
-                                                                 int K, int* __restrict__ status) {
+                                                                 int K, int row0, int* __restrict__ status) {
     __shared__ __attribute__((aligned(16))) float As[128 * LD];
     __shared__ __attribute__((aligned(16))) float Bs[64 * LD];
     // source j is the fastest grid dimension: workgroups are dealt round-robin over the 8 XCDs by
     // linear id, and with the m-tile fastest (most sources have one tile) 3/4 of the work landed on
-    // two XCDs
-    const int j = blockIdx.x, slice = blockIdx.z;
+    // two XCDs.  The launch covers sources row0 .. row0+gridDim.x-1; Y holds that chunk only.
+    const int j = row0 + blockIdx.x, slice = blockIdx.z;
     const int beg = row_ptr[j], end = row_ptr[j + 1];
     const int r0 = beg + blockIdx.y * 128;
     if (blockIdx.y == gridDim.y - 1 && slice == 0 && threadIdx.x == 0 && end - beg > (int)gridDim.y * 128 && status)
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256, 4) void gemm_per_source_kernel(const float* __
     const float* A1 = aptr(srow + 32);
     const float* A2 = aptr(srow + 64);
     const float* A3 = aptr(srow + 96);
-    const float* Bg = Y + (size_t)j * 64 * K + (size_t)kt0 * 2048 + srow * 32 + scol;
+    const float* Bg = Y + (size_t)(j - row0) * 64 * K + (size_t)kt0 * 2048 + srow * 32 + scol;
     float4 ra0, ra1, ra2, ra3, rb0, rb1;
 #define MDNO_LOAD(KT)                                                         \
     ra0 = *reinterpret_cast<const float4*>(A0 + (size_t)(KT) * 4096);         \
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256, 4) void gemm_per_source_split_kernel(const flo
                                                                        const float* __restrict__ Q,
                                                                        const int* __restrict__ row_ptr,
                                                                        float* __restrict__ Mp, long long part_stride,
-                                                                       int K, int ks_tail, int slots,
+                                                                       int K, int ks_tail, int slots, int row0,
                                                                        int* __restrict__ status) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[3 * SPL_A_PLANE + 3 * SPL_B_PLANE];
     // slots of a source: [tile 0: slices 0..KS-1 | tile 1: slices 0..ks_tail-1 | tile 2 ...].
@@ -346,6 +346,8 @@ __global__ __launch_bounds__(256, 4) void gemm_per_source_split_kernel(const flo
         j = (int)(blockIdx.x / (unsigned)slots);
         slot = (int)((blockIdx.x % (unsigned)slots + (unsigned)j) % (unsigned)slots);
     }
+    const int jl = j;      // index inside this launch's chunk of sources (Y holds the chunk only)
+    j += row0;
     const int mt = slot < KS ? 0 : 1 + (slot - KS) / ks_tail;
     const int slice = slot < KS ? slot : (slot - KS) % ks_tail;
     const int ks = mt == 0 ? KS : ks_tail;
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(256, 4) void gemm_per_source_split_kernel(const flo
     const float* A1 = aptr(srow + 32);
     const float* A2 = aptr(srow + 64);
     const float* A3 = aptr(srow + 96);
-    const float* Bg = Y + (size_t)j * 64 * K + (size_t)kt0 * 2048 + srow * 32 + scol;
+    const float* Bg = Y + (size_t)jl * 64 * K + (size_t)kt0 * 2048 + srow * 32 + scol;
     float4 ra0, ra1 = make_float4(0.f, 0.f, 0.f, 0.f), ra2 = ra1, ra3 = ra1, rb0, rb1;
     // H is streamed once per application: non-temporal loads (global_load ... nt) leave the caches to
     // Y_j and the partial sums (-4.5 % kernel time)
@@ -472,7 +474,10 @@ __global__ __launch_bounds__(256) void reverse_edges_kernel(const int* __restric
                                                             const int* __restrict__ col,
                                                             const int* __restrict__ rowid, int num_rows,
                                                             int* __restrict__ rev, int* __restrict__ status,
-                                                            int tail_planes) {
+                                                            int tail_planes, int* __restrict__ f16_x_flags) {
+    // once per forward, before any conv application: no node feature has been seen out of fp16 range
+    // yet (a kernel's stores rather than a memset node: the captured step stays a chain of kernels)
+    if (blockIdx.x == 0 && threadIdx.x <= kMaxF16Applications) f16_x_flags[threadIdx.x] = 0;
     const int E = row_ptr[num_rows];
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= E) return;
@@ -511,7 +516,9 @@ __global__ __launch_bounds__(256) void aggregate_rev_kernel(const float* __restr
                                                             int num_rows, int aggr, int relu,
                                                             const float* __restrict__ next_b3,
                                                             float* __restrict__ next_q,
-                                                            unsigned char* __restrict__ next_xp) {
+                                                            unsigned char* __restrict__ next_xp,
+                                                            unsigned char* __restrict__ next_xh,
+                                                            int* __restrict__ next_flag) {
     __shared__ float4 part[16][16];
     const int tid = threadIdx.x, es = tid >> 4, q = tid & 15;
     const int t = blockIdx.x;
@@ -628,6 +635,19 @@ __global__ __launch_bounds__(256) void aggregate_rev_kernel(const float* __restr
 #pragma unroll
             for (int p = 0; p < 3; ++p)
                 *reinterpret_cast<uint4*>(next_xp + tiled_off(t, 8 * c, 4, p)) = *reinterpret_cast<const uint4*>(pl[p]);
+            if (next_xh != nullptr) {
+                _Float16 ph[2][8];
+                bool bad = false;
+#pragma unroll
+                for (int j2 = 0; j2 < 8; ++j2) {
+                    bad |= !(fabsf(row[8 * c + j2]) < F16_MAX);
+                    split2h(row[8 * c + j2], ph[0][j2], ph[1][j2]);
+                }
+                if (bad) atomicOr(next_flag, 1);
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+                    *reinterpret_cast<uint4*>(next_xh + tiled_off2(t, 8 * c, 4, p)) = *reinterpret_cast<const uint4*>(ph[p]);
+            }
         }
     }
 }
@@ -637,15 +657,27 @@ __global__ __launch_bounds__(256) void aggregate_rev_kernel(const float* __restr
 // ---------------------------------------------------------------- host side
 bool factored_supported(int width, int ker_width) { return width == 64 && ker_width % (KS_TAIL * BK) == 0; }
 
+// Steps (1) and (2) run chunk by chunk over the sources: a chunk's Y (512 rows x 256 KiB = 128 MiB at
+// k = 1024) is written by the Y GEMM and read back by the per-source GEMM right behind it, while it is
+// still in the 256 MiB Infinity Cache — and always at the same addresses, so an ensemble of any size
+// keeps ONE chunk of Y alive instead of one Y per member (8 members: 1 GB, evicted between producer and
+// consumer).  Chunks are cut at multiples of the GEMM's 256-row tile, not at member boundaries; a
+// source's arithmetic does not depend on the chunk it is in.
+constexpr int kYChunkRows = 512;
+static int y_chunk_rows(int num_rows) { return num_rows < kYChunkRows ? num_rows : kYChunkRows; }
+
 size_t factored_workspace_bytes(int num_rows, int ker_width, long long edge_cap) {
     Carver cv(nullptr);
     cv.take<float>((size_t)64 * ker_width * 64);               // W3T
-    cv.take<float>((size_t)num_rows * 64 * ker_width);         // Y
+    cv.take<float>((size_t)y_chunk_rows(num_rows) * 64 * ker_width);   // Y, one chunk of sources
     cv.take<float>((size_t)num_rows * 64);                     // q
     cv.take<float>((size_t)MAX_PLANES * edge_cap * 64);        // M: k-slice partials, one plane each
     cv.take<int>((size_t)edge_cap);                            // rev
     cv.take<char>(split_planes_bytes((long long)64 * ker_width, 64));   // W3T as bf16 planes
     cv.take<char>(split_planes_bytes(num_rows, 64));                    // X as bf16 planes
+    cv.take<char>(split_planes_f16_bytes((long long)64 * ker_width, 64));   // W3T as fp16 planes
+    cv.take<char>(split_planes_f16_bytes(num_rows, 64));                    // X as fp16 planes
+    cv.take<int>(64);                                                   // fp16 range flags
     return cv.used();
 }
 
@@ -653,13 +685,16 @@ FactoredWs factored_carve(void* ws, int num_rows, int ker_width, long long edge_
     FactoredWs f{};
     Carver cv(ws);
     f.w3t = cv.take<float>((size_t)64 * ker_width * 64);
-    f.y = cv.take<float>((size_t)num_rows * 64 * ker_width);
+    f.y = cv.take<float>((size_t)y_chunk_rows(num_rows) * 64 * ker_width);
     f.q = cv.take<float>((size_t)num_rows * 64);
     f.m = cv.take<float>((size_t)MAX_PLANES * edge_cap * 64);
     f.part_stride = (long long)edge_cap * 64;
     f.rev = cv.take<int>((size_t)edge_cap);
     f.w3tp = cv.take<char>(split_planes_bytes((long long)64 * ker_width, 64));
     f.xp = cv.take<char>(split_planes_bytes(num_rows, 64));
+    f.w3th = cv.take<char>(split_planes_f16_bytes((long long)64 * ker_width, 64));
+    f.xh = cv.take<char>(split_planes_f16_bytes(num_rows, 64));
+    f.f16_flags = cv.take<int>(64);
     return f;
 }
 
@@ -668,7 +703,11 @@ int factored_prepare_weights(const float* w3, int ker_width, int gemm_mode, cons
     hipLaunchKernelGGL(w3_transpose_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w3, 64, ker_width,
                        f.w3t);
     MDNO_TRY(check_launch("w3_transpose_kernel"));
-    if (gemm_mode == MDNO_GEMM_SPLIT_BF16) MDNO_TRY(split_planes(f.w3t, 64 * ker_width, 64, f.w3tp, s));
+    if (gemm_mode == MDNO_GEMM_SPLIT_BF16) {
+        MDNO_TRY(split_planes(f.w3t, 64 * ker_width, 64, f.w3tp, s));
+        MDNO_TRY(fill_ints(f.f16_flags, 1, 0, s));
+        MDNO_TRY(split_planes_f16(f.w3t, 64 * ker_width, 64, f.w3th, f.f16_flags, s));
+    }
     return MDNO_OK;
 }
 
@@ -682,55 +721,82 @@ int factored_prepare_graph(const int* row_ptr, const int* col, const int* rowid,
     MDNO_REQUIRE(edge_cap <= REV_MASK, MDNO_EUNSUPPORTED, "factored conv: edge_cap %lld exceeds %d", edge_cap, REV_MASK);
     TimedSection ts(KID_GRAPH, s);
     hipLaunchKernelGGL(reverse_edges_kernel, dim3((unsigned)((edge_cap + 255) / 256)), dim3(256), 0, s, row_ptr, col,
-                       rowid, num_rows, f.rev, status, tail_slices(gemm_mode, rows_per_member));
+                       rowid, num_rows, f.rev, status, tail_slices(gemm_mode, rows_per_member), f.f16_flags + 1);
     return check_launch("reverse_edges_kernel");
 }
 
 int factored_conv(const float* x, const float* h2, const int* row_ptr, int num_rows, int rows_per_member,
                   int max_degree, int ker_width,
                   int gemm_mode, const float* b3, const float* root, const float* bias, int aggr, int relu, float* y,
-                  const FactoredWs& f, int* status, hipStream_t s, bool x_prepared, const float* next_b3) {
+                  const FactoredWs& f, int* status, hipStream_t s, bool x_prepared, const float* next_b3,
+                  int application) {
     const size_t lds1 = sizeof(float) * 2 * 256 * LD;   // 73,728 B
+    MDNO_REQUIRE(kYChunkRows % 256 == 0, MDNO_EINVAL, "Y chunk must be a multiple of the GEMM row tile");
     const int ncols = 64 * ker_width;
-    if (gemm_mode == MDNO_GEMM_SPLIT_BF16) {
-        // 6 bf16 plane products (fp32-level accuracy, edge_mlp_split.hip): the matrix work drops under
-        // the 132 MB store of Y, which is what bounds this step
-        TimedSection ts(KID_FACT_Y, s);
+    const bool split = gemm_mode == MDNO_GEMM_SPLIT_BF16;
+    const bool y_f16 = split && application >= 0;
+    MDNO_REQUIRE(application < kMaxF16Applications, MDNO_EUNSUPPORTED, "factored conv: more than %d applications",
+                 kMaxF16Applications);
+    int* flag_x = y_f16 ? f.f16_flags + 1 + application : nullptr;
+    if (split) {
         // X -> planes and q = X . B3: done by the previous application's aggregation when x_prepared
-        if (!x_prepared) MDNO_TRY(split_planes_bias64(x, num_rows, b3, f.q, f.xp, s));
-        MDNO_TRY(split_gemm_rows(f.xp, f.w3tp, num_rows, ncols, 64, f.y, s));
+        if (!x_prepared) {
+            TimedSection ts(KID_FACT_Y, s);
+            MDNO_TRY(split_planes_bias64(x, num_rows, b3, f.q, f.xp, s, y_f16 ? f.xh : nullptr, flag_x));
+        }
     } else {
         static std::atomic<unsigned long long> lds_raised{0};
         MDNO_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(&gemm_rows_guarded_kernel), (int)lds1, lds_raised));
         TimedSection ts(KID_FACT_Y, s);
         hipLaunchKernelGGL(node_bias_kernel, dim3((num_rows + 3) / 4), dim3(256), 0, s, x, b3, num_rows, f.q);
-        hipLaunchKernelGGL(gemm_rows_guarded_kernel, dim3(ncols / 128, (num_rows + 127) / 128), dim3(256), lds1, s, x,
-                           (const float*)f.w3t, f.y, num_rows, ncols, 64);
     }
-    {
-        TimedSection ts(KID_NNCONV, s);
-        const int mtiles = (max_degree + 127) / 128;
-        const int kt = tail_slices(gemm_mode, rows_per_member);
-        if (gemm_mode == MDNO_GEMM_SPLIT_BF16) {
-            const int slots = KS + (mtiles - 1) * kt;
-            // many rounds of workgroups (large members, or many members): source-major
-            const long long nwg = (long long)num_rows * slots;
-            const bool source_major = nwg >= 8192 && nwg < (1ll << 31);
-            hipLaunchKernelGGL(gemm_per_source_split_kernel,
-                               source_major ? dim3((unsigned)(num_rows * slots), 1) : dim3(num_rows, slots), dim3(256),
-                               0, s, h2, (const float*)f.y, (const float*)f.q, row_ptr, f.m, f.part_stride, ker_width,
-                               kt, slots, status);
+    const int mtiles = (max_degree + 127) / 128;
+    const int kt = tail_slices(gemm_mode, rows_per_member);
+    const int slots = KS + (mtiles - 1) * kt;
+    for (int r0 = 0; r0 < num_rows; r0 += kYChunkRows) {
+        const int cnt = num_rows - r0 < kYChunkRows ? num_rows - r0 : kYChunkRows;
+        {   // (1) Y of sources r0 .. r0+cnt-1
+            TimedSection ts(KID_FACT_Y, s);
+            if (split) {
+                // 6 bf16 plane products (fp32-level accuracy, edge_mlp_split.hip): the matrix work drops
+                // under the store of Y, which is what bounds this step.  r0 is a multiple of the 128-row
+                // plane tiles: the chunk's planes start at tile r0/128 (K = 64: 4 k-steps x 12 KiB each)
+                const unsigned char* xp = static_cast<const unsigned char*>(f.xp) + (size_t)(r0 >> 7) * 4 * 3 * 4096;
+                if (y_f16) {   // two fp16 planes, 32 KiB per 128-row tile (bf16 images ride along for the fallback)
+                    const unsigned char* xh = static_cast<const unsigned char*>(f.xh) + ((size_t)(r0 >> 7) << 15);
+                    MDNO_TRY(split_gemm_rows_k64_f16(xh, f.w3th, xp, f.w3tp, f.f16_flags, flag_x, cnt, ncols, f.y, s));
+                } else {
+                    MDNO_TRY(split_gemm_rows(xp, f.w3tp, cnt, ncols, 64, f.y, s));
+                }
+            } else {
+                hipLaunchKernelGGL(gemm_rows_guarded_kernel, dim3(ncols / 128, (cnt + 127) / 128), dim3(256), lds1, s,
+                                   x + (size_t)r0 * 64, (const float*)f.w3t, f.y, cnt, ncols, 64);
+            }
         }
-        else
-            hipLaunchKernelGGL(gemm_per_source_kernel, dim3(num_rows, mtiles, KS), dim3(256), 0, s, h2,
-                               (const float*)f.y, (const float*)f.q, row_ptr, f.m, f.part_stride, ker_width, status);
+        {   // (2) the per-source GEMMs of the same sources
+            TimedSection ts(KID_NNCONV, s);
+            if (split) {
+                // many rounds of workgroups (large members): source-major
+                const long long nwg = (long long)cnt * slots;
+                const bool source_major = nwg >= 8192 && nwg < (1ll << 31);
+                hipLaunchKernelGGL(gemm_per_source_split_kernel,
+                                   source_major ? dim3((unsigned)(cnt * slots), 1) : dim3(cnt, slots), dim3(256), 0, s,
+                                   h2, (const float*)f.y, (const float*)f.q, row_ptr, f.m, f.part_stride, ker_width,
+                                   kt, slots, r0, status);
+            } else {
+                hipLaunchKernelGGL(gemm_per_source_kernel, dim3(cnt, mtiles, KS), dim3(256), 0, s, h2,
+                                   (const float*)f.y, (const float*)f.q, row_ptr, f.m, f.part_stride, ker_width, r0,
+                                   status);
+            }
+        }
     }
     const bool split_next = gemm_mode == MDNO_GEMM_SPLIT_BF16 && next_b3 != nullptr;
     {
         TimedSection ts(KID_NNCONV_COMBINE, s);
         hipLaunchKernelGGL(aggregate_rev_kernel, dim3(num_rows), dim3(256), 0, s, (const float*)f.m,
                            f.part_stride, (const int*)f.rev, row_ptr, x, root, bias, y, num_rows, aggr, relu,
-                           split_next ? next_b3 : nullptr, f.q, static_cast<unsigned char*>(f.xp));
+                           split_next ? next_b3 : nullptr, f.q, static_cast<unsigned char*>(f.xp),
+                           y_f16 ? static_cast<unsigned char*>(f.xh) : nullptr, y_f16 ? flag_x + 1 : nullptr);
     }
     return check_launch("factored_conv");
 }

@@ -66,7 +66,16 @@ inline int conv_gemm_mode(int gemm_mode) { return gemm_mode == MDNO_GEMM_SPLIT_F
 size_t split_planes_bytes(long long rows, int K);
 int split_planes(const float* a, int rows, int K, void* planes, hipStream_t s);
 // K = 64 only: the same split of x [rows,64], fused with q[r][o] = sum_i x[r][i] * b[i*64 + o] (fp32 [rows,64])
-int split_planes_bias64(const float* x, int rows, const float* b, float* q, void* planes, hipStream_t s);
+int split_planes_bias64(const float* x, int rows, const float* b, float* q, void* planes, hipStream_t s,
+                        void* planes_f16 = nullptr, int* range_flag = nullptr);   // planes_f16: also the two-plane
+                                                       // fp16 image of x; *range_flag raised when |x| >= 65504
+int fill_ints(int* p, int n, int value, hipStream_t s);     // n <= 256, by a kernel
+// two-plane fp16 images (SPLIT_F16) and the K = 64 GEMM on them (the factored conv's Y = X . W3T)
+size_t split_planes_f16_bytes(long long rows, int K);
+int split_planes_f16(const float* a, int rows, int K, void* planes, int* range_flag, hipStream_t s);
+// (bf16 images of the same operands + the two range flags: the kernel multiplies those when a flag is up)
+int split_gemm_rows_k64_f16(const void* a_planes, const void* b_planes, const void* a_bf16, const void* b_bf16,
+                            const int* flag_w, const int* flag_x, int rows, int N, float* C, hipStream_t s);
 int split_gemm_rows(const void* a_planes, const void* b_planes, int rows, int N, int K, float* C, hipStream_t s);
 // C = act(A . W^T + b) with both operands split on the way in (training ops)
 size_t split_linear_workspace_bytes(long long rows, int N, int K);
@@ -78,6 +87,8 @@ int split_linear(const float* a, const float* w, const float* bias, long long ro
 struct FactoredWs {
     float *w3t, *y, *m, *q;
     void *w3tp, *xp;          // split-bf16 images of W3T and of the current node features
+    void *w3th, *xh;          // the same as two fp16 planes (SPLIT_F16)
+    int* f16_flags;           // [0]: W3T out of fp16 range; [1 + a]: the node features entering application a are
     int* rev;
     long long part_stride;
 };
@@ -90,7 +101,11 @@ int factored_prepare_graph(const int* row_ptr, const int* col, const int* rowid,
 int factored_conv(const float* x, const float* h2, const int* row_ptr, int num_rows, int rows_per_member,
                   int max_degree, int ker_width,
                   int gemm_mode, const float* b3, const float* root, const float* bias, int aggr, int relu, float* y,
-                  const FactoredWs& f, int* status, hipStream_t s, bool x_prepared, const float* next_b3);
+                  const FactoredWs& f, int* status, hipStream_t s, bool x_prepared, const float* next_b3,
+                  int application = -1);
+// application >= 0 (SPLIT_F16): index of this conv application inside the forward; step (1) then runs on
+// the fp16 planes, guarded by f16_flags[0] and f16_flags[1 + application].  -1: bf16 planes.
+constexpr int kMaxF16Applications = 62;
 // x_prepared: the bf16 image of x and q = x.B3 are already in f.xp / f.q (left there by the previous
 // application, which was given this application's b3 as next_b3); next_b3 NULL: nothing follows.
 

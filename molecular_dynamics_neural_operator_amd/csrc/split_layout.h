@@ -22,4 +22,20 @@ __device__ __forceinline__ size_t tiled_off(long long row, int kcol, int nkt, in
     return ((size_t)((rt * nkt + kt) * 3 + p) << 12) + r * 32 + ((c ^ ((r >> 3) & 1)) << 4) + e * 2;
 }
 
+// ---- two fp16 planes (SPLIT_F16, see edge_mlp_split.hip): x = hi + 2^-11 lo', exact for |x| < 65504
+constexpr float F16_LO_SCALE = 2048.f, F16_LO_UNSCALE = 1.f / 2048.f, F16_MAX = 65504.f;
+
+__device__ __forceinline__ void split2h(float x, _Float16& h, _Float16& l) {
+    h = (_Float16)x;
+    l = (_Float16)((x - (float)h) * F16_LO_SCALE);
+}
+
+// Byte offset of element (row, kcol) of plane p in the two-plane image (same 4 KiB plane tiles and
+// swizzle as tiled_off, two planes per k-step instead of three).
+__device__ __forceinline__ size_t tiled_off2(long long row, int kcol, int nkt, int p) {
+    const long long rt = row >> 7;
+    const int r = (int)(row & 127), kt = kcol >> 4, c = (kcol >> 3) & 1, e = kcol & 7;
+    return ((size_t)((rt * nkt + kt) * 2 + p) << 12) + r * 32 + ((c ^ ((r >> 3) & 1)) << 4) + e * 2;
+}
+
 }  // namespace mdno

@@ -197,10 +197,13 @@ class KernelNN(nn.Module):
         self.fc2 = nn.Linear(width, out_width)
         self._pack = None
         self._pack_key = None
-        # how the two wide edge-MLP GEMMs run (include/mdno.h MDNO_GEMM_*): "split_bf16" = exact 3-way
-        # bf16 split of the fp32 operands, 6 products, fp32 accumulation (fp32-level error, 2-3x faster);
+        # how the wide edge-MLP GEMMs run (include/mdno.h MDNO_GEMM_*): "split_bf16" = exact 3-way bf16
+        # split of the fp32 operands, 6 products, fp32 accumulation (fp32-level error, 2-3x faster than
+        # fp32 MFMA); "split_f16" (default) = the same, with the k x k hidden layer of the factored path on
+        # two fp16 planes and 3 products (half the matrix work at the same measured error; values outside
+        # fp16's range are detected on the device and that chunk is redone by the bf16 kernels);
         # "f32" = fp32-input MFMA, bit-for-bit an fmaf chain
-        self.gemm_mode = "split_bf16"
+        self.gemm_mode = "split_f16"
         # how conv applications run inside the on-device rollout / position-graph forward
         # (include/mdno.h MDNO_CONV_*): "factored" = the reference's sums reassociated per node, W_e
         # never formed (csrc/factored.hip; needs width 64 and a radius graph built by the library,
@@ -269,7 +272,7 @@ class KernelNNNotebook(KernelNN):
         self.fc2 = nn.Linear(width, out_width)
         self._pack = None
         self._pack_key = None
-        self.gemm_mode = "split_bf16"
+        self.gemm_mode = "split_f16"
         # how conv applications run inside the on-device rollout / position-graph forward
         # (include/mdno.h MDNO_CONV_*): "factored" = the reference's sums reassociated per node, W_e
         # never formed (csrc/factored.hip; needs width 64 and a radius graph built by the library,

@@ -473,7 +473,7 @@ def test_factored_conv_matches_materialized_and_reference(dev):
     model = KernelNN(*[int(v) for v in z["ctor"]]).eval().to(dev)
     frames = t(z["x_position"], dev)
     g = ops.radius_graph(frames[-1], 504, float(z["threshold"]))
-    for gemm in ("f32", "split_bf16"):
+    for gemm in ("f32", "split_bf16", "split_f16"):
         model.gemm_mode = gemm
         out, lat = ops.kernelnn_forward(model.param_pack(dev, conv_mode="factored"), frames.unsqueeze(1),
                                         t(z["x_aminoacid"]), g, edge_pos=frames[-1], return_latent=True)

@@ -442,18 +442,19 @@ __global__ __launch_bounds__(TM * 2, 2) void gemm_split_bf16_kernel(SplitGemmArg
 // (two k-steps = 32 k: 24 MFMAs + 16 fragment reads per wave, one barrier) and live in a ring of three
 // (3 x 48 KiB), two stages ahead of the MFMAs, with a COUNTED wait — `s_waitcnt vmcnt(6)` lets the
 // newest stage's six pieces stay in flight (loads return in order; the K loop issues no stores).
-__device__ __forceinline__ void mma_f16_kstep(f32x16 (&acc)[2][2], f32x16 (&accx)[2][2], const unsigned char* st,
+template <int MI>   // MI 32-row tiles x 2 32-column tiles per wave
+__device__ __forceinline__ void mma_f16_kstep(f32x16 (&acc)[MI][2], f32x16 (&accx)[MI][2], const unsigned char* st,
                                               int a_rd, int b_rd) {
-    f16x8 a[2][2], b[2][2];
+    f16x8 a[MI][2], b[2][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int p = 0; p < 2; ++p) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            a[i][p] = *reinterpret_cast<const f16x8*>(st + p * PLANE_BYTES + a_rd + i * 32 * 32);
-            b[i][p] = *reinterpret_cast<const f16x8*>(st + p * PLANE_BYTES + b_rd + i * 32 * 32);
-        }
+        for (int i = 0; i < MI; ++i) a[i][p] = *reinterpret_cast<const f16x8*>(st + p * PLANE_BYTES + a_rd + i * 32 * 32);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j) b[j][p] = *reinterpret_cast<const f16x8*>(st + p * PLANE_BYTES + b_rd + j * 32 * 32);
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], accx[i][j], 0, 0, 0);
@@ -462,16 +463,21 @@ __device__ __forceinline__ void mma_f16_kstep(f32x16 (&acc)[2][2], f32x16 (&accx
         }
 }
 
-constexpr int F16_TM = 256, F16_WAVES = 8, F16_RING = 3;
+constexpr int F16_TM = 256, F16_RING = 3;
 constexpr int F16_TILE_BYTES = 2 * 2 * PLANE_BYTES;       // one 128-row tile: two k-steps x two planes = 16 KiB
 constexpr int F16_STAGE_BYTES = 3 * F16_TILE_BYTES;       // A tile 0 | A tile 1 | B = 48 KiB
-constexpr int F16_PPW = F16_STAGE_BYTES / 1024 / F16_WAVES;   // 6 one-KiB DMA pieces per wave per stage
 
 // OUT: 2 = fp32 k-tiled after ReLU (the factored conv's H), 0 = fp32 row-major, 3 = fp32 row-major after ReLU
-template <int OUT>
-__global__ __launch_bounds__(F16_TM * 2) void gemm_split_f16_kernel(SplitGemmArgs g) {
+// MI = 32-row tiles per wave: 2 -> 8 waves of 64x64 (162 VGPRs, two waves per SIMD).  The LDS pipe, not
+// the matrix pipe, is what this shape runs into (176 KiB of LDS traffic per 1,536 matrix-pipe cycles at
+// 128 B/clk); MI = 4 — 4 waves of 128x64, a third fewer fragment reads per MFMA, but 2 x 128 accumulator
+// registers and hence ONE wave per SIMD — was measured at 452 us against 392: nothing hides the
+// barrier and the fragment-read latency any more.  Only MI = 2 is instantiated.
+template <int OUT, int MI>
+__global__ __launch_bounds__(1024 / MI) void gemm_split_f16_kernel(SplitGemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    constexpr int TM = F16_TM, WAVES = F16_WAVES, PPW = F16_PPW;
+    constexpr int TM = F16_TM, WAVES = 16 / MI;
+    constexpr int PPW = F16_STAGE_BYTES / 1024 / WAVES;   // one-KiB DMA pieces per wave per stage: 6 or 12
     if (g.f16_flags != nullptr && f16_blocked(g.f16_flags)) return;   // out of fp16 range: the bf16 launch behind us runs
     long long valid = g.num_edges ? (long long)(*g.num_edges) - g.row_begin : (long long)g.rows_valid;
     if (valid > g.rows) valid = g.rows;
@@ -487,7 +493,7 @@ __global__ __launch_bounds__(F16_TM * 2) void gemm_split_f16_kernel(SplitGemmArg
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave >> 1, wn = wave & 1;              // (8 / MI) x 2 waves
     const int l31 = lane & 31, h = lane >> 5;
 
     // piece qq of a stage: block qq/16 (A row tile 0, A row tile 1, B), KiB qq%16 of that block's 16 KiB;
@@ -512,12 +518,13 @@ __global__ __launch_bounds__(F16_TM * 2) void gemm_split_f16_kernel(SplitGemmArg
     }
 
     const int hsw = (h ^ ((l31 >> 3) & 1)) << 4;
-    const int a_rd = (wm >> 1) * F16_TILE_BYTES + ((wm & 1) * 64 + l31) * 32 + hsw;
+    const int arow = wm * (MI * 32) + l31;                // first of the wave's rows inside the 256-row block
+    const int a_rd = (arow >> 7) * F16_TILE_BYTES + (arow & 127) * 32 + hsw;
     const int b_rd = 2 * F16_TILE_BYTES + (wn * 64 + l31) * 32 + hsw;
 
-    f32x16 acc[2][2], accx[2][2];
+    f32x16 acc[MI][2], accx[MI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -544,8 +551,8 @@ __global__ __launch_bounds__(F16_TM * 2) void gemm_split_f16_kernel(SplitGemmArg
         asm volatile("" ::: "memory");
         if (st + 2 < nst) MDNO_DMA_STAGE(st + 2, slot_in)
         const unsigned char* sb = lds + slot * F16_STAGE_BYTES;
-        mma_f16_kstep(acc, accx, sb, a_rd, b_rd);
-        mma_f16_kstep(acc, accx, sb + 2 * PLANE_BYTES, a_rd, b_rd);
+        mma_f16_kstep<MI>(acc, accx, sb, a_rd, b_rd);
+        mma_f16_kstep<MI>(acc, accx, sb + 2 * PLANE_BYTES, a_rd, b_rd);
         slot = slot == F16_RING - 1 ? 0 : slot + 1;
         slot_in = slot_in == F16_RING - 1 ? 0 : slot_in + 1;
     }
@@ -556,10 +563,10 @@ __global__ __launch_bounds__(F16_TM * 2) void gemm_split_f16_kernel(SplitGemmArg
         const int n = bn + wn * 64 + j * 32 + l31;
         const float bv = j ? bv1 : bv0;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < MI; ++i) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int m = bm + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const int m = bm + wm * (MI * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (m < valid) {
                     const float v = (acc[i][j][e] + accx[i][j][e] * F16_LO_UNSCALE) + bv;
                     if (OUT == 2)
@@ -572,19 +579,18 @@ __global__ __launch_bounds__(F16_TM * 2) void gemm_split_f16_kernel(SplitGemmArg
     }
 }
 
-template <int OUT>
+template <int OUT, int MI>
 int launch_split_f16_gemm(SplitGemmArgs g, hipStream_t s) {
     constexpr int lds_bytes = F16_RING * F16_STAGE_BYTES;     // 147,456 B: one workgroup per CU
     static std::atomic<unsigned long long> lds_raised{0};
-    MDNO_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(&gemm_split_f16_kernel<OUT>), lds_bytes, lds_raised));
+    MDNO_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(&gemm_split_f16_kernel<OUT, MI>), lds_bytes, lds_raised));
     MDNO_REQUIRE(g.K % 32 == 0 && g.N % TN == 0 && g.rows % F16_TM == 0, MDNO_EUNSUPPORTED,
                  "split-f16 GEMM: rows=%d N=%d K=%d", g.rows, g.N, g.K);
     g.tiles_n = g.N / TN;
     g.tiles_m = g.rows / F16_TM;
-    hipLaunchKernelGGL((gemm_split_f16_kernel<OUT>), dim3(g.tiles_n * g.tiles_m), dim3(F16_TM * 2), lds_bytes, s, g);
+    hipLaunchKernelGGL((gemm_split_f16_kernel<OUT, MI>), dim3(g.tiles_n * g.tiles_m), dim3(1024 / MI), lds_bytes, s, g);
     return check_launch("split-f16 GEMM");
 }
-
 
 // ---------------------------------------------------------------- K = 64 GEMM on two fp16 planes
 // C [rows, N] = A . Bt^T for the factored conv's Y = X . W3T (factored.hip step (1)): 4.2 GFLOP for a
@@ -598,7 +604,9 @@ int launch_split_f16_gemm(SplitGemmArgs g, hipStream_t s) {
 // in two halves of K through the same LDS: no second launch, bit-identical to gemm_split_bf16_kernel.
 constexpr int K64_LDS_BYTES = 2 * 4 * 2 * PLANE_BYTES;     // A | B, 4 k-steps x 2 planes x 4 KiB each
 
-__global__ __launch_bounds__(256) void gemm_k64_f16_kernel(const unsigned char* __restrict__ Ah,
+// (two waves per SIMD = the two workgroups per CU the LDS allows: without the bound the two code paths
+// together take 260 registers and leave one)
+__global__ __launch_bounds__(256, 2) void gemm_k64_f16_kernel(const unsigned char* __restrict__ Ah,
                                                            const unsigned char* __restrict__ Bh,
                                                            const unsigned char* __restrict__ Ab,
                                                            const unsigned char* __restrict__ Bb,
@@ -637,7 +645,7 @@ __global__ __launch_bounds__(256) void gemm_k64_f16_kernel(const unsigned char* 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) mma_f16_kstep(acc, accx, lds + ks * 2 * PLANE_BYTES, a_rd, b_rd);
+        for (int ks = 0; ks < 4; ++ks) mma_f16_kstep<2>(acc, accx, lds + ks * 2 * PLANE_BYTES, a_rd, b_rd);
     } else {
         // bf16 planes: 12 KiB per k-step per 128-row tile; two k-steps (24 KiB of A, 24 KiB of B) at a time
         const unsigned char* a_src = Ab + (size_t)tm * 4 * 3 * PLANE_BYTES + lane * 16;
@@ -884,7 +892,7 @@ int edge_mlp_split_hidden(const float* frames, int frame, const int* t_dev, int 
             }
             TimedSection ts(KID_GEMM_L1, s);
             SplitGemmArgs gh{h1p, sw.w1h, w.b1, out, nullptr, num_edges, e0, (int)chunk, k, k, 0, 0, 0, 0, sw.f16_flags};
-            MDNO_TRY(launch_split_f16_gemm<2>(gh, s));
+            MDNO_TRY((launch_split_f16_gemm<2, 2>(gh, s)));
             // the same chunk on the bf16 kernels: both exit at their first instruction unless a range flag is up
             MDNO_TRY(launch_edge_l0_split(pos_mode, frame, t_dev, rows_per_frame, src, dst, edge_attr, perm, num_edges,
                                           e0, cnt, ker_in, k, w.w0, w.b0, h1p, s, false, sw.f16_flags));

@@ -1,10 +1,15 @@
 #!/usr/bin/env python3
-"""Turn rocprofv3 output (gpurun_out/prof/{trace,pmc_fetch,pmc_write}) into the small committed
-summaries under profiles/:  <tag>_kernel_stats.csv, <tag>_pmc.json and roofline_traffic.json.
+"""Turn rocprofv3 output (gpurun_out/prof/{trace,pmc_fetch,pmc_write}_m{1,8}, train_trace — written by
+scripts/collect_profiles.sh) into the small committed summaries under profiles/:
+  <tag>_m<M>_kernel_stats.csv, <tag>_m<M>_bench_under_rocprof.json, <tag>_m<M>_pmc.json,
+  <tag>_train_kernel_stats.csv and roofline_traffic.json.
 
 HBM bytes from PMC as MI355X_MICROARCH.md §HBM prescribes: FETCH_SIZE / WRITE_SIZE are KB, collected
 in separate passes; on gfx950 FETCH_SIZE reports exactly half the bytes of a wide coalesced
 streaming read, so the read side is doubled; WRITE_SIZE is exact for 16-B stores.
+
+roofline_traffic.json holds one entry per (kernel, atoms, members, conv_mode, gemm_mode): bench.py prints
+`traffic` only for the configuration an entry was measured on.
 """
 import csv
 import glob
@@ -15,7 +20,7 @@ from collections import defaultdict
 from pathlib import Path
 
 src = Path(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof")
-tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
 out = Path("profiles")
 out.mkdir(exist_ok=True)
 
@@ -25,45 +30,76 @@ def short(name):
     return (m.group(1) + (m.group(2) or "")) if m else name[:60]
 
 
-stats = glob.glob(str(src / "trace" / "*" / "*_kernel_stats.csv"))
-if stats:
+def kernel_stats(sub, dest):
+    stats = glob.glob(str(src / sub / "*" / "*_kernel_stats.csv"))
+    if not stats:
+        return
     rows = list(csv.DictReader(open(stats[0])))
-    with open(out / f"{tag}_kernel_stats.csv", "w", newline="") as fh:
+    with open(dest, "w", newline="") as fh:
         w = csv.writer(fh)
         w.writerow(["Kernel", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
         for r in rows:
             w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
                         r["MinNs"], r["MaxNs"], r["StdDev"]])
-    print("wrote", out / f"{tag}_kernel_stats.csv")
+    print("wrote", dest)
 
-pmc = {}
-for counter, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
-    files = glob.glob(str(src / sub / "*" / "*_counter_collection.csv"))
-    if not files:
+
+def last_json_line(path):
+    try:
+        return json.loads(Path(path).read_text().strip().splitlines()[-1])
+    except Exception:
+        return None
+
+
+traffic = []
+for M in (1, 8):
+    kernel_stats(f"trace_m{M}", out / f"{tag}_m{M}_kernel_stats.csv")
+    line = last_json_line(src / f"bench_m{M}.json")
+    if line is not None:
+        (out / f"{tag}_m{M}_bench_under_rocprof.json").write_text(json.dumps(line, indent=1))
+    pmc = {}
+    cfg = last_json_line(src / f"pmc_fetch_m{M}.json")
+    for counter, sub in (("FETCH_SIZE", f"pmc_fetch_m{M}"), ("WRITE_SIZE", f"pmc_write_m{M}")):
+        files = glob.glob(str(src / sub / "*" / "*_counter_collection.csv"))
+        if not files:
+            continue
+        agg = defaultdict(list)
+        for r in csv.DictReader(open(files[0])):
+            if r["Counter_Name"] == counter:
+                agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+        for k, v in agg.items():
+            pmc.setdefault(k, {})[counter + "_KB_avg"] = sum(v) / len(v)
+            pmc[k][counter + "_launches"] = len(v)
+    if not pmc:
         continue
-    agg = defaultdict(list)
-    for r in csv.DictReader(open(files[0])):
-        if r["Counter_Name"] == counter:
-            agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
-    for k, v in agg.items():
-        pmc.setdefault(k, {})[counter + "_KB_avg"] = sum(v) / len(v)
-        pmc[k][counter + "_launches"] = len(v)
-if pmc:
     for k, d in pmc.items():
-        f = d.get("FETCH_SIZE_KB_avg")
-        w = d.get("WRITE_SIZE_KB_avg")
+        f, w = d.get("FETCH_SIZE_KB_avg"), d.get("WRITE_SIZE_KB_avg")
         if f is not None and w is not None:
             d["hbm_bytes_per_launch_corrected"] = 2.0 * f * 1024 + w * 1024
-    (out / f"{tag}_pmc.json").write_text(json.dumps(pmc, indent=1, sort_keys=True))
-    print("wrote", out / f"{tag}_pmc.json")
-    def corrected(prefix):
-        n = next((n for n in pmc if n.startswith(prefix) and "hbm_bytes_per_launch_corrected" in pmc[n]), None)
-        return None if n is None else pmc[n]["hbm_bytes_per_launch_corrected"]
-
-    traffic = {"source": f"profiles/{tag}_pmc.json",
-               "nnconv_hbm_bytes_per_launch": corrected("nnconv64_row_kernel"),
-               "gemm_per_source_split_kernel_hbm_bytes_per_launch": corrected("gemm_per_source_split_kernel"),
-               "gemm_per_source_kernel_hbm_bytes_per_launch": corrected("gemm_per_source_kernel"),
-               "note": "2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 read-side correction), separate --pmc passes"}
-    (out / "roofline_traffic.json").write_text(json.dumps(traffic, indent=1))
+    (out / f"{tag}_m{M}_pmc.json").write_text(json.dumps(pmc, indent=1, sort_keys=True))
+    print("wrote", out / f"{tag}_m{M}_pmc.json")
+    if cfg is None:
+        continue
+    c = cfg["config"]
+    # both conv formulations run in a bench (timed path + comparison leg at M <= 8)
+    for kernel, conv_mode in (("gemm_per_source_split_kernel", "factored"), ("nnconv64_row_kernel", "materialized")):
+        name = next((n for n in pmc if n.startswith(kernel) and "hbm_bytes_per_launch_corrected" in pmc[n]), None)
+        if name is None:
+            continue
+        per_launch = pmc[name]["hbm_bytes_per_launch_corrected"]
+        # the factored conv runs chunk by chunk over the sources: report per conv application
+        launches_per_app = 1
+        if kernel == "gemm_per_source_split_kernel":
+            launches_per_app = -(-c["members_this_rank"] * c["atoms"] // 512)
+        traffic.append({"kernel": kernel, "atoms": c["atoms"], "members": c["members_this_rank"], "conv_mode": conv_mode,
+                        "gemm_mode": c["edge_mlp_gemm"], "hbm_bytes_per_launch": per_launch * launches_per_app,
+                        "launches_per_application": launches_per_app, "source": f"profiles/{tag}_m{M}_pmc.json"})
+kernel_stats("train_trace", out / f"{tag}_train_kernel_stats.csv")
+tj = last_json_line(src / "train.json")
+if tj is not None:
+    (out / f"{tag}_train_under_rocprof.json").write_text(json.dumps(tj, indent=1))
+if traffic:
+    (out / "roofline_traffic.json").write_text(json.dumps(
+        {"note": "2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 read-side correction), separate --pmc passes; bytes per "
+                 "conv application (all chunk launches of the per-source GEMM)", "configs": traffic}, indent=1))
     print("wrote profiles/roofline_traffic.json")

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDNO_ABI_VERSION 6
+#define MDNO_ABI_VERSION 7
 
 #define MDNO_OK            0
 #define MDNO_EINVAL       -1   /* bad argument (null pointer, non-positive size, unsupported dim) */
@@ -300,6 +300,41 @@ int mdno_nnconv_bwd_root(const float* x, const float* gz, int64_t rows, int Cin,
 int mdno_nnconv_bwd_we(const float* x, const float* gs, const int32_t* src, const int32_t* dst, int64_t E,
                        int layers, int64_t layer_stride, int Cin, int Cout, float* d_we, int accumulate,
                        void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Training ops, bf16 (BASELINE configs[3] names bf16; csrc/train_bf16.hip).  The block's large tensors —
+ * h1, h2 [E,k], W_e and dW_e [E,64*64] — are bf16, row-major (pointers typed void*), every GEMM is one
+ * bf16 x bf16 MFMA product with fp32 accumulation; parameters (cast per call from the fp32 masters), node
+ * features, conv outputs and all reductions are fp32.  Same formulas as the fp32 ops above, width 64.
+ *   mdno_cast_bf16          out[i] = bf16(in[i])  (round to nearest even), count % 4 == 0
+ *   mdno_linear_bf16_fwd    c = act(a . w^T + b): a bf16 [rows,k], w fp32 [n,k]; c bf16 (out_bf16) or fp32;
+ *                           n % 128 == 0, k % 32 == 0; workspace mdno_linear_bf16_workspace_bytes(n, k)
+ *   mdno_gemm_atb_bf16      c [n1,n2] fp32 = a^T . b over rows, a bf16 [rows,n1], b bf16 [rows,n2], n1, n2 % 128 == 0;
+ *                           16 fixed row slices added in order; workspace mdno_gemm_atb_bf16_workspace_bytes
+ *   mdno_nnconv_bf16w_fwd   mdno_nnconv_fwd at 64x64 with w_e bf16 [E,4096]
+ *   mdno_nnconv_bwd_x_bf16w mdno_nnconv_bwd_x with w_e bf16
+ *   mdno_nnconv_bwd_we_bf16 d_we bf16 [E,4096] = sum_l x_l[src p] (x) gs_l[dst p] (rounded once, at the end)
+ *   mdno_relu_bwd_bf16      out = g * (y > 0): g fp32, y bf16, out bf16 (out_bf16) or fp32; n % 4 == 0
+ *   mdno_colsum_bf16        out [n] fp32 = column sums of a bf16 [rows,n]; workspace mdno_colsum_bf16_workspace_bytes(n)
+ * ---------------------------------------------------------------------------------------- */
+int mdno_cast_bf16(const float* in, int64_t count, void* out, void* stream);
+size_t mdno_linear_bf16_workspace_bytes(int n, int k);
+int mdno_linear_bf16_fwd(const void* a, const float* w, const float* bias, int64_t rows, int n, int k, int relu,
+                         int out_bf16, void* c, void* workspace, size_t workspace_bytes, void* stream);
+size_t mdno_gemm_atb_bf16_workspace_bytes(int n1, int n2);
+int mdno_gemm_atb_bf16(const void* a, const void* b, int64_t rows, int n1, int n2, float* c,
+                       void* workspace, size_t workspace_bytes, void* stream);
+int mdno_nnconv_bf16w_fwd(const float* x, const int32_t* row_ptr, const int32_t* src, int num_rows, const void* w_e,
+                          const float* root, const float* bias, int aggr, int relu, float* y, void* stream);
+int mdno_nnconv_bwd_x_bf16w(const float* gz, const float* gs, const int32_t* row_ptr_s, const int32_t* eid_s,
+                            const int32_t* dst_s, int num_rows, const void* w_e, const float* root, float* g_prev,
+                            void* stream);
+int mdno_nnconv_bwd_we_bf16(const float* x, const float* gs, const int32_t* src, const int32_t* dst, int64_t E,
+                            int layers, int64_t layer_stride, void* d_we, void* stream);
+int mdno_relu_bwd_bf16(const float* g, const void* y, int64_t rows, int n, int out_bf16, void* out, void* stream);
+size_t mdno_colsum_bf16_workspace_bytes(int n);
+int mdno_colsum_bf16(const void* a, int64_t rows, int n, float* out, void* workspace, size_t workspace_bytes,
+                     void* stream);
 
 #ifdef __cplusplus
 }

@@ -5,14 +5,14 @@ set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 out="$here/../libmdno.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-srcs=(engine.hip graph.hip edge_mlp.hip edge_mlp_split.hip factored.hip nnconv.hip node_ops.hip train.hip)
+srcs=(engine.hip graph.hip edge_mlp.hip edge_mlp_split.hip factored.hip nnconv.hip node_ops.hip train.hip train_bf16.hip)
 objs=()
 pids=()
 mkdir -p "$here/build"
 for f in "${srcs[@]}"; do
   o="$here/build/${f%.hip}.o"
   objs+=("$o")
-  if [[ ! -f "$o" || "$here/$f" -nt "$o" || "$here/common.h" -nt "$o" || "$here/kernels.h" -nt "$o" || "$here/../../include/mdno.h" -nt "$o" ]]; then
+  if [[ ! -f "$o" || "$here/$f" -nt "$o" || "$here/common.h" -nt "$o" || "$here/kernels.h" -nt "$o" || "$here/split_layout.h" -nt "$o" || "$here/../../include/mdno.h" -nt "$o" ]]; then
     "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function \
       -c "$here/$f" -o "$o" "$@" &
     pids+=($!)

@@ -1,0 +1,548 @@
+// Training in bf16 (BASELINE.json configs[3] names bf16; reference: graph_kernel.py:445-474, 541-547).
+//
+// The kernel-integral block's large tensors — the edge-MLP activations h1, h2 [E,k], the edge weights
+// W_e [E, Cin*Cout] and their gradient dW_e — are STORED in bf16 (row-major), and every GEMM of the
+// block is a single bf16 x bf16 MFMA product with fp32 accumulation; the parameters stay fp32 (master
+// weights, cast per call), as do the node features, the conv outputs and every reduction.  That halves
+// the two E x 16 KiB tensors of the fp32 path (train.hip), takes the weight-gradient products A^T.B
+// off the fp32 MFMA (1/16 of the bf16 rate) and halves what the conv kernels stream.
+//
+//   cast_bf16            fp32 -> bf16 (RNE), row-major
+//   gemm_nt_bf16         C = act(A . W^T + b)      A bf16 [rows,K], W bf16 [N,K]      -> bf16 or fp32
+//   gemm_tn_bf16         C = A^T . B over rows     A bf16 [rows,n1], B bf16 [rows,n2] -> fp32 [n1,n2]
+//   nnconv64_bf16w_*     the conv forward / input-gradient kernels of nnconv.hip / train.hip reading bf16 W_e
+//   nnconv_bwd_we_bf16   dW_e written as bf16
+//   relu_bwd_bf16, colsum_bf16   the elementwise / reduction ops on bf16 operands
+// Reductions keep fixed-order partial sums (no float atomics): gradients are bitwise reproducible.
+#include "kernels.h"
+
+namespace mdno {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float bf2f(unsigned short u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
+__device__ __forceinline__ float4 ld4_bf16(const __bf16* p) {      // 4 consecutive bf16 -> float4 (8-B load)
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                       __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u));
+}
+__device__ __forceinline__ uint2 pack4_bf16(float a, float b, float c, float d) {
+    const bf16x4 v = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
+    return __builtin_bit_cast(uint2, v);
+}
+
+// ---------------------------------------------------------------- cast
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ in, long long n4,
+                                                        uint2* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 v = reinterpret_cast<const float4*>(in)[i];
+    out[i] = pack4_bf16(v.x, v.y, v.z, v.w);
+}
+
+// ---------------------------------------------------------------- C = act(A . W^T + b)
+// 128 x 128 block tile, 4 waves of 64 x 64 (2 x 2 v_mfma_f32_32x32x16_bf16), 32 k per stage, register
+// staging into double-buffered LDS.  Rows of 32 bf16 are padded to 80 B: 16-B aligned fragment reads,
+// five-quad row stride.
+constexpr int NK = 32, NLD = 40;     // k per stage; LDS row length in bf16 (80 B)
+
+__device__ __forceinline__ void mma_bf16_tile(f32x16 (&acc)[2][2], const __bf16* as, const __bf16* bs, int l31, int h) {
+#pragma unroll
+    for (int kk = 0; kk < NK / 16; ++kk) {
+        bf16x8 a[2], b[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            a[i] = *reinterpret_cast<const bf16x8*>(as + (i * 32 + l31) * NLD + kk * 16 + 8 * h);
+            b[i] = *reinterpret_cast<const bf16x8*>(bs + (i * 32 + l31) * NLD + kk * 16 + 8 * h);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+}
+
+template <bool RELU, bool OUT_BF16>
+__global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__ W,
+                                                           const float* __restrict__ bias, void* __restrict__ Cv,
+                                                           long long rows, int N, int K) {
+    __shared__ __attribute__((aligned(16))) __bf16 As[2][128 * NLD];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][128 * NLD];
+    const long long bm = (long long)blockIdx.y * 128;
+    const int bn = blockIdx.x * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
+    const int srow = tid >> 2, sk = (tid & 3) * 8;          // rows srow, srow + 64; 8 k each
+    auto arow = [&](int r) { const long long rr = bm + r; return (size_t)(rr < rows ? rr : rows - 1); };
+    const __bf16* A0 = A + arow(srow) * K + sk;
+    const __bf16* A1 = A + arow(srow + 64) * K + sk;
+    const __bf16* B0 = W + (size_t)(bn + srow) * K + sk;
+    const __bf16* B1 = W + (size_t)(bn + srow + 64) * K + sk;
+    uint4 ra0, ra1, rb0, rb1;
+#define MDNO_LD(KO)                                              \
+    ra0 = *reinterpret_cast<const uint4*>(A0 + (KO));            \
+    ra1 = *reinterpret_cast<const uint4*>(A1 + (KO));            \
+    rb0 = *reinterpret_cast<const uint4*>(B0 + (KO));            \
+    rb1 = *reinterpret_cast<const uint4*>(B1 + (KO));
+#define MDNO_ST(BUF)                                                                  \
+    *reinterpret_cast<uint4*>(&As[BUF][srow * NLD + sk]) = ra0;                       \
+    *reinterpret_cast<uint4*>(&As[BUF][(srow + 64) * NLD + sk]) = ra1;                \
+    *reinterpret_cast<uint4*>(&Bs[BUF][srow * NLD + sk]) = rb0;                       \
+    *reinterpret_cast<uint4*>(&Bs[BUF][(srow + 64) * NLD + sk]) = rb1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    float bv0 = 0.f, bv1 = 0.f;        // before the K loop and pinned (see edge_mlp_split.hip, epilogue stores)
+    if (bias) {
+        bv0 = bias[bn + wn * 64 + l31];
+        bv1 = bias[bn + wn * 64 + 32 + l31];
+    }
+    asm volatile("" : "+v"(bv0), "+v"(bv1));
+    const int nk = K / NK;
+    MDNO_LD(0)
+    MDNO_ST(0)
+    __syncthreads();
+    for (int kt = 0; kt < nk - 1; ++kt) {
+        MDNO_LD((size_t)(kt + 1) * NK)
+        mma_bf16_tile(acc, &As[kt & 1][wm * 64 * NLD], &Bs[kt & 1][wn * 64 * NLD], l31, h);
+        MDNO_ST((kt & 1) ^ 1)
+        __syncthreads();
+    }
+    mma_bf16_tile(acc, &As[(nk - 1) & 1][wm * 64 * NLD], &Bs[(nk - 1) & 1][wn * 64 * NLD], l31, h);
+#undef MDNO_LD
+#undef MDNO_ST
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = bn + wn * 64 + j * 32 + l31;
+        const float bv = j ? bv1 : bv0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const long long m = bm + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (m < rows) {
+                    float v = acc[i][j][e] + bv;
+                    if (RELU) v = fmaxf(v, 0.f);
+                    if (OUT_BF16) static_cast<__bf16*>(Cv)[(size_t)m * N + n] = (__bf16)v;
+                    else static_cast<float*>(Cv)[(size_t)m * N + n] = v;
+                }
+            }
+    }
+}
+
+// ---------------------------------------------------------------- C = A^T . B over rows (one K-slice)
+// A [rows, n1], B [rows, n2] row-major: the contraction index (the edge) is the SLOW index of both
+// operands, the opposite of what an MFMA fragment wants (8 consecutive k per lane).  Each staged 16-B
+// piece (8 columns of one row) is therefore written to LDS transposed, [column][row], as eight 2-byte
+// writes; a column's data starts 4*((column>>3)&3) dwords into its 112-B LDS row, which spreads the 16
+// lanes that write the same row index over 8 banks instead of 2.  Fragment reads are then the same
+// 16-B reads as in gemm_nt_bf16_kernel.  Rows are cut into `slices` equal runs (blockIdx.z), partial
+// products go to part[slice][n1][n2] and are added in slice order by reduce_slices_kernel (train.hip).
+constexpr int TLD = 56;      // LDS row of the transposed tiles: 32 rows of data + up to 24 of rotation, 112 B
+__device__ __forceinline__ int tn_col_base(int col) { return col * TLD + 8 * ((col >> 3) & 3); }   // in bf16 units
+
+__global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__ B,
+                                                           float* __restrict__ part, long long rows, int n1, int n2,
+                                                           long long slice_rows) {
+    __shared__ __attribute__((aligned(16))) __bf16 As[2][128 * TLD];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][128 * TLD];
+    const int bm = blockIdx.y * 128, bn = blockIdx.x * 128;
+    const long long r0 = (long long)blockIdx.z * slice_rows;
+    long long r1 = r0 + slice_rows;
+    if (r1 > rows) r1 = rows;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
+    const int se = tid >> 4, sc = (tid & 15) * 8;           // staged rows se, se + 16 of the 32-row stage; 8 columns at sc
+    uint4 ra0, ra1, rb0, rb1;
+    const uint4 zero = make_uint4(0, 0, 0, 0);
+#define MDNO_LD(E0)                                                                                         \
+    {                                                                                                       \
+        const long long e0_ = (E0) + se, e1_ = (E0) + se + 16;                                              \
+        ra0 = e0_ < r1 ? *reinterpret_cast<const uint4*>(A + (size_t)e0_ * n1 + bm + sc) : zero;            \
+        ra1 = e1_ < r1 ? *reinterpret_cast<const uint4*>(A + (size_t)e1_ * n1 + bm + sc) : zero;            \
+        rb0 = e0_ < r1 ? *reinterpret_cast<const uint4*>(B + (size_t)e0_ * n2 + bn + sc) : zero;            \
+        rb1 = e1_ < r1 ? *reinterpret_cast<const uint4*>(B + (size_t)e1_ * n2 + bn + sc) : zero;            \
+    }
+    auto scatter = [&](__bf16* dst, const uint4& v, int e) {
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            reinterpret_cast<unsigned short*>(dst)[tn_col_base(sc + 2 * i) + e] = (unsigned short)(w[i] & 0xffffu);
+            reinterpret_cast<unsigned short*>(dst)[tn_col_base(sc + 2 * i + 1) + e] = (unsigned short)(w[i] >> 16);
+        }
+    };
+#define MDNO_ST(BUF)                     \
+    scatter(As[BUF], ra0, se);           \
+    scatter(As[BUF], ra1, se + 16);      \
+    scatter(Bs[BUF], rb0, se);           \
+    scatter(Bs[BUF], rb1, se + 16);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    auto mma = [&](int buf) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = *reinterpret_cast<const bf16x8*>(&As[buf][tn_col_base(wm * 64 + i * 32 + l31) + kk * 16 + 8 * h]);
+                b[i] = *reinterpret_cast<const bf16x8*>(&Bs[buf][tn_col_base(wn * 64 + i * 32 + l31) + kk * 16 + 8 * h]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    const long long nst = (r1 - r0 + 31) / 32;
+    if (nst > 0) {
+        MDNO_LD(r0)
+        MDNO_ST(0)
+        __syncthreads();
+        for (long long st = 0; st < nst - 1; ++st) {
+            MDNO_LD(r0 + (st + 1) * 32)
+            mma((int)(st & 1));
+            MDNO_ST((int)((st & 1) ^ 1))
+            __syncthreads();
+        }
+        mma((int)((nst - 1) & 1));
+    }
+#undef MDNO_LD
+#undef MDNO_ST
+    float* P = part + (size_t)blockIdx.z * n1 * n2;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = bn + wn * 64 + j * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = bm + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                P[(size_t)m * n2 + n] = acc[i][j][e];
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void reduce_slices_bf16path_kernel(const float* __restrict__ part, int slices,
+                                                                     long long count, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    float s = 0.f;
+    for (int k = 0; k < slices; ++k) s += part[(size_t)k * count + i];     // fixed order
+    out[i] = s;
+}
+
+// ---------------------------------------------------------------- conv forward, bf16 W_e
+// nnconv64_row_kernel (nnconv.hip) with 8-B loads of four bf16: same lane map (lane (g,q) owns input rows
+// 16g..16g+15 x output columns 4q..4q+3), same 16 summation chains, fp32 accumulation.
+__device__ __forceinline__ void fma4(float4& a, float s, const float4& w) {
+    a.x = fmaf(s, w.x, a.x); a.y = fmaf(s, w.y, a.y); a.z = fmaf(s, w.z, a.z); a.w = fmaf(s, w.w, a.w);
+}
+__device__ __forceinline__ float4 reduce_over_g(float4 a) {
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+        a.x += __shfl_xor(a.x, o); a.y += __shfl_xor(a.y, o); a.z += __shfl_xor(a.z, o); a.w += __shfl_xor(a.w, o);
+    }
+    return a;
+}
+template <class WT>
+__device__ __forceinline__ float4 ldw4(const WT* p);
+template <>
+__device__ __forceinline__ float4 ldw4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <>
+__device__ __forceinline__ float4 ldw4<__bf16>(const __bf16* p) { return ld4_bf16(p); }
+
+template <class WT>
+__device__ __forceinline__ void edge_acc64(float4& acc, const float* __restrict__ xrow, const WT* __restrict__ wmat,
+                                           int g, int q) {
+    const float* xp = xrow + 16 * g;
+    const float4 x0 = *reinterpret_cast<const float4*>(xp), x1 = *reinterpret_cast<const float4*>(xp + 4);
+    const float4 x2 = *reinterpret_cast<const float4*>(xp + 8), x3 = *reinterpret_cast<const float4*>(xp + 12);
+    const WT* wp = wmat + (16 * g) * 64 + 4 * q;
+    float4 w[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) w[r] = ldw4<WT>(wp + r * 64);
+    fma4(acc, x0.x, w[0]);  fma4(acc, x0.y, w[1]);  fma4(acc, x0.z, w[2]);  fma4(acc, x0.w, w[3]);
+    fma4(acc, x1.x, w[4]);  fma4(acc, x1.y, w[5]);  fma4(acc, x1.z, w[6]);  fma4(acc, x1.w, w[7]);
+    fma4(acc, x2.x, w[8]);  fma4(acc, x2.y, w[9]);  fma4(acc, x2.z, w[10]); fma4(acc, x2.w, w[11]);
+    fma4(acc, x3.x, w[12]); fma4(acc, x3.y, w[13]); fma4(acc, x3.z, w[14]); fma4(acc, x3.w, w[15]);
+}
+
+__global__ __launch_bounds__(1024) void nnconv64_bf16w_kernel(const float* __restrict__ x, const int* __restrict__ row_ptr,
+                                                              const int* __restrict__ src,
+                                                              const __bf16* __restrict__ w_e,
+                                                              const float* __restrict__ root,
+                                                              const float* __restrict__ bias, float* __restrict__ y,
+                                                              int num_rows, int aggr, int relu) {
+    __shared__ float red[16][64];
+    __shared__ float rootred[64];
+    const int row = blockIdx.x;
+    if (row >= num_rows) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, q = lane & 15;
+    const int beg = row_ptr[row], end = row_ptr[row + 1], deg = end - beg;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = beg + wave; p < end; p += 16) edge_acc64<__bf16>(acc, x + (size_t)src[p] * 64, w_e + (size_t)p * 4096, g, q);
+    acc = reduce_over_g(acc);
+    if (lane < 16) *reinterpret_cast<float4*>(&red[wave][4 * lane]) = acc;
+    const bool root_wave = root != nullptr && wave == (deg & 15);
+    float4 racc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (root_wave) edge_acc64<float>(racc, x + (size_t)row * 64, root, g, q);
+    racc = reduce_over_g(racc);
+    if (root_wave && lane < 16) *reinterpret_cast<float4*>(&rootred[4 * lane]) = racc;
+    __syncthreads();
+    if (tid < 64) {
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) s += red[c][tid];
+        if (aggr == MDNO_AGGR_MEAN) s = s / (float)(deg > 1 ? deg : 1);
+        if (root != nullptr) s += rootred[tid];
+        if (bias != nullptr) s += bias[tid];
+        if (relu) s = fmaxf(s, 0.f);
+        y[(size_t)row * 64 + tid] = s;
+    }
+}
+
+// ---------------------------------------------------------------- conv backward wrt the input, bf16 W_e
+// nnconv_bwd_x_kernel (train.hip): g_prev[r] = gz[r] . root^T + sum_{e: src e = r} W_e . gs[dst e]
+template <class WT>
+__device__ __forceinline__ void wg_acc(float (&acc)[16], const WT* __restrict__ wmat, const float* __restrict__ gvec,
+                                       int g, int q) {
+    const float4 gq = *reinterpret_cast<const float4*>(gvec + 4 * q);
+    const WT* wp = wmat + (16 * g) * 64 + 4 * q;
+    float4 w[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) w[r] = ldw4<WT>(wp + r * 64);
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        acc[r] = fmaf(w[r].x, gq.x, fmaf(w[r].y, gq.y, fmaf(w[r].z, gq.z, fmaf(w[r].w, gq.w, acc[r]))));
+}
+
+__global__ __launch_bounds__(256) void nnconv_bwd_x_bf16w_kernel(const float* __restrict__ gz, const float* __restrict__ gs,
+                                                                 const int* __restrict__ row_ptr_s,
+                                                                 const int* __restrict__ eid_s,
+                                                                 const int* __restrict__ dst_s,
+                                                                 const __bf16* __restrict__ w_e,
+                                                                 const float* __restrict__ root,
+                                                                 float* __restrict__ g_prev, int num_rows) {
+    __shared__ float red[4][64];
+    const int row = blockIdx.x;
+    if (row >= num_rows) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, q = lane & 15;
+    const int beg = row_ptr_s[row], end = row_ptr_s[row + 1];
+    float acc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int p = beg + wave; p < end; p += 4)
+        wg_acc<__bf16>(acc, w_e + (size_t)eid_s[p] * 4096, gs + (size_t)dst_s[p] * 64, g, q);
+    if (root != nullptr && wave == ((end - beg) & 3)) wg_acc<float>(acc, root, gz + (size_t)row * 64, g, q);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v = acc[r];
+        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+        acc[r] = v;
+    }
+    if (q == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave][16 * g + r] = acc[r];
+    }
+    __syncthreads();
+    if (tid < 64) g_prev[(size_t)row * 64 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
+// ---------------------------------------------------------------- d W_e as bf16
+// nnconv_bwd_we_kernel (train.hip) with the result rounded once, at the end, and written as 8-B stores
+__global__ __launch_bounds__(256) void nnconv_bwd_we_bf16_kernel(const float* __restrict__ x, const float* __restrict__ gs,
+                                                                 const int* __restrict__ src, const int* __restrict__ dst,
+                                                                 long long E, int L, long long layer_stride,
+                                                                 __bf16* __restrict__ dwe) {
+    const int lane = threadIdx.x & 63, g = lane >> 4, q = lane & 15;
+    const long long p = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= E) return;
+    const float* xs = x + (size_t)src[p] * 64 + 16 * g;
+    const float* gq = gs + (size_t)dst[p] * 64 + 4 * q;
+    float4 acc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int l = 0; l < L; ++l) {
+        const float4 gv = *reinterpret_cast<const float4*>(gq + (size_t)l * layer_stride);
+        const float* xl = xs + (size_t)l * layer_stride;
+        const float4 x0 = *reinterpret_cast<const float4*>(xl), x1 = *reinterpret_cast<const float4*>(xl + 4);
+        const float4 x2 = *reinterpret_cast<const float4*>(xl + 8), x3 = *reinterpret_cast<const float4*>(xl + 12);
+        const float xv[16] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w,
+                              x2.x, x2.y, x2.z, x2.w, x3.x, x3.y, x3.z, x3.w};
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc[r].x = fmaf(xv[r], gv.x, acc[r].x); acc[r].y = fmaf(xv[r], gv.y, acc[r].y);
+            acc[r].z = fmaf(xv[r], gv.z, acc[r].z); acc[r].w = fmaf(xv[r], gv.w, acc[r].w);
+        }
+    }
+    __bf16* out = dwe + (size_t)p * 4096 + (16 * g) * 64 + 4 * q;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) *reinterpret_cast<uint2*>(out + r * 64) = pack4_bf16(acc[r].x, acc[r].y, acc[r].z, acc[r].w);
+}
+
+// ---------------------------------------------------------------- elementwise / reductions on bf16
+// out = g * (y > 0): g fp32, y bf16 (the saved activation), out bf16 or fp32
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256) void relu_bwd_bf16_kernel(const float* __restrict__ g, const __bf16* __restrict__ y,
+                                                            long long rows, int n, void* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;       // over groups of 4 elements
+    if (i >= rows * (n / 4)) return;
+    const float4 gv = reinterpret_cast<const float4*>(g)[i];
+    const float4 yv = ld4_bf16(y + 4 * i);
+    const float4 r = make_float4(yv.x > 0.f ? gv.x : 0.f, yv.y > 0.f ? gv.y : 0.f, yv.z > 0.f ? gv.z : 0.f,
+                                 yv.w > 0.f ? gv.w : 0.f);
+    if (OUT_BF16) static_cast<uint2*>(out)[i] = pack4_bf16(r.x, r.y, r.z, r.w);
+    else static_cast<float4*>(out)[i] = r;
+}
+
+// column sums of a bf16 matrix: block (column group of 64, row slice) -> part[slice][n]; reduced in slice order
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const __bf16* __restrict__ a, float* __restrict__ part,
+                                                          long long rows, int n, long long slice_rows) {
+    __shared__ float red[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const long long r0 = (long long)blockIdx.y * slice_rows;
+    long long r1 = r0 + slice_rows;
+    if (r1 > rows) r1 = rows;
+    float s = 0.f;
+    if (col < n)
+        for (long long r = r0 + rl; r < r1; r += 4) s += bf2f(reinterpret_cast<const unsigned short*>(a)[(size_t)r * n + col]);
+    red[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && col < n)
+        part[(size_t)blockIdx.y * n + col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+constexpr int kTnSlices = 16, kColSlicesB = 128;
+
+}  // namespace
+}  // namespace mdno
+
+using namespace mdno;
+
+extern "C" int mdno_cast_bf16(const float* in, int64_t count, void* out, void* stream) {
+    MDNO_REQUIRE(in && out && count >= 0 && count % 4 == 0, MDNO_EINVAL, "mdno_cast_bf16: count=%lld (multiple of 4)",
+                 (long long)count);
+    if (count == 0) return MDNO_OK;
+    const long long n4 = count / 4;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       in, n4, static_cast<uint2*>(out));
+    return check_launch("cast_bf16_kernel");
+}
+
+extern "C" size_t mdno_linear_bf16_workspace_bytes(int n, int k) {
+    return align_up((size_t)n * k * sizeof(__bf16), 256);
+}
+
+extern "C" int mdno_linear_bf16_fwd(const void* a, const float* w, const float* bias, int64_t rows, int n, int k,
+                                    int relu, int out_bf16, void* c, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+    MDNO_REQUIRE(a && w && c && workspace && rows > 0, MDNO_EINVAL, "mdno_linear_bf16_fwd: bad arguments");
+    MDNO_REQUIRE(n % 128 == 0 && k % 32 == 0, MDNO_EUNSUPPORTED, "mdno_linear_bf16_fwd: n=%d (x128) k=%d (x32)", n, k);
+    MDNO_REQUIRE(workspace_bytes >= mdno_linear_bf16_workspace_bytes(n, k), MDNO_EWORKSPACE,
+                 "mdno_linear_bf16_fwd: workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    MDNO_TRY(mdno_cast_bf16(w, (int64_t)n * k, workspace, stream));      // master weights -> bf16, every call
+    const __bf16* A = static_cast<const __bf16*>(a);
+    const __bf16* W = static_cast<const __bf16*>(workspace);
+    const dim3 grid(n / 128, (unsigned)((rows + 127) / 128));
+#define MDNO_GO(R, O) hipLaunchKernelGGL((gemm_nt_bf16_kernel<R, O>), grid, dim3(256), 0, s, A, W, bias, c, (long long)rows, n, k)
+    if (relu) { if (out_bf16) MDNO_GO(true, true); else MDNO_GO(true, false); }
+    else      { if (out_bf16) MDNO_GO(false, true); else MDNO_GO(false, false); }
+#undef MDNO_GO
+    return check_launch("gemm_nt_bf16_kernel");
+}
+
+extern "C" size_t mdno_gemm_atb_bf16_workspace_bytes(int n1, int n2) {
+    return align_up((size_t)kTnSlices * n1 * n2 * sizeof(float), 256);
+}
+
+extern "C" int mdno_gemm_atb_bf16(const void* a, const void* b, int64_t rows, int n1, int n2, float* c,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+    MDNO_REQUIRE(a && b && c && workspace && rows > 0, MDNO_EINVAL, "mdno_gemm_atb_bf16: bad arguments");
+    MDNO_REQUIRE(n1 % 128 == 0 && n2 % 128 == 0, MDNO_EUNSUPPORTED, "mdno_gemm_atb_bf16: n1=%d n2=%d (x128)", n1, n2);
+    MDNO_REQUIRE(workspace_bytes >= mdno_gemm_atb_bf16_workspace_bytes(n1, n2), MDNO_EWORKSPACE,
+                 "mdno_gemm_atb_bf16: workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long long slice_rows = ((rows + kTnSlices - 1) / kTnSlices + 31) / 32 * 32;
+    hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(n2 / 128, n1 / 128, kTnSlices), dim3(256), 0, s,
+                       static_cast<const __bf16*>(a), static_cast<const __bf16*>(b), static_cast<float*>(workspace),
+                       (long long)rows, n1, n2, slice_rows);
+    const long long count = (long long)n1 * n2;
+    hipLaunchKernelGGL(reduce_slices_bf16path_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s,
+                       static_cast<const float*>(workspace), kTnSlices, count, c);
+    return check_launch("gemm_tn_bf16_kernel");
+}
+
+extern "C" int mdno_nnconv_bf16w_fwd(const float* x, const int32_t* row_ptr, const int32_t* src, int num_rows,
+                                     const void* w_e, const float* root, const float* bias, int aggr, int relu,
+                                     float* y, void* stream) {
+    MDNO_REQUIRE(x && row_ptr && src && w_e && y && num_rows > 0, MDNO_EINVAL, "mdno_nnconv_bf16w_fwd: bad arguments");
+    MDNO_REQUIRE(aggr == MDNO_AGGR_ADD || aggr == MDNO_AGGR_MEAN, MDNO_EUNSUPPORTED, "mdno_nnconv_bf16w_fwd: aggr %d", aggr);
+    hipLaunchKernelGGL(nnconv64_bf16w_kernel, dim3(num_rows), dim3(1024), 0, static_cast<hipStream_t>(stream), x, row_ptr,
+                       src, static_cast<const __bf16*>(w_e), root, bias, y, num_rows, aggr, relu);
+    return check_launch("nnconv64_bf16w_kernel");
+}
+
+extern "C" int mdno_nnconv_bwd_x_bf16w(const float* gz, const float* gs, const int32_t* row_ptr_s, const int32_t* eid_s,
+                                       const int32_t* dst_s, int num_rows, const void* w_e, const float* root,
+                                       float* g_prev, void* stream) {
+    MDNO_REQUIRE(gz && gs && row_ptr_s && eid_s && dst_s && w_e && g_prev && num_rows > 0, MDNO_EINVAL,
+                 "mdno_nnconv_bwd_x_bf16w: bad arguments");
+    hipLaunchKernelGGL(nnconv_bwd_x_bf16w_kernel, dim3(num_rows), dim3(256), 0, static_cast<hipStream_t>(stream), gz, gs,
+                       row_ptr_s, eid_s, dst_s, static_cast<const __bf16*>(w_e), root, g_prev, num_rows);
+    return check_launch("nnconv_bwd_x_bf16w_kernel");
+}
+
+extern "C" int mdno_nnconv_bwd_we_bf16(const float* x, const float* gs, const int32_t* src, const int32_t* dst, int64_t E,
+                                       int L, int64_t layer_stride, void* d_we, void* stream) {
+    MDNO_REQUIRE(x && gs && src && dst && d_we && E >= 0 && L > 0, MDNO_EINVAL, "mdno_nnconv_bwd_we_bf16: bad arguments");
+    if (E == 0) return MDNO_OK;
+    hipLaunchKernelGGL(nnconv_bwd_we_bf16_kernel, dim3((unsigned)((E + 3) / 4)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, gs, src, dst, (long long)E, L, (long long)layer_stride,
+                       static_cast<__bf16*>(d_we));
+    return check_launch("nnconv_bwd_we_bf16_kernel");
+}
+
+extern "C" int mdno_relu_bwd_bf16(const float* g, const void* y, int64_t rows, int n, int out_bf16, void* out,
+                                  void* stream) {
+    MDNO_REQUIRE(g && y && out && rows >= 0 && n % 4 == 0, MDNO_EINVAL, "mdno_relu_bwd_bf16: bad arguments");
+    const long long groups = (long long)rows * (n / 4);
+    if (groups == 0) return MDNO_OK;
+    const dim3 grid((unsigned)((groups + 255) / 256));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (out_bf16)
+        hipLaunchKernelGGL(relu_bwd_bf16_kernel<true>, grid, dim3(256), 0, s, g, static_cast<const __bf16*>(y),
+                           (long long)rows, n, out);
+    else
+        hipLaunchKernelGGL(relu_bwd_bf16_kernel<false>, grid, dim3(256), 0, s, g, static_cast<const __bf16*>(y),
+                           (long long)rows, n, out);
+    return check_launch("relu_bwd_bf16_kernel");
+}
+
+extern "C" size_t mdno_colsum_bf16_workspace_bytes(int n) { return align_up((size_t)kColSlicesB * n * sizeof(float), 256); }
+
+extern "C" int mdno_colsum_bf16(const void* a, int64_t rows, int n, float* out, void* workspace, size_t workspace_bytes,
+                                void* stream) {
+    MDNO_REQUIRE(a && out && workspace && rows > 0 && n > 0, MDNO_EINVAL, "mdno_colsum_bf16: bad arguments");
+    MDNO_REQUIRE(workspace_bytes >= mdno_colsum_bf16_workspace_bytes(n), MDNO_EWORKSPACE, "mdno_colsum_bf16: workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long long slice_rows = (rows + kColSlicesB - 1) / kColSlicesB;
+    hipLaunchKernelGGL(colsum_bf16_kernel, dim3((n + 63) / 64, kColSlicesB), dim3(256), 0, s, static_cast<const __bf16*>(a),
+                       static_cast<float*>(workspace), (long long)rows, n, slice_rows);
+    hipLaunchKernelGGL(reduce_slices_bf16path_kernel, dim3((n + 255) / 256), dim3(256), 0, s,
+                       static_cast<const float*>(workspace), kColSlicesB, (long long)n, out);
+    return check_launch("colsum_bf16_kernel");
+}

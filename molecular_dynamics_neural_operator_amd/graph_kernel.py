@@ -204,6 +204,9 @@ class KernelNN(nn.Module):
         # fp16's range are detected on the device and that chunk is redone by the bf16 kernels);
         # "f32" = fp32-input MFMA, bit-for-bit an fmaf chain
         self.gemm_mode = "split_f16"
+        # training (training.py): "fp32" or "bf16" (bf16 storage of h1, h2, W_e, dW_e + single-product bf16
+        # GEMMs with fp32 accumulation; fp32 master parameters)
+        self.train_precision = "fp32"
         # how conv applications run inside the on-device rollout / position-graph forward
         # (include/mdno.h MDNO_CONV_*): "factored" = the reference's sums reassociated per node, W_e
         # never formed (csrc/factored.hip; needs width 64 and a radius graph built by the library,

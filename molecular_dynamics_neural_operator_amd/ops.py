@@ -375,3 +375,101 @@ def nnconv_bwd_we(x_layers: torch.Tensor, gs_layers: torch.Tensor, graph: CSRGra
     check(lib.mdno_nnconv_bwd_we(ptr(x_layers), ptr(gs_layers), ptr(graph.src), ptr(graph.dst), e, L, R * 64, 64, 64,
                                  ptr(d_we), 0, stream_ptr(d_we.device)), "mdno_nnconv_bwd_we")
     return d_we
+
+
+# ------------------------------------------------------------------------------------------------
+# Training ops, bf16 (include/mdno.h "Training ops, bf16"): torch only allocates; dtype torch.bfloat16
+# tensors are the bf16 buffers of the C ABI.
+def _bf16(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.bfloat16:
+        raise MdnoError(f"expected a bfloat16 tensor, got {t.dtype}")
+    return t.contiguous()
+
+
+def cast_bf16(a: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    a = f32(a)
+    if a.numel() % 4:
+        raise MdnoError("cast_bf16: element count must be a multiple of 4")
+    out = torch.empty(a.shape, dtype=torch.bfloat16, device=a.device)
+    check(lib.mdno_cast_bf16(ptr(a), a.numel(), ptr(out), stream_ptr(a.device)), "mdno_cast_bf16")
+    return out
+
+
+def linear_bf16(a: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], relu: bool = False,
+                out_bf16: bool = True) -> torch.Tensor:
+    """act(a . w^T + b): a bf16 [rows,k], w fp32 master [n,k] (cast per call), fp32 accumulation."""
+    lib = _lib.load()
+    a, w = _bf16(a), f32(w)
+    rows, k = a.shape
+    n = w.shape[0]
+    c = torch.empty((rows, n), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=a.device)
+    ws = _ws(lib.mdno_linear_bf16_workspace_bytes(n, k), a.device)
+    check(lib.mdno_linear_bf16_fwd(ptr(a), ptr(w), ptr(f32(b)) if b is not None else None, rows, n, k, int(relu),
+                                   int(out_bf16), ptr(c), ptr(ws), ws.numel(), stream_ptr(a.device)), "mdno_linear_bf16_fwd")
+    return c
+
+
+def gemm_atb_bf16(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    a, b = _bf16(a), _bf16(b)
+    rows, n1 = a.shape
+    n2 = b.shape[1]
+    c = torch.empty((n1, n2), dtype=torch.float32, device=a.device)
+    ws = _ws(lib.mdno_gemm_atb_bf16_workspace_bytes(n1, n2), a.device)
+    check(lib.mdno_gemm_atb_bf16(ptr(a), ptr(b), rows, n1, n2, ptr(c), ptr(ws), ws.numel(), stream_ptr(a.device)),
+          "mdno_gemm_atb_bf16")
+    return c
+
+
+def nnconv_bf16w(x: torch.Tensor, graph: CSRGraph, w_e: torch.Tensor, root, bias, aggr: str = "mean",
+                 relu: bool = False) -> torch.Tensor:
+    lib = _lib.load()
+    x, w_e = f32(x), _bf16(w_e)
+    if x.shape[1] != 64 or w_e.shape[1] != 4096:
+        raise MdnoError("nnconv_bf16w: width 64 only")
+    y = torch.empty_like(x)
+    check(lib.mdno_nnconv_bf16w_fwd(ptr(x), ptr(graph.row_ptr), ptr(graph.src), x.shape[0], ptr(w_e),
+                                    ptr(f32(root)) if root is not None else None,
+                                    ptr(f32(bias)) if bias is not None else None, AGGR[aggr], int(relu), ptr(y),
+                                    stream_ptr(x.device)), "mdno_nnconv_bf16w_fwd")
+    return y
+
+
+def nnconv_bwd_x_bf16w(gz: torch.Tensor, gs: torch.Tensor, by_src: CSRGraph, w_e: torch.Tensor, root) -> torch.Tensor:
+    lib = _lib.load()
+    g_prev = torch.empty_like(gz)
+    check(lib.mdno_nnconv_bwd_x_bf16w(ptr(gz), ptr(gs), ptr(by_src.row_ptr), ptr(by_src.perm), ptr(by_src.src),
+                                      gz.shape[0], ptr(_bf16(w_e)), ptr(f32(root)) if root is not None else None,
+                                      ptr(g_prev), stream_ptr(gz.device)), "mdno_nnconv_bwd_x_bf16w")
+    return g_prev
+
+
+def nnconv_bwd_we_bf16(x_layers: torch.Tensor, gs_layers: torch.Tensor, graph: CSRGraph) -> torch.Tensor:
+    lib = _lib.load()
+    L, R, _ = x_layers.shape
+    e = graph.edge_count()
+    d_we = torch.empty((e, 4096), dtype=torch.bfloat16, device=x_layers.device)
+    check(lib.mdno_nnconv_bwd_we_bf16(ptr(x_layers), ptr(gs_layers), ptr(graph.src), ptr(graph.dst), e, L, R * 64,
+                                      ptr(d_we), stream_ptr(d_we.device)), "mdno_nnconv_bwd_we_bf16")
+    return d_we
+
+
+def relu_bwd_bf16(g: torch.Tensor, y: torch.Tensor, out_bf16: bool = True) -> torch.Tensor:
+    lib = _lib.load()
+    g, y = f32(g), _bf16(y)
+    rows, n = g.shape
+    out = torch.empty((rows, n), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=g.device)
+    check(lib.mdno_relu_bwd_bf16(ptr(g), ptr(y), rows, n, int(out_bf16), ptr(out), stream_ptr(g.device)),
+          "mdno_relu_bwd_bf16")
+    return out
+
+
+def colsum_bf16(a: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    a = _bf16(a)
+    rows, n = a.shape
+    out = torch.empty(n, dtype=torch.float32, device=a.device)
+    ws = _ws(lib.mdno_colsum_bf16_workspace_bytes(n), a.device)
+    check(lib.mdno_colsum_bf16(ptr(a), rows, n, ptr(out), ptr(ws), ws.numel(), stream_ptr(a.device)), "mdno_colsum_bf16")
+    return out

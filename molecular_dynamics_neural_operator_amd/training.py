@@ -6,7 +6,15 @@ autograd differentiates them ("one small fused kernel (or st
 
 Replaces what autograd + torch_geometric do in `train()` (graph_kernel.py:445-474).  Members of a
 batch are independent B=1 problems (block-diagonal graph); the reference's batched mode threads one
-LSTM state through the batch axis and is not reproduced.  fp32 throughout.
+LSTM state through the batch axis and is not reproduced.
+
+Two precisions (`model.train_precision`):
+  "fp32" (default)  fp32 storage everywhere; the wide GEMMs per `model.gemm_mode` (bf16-split planes at
+                    fp32-level accuracy, or fp32 MFMA); gradients match an fp64 replica to ~1e-6.
+  "bf16"            BASELINE.json configs[3] ("bf16"): the block's large tensors (h1, h2, W_e, dW_e) are
+                    stored in bf16 and every GEMM is one bf16 MFMA product with fp32 accumulation
+                    (csrc/train_bf16.hip); parameters stay fp32 masters, reductions stay fp32.  Half the
+                    memory of the two E x 16 KiB tensors, gradients match the fp64 replica to ~1e-2.
 """
 from __future__ import annotations
 
@@ -33,6 +41,10 @@ class KernelIntegralBlock(torch.autograd.Function):
         E = graph.edge_count()
         ea = ops.f32(edge_attr)[graph.perm[:E].long()] if graph.perm is not None else ops.f32(edge_attr)
         ea = ea.contiguous()
+        ctx.bf16 = gemm_mode == "bf16"
+        if ctx.bf16:
+            return KernelIntegralBlock._forward_bf16(ctx, x0, ea, graph, depth, w0, b0, w1, b1, w2, b2, root1, bias1,
+                                                     root2, bias2)
         h1 = ops.linear(ea, w0, b0, relu=True)
         h2 = ops.linear(h1, w1, b1, relu=True, gemm_mode=gemm_mode)
         w_e = ops.linear(h2, w2, b2, relu=False, gemm_mode=gemm_mode)
@@ -47,7 +59,54 @@ class KernelIntegralBlock(torch.autograd.Function):
         return X[L].clone()
 
     @staticmethod
+    def _forward_bf16(ctx, x0, ea, graph, depth, w0, b0, w1, b1, w2, b2, root1, bias1, root2, bias2):
+        R = x0.shape[0]
+        h1 = ops.cast_bf16(ops.linear(ea, w0, b0, relu=True))            # K = 6: fp32 kernel, stored bf16
+        h2 = ops.linear_bf16(h1, w1, b1, relu=True, out_bf16=True)
+        w_e = ops.linear_bf16(h2, w2, b2, relu=False, out_bf16=True)     # [E, 4096] bf16: 8 KiB per edge
+        L = 2 * depth
+        X = torch.empty((L + 1, R, 64), dtype=torch.float32, device=x0.device)
+        X[0].copy_(x0)
+        for a in range(1, L + 1):
+            root, bias = (root1, bias1) if a <= depth else (root2, bias2)
+            X[a].copy_(ops.nnconv_bf16w(X[a - 1], graph, w_e, root, bias, "mean", relu=True))
+        ctx.graph, ctx.depth, ctx.gemm_mode = graph, depth, "bf16"
+        ctx.save_for_backward(ea, h1, h2, w_e, X, w0, w1, w2, root1, root2)
+        return X[L].clone()
+
+    @staticmethod
+    def _backward_bf16(ctx, g_out):
+        ea, h1, h2, w_e, X, w0, w1, w2, root1, root2 = ctx.saved_tensors
+        graph, depth = ctx.graph, ctx.depth
+        L, R = 2 * depth, X.shape[1]
+        by_src = ops.source_sorted(graph, R)
+        inv = ops.inv_degree(graph, "mean")
+        GZ = torch.empty((L, R, 64), dtype=torch.float32, device=X.device)
+        GS = torch.empty((L, R, 64), dtype=torch.float32, device=X.device)
+        g = ops.f32(g_out)
+        for a in range(L, 0, -1):
+            ops.relu_bwd(g, X[a], None, out=GZ[a - 1])
+            ops.relu_bwd(g, X[a], inv, out=GS[a - 1])
+            g = ops.nnconv_bwd_x_bf16w(GZ[a - 1], GS[a - 1], by_src, w_e, root1 if a <= depth else root2)
+        d_root1, d_bias1 = ops.nnconv_bwd_root(X[0:depth].reshape(-1, 64), GZ[0:depth].reshape(-1, 64))
+        d_root2, d_bias2 = ops.nnconv_bwd_root(X[depth:L].reshape(-1, 64), GZ[depth:L].reshape(-1, 64))
+        d_we = ops.nnconv_bwd_we_bf16(X[0:L], GS, graph)                 # bf16 [E, 4096]
+        del GZ, GS
+        d_b2 = ops.colsum_bf16(d_we)
+        d_w2 = ops.gemm_atb_bf16(d_we, h2)
+        gz2 = ops.relu_bwd_bf16(ops.linear_bf16(d_we, ops.transpose(w2), None, out_bf16=False), h2, out_bf16=True)
+        del d_we
+        d_b1 = ops.colsum_bf16(gz2)
+        d_w1 = ops.gemm_atb_bf16(gz2, h1)
+        gz1 = ops.relu_bwd_bf16(ops.linear_bf16(gz2, ops.transpose(w1), None, out_bf16=False), h1, out_bf16=False)
+        d_b0 = ops.colsum(gz1)
+        d_w0 = ops.gemm_atb(gz1, ea)                                     # n2 = 6: the fp32 kernel
+        return (g, None, None, None, None, d_w0, d_b0, d_w1, d_b1, d_w2, d_b2, d_root1, d_bias1, d_root2, d_bias2)
+
+    @staticmethod
     def backward(ctx, g_out):
+        if ctx.bf16:
+            return KernelIntegralBlock._backward_bf16(ctx, g_out)
         ea, h1, h2, w_e, X, w0, w1, w2, root1, root2 = ctx.saved_tensors
         graph, depth, gemm_mode = ctx.graph, ctx.depth, ctx.gemm_mode
         L, R = 2 * depth, X.shape[1]
@@ -120,7 +179,13 @@ def train_forward(model, data) -> torch.Tensor:
     if conv2 is None and model.depth % 2:
         raise NotImplementedError("notebook-era variant: training needs an even depth")
     c2 = conv2 if conv2 is not None else model.conv1
-    x = KernelIntegralBlock.apply(x0, batch.edge_attr.to(dev), graph, depth, getattr(model, "gemm_mode", "f32"),
+    precision = getattr(model, "train_precision", "fp32")
+    if precision not in ("fp32", "bf16"):
+        raise MdnoError(f"train_precision={precision!r} (fp32, bf16)")
+    if precision == "bf16" and (model.fc1.out_features != 64 or w1.shape[0] % 128 or w1.shape[1] % 32):
+        raise NotImplementedError("bf16 training needs width 64 and ker_width a multiple of 128")
+    x = KernelIntegralBlock.apply(x0, batch.edge_attr.to(dev), graph, depth,
+                                  "bf16" if precision == "bf16" else getattr(model, "gemm_mode", "f32"),
                                   w0, b0, w1, b1, w2, b2,
                                   model.conv1.root, model.conv1.bias, c2.root, c2.bias)
     return model.fc2(x)

@@ -33,6 +33,9 @@ ap.add_argument("--kernel-width", type=int, default=1024)
 ap.add_argument("--depth", type=int, default=6)
 ap.add_argument("--lr", type=float, default=1e-4)
 ap.add_argument("--cpu-batches", type=int, default=0)
+ap.add_argument("--precision", choices=["fp32", "bf16"], default="bf16",
+                help="bf16 (BASELINE configs[3]): h1, h2, W_e, dW_e stored in bf16, single-product bf16 GEMMs with "
+                     "fp32 accumulation, fp32 master weights; fp32: split-bf16 GEMMs at fp32-level accuracy")
 ap.add_argument("--workdir", default="/tmp/mdno_train")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -58,6 +61,7 @@ with torch.no_grad():     # the reference's init makes activations explode throu
         p_.mul_(0.05)
 cpu_model = copy.deepcopy(model)
 model.to(dev)
+model.train_precision = a.precision
 opt = torch.optim.Adam(model.parameters(), lr=a.lr, weight_decay=5e-4)
 sched = torch.optim.lr_scheduler.StepLR(opt, step_size=50, gamma=0.8)
 loss_fn = LpLoss(size_average=False)
@@ -76,8 +80,10 @@ def validate():
 
 summary = {"frames": a.frames, "batch_size": B, "train_batches": len(batches), "edges_per_batch":
            int(sum(s.edge_index.shape[1] for s in batches[0])), "kernel_width": a.kernel_width, "depth": a.depth}
+summary["precision"] = a.precision
 train_epoch(model, batches[:1], opt, loss_fn)          # warm-up (allocator, kernels)
 torch.cuda.synchronize()
+torch.cuda.reset_peak_memory_stats()
 for ep in range(a.epochs):
     t0 = time.perf_counter()
     tl, mse = train_epoch(model, batches, opt, loss_fn)
@@ -86,7 +92,8 @@ for ep in range(a.epochs):
     vl = validate()
     sched.step()
     print(f"Epoch: {ep}\tTime: {dt}\ttrain_loss: {tl}\tvalid_loss: {vl}")
-    summary.update(epoch_seconds=dt, samples_per_s=len(batches) * B / dt, train_loss=tl, valid_loss=vl, train_mse=mse)
+    summary.update(epoch_seconds=dt, samples_per_s=len(batches) * B / dt, train_loss=tl, valid_loss=vl, train_mse=mse,
+                   peak_memory_MiB=torch.cuda.max_memory_allocated() / 2**20)
 
 if a.cpu_batches:
     # same step in plain torch autograd on the host (oracle formulas, edge-MLP evaluated once per forward):

@@ -178,3 +178,125 @@ def test_training_reduces_loss(dev, tmp_path):
     for _ in range(5):
         last, _ = train_epoch(model, batches, opt, LpLoss(size_average=False))
     assert last < 0.8 * first, (first, last)
+
+
+# ------------------------------------------------------------------------------- bf16 training (cfg4)
+def test_bf16_ops_against_fp64_of_the_rounded_operands(dev, O):
+    """csrc/train_bf16.hip op by op.  GEMMs are exact products of the bf16-rounded operands with fp32
+    accumulation, so against fp64 of the SAME rounded operands they are as accurate as an fp32 GEMM; the
+    conv kernels with bf16 W_e equal the fp32 kernels fed the rounded weights (same chains, same FMAs)."""
+    from molecular_dynamics_neural_operator_amd import ops
+    g = torch.Generator().manual_seed(7)
+    bf = lambda t_: t_.to(torch.bfloat16)
+    for rows, n, k in ((300, 128, 64), (1000, 256, 1024), (517, 4096, 128)):
+        a, w, b = torch.randn(rows, k, generator=g), torch.randn(n, k, generator=g) / k ** 0.5, torch.randn(n, generator=g)
+        ab = ops.cast_bf16(a.to(dev))
+        assert torch.equal(ab.cpu(), bf(a))                                             # round to nearest even
+        want = F.linear(bf(a).double(), bf(w).double(), b.double())
+        got = ops.linear_bf16(ab, w.to(dev), b.to(dev), relu=False, out_bf16=False)
+        assert rel_err(got, want) < 3e-6
+        got = ops.linear_bf16(ab, w.to(dev), b.to(dev), relu=True, out_bf16=True)
+        assert got.dtype == torch.bfloat16 and rel_err(got.float(), want.relu()) < 4e-3      # one bf16 rounding
+        assert rel_err(ops.linear_bf16(ab, w.to(dev), None, out_bf16=False), F.linear(bf(a).double(), bf(w).double())) < 3e-6
+    for rows, n1, n2 in ((5000, 128, 256), (333, 1024, 128), (4097, 256, 4096), (31, 128, 128)):
+        a, b = torch.randn(rows, n1, generator=g), torch.randn(rows, n2, generator=g)
+        got = ops.gemm_atb_bf16(bf(a).to(dev), bf(b).to(dev))
+        assert rel_err(got, bf(a).double().t() @ bf(b).double()) < 3e-6
+        assert torch.equal(got, ops.gemm_atb_bf16(bf(a).to(dev), bf(b).to(dev)))        # fixed-order slices
+        assert rel_err(ops.colsum_bf16(bf(a).to(dev)), bf(a).double().sum(0)) < 3e-6
+    gq, y = torch.randn(40, 64, generator=g), torch.randn(40, 64, generator=g)
+    assert torch.equal(ops.relu_bwd_bf16(gq.to(dev), bf(y).to(dev), out_bf16=False).cpu(), gq * (bf(y).float() > 0))
+    assert torch.equal(ops.relu_bwd_bf16(gq.to(dev), bf(y).to(dev), out_bf16=True).cpu(), bf(gq * (bf(y).float() > 0)))
+    # conv kernels on an irregular graph (hub, isolated node, duplicate edges)
+    n, E = 90, 1500
+    ei = torch.randint(0, n, (2, E), generator=g)
+    ei[1, :220] = 11
+    ei[1, ei[1] == 30] = 31
+    x = torch.randn(n, 64, generator=g).to(dev)
+    w_e = (torch.randn(E, 4096, generator=g) * 0.1)
+    root, bias = (torch.randn(64, 64, generator=g) * 0.1).to(dev), torch.randn(64, generator=g).to(dev)
+    gr = ops.coo_to_csr(ei.to(dev), n)
+    perm = gr.perm[:E].long()
+    wb = bf(w_e).to(dev)[perm].contiguous()
+    y32 = ops.nnconv(x, gr, wb.float(), root, bias, "mean", relu=True)
+    yb = ops.nnconv_bf16w(x, gr, wb, root, bias, "mean", relu=True)
+    assert torch.equal(yb, y32)
+    gy = torch.randn(n, 64, generator=g).to(dev)
+    inv = ops.inv_degree(gr, "mean")
+    gz, gs = ops.relu_bwd(gy, yb), ops.relu_bwd(gy, yb, inv)
+    by_src = ops.source_sorted(gr, n)
+    assert torch.equal(ops.nnconv_bwd_x_bf16w(gz, gs, by_src, wb, root), ops.nnconv_bwd_x(gz, gs, by_src, wb.float(), root))
+    d32 = ops.nnconv_bwd_we(x.unsqueeze(0), gs.unsqueeze(0), gr)
+    assert torch.equal(ops.nnconv_bwd_we_bf16(x.unsqueeze(0), gs.unsqueeze(0), gr), bf(d32))
+
+
+def test_bf16_model_gradients_vs_fp64_replica(dev, O, tmp_path):
+    """train_precision="bf16" on the batch of test_model_gradients_vs_fp64_replica: loss, outputs and every
+    parameter gradient against the fp64 replica at the tolerance bf16 storage of h1, h2, W_e, dW_e allows.
+    Each stored value carries 8 mantissa bits (2^-9 = 2e-3 relative); the gradients of the block's own
+    parameters come out at ~3e-2 relative L2 on this 3-sample batch (1e-2 at 16 samples: the error
+    averages over edges), those of the parameters upstream of 2*depth backward conv steps (LSTM, fc1,
+    embedding — sums with heavy cancellation, 20-40x the conditioning the fp32 path shows at 1e-6) at up to
+    0.25; every gradient points the same way (cosine > 0.97).  Bitwise repeatable."""
+    from molecular_dynamics_neural_operator_amd.dataset import ContactMapDataset
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN, LpLoss
+    from molecular_dynamics_neural_operator_amd.training import collate, train_forward
+    z = load_golden("rollout_20.npz")
+    path = tmp_path / "traj.npz"
+    write_golden_trajectory(path, z)
+    dset = ContactMapDataset(str(path), window_size=int(z["window"]), horizon=1)
+    samples = [dset[i] for i in (0, 7, 19)]
+    B = len(samples)
+    torch.manual_seed(3)
+    model = KernelNN(64, 128, 2, 6, 7, 3, 20, 4)
+    with torch.no_grad():
+        for p_ in model.conv1.net.layers[4].parameters():
+            p_.mul_(0.2)
+    model.to(dev).train()
+    model.train_precision = "bf16"
+    out = model(samples)
+    y = torch.cat([s.y for s in samples]).to(dev)
+    loss = LpLoss(size_average=False)(out.view(B, -1), y.view(B, -1))
+    loss.backward()
+    want_loss, want_out, want_grads = _replica_loss(model, O, collate(samples), B)
+    assert abs(float(loss) - want_loss) < 5e-3 * abs(want_loss)
+    assert rel_err(out, want_out) < 5e-3
+    errs = {n: rel_err(p_.grad, want_grads[n]) for n, p_ in model.named_parameters()}
+    print("bf16 gradient rel errors:", {k: f"{v:.1e}" for k, v in errs.items()})
+    for n, p_ in model.named_parameters():
+        upstream = n.startswith(("lstm", "emb", "fc1"))
+        assert errs[n] < (0.3 if upstream else 6e-2), (n, errs[n])
+        cos = F.cosine_similarity(p_.grad.detach().cpu().double().flatten(), want_grads[n].flatten(), dim=0)
+        assert float(cos) > 0.97, (n, float(cos))
+    g1 = {n: p_.grad.clone() for n, p_ in model.named_parameters()}
+    model.zero_grad()
+    out2 = train_forward(model, samples)
+    LpLoss(size_average=False)(out2.view(B, -1), y.view(B, -1)).backward()
+    for n, p_ in model.named_parameters():
+        if not n.startswith(("lstm", "emb", "fc1", "fc2", "lstm_fc")):
+            assert torch.equal(p_.grad, g1[n]), n
+
+
+def test_bf16_training_reduces_loss(dev, tmp_path):
+    from molecular_dynamics_neural_operator_amd import synthetic as syn
+    from molecular_dynamics_neural_operator_amd.dataset import ContactMapDataset, write_trajectory_npz
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN, LpLoss
+    from molecular_dynamics_neural_operator_amd.training import train_epoch
+    base = syn.chain_frame(28, seed=0)
+    traj = syn.ou_trajectory(base, 60, sigma=0.15, theta=0.2, seed=2)
+    path = tmp_path / "t.npz"
+    write_trajectory_npz(path, traj, [syn.contact_map(f, 8.0) for f in traj], syn.amino_acids(28, seed=0))
+    dset = ContactMapDataset(str(path), window_size=10, horizon=1)
+    torch.manual_seed(0)
+    model = KernelNN(64, 128, 2, 6, 7, 3, 20, 4)
+    with torch.no_grad():
+        for p_ in model.conv1.net.layers[4].parameters():
+            p_.mul_(0.2)
+    model.to(dev)
+    model.train_precision = "bf16"
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-4)
+    batches = [[dset[i] for i in range(s, s + 8)] for s in range(0, 40, 8)]
+    first, _ = train_epoch(model, batches, opt, LpLoss(size_average=False))
+    for _ in range(5):
+        last, _ = train_epoch(model, batches, opt, LpLoss(size_average=False))
+    assert last < 0.8 * first, (first, last)

@@ -98,9 +98,13 @@ class KernelIntegralBlock(torch.autograd.Function):
         del d_we
         d_b1 = ops.colsum_bf16(gz2)
         d_w1 = ops.gemm_atb_bf16(gz2, h1)
-        gz1 = ops.relu_bwd_bf16(ops.linear_bf16(gz2, ops.transpose(w1), None, out_bf16=False), h1, out_bf16=False)
-        d_b0 = ops.colsum(gz1)
-        d_w0 = ops.gemm_atb(gz1, ea)                                     # n2 = 6: the fp32 kernel
+        gz1 = ops.relu_bwd_bf16(ops.linear_bf16(gz2, ops.transpose(w1), None, out_bf16=False), h1, out_bf16=True)
+        d_b0 = ops.colsum_bf16(gz1)
+        # d_w0 = gz1^T . ea with ea [E, 6]: the six attribute columns ride in a zero-padded 128-column bf16
+        # operand of the same A^T.B kernel (the generic fp32 kernel took as long as the big products)
+        ea_pad = torch.zeros((ea.shape[0], 128), dtype=torch.float32, device=ea.device)
+        ea_pad[:, :ea.shape[1]].copy_(ea)
+        d_w0 = ops.gemm_atb_bf16(gz1, ops.cast_bf16(ea_pad))[:, :ea.shape[1]].contiguous()
         return (g, None, None, None, None, d_w0, d_b0, d_w1, d_b1, d_w2, d_b2, d_root1, d_bias1, d_root2, d_bias2)
 
     @staticmethod

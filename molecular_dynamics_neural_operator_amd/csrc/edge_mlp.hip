@@ -22,6 +22,7 @@
 // The number of valid rows (edges) lives in device memory (the graph is rebuilt on the device every
 // rollout step), so grids are sized by capacity and whole tiles beyond *num_edges exit at once.
 #include "kernels.h"
+#include "mfma_f32.h"
 
 namespace mdno {
 namespace {
@@ -94,26 +95,11 @@ struct GemmArgs {
     int tiled_out;        // 1: C written k-tiled [rows/128][N/32][128][32] (csrc/factored.hip step (2))
 };
 
-// One K-tile of MFMA work for a wave: 2x2 tiles of 32x32, BK/8 groups of 4 k-steps each.
+// One K-tile of MFMA work for a wave: 2x2 tiles of 32x32 (mfma_f32.h)
+static_assert(LDS_LD == f32mma::LD && BK == f32mma::BK, "tile helpers assume 36-float LDS rows");
 __device__ __forceinline__ void mma_tile(f32x16 (&acc)[2][2], const float* __restrict__ a_base,
                                          const float* __restrict__ b_base) {
-#pragma unroll
-    for (int t = 0; t < BK / 8; ++t) {
-        const float4 a0 = *reinterpret_cast<const float4*>(a_base + 8 * t);
-        const float4 a1 = *reinterpret_cast<const float4*>(a_base + 32 * LDS_LD + 8 * t);
-        const float4 b0 = *reinterpret_cast<const float4*>(b_base + 8 * t);
-        const float4 b1 = *reinterpret_cast<const float4*>(b_base + 32 * LDS_LD + 8 * t);
-#define MDNO_MMA4(A, B, ACC)                                                   \
-    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A.x, B.x, ACC, 0, 0, 0);        \
-    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A.y, B.y, ACC, 0, 0, 0);        \
-    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A.z, B.z, ACC, 0, 0, 0);        \
-    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A.w, B.w, ACC, 0, 0, 0);
-        MDNO_MMA4(a0, b0, acc[0][0])
-        MDNO_MMA4(a0, b1, acc[0][1])
-        MDNO_MMA4(a1, b0, acc[1][0])
-        MDNO_MMA4(a1, b1, acc[1][1])
-#undef MDNO_MMA4
-    }
+    f32mma::mma_64x64(acc, a_base, b_base);
 }
 
 template <bool RELU>

@@ -26,45 +26,16 @@
 //                         (v_mfma_f32_32x32x2_f32), bit-for-bit an fmaf chain.
 // (2) is bound by the H / Y stream (4 KiB of H per edge per application), not by the matrix pipe.
 #include "kernels.h"
+#include "mfma_f32.h"
 #include "split_layout.h"
 
 namespace mdno {
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int BK = 32, LD = BK + 4;   // LDS rows padded to 36 floats (conflict-free ds_read_b128)
-
-#define MDNO_MMA4(A, B, ACC)                                                   \
-    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A.x, B.x, ACC, 0, 0, 0);        \
-    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A.y, B.y, ACC, 0, 0, 0);        \
-    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A.z, B.z, ACC, 0, 0, 0);        \
-    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A.w, B.w, ACC, 0, 0, 0);
-
-// One K-tile for a wave owning a 64x64 sub-tile (2x2 MFMA tiles).
-__device__ __forceinline__ void mma_64x64(f32x16 (&acc)[2][2], const float* __restrict__ ab,
-                                          const float* __restrict__ bb) {
-#pragma unroll
-    for (int t = 0; t < BK / 8; ++t) {
-        const float4 a0 = *reinterpret_cast<const float4*>(ab + 8 * t);
-        const float4 a1 = *reinterpret_cast<const float4*>(ab + 32 * LD + 8 * t);
-        const float4 b0 = *reinterpret_cast<const float4*>(bb + 8 * t);
-        const float4 b1 = *reinterpret_cast<const float4*>(bb + 32 * LD + 8 * t);
-        MDNO_MMA4(a0, b0, acc[0][0]) MDNO_MMA4(a0, b1, acc[0][1])
-        MDNO_MMA4(a1, b0, acc[1][0]) MDNO_MMA4(a1, b1, acc[1][1])
-    }
-}
-
-// One K-tile for a wave owning a 32x64 sub-tile (1x2 MFMA tiles).
-__device__ __forceinline__ void mma_32x64(f32x16& acc0, f32x16& acc1, const float* __restrict__ ab,
-                                          const float* __restrict__ bb) {
-#pragma unroll
-    for (int t = 0; t < BK / 8; ++t) {
-        const float4 a0 = *reinterpret_cast<const float4*>(ab + 8 * t);
-        const float4 b0 = *reinterpret_cast<const float4*>(bb + 8 * t);
-        const float4 b1 = *reinterpret_cast<const float4*>(bb + 32 * LD + 8 * t);
-        MDNO_MMA4(a0, b0, acc0) MDNO_MMA4(a0, b1, acc1)
-    }
-}
+using f32mma::f32x16;
+using f32mma::mma_32x64;
+using f32mma::mma_64x64;
+constexpr int BK = f32mma::BK, LD = f32mma::LD;   // LDS rows padded to 36 floats (conflict-free ds_read_b128)
 
 // ---------------------------------------------------------------- W3 [Cin*Cout, k] -> W3T [n', i]
 // Row order n' = (c/32)*(C*32) + o*32 + c%32: the GEMM output row  Y[node][n']  is then already the

@@ -12,31 +12,14 @@
 // and ReLU masks.  Everything is fp32; reductions over rows/edges use fixed-order partial sums
 // (no float atomics), so gradients are bitwise reproducible.
 #include "kernels.h"
+#include "mfma_f32.h"
 
 namespace mdno {
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int BK = 32, LD = BK + 4;
-
-#define MDNO_MMA4(A, B, ACC)                                                   \
-    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A.x, B.x, ACC, 0, 0, 0);        \
-    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A.y, B.y, ACC, 0, 0, 0);        \
-    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A.z, B.z, ACC, 0, 0, 0);        \
-    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A.w, B.w, ACC, 0, 0, 0);
-
-__device__ __forceinline__ void mma_64x64(f32x16 (&acc)[2][2], const float* __restrict__ ab,
-                                          const float* __restrict__ bb) {
-#pragma unroll
-    for (int t = 0; t < BK / 8; ++t) {
-        const float4 a0 = *reinterpret_cast<const float4*>(ab + 8 * t);
-        const float4 a1 = *reinterpret_cast<const float4*>(ab + 32 * LD + 8 * t);
-        const float4 b0 = *reinterpret_cast<const float4*>(bb + 8 * t);
-        const float4 b1 = *reinterpret_cast<const float4*>(bb + 32 * LD + 8 * t);
-        MDNO_MMA4(a0, b0, acc[0][0]) MDNO_MMA4(a0, b1, acc[0][1])
-        MDNO_MMA4(a1, b0, acc[1][0]) MDNO_MMA4(a1, b1, acc[1][1])
-    }
-}
+using f32mma::f32x16;
+using f32mma::mma_64x64;
+constexpr int BK = f32mma::BK, LD = f32mma::LD;
 
 // ---------------------------------------------------------------- C = act(A . Bt^T + bias), any M
 // A [M,K], Bt [N,K], C [M,N]; N % 128 == 0, K % 32 == 0 (MFMA path).  128x128x32 tile, 4 waves.

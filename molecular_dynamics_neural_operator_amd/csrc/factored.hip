@@ -470,15 +470,17 @@ __global__ __launch_bounds__(256) void reverse_edges_kernel(const int* __restric
 }
 
 // ---------------------------------------------------------------- (3) aggregate + root + bias + act
-// One workgroup (4 waves) per destination row; thread = (es, q): sixteen in-edges are gathered per
-// step (es = tid>>4), 16 B of the 64-float message per thread (q = tid&15), two steps in flight.
+// One workgroup (8 waves) per destination row; thread = (es, q): thirty-two in-edges are gathered per
+// step (es = tid>>4), 16 B of the 64-float message per thread (q = tid&15), four steps in flight.
 // The rows gathered are 256 B each at random positions of M, so the kernel is bound by how many
 // loads are outstanding, not by bytes: one wave per row (4 chains) took 35 us per application,
 // this shape 3x less.  Each es-chain adds its edges in row order (and an edge's k-slice partials
-// in slice order); the sixteen chains are then added in es order through LDS — a fixed order, so the
-// result is deterministic.  The root term x_t.root is accumulated the same way (es picks 4 of the
+// in slice order); the 32 chains are then added in es order through LDS — a fixed order, so the
+// result is deterministic.  The root term x_t.root is accumulated the same way (es picks 2 of the
 // 64 input channels).
-__global__ __launch_bounds__(256) void aggregate_rev_kernel(const float* __restrict__ Mp, long long part_stride,
+constexpr int AGG_CHAINS = 32;      // summation chains per destination row (es), 16 threads (q) each
+
+__global__ __launch_bounds__(AGG_CHAINS * 16) void aggregate_rev_kernel(const float* __restrict__ Mp, long long part_stride,
                                                             const int* __restrict__ rev,
                                                             const int* __restrict__ row_ptr,
                                                             const float* __restrict__ x,
@@ -490,11 +492,32 @@ __global__ __launch_bounds__(256) void aggregate_rev_kernel(const float* __restr
                                                             unsigned char* __restrict__ next_xp,
                                                             unsigned char* __restrict__ next_xh,
                                                             int* __restrict__ next_flag) {
-    __shared__ float4 part[16][16];
+    constexpr int CPT = 64 / AGG_CHAINS;     // input channels per thread in the root / B3 products
+    __shared__ float4 part[AGG_CHAINS][16];
     const int tid = threadIdx.x, es = tid >> 4, q = tid & 15;
     const int t = blockIdx.x;
     const int beg = row_ptr[t], end = row_ptr[t + 1];
     const int deg = end - beg;
+    // Everything the tail of this kernel needs from memory besides the messages is fetched NOW, so that
+    // its latency hides behind the message loop instead of forming a chain behind it: the thread's
+    // CPT x 4 block of root and of the next application's B3 (input channels CPT*es.., output columns
+    // 4q..4q+3), its input features and the bias.
+    float4 rootv[CPT], b3v[CPT], biasv = make_float4(0.f, 0.f, 0.f, 0.f);
+    float xin[CPT];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) { rootv[i] = b3v[i] = make_float4(0.f, 0.f, 0.f, 0.f); xin[i] = 0.f; }
+    if (root != nullptr) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            xin[i] = x[(size_t)t * 64 + CPT * es + i];
+            rootv[i] = *reinterpret_cast<const float4*>(root + (CPT * es + i) * 64 + 4 * q);
+        }
+    }
+    if (next_b3 != nullptr) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) b3v[i] = *reinterpret_cast<const float4*>(next_b3 + (CPT * es + i) * 64 + 4 * q);
+    }
+    if (bias != nullptr && es == 0) biasv = *reinterpret_cast<const float4*>(bias + 4 * q);
     // Every entry has KS partials; an entry in a later tile of its row has MAX_PLANES (top bits of
     // rev[]; rare).  All loads of a step are issued before any is consumed — the extra planes under a
     // predicate, zero when absent — so a step costs one memory round trip either way; partials are
@@ -517,34 +540,36 @@ __global__ __launch_bounds__(256) void aggregate_rev_kernel(const float* __restr
         for (int k = 1; k < MAX_PLANES; ++k) { e.x += g.v[k].x; e.y += g.v[k].y; e.z += g.v[k].z; e.w += g.v[k].w; }
         return e;
     };
+    // Chain es adds entries beg+es, beg+es+32, ... in that order.  Batches of four: the four rev[] words,
+    // then every plane of the four messages, are in flight together, so a batch costs two dependent
+    // round trips whatever its size — and a row of up to 128 entries is ONE batch per chain (the first
+    // version, 16 chains and a 4-2-1 ladder of loops, took three batches for a row of 120).
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    int p = beg + es;
-    for (; p + 48 < end; p += 64) {      // four messages (8+ loads) in flight per thread
-        const int rp0 = rev[p], rp1 = rev[p + 16], rp2 = rev[p + 32], rp3 = rev[p + 48];
-        const Msg g0 = fetch(rp0), g1 = fetch(rp1), g2 = fetch(rp2), g3 = fetch(rp3);
-        const float4 e0 = total(g0), e1 = total(g1), e2 = total(g2), e3 = total(g3);
-        acc.x += e0.x; acc.y += e0.y; acc.z += e0.z; acc.w += e0.w;
-        acc.x += e1.x; acc.y += e1.y; acc.z += e1.z; acc.w += e1.w;
-        acc.x += e2.x; acc.y += e2.y; acc.z += e2.z; acc.w += e2.w;
-        acc.x += e3.x; acc.y += e3.y; acc.z += e3.z; acc.w += e3.w;
-    }
-    for (; p + 16 < end; p += 32) {
-        const int rp0 = rev[p], rp1 = rev[p + 16];
-        const Msg g0 = fetch(rp0), g1 = fetch(rp1);
-        const float4 e0 = total(g0), e1 = total(g1);
-        acc.x += e0.x; acc.y += e0.y; acc.z += e0.z; acc.w += e0.w;
-        acc.x += e1.x; acc.y += e1.y; acc.z += e1.z; acc.w += e1.w;
-    }
-    if (p < end) {
-        const float4 e0 = total(fetch(rev[p]));
-        acc.x += e0.x; acc.y += e0.y; acc.z += e0.z; acc.w += e0.w;
+    for (int p = beg + es; p < end; p += 4 * AGG_CHAINS) {
+        int rp[4];
+        bool on[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            on[k] = p + k * AGG_CHAINS < end;
+            rp[k] = on[k] ? rev[p + k * AGG_CHAINS] : 0;
+        }
+        Msg g[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (on[k]) g[k] = fetch(rp[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (on[k]) {
+                const float4 e = total(g[k]);
+                acc.x += e.x; acc.y += e.y; acc.z += e.z; acc.w += e.w;
+            }
     }
     part[es][q] = acc;
     __syncthreads();
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (es == 0) {
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
+        for (int c = 0; c < AGG_CHAINS; ++c) {
             const float4 v = part[c][q];
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
@@ -556,21 +581,17 @@ __global__ __launch_bounds__(256) void aggregate_rev_kernel(const float* __restr
     if (root != nullptr) {
         __syncthreads();
         float4 racc = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float* xr = x + (size_t)t * 64 + 4 * es;
-        const float* rp = root + (4 * es) * 64 + 4 * q;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float xi = xr[i];
-            const float4 w = *reinterpret_cast<const float4*>(rp + i * 64);
-            racc.x = fmaf(xi, w.x, racc.x); racc.y = fmaf(xi, w.y, racc.y);
-            racc.z = fmaf(xi, w.z, racc.z); racc.w = fmaf(xi, w.w, racc.w);
+        for (int i = 0; i < CPT; ++i) {
+            racc.x = fmaf(xin[i], rootv[i].x, racc.x); racc.y = fmaf(xin[i], rootv[i].y, racc.y);
+            racc.z = fmaf(xin[i], rootv[i].z, racc.z); racc.w = fmaf(xin[i], rootv[i].w, racc.w);
         }
         part[es][q] = racc;
         __syncthreads();
         if (es == 0) {
             float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int c = 0; c < 16; ++c) {
+            for (int c = 0; c < AGG_CHAINS; ++c) {
                 const float4 v = part[c][q];
                 r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w;
             }
@@ -578,27 +599,42 @@ __global__ __launch_bounds__(256) void aggregate_rev_kernel(const float* __restr
         }
     }
     if (es == 0) {
-        if (bias != nullptr) {
-            const float4 b = *reinterpret_cast<const float4*>(bias + 4 * q);
-            s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
-        }
+        if (bias != nullptr) { s.x += biasv.x; s.y += biasv.y; s.z += biasv.z; s.w += biasv.w; }
         if (relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
         *reinterpret_cast<float4*>(y + (size_t)t * 64 + 4 * q) = s;
     }
     // What the NEXT conv application needs from this row, while it is at hand (saves a launch per
-    // application): q = y_t . B3 (bias of the last MLP layer seen through the node) and the bf16
-    // plane image of y_t (operand of the Y GEMM).  Same arithmetic as split_bias64_kernel.
+    // application): q = y_t . B3 (bias of the last MLP layer seen through the node) and the plane
+    // images of y_t (operand of the Y GEMM).  q is summed like the root term — sixteen 4-term partial
+    // products (es picks the input channels) added in es order — from the B3 block fetched up front;
+    // the first version ran 64 dependent-latency loads per thread behind everything else.
     if (next_b3 != nullptr) {
         __syncthreads();
         if (es == 0) part[0][q] = s;
         __syncthreads();
         const float* row = reinterpret_cast<const float*>(&part[0][0]);
-        if (tid < 64) {
-            float acc2 = 0.f;
-#pragma unroll 16
-            for (int i = 0; i < 64; ++i) acc2 = fmaf(row[i], next_b3[i * 64 + tid], acc2);
-            next_q[(size_t)t * 64 + tid] = acc2;
-        } else if (tid < 72) {
+        float4 qacc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const float yi = row[CPT * es + i];
+            qacc.x = fmaf(yi, b3v[i].x, qacc.x); qacc.y = fmaf(yi, b3v[i].y, qacc.y);
+            qacc.z = fmaf(yi, b3v[i].z, qacc.z); qacc.w = fmaf(yi, b3v[i].w, qacc.w);
+        }
+        // the plane images are cut from `row` by threads 64..71 while the partial products are parked
+        // in a second LDS array
+        __shared__ float4 qpart[AGG_CHAINS][16];
+        qpart[es][q] = qacc;
+        __syncthreads();
+        if (es == 0) {
+            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int c = 0; c < AGG_CHAINS; ++c) {
+                const float4 v = qpart[c][q];
+                r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w;
+            }
+            *reinterpret_cast<float4*>(next_q + (size_t)t * 64 + 4 * q) = r;
+        }
+        if (tid >= 64 && tid < 72) {
             const int c = tid - 64;
             __bf16 pl[3][8];
 #pragma unroll
@@ -764,7 +800,7 @@ int factored_conv(const float* x, const float* h2, const int* row_ptr, int num_r
     const bool split_next = gemm_mode == MDNO_GEMM_SPLIT_BF16 && next_b3 != nullptr;
     {
         TimedSection ts(KID_NNCONV_COMBINE, s);
-        hipLaunchKernelGGL(aggregate_rev_kernel, dim3(num_rows), dim3(256), 0, s, (const float*)f.m,
+        hipLaunchKernelGGL(aggregate_rev_kernel, dim3(num_rows), dim3(AGG_CHAINS * 16), 0, s, (const float*)f.m,
                            f.part_stride, (const int*)f.rev, row_ptr, x, root, bias, y, num_rows, aggr, relu,
                            split_next ? next_b3 : nullptr, f.q, static_cast<unsigned char*>(f.xp),
                            y_f16 ? static_cast<unsigned char*>(f.xh) : nullptr, y_f16 ? flag_x + 1 : nullptr);

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDNO_ABI_VERSION 7
+#define MDNO_ABI_VERSION 8
 
 #define MDNO_OK            0
 #define MDNO_EINVAL       -1   /* bad argument (null pointer, non-positive size, unsupported dim) */
@@ -335,6 +335,26 @@ int mdno_relu_bwd_bf16(const float* g, const void* y, int64_t rows, int n, int o
 size_t mdno_colsum_bf16_workspace_bytes(int n);
 int mdno_colsum_bf16(const void* a, int64_t rows, int n, float* out, void* workspace, size_t workspace_bytes,
                      void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Training: backward of the per-atom ends (csrc/train_nodes.hip) — the node prologue (graph_kernel.py:279-298;
+ * forward = mdno_node_prologue_fwd) and fc2 (:305; forward = mdno_fc_out_fwd).  Fixed-order reductions.
+ *   mdno_node_prologue_bwd   x0, g0 f32 [M*N,width]: the forward's output and dLoss/dx0.  Outputs (overwritten):
+ *                            d_lstm f32 [96] = [w_ih 36 | w_hh 36 | bias 12 (the gradient of b_ih AND of b_hh) |
+ *                            lstm_fc.weight 9 | lstm_fc.bias 3] (NULL for the notebook-era model), d_emb
+ *                            [num_embeddings, embedding_dim], d_fc1_w [width, in_width], d_fc1_b [width].
+ *                            window <= 16.
+ *   mdno_fc_out_bwd          out = x . w^T + b:  dx [rows,width] = g . w,  d_w [out_width,width] = g^T . x,
+ *                            d_b [out_width] = colsum(g);  g f32 [rows,out_width]
+ * ---------------------------------------------------------------------------------------- */
+size_t mdno_node_prologue_bwd_workspace_bytes(const mdno_kernelnn_params* p, int rows);
+int mdno_node_prologue_bwd(const mdno_kernelnn_params* p, const float* frames, int M, int W, int N,
+                           const int64_t* x_aminoacid, int aa_per_member, const float* x0, const float* g0,
+                           float* d_lstm, float* d_emb, float* d_fc1_w, float* d_fc1_b,
+                           void* workspace, size_t workspace_bytes, void* stream);
+size_t mdno_fc_out_bwd_workspace_bytes(int rows, int width, int out_width);
+int mdno_fc_out_bwd(const float* x, const float* w, const float* g, int rows, int width, int out_width,
+                    float* dx, float* d_w, float* d_b, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

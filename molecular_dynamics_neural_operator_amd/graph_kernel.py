@@ -216,6 +216,13 @@ class KernelNN(nn.Module):
         # explicit edge_index/edge_attr always runs materialized.
         self.conv_mode = "auto"
 
+    def __getstate__(self):
+        # the cached ParamPack holds device pointers in a ctypes struct: never copied or pickled
+        # (copy.deepcopy(model), torch.save(model)); it is rebuilt on first use
+        state = self.__dict__.copy()
+        state["_pack"], state["_pack_key"] = None, None
+        return state
+
     # -- parameter pack (device pointers) cached until a parameter changes
     def param_pack(self, device=None, conv_mode: Optional[str] = None) -> ops.ParamPack:
         device = require_gpu(device)

@@ -473,3 +473,60 @@ def colsum_bf16(a: torch.Tensor) -> torch.Tensor:
     ws = _ws(lib.mdno_colsum_bf16_workspace_bytes(n), a.device)
     check(lib.mdno_colsum_bf16(ptr(a), rows, n, ptr(out), ptr(ws), ws.numel(), stream_ptr(a.device)), "mdno_colsum_bf16")
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# Per-atom ends (node prologue, fc2) forward + backward for training (include/mdno.h, csrc/train_nodes.hip)
+def fc_out(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
+    """x . w^T + b  (fc2, graph_kernel.py:305): x [rows,width], w [out_width,width]."""
+    lib = _lib.load()
+    x, w = f32(x), f32(w)
+    rows, width = x.shape
+    ow = w.shape[0]
+    out = torch.empty((rows, ow), dtype=torch.float32, device=x.device)
+    check(lib.mdno_fc_out_fwd(ptr(x), ptr(w), ptr(f32(b)) if b is not None else None, rows, width, ow, ptr(out),
+                              stream_ptr(x.device)), "mdno_fc_out_fwd")
+    return out
+
+
+def fc_out_bwd(x: torch.Tensor, w: torch.Tensor, g: torch.Tensor):
+    """-> (dx [rows,width], d_w [out_width,width], d_b [out_width])"""
+    lib = _lib.load()
+    x, w, g = f32(x), f32(w), f32(g)
+    rows, width = x.shape
+    ow = w.shape[0]
+    dx = torch.empty_like(x)
+    d_w = torch.empty_like(w)
+    d_b = torch.empty(ow, dtype=torch.float32, device=x.device)
+    ws = _ws(lib.mdno_fc_out_bwd_workspace_bytes(rows, width, ow), x.device)
+    check(lib.mdno_fc_out_bwd(ptr(x), ptr(w), ptr(g), rows, width, ow, ptr(dx), ptr(d_w), ptr(d_b), ptr(ws), ws.numel(),
+                              stream_ptr(x.device)), "mdno_fc_out_bwd")
+    return dx, d_w, d_b
+
+
+def node_prologue_bwd(pack: ParamPack, frames: torch.Tensor, x_aminoacid: torch.Tensor, x0: torch.Tensor,
+                      g0: torch.Tensor):
+    """Backward of `node_prologue`: -> dict of gradients under the state_dict key names."""
+    lib = _lib.load()
+    frames = f32(frames)
+    if frames.dim() == 3:
+        frames = frames.unsqueeze(1)
+    W, M, N, _ = frames.shape
+    dev = frames.device
+    aa = x_aminoacid.to(device=dev, dtype=torch.long).contiguous()
+    p = pack.struct
+    has_lstm = "lstm_w_ih" in pack.tensors
+    d_lstm = torch.empty(96, dtype=torch.float32, device=dev) if has_lstm else None
+    d_emb = torch.empty((p.num_embeddings, p.embedding_dim), dtype=torch.float32, device=dev)
+    d_w = torch.empty((p.width, p.in_width), dtype=torch.float32, device=dev)
+    d_b = torch.empty(p.width, dtype=torch.float32, device=dev)
+    ws = _ws(lib.mdno_node_prologue_bwd_workspace_bytes(pack.ref, M * N), dev)
+    check(lib.mdno_node_prologue_bwd(pack.ref, ptr(frames), M, W, N, ptr(aa), int(aa.numel() == M * N and M > 1),
+                                     ptr(f32(x0)), ptr(f32(g0)), ptr(d_lstm), ptr(d_emb), ptr(d_w), ptr(d_b), ptr(ws),
+                                     ws.numel(), stream_ptr(dev)), "mdno_node_prologue_bwd")
+    out = {"emb.weight": d_emb, "fc1.weight": d_w, "fc1.bias": d_b}
+    if has_lstm:
+        out.update({"lstm.weight_ih_l0": d_lstm[0:36].reshape(12, 3), "lstm.weight_hh_l0": d_lstm[36:72].reshape(12, 3),
+                    "lstm.bias_ih_l0": d_lstm[72:84], "lstm.bias_hh_l0": d_lstm[72:84],
+                    "lstm_fc.weight": d_lstm[84:93].reshape(3, 3), "lstm_fc.bias": d_lstm[93:96]})
+    return out

@@ -1,8 +1,8 @@
-"""Training path (BASELINE.json configs[3]): the kernel-integral block — the
-shared edge-MLP and the 2*depth conv applications, i.e. all but ~1e3 flop/atom of the model — runs
-forward AND backward in libmdno's HIP kernels behind one `torch.autograd.Function`; the per-atom
-ends (LSTM(3,3), lstm_fc, Embedding, fc1, fc2: graph_kernel.py:279-298, :305) stay torch modules so
-autograd differentiates them ("one small fused kernel (or stay in torch)").
+"""Training path (BASELINE.json configs[3]): the whole differentiable forward and
+backward of `KernelNN` runs in libmdno's HIP kernels behind three `torch.autograd.Function`s — the node
+prologue (LSTM(3,3) over the window, lstm_fc, Embedding, fc1, ReLU: graph_kernel.py:279-298), the
+kernel-integral block (shared edge-MLP + 2*depth conv applications, :299-302) and fc2 (:305).  PyTorch
+holds the parameters, chains the three functions and runs the optimizer; it computes nothing.
 
 Replaces what autograd + torch_geometric do in `train()` (graph_kernel.py:445-474).  Members of a
 batch are independent B=1 problems (block-diagonal graph); the reference's batched mode threads one
@@ -140,6 +140,43 @@ class KernelIntegralBlock(torch.autograd.Function):
         return (g, None, None, None, None, d_w0, d_b0, d_w1, d_b1, d_w2, d_b2, d_root1, d_bias1, d_root2, d_bias2)
 
 
+class NodePrologue(torch.autograd.Function):
+    """x0 = relu(fc1([emb(aa), lstm_fc(LSTM over the window)]))  (graph_kernel.py:279-298), B=1 semantics per
+    sample.  Parameters arrive as tensors (autograd tracks them) and as the model's ParamPack (device pointers)."""
+
+    @staticmethod
+    def forward(ctx, pack, frames, aa, *params):
+        x0 = ops.node_prologue(pack, frames, aa)
+        ctx.pack, ctx.names = pack, pack.prologue_names
+        ctx.save_for_backward(frames, aa, x0)
+        return x0
+
+    @staticmethod
+    def backward(ctx, g0):
+        frames, aa, x0 = ctx.saved_tensors
+        grads = ops.node_prologue_bwd(ctx.pack, frames, aa, x0, g0.contiguous())
+        return (None, None, None) + tuple(grads[n] for n in ctx.names)
+
+
+class FcOut(torch.autograd.Function):
+    """fc2 (graph_kernel.py:305)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return ops.fc_out(x, w, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        dx, d_w, d_b = ops.fc_out_bwd(x, w, g.contiguous())
+        return dx, d_w, d_b
+
+
+_PROLOGUE_KEYS = ("lstm.weight_ih_l0", "lstm.weight_hh_l0", "lstm.bias_ih_l0", "lstm.bias_hh_l0", "lstm_fc.weight",
+                  "lstm_fc.bias", "emb.weight", "fc1.weight", "fc1.bias")
+
+
 def collate(samples: Sequence[PairData]) -> PairData:
     """Block-diagonal batch; x_position stacked time-major [W, B*N, 3]."""
     if isinstance(samples, PairData):
@@ -165,16 +202,14 @@ def train_forward(model, data) -> torch.Tensor:
     aa = batch.x_aminoacid.to(dev)
     if model.conv1.net is not model.conv2.net:
         raise NotImplementedError("training assumes the reference's single shared edge-MLP (graph_kernel.py:271-273)")
-    # per-atom prologue (torch, differentiable): graph_kernel.py:279-298 with B=1 semantics per sample
-    if hasattr(model, "lstm"):
-        hidden = (torch.zeros(1, R, 3, device=dev), torch.zeros(1, R, 3, device=dev))
-        out = None
-        for t in range(W):
-            out, hidden = model.lstm(xp[t].unsqueeze(0), hidden)
-        feat = model.lstm_fc(out.reshape(R, 3))
-    else:
-        feat = xp[-1]
-    x0 = F.relu(model.fc1(torch.cat((model.emb(aa), feat), dim=1)))
+    # per-atom prologue (graph_kernel.py:279-298 with B=1 semantics per sample): HIP forward + backward.
+    # The ParamPack holds device pointers to the parameters' CURRENT storage (fp32 contiguous parameters
+    # are viewed, not copied), the tensors themselves are passed so that autograd routes their gradients.
+    sd = dict(model.named_parameters())
+    names = tuple(k for k in _PROLOGUE_KEYS if k in sd)
+    pack = model.param_pack(dev, conv_mode="materialized")
+    pack.prologue_names = names
+    x0 = NodePrologue.apply(pack, xp.unsqueeze(1).contiguous(), aa, *[sd[k] for k in names])
     graph = ops.coo_to_csr(batch.edge_index.to(dev), R)
     net = model.conv1.net
     w0, b0, w1, b1, w2, b2 = net.hip_weights()
@@ -192,7 +227,7 @@ def train_forward(model, data) -> torch.Tensor:
                                   "bf16" if precision == "bf16" else getattr(model, "gemm_mode", "f32"),
                                   w0, b0, w1, b1, w2, b2,
                                   model.conv1.root, model.conv1.bias, c2.root, c2.bias)
-    return model.fc2(x)
+    return FcOut.apply(x, model.fc2.weight, model.fc2.bias)
 
 
 def train_epoch(model, batches, optimizer, loss_fn, batch_size: Optional[int] = None):

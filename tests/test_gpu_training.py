@@ -148,9 +148,8 @@ def test_model_gradients_vs_fp64_replica(dev, O, tmp_path, gemm_mode):
     model.zero_grad()
     out2 = train_forward(model, samples)
     LpLoss(size_average=False)(out2.view(B, -1), y.view(B, -1)).backward()
-    for n, p_ in model.named_parameters():
-        if not n.startswith(("lstm", "emb", "fc1", "fc2", "lstm_fc")):     # torch's own ends may use atomics
-            assert torch.equal(p_.grad, g1[n]), n
+    for n, p_ in model.named_parameters():      # every parameter: the per-atom ends are HIP kernels too
+        assert torch.equal(p_.grad, g1[n]), n
 
 
 def test_training_reduces_loss(dev, tmp_path):
@@ -273,8 +272,7 @@ def test_bf16_model_gradients_vs_fp64_replica(dev, O, tmp_path):
     out2 = train_forward(model, samples)
     LpLoss(size_average=False)(out2.view(B, -1), y.view(B, -1)).backward()
     for n, p_ in model.named_parameters():
-        if not n.startswith(("lstm", "emb", "fc1", "fc2", "lstm_fc")):
-            assert torch.equal(p_.grad, g1[n]), n
+        assert torch.equal(p_.grad, g1[n]), n
 
 
 def test_bf16_training_reduces_loss(dev, tmp_path):
@@ -300,3 +298,53 @@ def test_bf16_training_reduces_loss(dev, tmp_path):
     for _ in range(5):
         last, _ = train_epoch(model, batches, opt, LpLoss(size_average=False))
     assert last < 0.8 * first, (first, last)
+
+
+# ------------------------------------------------------------------------------- per-atom ends in HIP
+@pytest.mark.parametrize("variant", ["intree", "notebook"])
+def test_node_prologue_and_fc2_backward_vs_autograd(dev, variant):
+    """csrc/train_nodes.hip against torch autograd (fp64) of the same modules: LSTM(3,3) over the window with
+    the atoms as the batch and zero initial state, lstm_fc, Embedding, concat, fc1, ReLU (graph_kernel.py:279-298)
+    and fc2 (:305).  300 atoms = two workgroups, one partial; repeated residue types; bitwise repeatable."""
+    from molecular_dynamics_neural_operator_amd import ops
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN, KernelNNNotebook
+    gen = torch.Generator().manual_seed(21)
+    R, W = 300, (10 if variant == "intree" else 1)
+    torch.manual_seed(5)
+    model = (KernelNN if variant == "intree" else KernelNNNotebook)(64, 128, 2, 6, 7, 3, 20, 4).to(dev)
+    frames = (torch.randn(W, R, 3, generator=gen) * 2.0).to(dev)
+    aa = torch.randint(0, 20, (R,), generator=gen).to(dev)
+    g0 = torch.randn(R, 64, generator=gen).to(dev)
+    pack = model.param_pack(dev, conv_mode="materialized")
+    x0 = ops.node_prologue(pack, frames.unsqueeze(1), aa)
+    got = ops.node_prologue_bwd(pack, frames.unsqueeze(1), aa, x0, g0)
+    # reference: the torch modules in fp64
+    import copy
+    ref = copy.deepcopy(model).cpu().double()
+    fr = frames.cpu().double()
+    if variant == "intree":
+        hidden = (torch.zeros(1, R, 3, dtype=torch.double), torch.zeros(1, R, 3, dtype=torch.double))
+        out = None
+        for t_ in range(W):
+            out, hidden = ref.lstm(fr[t_].unsqueeze(0), hidden)
+        feat = ref.lstm_fc(out.reshape(R, 3))
+    else:
+        feat = fr[-1]
+    want_x0 = F.relu(ref.fc1(torch.cat((ref.emb(aa.cpu()), feat), dim=1)))
+    assert rel_err(x0, want_x0) < 1e-6
+    want_x0.backward(g0.cpu().double())
+    sd = dict(ref.named_parameters())
+    for name, g in got.items():
+        assert rel_err(g, sd[name].grad) < 2e-5, (name, rel_err(g, sd[name].grad))
+    again = ops.node_prologue_bwd(pack, frames.unsqueeze(1), aa, x0, g0)
+    assert all(torch.equal(again[k], got[k]) for k in got)
+    # fc2
+    x = torch.randn(R, 64, generator=gen).to(dev)
+    g = torch.randn(R, 3, generator=gen).to(dev)
+    w, b = model.fc2.weight.detach(), model.fc2.bias.detach()
+    out = ops.fc_out(x, w, b)
+    assert rel_err(out, F.linear(x.double().cpu(), w.double().cpu(), b.double().cpu())) < 1e-6
+    dx, d_w, d_b = ops.fc_out_bwd(x, w, g)
+    assert rel_err(dx, g.double().cpu() @ w.double().cpu()) < 1e-6
+    assert rel_err(d_w, g.double().cpu().t() @ x.double().cpu()) < 1e-6
+    assert rel_err(d_b, g.double().cpu().sum(0)) < 1e-6

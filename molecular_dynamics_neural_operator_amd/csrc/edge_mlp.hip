@@ -287,9 +287,10 @@ int mdno::edge_mlp(const float* frames, int frame, const int* t_dev, int rows_pe
     const size_t need = mdno_edge_mlp_workspace_bytes(ker_width, out_dim, edge_cap, gemm_mode);
     MDNO_REQUIRE(workspace_bytes >= need, MDNO_EWORKSPACE, "edge_mlp: workspace %zu < %zu", workspace_bytes, need);
     const long long chunk = chunk_rows_for(edge_cap);
-    if (gemm_mode != MDNO_GEMM_F32 && edge_mlp_split_supported(ker_width, out_dim))   // (SPLIT_F16: bf16 kernels here)
+    if (gemm_mode != MDNO_GEMM_F32 && edge_mlp_split_supported(ker_width, out_dim))
         return edge_mlp_split(frames, frame, t_dev, rows_per_frame, src, dst, edge_attr, perm, num_edges, edge_cap,
-                              chunk, ker_in, ker_width, out_dim, w, w_e, workspace, s, phase);
+                              chunk, ker_in, ker_width, out_dim, w, w_e, workspace, s, phase,
+                              gemm_mode == MDNO_GEMM_SPLIT_F16 && ker_width % 32 == 0);
     if (phase == WP_PREPARE_ONLY) return MDNO_OK;   // the fp32 GEMMs read the weights as they are
     Carver cv(workspace);
     float* h1 = cv.take<float>((size_t)chunk * ker_width);

@@ -467,7 +467,8 @@ constexpr int F16_TM = 256, F16_RING = 3;
 constexpr int F16_TILE_BYTES = 2 * 2 * PLANE_BYTES;       // one 128-row tile: two k-steps x two planes = 16 KiB
 constexpr int F16_STAGE_BYTES = 3 * F16_TILE_BYTES;       // A tile 0 | A tile 1 | B = 48 KiB
 
-// OUT: 2 = fp32 k-tiled after ReLU (the factored conv's H), 0 = fp32 row-major, 3 = fp32 row-major after ReLU
+// OUT: 2 = fp32 k-tiled after ReLU (the factored conv's H), 0 = fp32 row-major, 3 = fp32 row-major after ReLU,
+//      4 = two fp16 planes after ReLU (the next GEMM's operand; raises f16_flags[1] on a value out of range)
 // MI = 32-row tiles per wave: 2 -> 8 waves of 64x64 (162 VGPRs, two waves per SIMD).  The LDS pipe, not
 // the matrix pipe, is what this shape runs into (176 KiB of LDS traffic per 1,536 matrix-pipe cycles at
 // 128 B/clk); MI = 4 — 4 waves of 128x64, a third fewer fragment reads per MFMA, but 2 x 128 accumulator
@@ -558,6 +559,7 @@ __global__ __launch_bounds__(1024 / MI) void gemm_split_f16_kernel(SplitGemmArgs
     }
 #undef MDNO_DMA_STAGE
 
+    bool bad = false;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = bn + wn * 64 + j * 32 + l31;
@@ -569,14 +571,24 @@ __global__ __launch_bounds__(1024 / MI) void gemm_split_f16_kernel(SplitGemmArgs
                 const int m = bm + wm * (MI * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (m < valid) {
                     const float v = (acc[i][j][e] + accx[i][j][e] * F16_LO_UNSCALE) + bv;
-                    if (OUT == 2)
+                    if (OUT == 2) {
                         g.C[((size_t)(m >> 7) * (g.N >> 5) + (n >> 5)) * 4096 + (m & 127) * 32 + (n & 31)] = fmaxf(v, 0.f);
-                    else
+                    } else if (OUT == 4) {
+                        const float rv = fmaxf(v, 0.f);
+                        bad |= !(rv < F16_MAX);
+                        _Float16 ph, pl;
+                        split2h(rv, ph, pl);
+                        const size_t o = tiled_off2(m, n, g.N >> 4, 0);
+                        *reinterpret_cast<_Float16*>(g.Cp + o) = ph;
+                        *reinterpret_cast<_Float16*>(g.Cp + o + PLANE_BYTES) = pl;
+                    } else {
                         g.C[(size_t)m * g.N + n] = OUT == 3 ? fmaxf(v, 0.f) : v;
+                    }
                 }
             }
         }
     }
+    if (OUT == 4 && bad) atomicOr(const_cast<int*>(g.f16_flags) + 1, 1);
 }
 
 template <int OUT, int MI>
@@ -797,9 +809,9 @@ bool edge_mlp_split_supported(int ker_width, int out_dim) {
     return ker_width % 32 == 0 && ker_width % TN == 0 && out_dim % TN == 0;
 }
 
-// One layout for both entry points: [h1 planes][h2 planes][W1 planes][W2 planes][W1 fp16 planes][flags]
+// One layout for both entry points: [h1 planes][h2 planes][W1 planes][W2 planes][W1 fp16 planes][flags][W2 fp16 planes]
 struct SplitWs {
-    unsigned char *h1p, *h2p, *w1p, *w2p, *w1h;
+    unsigned char *h1p, *h2p, *w1p, *w2p, *w1h, *w2h;
     int* f16_flags;
     size_t total;
 };
@@ -813,6 +825,7 @@ static SplitWs carve_split(void* ws, int k, int out_dim, long long chunk) {
     w.w2p = reinterpret_cast<unsigned char*>(cv.take<__bf16>(3 * (size_t)out_dim * k));
     w.w1h = reinterpret_cast<unsigned char*>(cv.take<_Float16>(2 * (size_t)k * k));
     w.f16_flags = cv.take<int>(64);
+    w.w2h = reinterpret_cast<unsigned char*>(cv.take<_Float16>(2 * (size_t)out_dim * k));
     w.total = cv.used();
     return w;
 }
@@ -824,7 +837,7 @@ size_t edge_mlp_split_workspace_bytes(int ker_width, int out_dim, long long chun
 int edge_mlp_split(const float* frames, int frame, const int* t_dev, int rows_per_frame, const int* src,
                    const int* dst, const float* edge_attr, const int* perm, const int* num_edges,
                    long long edge_cap, long long chunk, int ker_in, int ker_width, int out_dim,
-                   const EdgeMlpWeights& w, float* w_e, void* workspace, hipStream_t s, int phase) {
+                   const EdgeMlpWeights& w, float* w_e, void* workspace, hipStream_t s, int phase, bool f16) {
     MDNO_REQUIRE(ker_in > 0 && ker_in <= MAX_F, MDNO_EUNSUPPORTED, "edge_mlp: ker_in=%d (1..%d)", ker_in, MAX_F);
     MDNO_REQUIRE(((reinterpret_cast<uintptr_t>(w.w1) | reinterpret_cast<uintptr_t>(w.w2)) & 15) == 0, MDNO_EINVAL,
                  "edge_mlp: weight pointers must be 16-byte aligned");
@@ -837,12 +850,50 @@ int edge_mlp_split(const float* frames, int frame, const int* t_dev, int rows_pe
         hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((c1 + 255) / 256)), dim3(256), 0, s, w.w1, k, k, w1p);
         hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((c2 + 255) / 256)), dim3(256), 0, s, w.w2, out_dim, k,
                            w2p);
+        if (f16) {   // fp16 images of W1, W2 + their range flag (flags[0]); the bf16 images serve the fallback
+            MDNO_TRY(fill_ints(sw.f16_flags, 1, 0, s));
+            hipLaunchKernelGGL(split_planes_f16_kernel, dim3((unsigned)((c1 + 255) / 256)), dim3(256), 0, s, w.w1, k, k,
+                               sw.w1h, sw.f16_flags);
+            hipLaunchKernelGGL(split_planes_f16_kernel, dim3((unsigned)((c2 + 255) / 256)), dim3(256), 0, s, w.w2,
+                               out_dim, k, sw.w2h, sw.f16_flags);
+        }
     }
     MDNO_TRY(check_launch("split_planes_kernel"));
     if (phase == WP_PREPARE_ONLY) return MDNO_OK;
     const float* pos_mode = edge_attr ? nullptr : frames;
+    if (f16) MDNO_TRY(fill_ints(sw.f16_flags + 1, 1, 0, s));   // activation flag of THIS forward
     for (long long e0 = 0; e0 < edge_cap; e0 += chunk) {
         const int cnt = (int)((edge_cap - e0) < chunk ? (edge_cap - e0) : chunk);
+        if (f16) {
+            // SPLIT_F16: layer 0 -> fp16 planes, hidden layer -> fp16 planes of h2 (its epilogue checks the
+            // range), last layer -> W_e; then the same chunk on the bf16 kernels, which exit at their first
+            // instruction unless a range flag is up
+            {
+                TimedSection ts(KID_EDGE_L0, s);
+                MDNO_TRY(launch_edge_l0_split(pos_mode, frame, t_dev, rows_per_frame, src, dst, edge_attr, perm, num_edges,
+                                              e0, cnt, ker_in, k, w.w0, w.b0, h1p, s, true, sw.f16_flags));
+            }
+            {
+                TimedSection ts(KID_GEMM_L1, s);
+                SplitGemmArgs gh{h1p, sw.w1h, w.b1, nullptr, h2p, num_edges, e0, (int)chunk, k, k, 0, 0, 0, 0, sw.f16_flags};
+                MDNO_TRY((launch_split_f16_gemm<4, 2>(gh, s)));
+            }
+            {
+                TimedSection ts(KID_GEMM_L2, s);
+                SplitGemmArgs gh{h2p, sw.w2h, w.b2, w_e + (size_t)e0 * out_dim, nullptr, num_edges, e0, (int)chunk, out_dim,
+                                 k, 0, 0, 0, 0, sw.f16_flags};
+                MDNO_TRY((launch_split_f16_gemm<0, 2>(gh, s)));
+                MDNO_TRY(launch_edge_l0_split(pos_mode, frame, t_dev, rows_per_frame, src, dst, edge_attr, perm, num_edges,
+                                              e0, cnt, ker_in, k, w.w0, w.b0, h1p, s, false, sw.f16_flags));
+                SplitGemmArgs g1{h1p, w1p, w.b1, nullptr, h2p, num_edges, e0, (int)chunk, k, k, 0, 0, 0, 0, sw.f16_flags};
+                MDNO_TRY((launch_split_gemm_tm<128, 1>(g1, s)));
+                SplitGemmArgs g2{h2p, w2p, w.b2, w_e + (size_t)e0 * out_dim, nullptr, num_edges, e0, (int)chunk, out_dim, k,
+                                 0, 0, 0, 0, sw.f16_flags};
+                if (out_dim >= 2048) MDNO_TRY((launch_split_gemm_tm<256, 0>(g2, s)));
+                else MDNO_TRY((launch_split_gemm_tm<128, 0>(g2, s)));
+            }
+            continue;
+        }
         {
             TimedSection ts(KID_EDGE_L0, s);
             MDNO_TRY(launch_edge_l0_split(pos_mode, frame, t_dev, rows_per_frame, src, dst, edge_attr, perm, num_edges,

@@ -45,7 +45,8 @@ size_t edge_mlp_split_workspace_bytes(int ker_width, int out_dim, long long chun
 int edge_mlp_split(const float* frames, int frame, const int* t_dev, int rows_per_frame, const int* src,
                    const int* dst, const float* edge_attr, const int* perm, const int* num_edges,
                    long long edge_cap, long long chunk, int ker_in, int ker_width, int out_dim,
-                   const EdgeMlpWeights& w, float* w_e, void* workspace, hipStream_t s, int phase = WP_BOTH);
+                   const EdgeMlpWeights& w, float* w_e, void* workspace, hipStream_t s, int phase = WP_BOTH,
+                   bool f16 = false);
 
 // Edge-MLP up to its last hidden activation: H = relu(L1(relu(L0(attr)))) as fp32 [edge_cap, ker_width]
 // row-major (what the factored conv consumes); same attr modes and gemm_mode as edge_mlp.
@@ -57,8 +58,8 @@ int edge_mlp_split_hidden(const float* frames, int frame, const int* t_dev, int 
                           const int* dst, const float* edge_attr, const int* perm, const int* num_edges,
                           long long edge_cap, long long chunk, int ker_in, int ker_width, const EdgeMlpWeights& w,
                           float* h_out, void* workspace, hipStream_t s, int phase = WP_BOTH, bool f16 = false);
-// gemm_mode as the bf16-split kernels see it: SPLIT_F16 changes the k x k hidden GEMM of the factored
-// path only; every other product of that mode runs the SPLIT_BF16 kernels
+// gemm_mode as the factored conv's own kernels see it: SPLIT_F16 changes the edge-MLP GEMMs and Y = X.W3T
+// (range-checked operands); the per-source GEMM of that mode runs the SPLIT_BF16 kernel
 inline int conv_gemm_mode(int gemm_mode) { return gemm_mode == MDNO_GEMM_SPLIT_F16 ? MDNO_GEMM_SPLIT_BF16 : gemm_mode; }
 
 // Pieces of the split-bf16 GEMM usable on their own (edge_mlp_split.hip): fp32 [rows,K] -> tiled bf16

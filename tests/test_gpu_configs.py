@@ -191,6 +191,25 @@ def test_split_f16_hidden_gemm_accuracy_and_range_fallback(dev, live504):
         model.fc1.bias.mul_(3.0e4)
     a, b = latent("split_f16"), latent("split_bf16")
     assert float(b.abs().max()) > 65504.0 and bool(torch.isfinite(a).all()) and torch.equal(a, b)
+    # (3) the materialized path (model(data) with the sample's own edge list): both edge-MLP GEMMs run on fp16
+    # planes; a last-layer weight out of range, or activations out of range, send all of it through the bf16
+    # kernels -> bit-identical to split_bf16
+    model.load_state_dict(sd)
+    model.to(dev)
+
+    def forward(mode, sample):
+        model.gemm_mode = mode
+        with torch.no_grad():
+            return model(sample)
+
+    assert rel(forward("split_f16", s), forward("split_bf16", s)) < 1e-6
+    assert not torch.equal(forward("split_f16", s), forward("split_bf16", s))
+    big = dset[0].to(dev)
+    big.x_position, big.edge_attr = big.x_position * 3.0e5, big.edge_attr * 3.0e5
+    assert torch.equal(forward("split_f16", big), forward("split_bf16", big))
+    with torch.no_grad():
+        model.conv1.net.layers[4].weight[3, 9] = 1.0e5
+    assert torch.equal(forward("split_f16", s), forward("split_bf16", s))
 
 
 # ------------------------------------------------------------------------------- propogate (nb:336-358)

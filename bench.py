@@ -419,7 +419,7 @@ def worker(a):
             return {"bound": "mfma", "kernel": "gemm_tn_mfma_kernel", "achieved": flops32 / step_s / 1e12,
                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops32 / step_s / 1e12 / MFMA_F32_PEAK_TFLOPS,
                     "ms_per_step": step_s * 1e3}
-        f16 = a.gemm_mode == "split_f16" and which == "edge_mlp_gemm1" and mode == "factored"
+        f16 = a.gemm_mode == "split_f16"              # both edge-MLP GEMMs run on two fp16 planes in that mode
         products = 3.0 if f16 else 6.0                # plane products executed per fp32 product
         ach = products * flops32 / step_s / 1e12
         return {"bound": "mfma", "kernel": "gemm_split_f16_kernel" if f16 else "gemm_split_bf16_kernel", "achieved": ach,

@@ -556,3 +556,40 @@ def test_gather_trajectories_over_rccl_two_gpus(tmp_path):
     for p in procs:
         out, err = p.communicate(timeout=300)
         assert p.returncode == 0 and "ok" in out, err[-2000:]
+
+
+def test_untied_conv2_kernel_is_evaluated_separately(dev, O):
+    """The reference ties conv1.net and conv2.net to ONE module (graph_kernel.py:271-273) and the library
+    evaluates the edge-MLP once per forward on that ground.  A state_dict whose conv2.net.* differ (loaded
+    from elsewhere) must still give the reference's function: the second block then gets its own
+    evaluation — forward with explicit edges, and both conv formulations of the on-device rollout, vs the
+    oracle (which evaluates `conv + ".net."` per block)."""
+    import copy
+    from molecular_dynamics_neural_operator_amd import synthetic as syn
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN, construct_pairdata
+    from molecular_dynamics_neural_operator_amd.rollout import RolloutEngine
+    from molecular_dynamics_neural_operator_amd.weights import near_identity_state_dict
+    sd = near_identity_state_dict(64, 128, seed=4, kernel_gain=2e-2, feature_gain=0.1, kernel_to_coords=1.0)
+    other = near_identity_state_dict(64, 128, seed=5, kernel_gain=3e-2, feature_gain=0.1, kernel_to_coords=1.0)
+    sd = dict(sd)
+    for k in list(sd):
+        if k.startswith("conv2.net."):
+            sd[k] = other[k].clone()
+    model = KernelNN(64, 128, 2, 6, 7, 3, 20, 4)
+    model.conv2.net = copy.deepcopy(model.conv1.net)          # untie, then load the two different kernels
+    model.load_state_dict(sd)
+    model.eval().to(dev)
+    assert not model.param_pack(dev).shared_kernel
+    N, W, steps = 70, 10, 3
+    win = syn.jitter_window(syn.box_frame(N, seed=6), W, seed=6)
+    aa = torch.from_numpy(syn.amino_acids(N, seed=6))
+    ref_pd = O.construct_pairdata(win, aa, 8.0)
+    want = O.kernelnn_forward(sd, ref_pd["x_position"], aa, ref_pd["edge_index"], ref_pd["edge_attr"], 2)
+    with torch.no_grad():
+        close(model(construct_pairdata(win, aa, 8.0)), want, name="untied conv2, forward")
+    fc = O.recursive_propagation(sd, 2, ref_pd, steps, 8.0, hoist=True)
+    ref = np.stack([f["x_position"][-1].numpy() for f in fc])
+    for conv in ("factored", "materialized"):
+        model.conv_mode = conv
+        eng = RolloutEngine(model, 1, N, W, 8.0, max_steps=steps, device=dev)
+        close(eng.run(torch.from_numpy(win), aa, steps)[:, 0], ref, name=f"untied conv2, rollout {conv}")

@@ -41,37 +41,46 @@ __global__ __launch_bounds__(256) void node_prologue_kernel(PrologueArgs a) {
 
     float h[H] = {0.f, 0.f, 0.f};
     if (a.w_ih != nullptr) {
-        // LSTM weights are 2*36 + 24 floats: every lane keeps them in registers (wave-uniform loads)
-        float wih[4 * H][H], whh[4 * H][H], bsum[4 * H];
+        // The W cells are a serial chain per atom, so the wave's lanes split each cell instead of repeating
+        // it: lane g < 12 owns gate g (its row of W_ih / W_hh, its bias, its nonlinearity), the twelve
+        // gate values are then broadcast and every lane updates (c, h) — still wave-uniform, and each
+        // gate's sum is formed in the same order as before (a cell's critical path is one gate, not twelve).
+        const int g = lane < 4 * H ? lane : 0;
+        float wih[H], whh[H];
 #pragma unroll
-        for (int g = 0; g < 4 * H; ++g) {
-#pragma unroll
-            for (int k = 0; k < H; ++k) {
-                wih[g][k] = a.w_ih[g * H + k];
-                whh[g][k] = a.w_hh[g * H + k];
-            }
-            bsum[g] = a.b_ih[g] + a.b_hh[g];
+        for (int k = 0; k < H; ++k) {
+            wih[k] = a.w_ih[g * H + k];
+            whh[k] = a.w_hh[g * H + k];
         }
+        const float bsum = a.b_ih[g] + a.b_hh[g];
+        const bool is_tanh = g >= 2 * H && g < 3 * H;
         float c[H] = {0.f, 0.f, 0.f};
-        for (int t = 0; t < a.W; ++t) {
-            const float* p = f0 + (size_t)t * R * 3;
-            const float x[H] = {p[0], p[1], p[2]};
-            float gate[4 * H];
+        for (int tb = 0; tb < a.W; tb += 8) {
+            // the window's frames do not depend on the recurrence: eight steps' positions are fetched at
+            // once, so the chain below waits for memory once per eight cells instead of once per cell
+            float xs[8][H];
 #pragma unroll
-            for (int g = 0; g < 4 * H; ++g) {
-                float s = bsum[g];
-#pragma unroll
-                for (int k = 0; k < H; ++k) s = fmaf(wih[g][k], x[k], s);
-#pragma unroll
-                for (int k = 0; k < H; ++k) s = fmaf(whh[g][k], h[k], s);
-                gate[g] = s;
+            for (int u = 0; u < 8; ++u) {
+                const float* p = f0 + (size_t)(tb + u < a.W ? tb + u : a.W - 1) * R * 3;
+                xs[u][0] = p[0]; xs[u][1] = p[1]; xs[u][2] = p[2];
             }
 #pragma unroll
-            for (int k = 0; k < H; ++k) {
-                const float ig = sigmoidf_(gate[k]), fg = sigmoidf_(gate[H + k]);
-                const float gg = tanhf(gate[2 * H + k]), og = sigmoidf_(gate[3 * H + k]);
-                c[k] = fg * c[k] + ig * gg;
-                h[k] = og * tanhf(c[k]);
+            for (int u = 0; u < 8; ++u) {
+                if (tb + u < a.W) {
+                    float s = bsum;
+#pragma unroll
+                    for (int k = 0; k < H; ++k) s = fmaf(wih[k], xs[u][k], s);
+#pragma unroll
+                    for (int k = 0; k < H; ++k) s = fmaf(whh[k], h[k], s);
+                    const float act = is_tanh ? tanhf(s) : sigmoidf_(s);
+#pragma unroll
+                    for (int k = 0; k < H; ++k) {
+                        const float ig = __shfl(act, k), fg = __shfl(act, H + k);
+                        const float gg = __shfl(act, 2 * H + k), og = __shfl(act, 3 * H + k);
+                        c[k] = fg * c[k] + ig * gg;
+                        h[k] = og * tanhf(c[k]);
+                    }
+                }
             }
         }
     }

@@ -606,11 +606,15 @@ int launch_split_f16_gemm(SplitGemmArgs g, hipStream_t s) {
 
 // ---------------------------------------------------------------- K = 64 GEMM on two fp16 planes
 // C [rows, N] = A . Bt^T for the factored conv's Y = X . W3T (factored.hip step (1)): 4.2 GFLOP for a
-// 132 MB result — a store with a little arithmetic in front.  K is four k-steps: a 128 x 128 tile's
-// whole operand set (32 KiB of A planes + 32 KiB of B planes, each ONE contiguous run of the tiled
-// images) is brought in by a single burst of LDS-DMA, waited for once, multiplied (48 MFMAs per wave)
-// and stored; 64 KiB of LDS: two workgroups per CU, so one's stores overlap the other's load + multiply
-// (37 -> 31 us per launch against the 256-row bf16 kernel with its four-stage pipeline).
+// 132 MB result — a store with a little arithmetic in front.  K is four k-steps, so a 128 x 128 tile's
+// whole operand set is 32 KiB of A planes + 32 KiB of B planes, each ONE contiguous run of the tiled
+// images.  A workgroup owns one 128-column panel of B for the whole launch (a launch is at most a Y
+// chunk of rows: a handful of row tiles): B comes in once, and the row tiles are walked with the NEXT
+// tile's A burst issued ahead of the current tile's 64 stores per lane, then waited for with a COUNTED
+// wait (vmcnt counts loads and stores in issue order on gfx9: `vmcnt(56)` = the 8 DMA pieces and the
+// oldest 8 stores are done), so the operand latency sits under the store stream instead of in front of
+// it.  64 KiB of LDS: two workgroups per CU.  (One tile per workgroup with everything reloaded: 31 us per
+// launch at N=504; the 256-row bf16 kernel with its four-stage pipeline: 37 us.)
 // Out of fp16 range (flag_w: a weight, flag_x: a node feature of this application — exploding
 // activations of an untrained net get there) the SAME launch multiplies the bf16 plane images instead,
 // in two halves of K through the same LDS: no second launch, bit-identical to gemm_split_bf16_kernel.
@@ -624,70 +628,95 @@ __global__ __launch_bounds__(256, 2) void gemm_k64_f16_kernel(const unsigned cha
                                                            const unsigned char* __restrict__ Bb,
                                                            const int* __restrict__ flag_w,
                                                            const int* __restrict__ flag_x, float* __restrict__ C,
-                                                           int rows_valid, int N, int tiles_m, int tiles_n) {
+                                                           int rows_valid, int N, int tiles_m) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    // XCD-contiguous tile ranges, m fastest (the tiles of one B panel run back to back on one XCD)
-    const int nwg = tiles_m * tiles_n, orig = blockIdx.x;
-    const int xcd = orig & 7, q = nwg >> 3, r8 = nwg & 7;
-    const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
-    const int tm = tile % tiles_m, tn = tile / tiles_m;
-    const int bm = tm * 128, bn = tn * TN;
+    const int tn = blockIdx.x, bn = tn * TN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
     const bool blocked = (__builtin_nontemporal_load(flag_w) | __builtin_nontemporal_load(flag_x)) != 0;
     f32x16 acc[2][2], accx[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.f; accx[i][j][e] = 0.f; }
     const int hsw = (h ^ ((l31 >> 3) & 1)) << 4;
     const int a_rd = (wm * 64 + l31) * 32 + hsw, b_rd = 32768 + (wn * 64 + l31) * 32 + hsw;
+    // (fallback: accx stays zero and the sum below is acc itself, bit for bit)
+#define MDNO_K64_STORE_IF(TM_, COND)                                                                    \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                      \
+        const int n = bn + wn * 64 + j * 32 + l31;                                                       \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                    \
+            _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                             \
+                const int m = (TM_) * 128 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;           \
+                if (COND) C[(size_t)m * N + n] = acc[i][j][e] + accx[i][j][e] * F16_LO_UNSCALE;          \
+            }                                                                                            \
+    }
+    // (a full tile stores without the 64 per-row tests; only a launch's last tile can be ragged)
+#define MDNO_K64_STORE(TM_)                                                                              \
+    if (((TM_) + 1) * 128 <= rows_valid) { MDNO_K64_STORE_IF(TM_, true) } else { MDNO_K64_STORE_IF(TM_, m < rows_valid) }
+#define MDNO_K64_ZERO()                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                        \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                    \
+            _Pragma("unroll") for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.f; accx[i][j][e] = 0.f; }
     if (!blocked) {
-        const unsigned char* a_src = Ah + ((size_t)tm << 15) + lane * 16;      // 32 KiB per 128-row tile
+        const unsigned char* a_src = Ah + lane * 16;                            // 32 KiB per 128-row tile
         const unsigned char* b_src = Bh + ((size_t)tn << 15) + lane * 16;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {       // wave w moves KiB w, w+4, ... of A and of B
+        for (int t = 0; t < 8; ++t) {       // wave w moves KiB w, w+4, ... of B and of the first A tile
             const int piece = wave + 4 * t;
-            __builtin_amdgcn_global_load_lds((glb_u8*)(a_src + piece * 1024), (lds_u8*)(lds + piece * 1024), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((glb_u8*)(b_src + piece * 1024), (lds_u8*)(lds + 32768 + piece * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_u8*)(a_src + piece * 1024), (lds_u8*)(lds + piece * 1024), 16, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        for (int tm = 0; tm < tiles_m; ++tm) {
+            // everybody's pieces of this tile's A (and of B) have landed.  Bare barrier instructions:
+            // __syncthreads() carries a fence the compiler lowers to vmcnt(0), i.e. a wait for the stores
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            MDNO_K64_ZERO()
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) mma_f16_kstep<2>(acc, accx, lds + ks * 2 * PLANE_BYTES, a_rd, b_rd);
+            for (int ks = 0; ks < 4; ++ks) mma_f16_kstep<2>(acc, accx, lds + ks * 2 * PLANE_BYTES, a_rd, b_rd);
+            // every wave's fragment reads of A have returned (they fed its MFMAs): A may be overwritten
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const bool more = tm + 1 < tiles_m;
+            if (more) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int piece = wave + 4 * t;
+                    __builtin_amdgcn_global_load_lds((glb_u8*)(a_src + ((size_t)(tm + 1) << 15) + piece * 1024),
+                                                     (lds_u8*)(lds + piece * 1024), 16, 0, 0);
+                }
+                asm volatile("" ::: "memory");
+            }
+            MDNO_K64_STORE(tm)
+            // a tile that is followed by another one is a full tile: exactly 64 stores per lane were issued
+            // behind the 8 DMA pieces
+            if (more) asm volatile("s_waitcnt vmcnt(56)" ::: "memory");
+        }
     } else {
         // bf16 planes: 12 KiB per k-step per 128-row tile; two k-steps (24 KiB of A, 24 KiB of B) at a time
-        const unsigned char* a_src = Ab + (size_t)tm * 4 * 3 * PLANE_BYTES + lane * 16;
-        const unsigned char* b_src = Bb + (size_t)tn * 4 * 3 * PLANE_BYTES + lane * 16;
-        for (int half = 0; half < 2; ++half) {
-            if (half) __syncthreads();      // everyone is done reading the first half
+        for (int tm = 0; tm < tiles_m; ++tm) {
+            const unsigned char* a_src = Ab + (size_t)tm * 4 * 3 * PLANE_BYTES + lane * 16;
+            const unsigned char* b_src = Bb + (size_t)tn * 4 * 3 * PLANE_BYTES + lane * 16;
+            MDNO_K64_ZERO()
+            for (int half = 0; half < 2; ++half) {
+                if (half || tm) __syncthreads();      // everyone is done reading what is about to be overwritten
 #pragma unroll
-            for (int t = 0; t < 6; ++t) {
-                const int piece = wave + 4 * t;       // 24 pieces of A, 24 of B
-                __builtin_amdgcn_global_load_lds((glb_u8*)(a_src + (half * 24 + piece) * 1024), (lds_u8*)(lds + piece * 1024), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((glb_u8*)(b_src + (half * 24 + piece) * 1024), (lds_u8*)(lds + 32768 + piece * 1024), 16, 0, 0);
+                for (int t = 0; t < 6; ++t) {
+                    const int piece = wave + 4 * t;       // 24 pieces of A, 24 of B
+                    __builtin_amdgcn_global_load_lds((glb_u8*)(a_src + (half * 24 + piece) * 1024), (lds_u8*)(lds + piece * 1024), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((glb_u8*)(b_src + (half * 24 + piece) * 1024), (lds_u8*)(lds + 32768 + piece * 1024), 16, 0, 0);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) mma_split_stage(acc, lds + ks * 3 * PLANE_BYTES, a_rd, b_rd);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) mma_split_stage(acc, lds + ks * 3 * PLANE_BYTES, a_rd, b_rd);
+            MDNO_K64_STORE(tm)
         }
     }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = bn + wn * 64 + j * 32 + l31;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = bm + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                // (fallback: accx is all zero and the sum below is acc itself, bit for bit)
-                if (m < rows_valid) C[(size_t)m * N + n] = acc[i][j][e] + accx[i][j][e] * F16_LO_UNSCALE;
-            }
-    }
+#undef MDNO_K64_STORE
+#undef MDNO_K64_STORE_IF
+#undef MDNO_K64_ZERO
 }
 
 template <int TM, int OUT>
@@ -767,10 +796,10 @@ int split_gemm_rows_k64_f16(const void* a_planes, const void* b_planes, const vo
     static std::atomic<unsigned long long> lds_raised{0};
     MDNO_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(&gemm_k64_f16_kernel), K64_LDS_BYTES, lds_raised));
     const int tiles_m = (rows + 127) / 128, tiles_n = N / TN;
-    hipLaunchKernelGGL(gemm_k64_f16_kernel, dim3(tiles_m * tiles_n), dim3(256), K64_LDS_BYTES, s,
+    hipLaunchKernelGGL(gemm_k64_f16_kernel, dim3(tiles_n), dim3(256), K64_LDS_BYTES, s,
                        static_cast<const unsigned char*>(a_planes), static_cast<const unsigned char*>(b_planes),
                        static_cast<const unsigned char*>(a_bf16), static_cast<const unsigned char*>(b_bf16), flag_w, flag_x,
-                       C, rows, N, tiles_m, tiles_n);
+                       C, rows, N, tiles_m);
     return check_launch("gemm_k64_f16_kernel");
 }
 

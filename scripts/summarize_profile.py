@@ -30,11 +30,17 @@ def short(name):
     return (m.group(1) + (m.group(2) or "")) if m else name[:60]
 
 
+def newest(paths):
+    # gpurun merges every call's files into gpurun_out/: an earlier collection's run directory can sit next
+    # to this one's
+    return max(paths, key=lambda p: Path(p).stat().st_mtime)
+
+
 def kernel_stats(sub, dest):
     stats = glob.glob(str(src / sub / "*" / "*_kernel_stats.csv"))
     if not stats:
         return
-    rows = list(csv.DictReader(open(stats[0])))
+    rows = list(csv.DictReader(open(newest(stats))))
     with open(dest, "w", newline="") as fh:
         w = csv.writer(fh)
         w.writerow(["Kernel", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
@@ -64,7 +70,7 @@ for M in (1, 8):
         if not files:
             continue
         agg = defaultdict(list)
-        for r in csv.DictReader(open(files[0])):
+        for r in csv.DictReader(open(newest(files))):
             if r["Counter_Name"] == counter:
                 agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
         for k, v in agg.items():

@@ -139,50 +139,77 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const __bf16* __restr
 
 // ---------------------------------------------------------------- C = A^T . B over rows (one K-slice)
 // A [rows, n1], B [rows, n2] row-major: the contraction index (the edge) is the SLOW index of both
-// operands, the opposite of what an MFMA fragment wants (8 consecutive k per lane).  Each staged 16-B
-// piece (8 columns of one row) is therefore written to LDS transposed, [column][row], as eight 2-byte
-// writes; a column's data starts 4*((column>>3)&3) dwords into its 112-B LDS row, which spreads the 16
-// lanes that write the same row index over 8 banks instead of 2.  Fragment reads are then the same
-// 16-B reads as in gemm_nt_bf16_kernel.  Rows are cut into `slices` equal runs (blockIdx.z), partial
-// products go to part[slice][n1][n2] and are added in slice order by reduce_slices_kernel (train.hip).
-constexpr int TLD = 56;      // LDS row of the transposed tiles: 32 rows of data + up to 24 of rotation, 112 B
-__device__ __forceinline__ int tn_col_base(int col) { return col * TLD + 8 * ((col >> 3) & 3); }   // in bf16 units
+// operands, the opposite of what an MFMA fragment wants (8 consecutive k per lane).  The staged 16-B
+// pieces go to LDS as they come — image [k 32][128 columns], 256-B rows, one ds_write_b128 each — and the
+// fragments are read with gfx950's transposing LDS read: ds_read_b64_tr_b16 hands each lane of a 16-lane
+// group one COLUMN of a 4-row x 16-column block, i.e. 4 consecutive k of its own m; two of them make the
+// 8-k operand of v_mfma_f32_32x32x16_bf16.  The 16-B chunks of a row are XOR-swizzled with
+// ((row&3)<<2 | (row>>2)&3), which keeps both the row writes and the transposed reads off each other's
+// banks (cdna_hip_programming.md T10, image (b)).  (The first version transposed on the way IN, with
+// eight 2-byte LDS writes per staged piece: 467 us per product at cfg4's batch against 253 now.)
+// Rows are cut into `slices` equal runs (blockIdx.z), partial products go to part[slice][n1][n2] and are
+// added in slice order by reduce_slices_bf16path_kernel.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ int tn_off(int row, int ch) {      // byte offset of 16-B chunk ch of row `row`
+    return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+
+__device__ __forceinline__ bf16x8 tn_frag(const unsigned char* base, int off0, int off1) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + off0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + off1));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+constexpr int TN_STAGE = 32 * 256;      // one operand, one stage: 32 k x 128 columns of bf16
 
 __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__ B,
                                                            float* __restrict__ part, long long rows, int n1, int n2,
                                                            long long slice_rows) {
-    __shared__ __attribute__((aligned(16))) __bf16 As[2][128 * TLD];
-    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][128 * TLD];
+    __shared__ __attribute__((aligned(16))) unsigned char As[2][TN_STAGE];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[2][TN_STAGE];
     const int bm = blockIdx.y * 128, bn = blockIdx.x * 128;
     const long long r0 = (long long)blockIdx.z * slice_rows;
     long long r1 = r0 + slice_rows;
     if (r1 > rows) r1 = rows;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
-    const int se = tid >> 4, sc = (tid & 15) * 8;           // staged rows se, se + 16 of the 32-row stage; 8 columns at sc
+    // staging: pieces tid and tid + 256 of the stage's 512: row = piece >> 4, 16-B chunk = piece & 15
+    const int srow = tid >> 4, sch = tid & 15;
+    const int st0 = tn_off(srow, sch), st1 = tn_off(srow + 16, sch);
     uint4 ra0, ra1, rb0, rb1;
     const uint4 zero = make_uint4(0, 0, 0, 0);
 #define MDNO_LD(E0)                                                                                         \
     {                                                                                                       \
-        const long long e0_ = (E0) + se, e1_ = (E0) + se + 16;                                              \
-        ra0 = e0_ < r1 ? *reinterpret_cast<const uint4*>(A + (size_t)e0_ * n1 + bm + sc) : zero;            \
-        ra1 = e1_ < r1 ? *reinterpret_cast<const uint4*>(A + (size_t)e1_ * n1 + bm + sc) : zero;            \
-        rb0 = e0_ < r1 ? *reinterpret_cast<const uint4*>(B + (size_t)e0_ * n2 + bn + sc) : zero;            \
-        rb1 = e1_ < r1 ? *reinterpret_cast<const uint4*>(B + (size_t)e1_ * n2 + bn + sc) : zero;            \
+        const long long e0_ = (E0) + srow, e1_ = (E0) + srow + 16;                                          \
+        ra0 = e0_ < r1 ? *reinterpret_cast<const uint4*>(A + (size_t)e0_ * n1 + bm + sch * 8) : zero;       \
+        ra1 = e1_ < r1 ? *reinterpret_cast<const uint4*>(A + (size_t)e1_ * n1 + bm + sch * 8) : zero;       \
+        rb0 = e0_ < r1 ? *reinterpret_cast<const uint4*>(B + (size_t)e0_ * n2 + bn + sch * 8) : zero;       \
+        rb1 = e1_ < r1 ? *reinterpret_cast<const uint4*>(B + (size_t)e1_ * n2 + bn + sch * 8) : zero;       \
     }
-    auto scatter = [&](__bf16* dst, const uint4& v, int e) {
-        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#define MDNO_ST(BUF)                                              \
+    *reinterpret_cast<uint4*>(As[BUF] + st0) = ra0;               \
+    *reinterpret_cast<uint4*>(As[BUF] + st1) = ra1;               \
+    *reinterpret_cast<uint4*>(Bs[BUF] + st0) = rb0;               \
+    *reinterpret_cast<uint4*>(Bs[BUF] + st1) = rb1;
+    // transposed reads: 16-lane group g = lane>>4 takes the 4-row x 16-column block at rows
+    // kk*16 + 8*(g>>1) + 4*r (r = 0, 1: the two reads of a fragment), columns m0 = tile + 16*(g&1); lane
+    // 4q+p of the group supplies row q, columns 4p..4p+3 of the block
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    int a_off[2][2][2], b_off[2][2][2];      // [m or n tile i][k-step kk][read r]
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            reinterpret_cast<unsigned short*>(dst)[tn_col_base(sc + 2 * i) + e] = (unsigned short)(w[i] & 0xffffu);
-            reinterpret_cast<unsigned short*>(dst)[tn_col_base(sc + 2 * i + 1) + e] = (unsigned short)(w[i] >> 16);
-        }
-    };
-#define MDNO_ST(BUF)                     \
-    scatter(As[BUF], ra0, se);           \
-    scatter(As[BUF], ra1, se + 16);      \
-    scatter(Bs[BUF], rb0, se);           \
-    scatter(Bs[BUF], rb1, se + 16);
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int row = kk * 16 + 8 * (g >> 1) + 4 * r + q;
+                a_off[i][kk][r] = tn_off(row, (wm * 64 + i * 32 + 16 * (g & 1)) / 8 + (p >> 1)) + 8 * (p & 1);
+                b_off[i][kk][r] = tn_off(row, (wn * 64 + i * 32 + 16 * (g & 1)) / 8 + (p >> 1)) + 8 * (p & 1);
+            }
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -196,8 +223,8 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const __bf16* __restr
             bf16x8 a[2], b[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                a[i] = *reinterpret_cast<const bf16x8*>(&As[buf][tn_col_base(wm * 64 + i * 32 + l31) + kk * 16 + 8 * h]);
-                b[i] = *reinterpret_cast<const bf16x8*>(&Bs[buf][tn_col_base(wn * 64 + i * 32 + l31) + kk * 16 + 8 * h]);
+                a[i] = tn_frag(As[buf], a_off[i][kk][0], a_off[i][kk][1]);
+                b[i] = tn_frag(Bs[buf], b_off[i][kk][0], b_off[i][kk][1]);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -206,7 +233,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const __bf16* __restr
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     };
-    const long long nst = (r1 - r0 + 31) / 32;
+    const long long nst = (r1 - r0 + 31) / 32;      // (uniform per workgroup: EXEC is all ones at the reads)
     if (nst > 0) {
         MDNO_LD(r0)
         MDNO_ST(0)
@@ -457,6 +484,8 @@ extern "C" int mdno_linear_bf16_fwd(const void* a, const float* w, const float* 
     MDNO_TRY(mdno_cast_bf16(w, (int64_t)n * k, workspace, stream));      // master weights -> bf16, every call
     const __bf16* A = static_cast<const __bf16*>(a);
     const __bf16* W = static_cast<const __bf16*>(workspace);
+    // (an XCD-aware order — all column tiles of a row tile on one XCD — was measured: 617 -> 640 us on the
+    // K = 1024, N = 4096 product, no change on the others; the plain grid stays)
     const dim3 grid(n / 128, (unsigned)((rows + 127) / 128));
 #define MDNO_GO(R, O) hipLaunchKernelGGL((gemm_nt_bf16_kernel<R, O>), grid, dim3(256), 0, s, A, W, bias, c, (long long)rows, n, k)
     if (relu) { if (out_bf16) MDNO_GO(true, true); else MDNO_GO(true, false); }

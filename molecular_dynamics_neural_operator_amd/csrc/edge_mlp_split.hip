@@ -463,6 +463,35 @@ __device__ __forceinline__ void mma_f16_kstep(f32x16 (&acc)[MI][2], f32x16 (&acc
         }
 }
 
+// The same k-step with something to do between its (i, j) groups of three MFMAs: fill(g), g = 0 .. 2*MI-1, is
+// called after group g has been issued and pinned there — the LDS-DMA pieces of the stage after next go
+// out one per group, in the shadow of MFMAs already in the pipe, instead of as a burst of six in front of
+// the stage's first fragment read (an LDS-DMA piece costs the issuing wave 60-180 cycles, more inside a
+// burst: MI355X_MICROARCH.md, cycle constants).
+template <int MI, class F>
+__device__ __forceinline__ void mma_f16_kstep_fill(f32x16 (&acc)[MI][2], f32x16 (&accx)[MI][2], const unsigned char* st,
+                                                   int a_rd, int b_rd, F&& fill) {
+    f16x8 a[MI][2], b[2][2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[i][p] = *reinterpret_cast<const f16x8*>(st + p * PLANE_BYTES + a_rd + i * 32 * 32);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j][p] = *reinterpret_cast<const f16x8*>(st + p * PLANE_BYTES + b_rd + j * 32 * 32);
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], accx[i][j], 0, 0, 0);
+            accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], accx[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            fill(i * 2 + j);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+}
+
 constexpr int F16_TM = 256, F16_RING = 3;
 constexpr int F16_TILE_BYTES = 2 * 2 * PLANE_BYTES;       // one 128-row tile: two k-steps x two planes = 16 KiB
 constexpr int F16_STAGE_BYTES = 3 * F16_TILE_BYTES;       // A tile 0 | A tile 1 | B = 48 KiB
@@ -550,10 +579,20 @@ __global__ __launch_bounds__(1024 / MI) void gemm_split_f16_kernel(SplitGemmArgs
         // which would wait for the stage just put in flight
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (st + 2 < nst) MDNO_DMA_STAGE(st + 2, slot_in)
         const unsigned char* sb = lds + slot * F16_STAGE_BYTES;
-        mma_f16_kstep<MI>(acc, accx, sb, a_rd, b_rd);
-        mma_f16_kstep<MI>(acc, accx, sb + 2 * PLANE_BYTES, a_rd, b_rd);
+        const bool more = st + 2 < nst;
+        const size_t ko = (size_t)(st + 2) * F16_TILE_BYTES;
+        lds_u8* ldst = (lds_u8*)(lds + slot_in * F16_STAGE_BYTES + d0);
+        // pieces of stage st+2: PPW / 2 behind the groups of each k-step (MI = 2: 3 + 3 of the 4 + 4 groups)
+        constexpr int HALF = (PPW + 1) / 2;
+        mma_f16_kstep_fill<MI>(acc, accx, sb, a_rd, b_rd, [&](int grp) {
+            if (more && grp < HALF)
+                __builtin_amdgcn_global_load_lds((glb_u8*)(psrc[grp] + ko), ldst + grp * WAVES * 1024, 16, 0, 0);
+        });
+        mma_f16_kstep_fill<MI>(acc, accx, sb + 2 * PLANE_BYTES, a_rd, b_rd, [&](int grp) {
+            if (more && grp < PPW - HALF)
+                __builtin_amdgcn_global_load_lds((glb_u8*)(psrc[HALF + grp] + ko), ldst + (HALF + grp) * WAVES * 1024, 16, 0, 0);
+        });
         slot = slot == F16_RING - 1 ? 0 : slot + 1;
         slot_in = slot_in == F16_RING - 1 ? 0 : slot_in + 1;
     }

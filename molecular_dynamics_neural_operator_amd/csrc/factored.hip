@@ -305,7 +305,8 @@ __global__ __launch_bounds__(256, 4) void gemm_per_source_split_kernel(const flo
                                                                        const int* __restrict__ row_ptr,
                                                                        float* __restrict__ Mp, long long part_stride,
                                                                        int K, int ks_tail, int slots, int row0,
-                                                                       int* __restrict__ status) {
+                                                                       int* __restrict__ status,
+                                                                       const int* __restrict__ order) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[3 * SPL_A_PLANE + 3 * SPL_B_PLANE];
     // slots of a source: [tile 0: slices 0..KS-1 | tile 1: slices 0..ks_tail-1 | tile 2 ...].
     // Small members: grid (source, slot), source fastest (XCD balance; first tiles before later ones).
@@ -317,6 +318,11 @@ __global__ __launch_bounds__(256, 4) void gemm_per_source_split_kernel(const flo
         j = (int)(blockIdx.x / (unsigned)slots);
         slot = (int)((blockIdx.x % (unsigned)slots + (unsigned)j) % (unsigned)slots);
     }
+    // the chunk's sources are visited in order of decreasing degree (source_order_kernel): workgroup ids
+    // b, b+256, b+512, ... land on one CU, which then gets one source from every quarter of the sorted list
+    // instead of four of any size — all workgroups of a launch are resident at once, so nothing else evens
+    // out what a CU has to stream
+    j = order[row0 + j];
     const int jl = j;      // index inside this launch's chunk of sources (Y holds the chunk only)
     j += row0;
     const int mt = slot < KS ? 0 : 1 + (slot - KS) / ks_tail;
@@ -436,6 +442,29 @@ __global__ __launch_bounds__(256, 4) void gemm_per_source_split_kernel(const flo
             Mo[(size_t)m * 64 + 32 + l31] = acc1[e] + q1;
         }
     }
+}
+
+// ---------------------------------------------------------------- sources by decreasing degree
+// One workgroup per Y chunk of kYChunkRows sources: order[chunk*kYChunkRows + rank] = index inside the
+// chunk of the source with that rank (degree descending, ties by index).  Once per graph.
+__global__ __launch_bounds__(512) void source_order_kernel(const int* __restrict__ row_ptr, int num_rows,
+                                                           int* __restrict__ order) {
+    __shared__ __attribute__((aligned(16))) int key[512];      // degree * 512 + (511 - index): all distinct
+    const int base = blockIdx.x * 512, t = threadIdx.x;
+    const int cnt = num_rows - base < 512 ? num_rows - base : 512;
+    int dg = t < cnt ? row_ptr[base + t + 1] - row_ptr[base + t] : 0;
+    dg = dg < (1 << 21) ? dg : (1 << 21);      // (the key must fit an int; beyond that the order does not matter)
+    const int mine = t < cnt ? dg * 512 + (511 - t) : -1;
+    key[t] = mine;
+    __syncthreads();
+    if (t >= cnt) return;
+    int rank = 0;
+#pragma unroll 4
+    for (int u = 0; u < 512; u += 4) {
+        const int4 k4 = *reinterpret_cast<const int4*>(&key[u]);
+        rank += (k4.x > mine) + (k4.y > mine) + (k4.z > mine) + (k4.w > mine);
+    }
+    order[base + rank] = t;
 }
 
 // ---------------------------------------------------------------- reverse-edge index
@@ -685,6 +714,7 @@ size_t factored_workspace_bytes(int num_rows, int ker_width, long long edge_cap)
     cv.take<char>(split_planes_f16_bytes((long long)64 * ker_width, 64));   // W3T as fp16 planes
     cv.take<char>(split_planes_f16_bytes(num_rows, 64));                    // X as fp16 planes
     cv.take<int>(64);                                                   // fp16 range flags
+    cv.take<int>((size_t)num_rows);                                     // sources of each Y chunk by decreasing degree
     return cv.used();
 }
 
@@ -702,6 +732,7 @@ FactoredWs factored_carve(void* ws, int num_rows, int ker_width, long long edge_
     f.w3th = cv.take<char>(split_planes_f16_bytes((long long)64 * ker_width, 64));
     f.xh = cv.take<char>(split_planes_f16_bytes(num_rows, 64));
     f.f16_flags = cv.take<int>(64);
+    f.order = cv.take<int>((size_t)num_rows);
     return f;
 }
 
@@ -729,6 +760,9 @@ int factored_prepare_graph(const int* row_ptr, const int* col, const int* rowid,
     TimedSection ts(KID_GRAPH, s);
     hipLaunchKernelGGL(reverse_edges_kernel, dim3((unsigned)((edge_cap + 255) / 256)), dim3(256), 0, s, row_ptr, col,
                        rowid, num_rows, f.rev, status, tail_slices(gemm_mode, rows_per_member), f.f16_flags + 1);
+    static_assert(kYChunkRows == 512, "source_order_kernel ranks one 512-source chunk per workgroup");
+    hipLaunchKernelGGL(source_order_kernel, dim3((num_rows + kYChunkRows - 1) / kYChunkRows), dim3(512), 0, s, row_ptr,
+                       num_rows, f.order);
     return check_launch("reverse_edges_kernel");
 }
 
@@ -789,7 +823,7 @@ int factored_conv(const float* x, const float* h2, const int* row_ptr, int num_r
                 hipLaunchKernelGGL(gemm_per_source_split_kernel,
                                    source_major ? dim3((unsigned)(cnt * slots), 1) : dim3(cnt, slots), dim3(256), 0, s,
                                    h2, (const float*)f.y, (const float*)f.q, row_ptr, f.m, f.part_stride, ker_width,
-                                   kt, slots, r0, status);
+                                   kt, slots, r0, status, (const int*)f.order);
             } else {
                 hipLaunchKernelGGL(gemm_per_source_kernel, dim3(cnt, mtiles, KS), dim3(256), 0, s, h2,
                                    (const float*)f.y, (const float*)f.q, row_ptr, f.m, f.part_stride, ker_width, r0,

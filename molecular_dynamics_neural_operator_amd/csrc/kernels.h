@@ -91,6 +91,7 @@ struct FactoredWs {
     void *w3th, *xh;          // the same as two fp16 planes (SPLIT_F16)
     int* f16_flags;           // [0]: W3T out of fp16 range; [1 + a]: the node features entering application a are
     int* rev;
+    int* order;               // sources of each Y chunk by decreasing degree (factored_prepare_graph)
     long long part_stride;
 };
 bool factored_supported(int width, int ker_width);

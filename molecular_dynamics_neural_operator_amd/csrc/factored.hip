@@ -447,20 +447,21 @@ __global__ __launch_bounds__(256, 4) void gemm_per_source_split_kernel(const flo
 // ---------------------------------------------------------------- sources by decreasing degree
 // One workgroup per Y chunk of kYChunkRows sources: order[chunk*kYChunkRows + rank] = index inside the
 // chunk of the source with that rank (degree descending, ties by index).  Once per graph.
-__global__ __launch_bounds__(512) void source_order_kernel(const int* __restrict__ row_ptr, int num_rows,
-                                                           int* __restrict__ order) {
-    __shared__ __attribute__((aligned(16))) int key[512];      // degree * 512 + (511 - index): all distinct
-    const int base = blockIdx.x * 512, t = threadIdx.x;
-    const int cnt = num_rows - base < 512 ? num_rows - base : 512;
+template <int CH>
+__global__ __launch_bounds__(CH) void source_order_kernel(const int* __restrict__ row_ptr, int num_rows,
+                                                          int* __restrict__ order) {
+    __shared__ __attribute__((aligned(16))) int key[CH];      // degree * CH + (CH - 1 - index): all distinct
+    const int base = blockIdx.x * CH, t = threadIdx.x;
+    const int cnt = num_rows - base < CH ? num_rows - base : CH;
     int dg = t < cnt ? row_ptr[base + t + 1] - row_ptr[base + t] : 0;
-    dg = dg < (1 << 21) ? dg : (1 << 21);      // (the key must fit an int; beyond that the order does not matter)
-    const int mine = t < cnt ? dg * 512 + (511 - t) : -1;
+    dg = dg < (1 << 20) ? dg : (1 << 20);      // (the key must fit an int; beyond that the order does not matter)
+    const int mine = t < cnt ? dg * CH + (CH - 1 - t) : -1;
     key[t] = mine;
     __syncthreads();
     if (t >= cnt) return;
     int rank = 0;
 #pragma unroll 4
-    for (int u = 0; u < 512; u += 4) {
+    for (int u = 0; u < CH; u += 4) {
         const int4 k4 = *reinterpret_cast<const int4*>(&key[u]);
         rank += (k4.x > mine) + (k4.y > mine) + (k4.z > mine) + (k4.w > mine);
     }
@@ -699,7 +700,7 @@ bool factored_supported(int width, int ker_width) { return width == 64 && ker_wi
 // keeps ONE chunk of Y alive instead of one Y per member (8 members: 1 GB, evicted between producer and
 // consumer).  Chunks are cut at multiples of the GEMM's 256-row tile, not at member boundaries; a
 // source's arithmetic does not depend on the chunk it is in.
-constexpr int kYChunkRows = 512;
+constexpr int kYChunkRows = 512;      // (256: 5 % slower at 8 members, 1024: the same)
 static int y_chunk_rows(int num_rows) { return num_rows < kYChunkRows ? num_rows : kYChunkRows; }
 
 size_t factored_workspace_bytes(int num_rows, int ker_width, long long edge_cap) {
@@ -760,8 +761,8 @@ int factored_prepare_graph(const int* row_ptr, const int* col, const int* rowid,
     TimedSection ts(KID_GRAPH, s);
     hipLaunchKernelGGL(reverse_edges_kernel, dim3((unsigned)((edge_cap + 255) / 256)), dim3(256), 0, s, row_ptr, col,
                        rowid, num_rows, f.rev, status, tail_slices(gemm_mode, rows_per_member), f.f16_flags + 1);
-    static_assert(kYChunkRows == 512, "source_order_kernel ranks one 512-source chunk per workgroup");
-    hipLaunchKernelGGL(source_order_kernel, dim3((num_rows + kYChunkRows - 1) / kYChunkRows), dim3(512), 0, s, row_ptr,
+    static_assert(kYChunkRows <= 1024, "source_order_kernel ranks one chunk per workgroup");
+    hipLaunchKernelGGL(source_order_kernel<kYChunkRows>, dim3((num_rows + kYChunkRows - 1) / kYChunkRows), dim3(kYChunkRows), 0, s, row_ptr,
                        num_rows, f.order);
     return check_launch("reverse_edges_kernel");
 }

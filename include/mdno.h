@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDNO_ABI_VERSION 8
+#define MDNO_ABI_VERSION 9
 
 #define MDNO_OK            0
 #define MDNO_EINVAL       -1   /* bad argument (null pointer, non-positive size, unsupported dim) */
@@ -307,6 +307,9 @@ int mdno_nnconv_bwd_we(const float* x, const float* gs, const int32_t* src, cons
  * bf16 x bf16 MFMA product with fp32 accumulation; parameters (cast per call from the fp32 masters), node
  * features, conv outputs and all reductions are fp32.  Same formulas as the fp32 ops above, width 64.
  *   mdno_cast_bf16          out[i] = bf16(in[i])  (round to nearest even), count % 4 == 0
+ *   mdno_linear_smallk_bf16_fwd  c bf16 [rows,n] = act(a . w^T + b) for the FIRST edge-MLP layer (graph_kernel.py:239-242,
+ *                           layers.0): a fp32 [rows,k] edge attributes, k <= 8, n % 8 == 0; the same fmaf chains
+ *                           as mdno_linear_fwd's generic kernel, rounded once to bf16
  *   mdno_linear_bf16_fwd    c = act(a . w^T + b): a bf16 [rows,k], w fp32 [n,k]; c bf16 (out_bf16) or fp32;
  *                           n % 128 == 0, k % 32 == 0; workspace mdno_linear_bf16_workspace_bytes(n, k)
  *   mdno_gemm_atb_bf16      c [n1,n2] fp32 = a^T . b over rows, a bf16 [rows,n1], b bf16 [rows,n2], n1, n2 % 128 == 0;
@@ -318,6 +321,8 @@ int mdno_nnconv_bwd_we(const float* x, const float* gs, const int32_t* src, cons
  *   mdno_colsum_bf16        out [n] fp32 = column sums of a bf16 [rows,n]; workspace mdno_colsum_bf16_workspace_bytes(n)
  * ---------------------------------------------------------------------------------------- */
 int mdno_cast_bf16(const float* in, int64_t count, void* out, void* stream);
+int mdno_linear_smallk_bf16_fwd(const float* a, const float* w, const float* bias, int64_t rows, int n, int k,
+                                int relu, void* c, void* stream);
 size_t mdno_linear_bf16_workspace_bytes(int n, int k);
 int mdno_linear_bf16_fwd(const void* a, const float* w, const float* bias, int64_t rows, int n, int k, int relu,
                          int out_bf16, void* c, void* workspace, size_t workspace_bytes, void* stream);

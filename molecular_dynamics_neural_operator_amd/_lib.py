@@ -14,7 +14,7 @@ LIB_PATH = Path(os.environ.get("MDNO_LIB", _HERE / "libmdno.so"))
 OK, EINVAL, ELAUNCH, EWORKSPACE, EUNSUPPORTED = 0, -1, -2, -3, -4
 AGGR = {"add": 0, "mean": 1}
 STATUS_EDGE_OVERFLOW, STATUS_BAD_AMINOACID = 1, 2
-ABI_VERSION = 8
+ABI_VERSION = 9
 GEMM_MODES = {"split_bf16": 0, "f32": 1, "split_f16": 2}
 CONV_MODES = {"materialized": 0, "factored": 1, "auto": 2}
 STATUS_ASYMMETRIC_GRAPH = 4
@@ -87,6 +87,7 @@ SIGNATURES = {
     "mdno_nnconv_bwd_root": (_I, [_P, _P, _L, _I, _I, _P, _P, _I, _P, _SZ, _P]),
     "mdno_nnconv_bwd_we": (_I, [_P, _P, _P, _P, _L, _I, _L, _I, _I, _P, _I, _P]),
     "mdno_cast_bf16": (_I, [_P, _L, _P, _P]),
+    "mdno_linear_smallk_bf16_fwd": (_I, [_P, _P, _P, _L, _I, _I, _I, _P, _P]),
     "mdno_linear_bf16_workspace_bytes": (_SZ, [_I, _I]),
     "mdno_linear_bf16_fwd": (_I, [_P, _P, _P, _L, _I, _I, _I, _I, _P, _P, _SZ, _P]),
     "mdno_gemm_atb_bf16_workspace_bytes": (_SZ, [_I, _I]),

@@ -526,8 +526,12 @@ extern "C" int mdno_nnconv_bwd_x(const float* gz, const float* gs, const int32_t
     return check_launch("mdno_nnconv_bwd_x");
 }
 
+// rows per workgroup of nnconv_bwd_root_kernel: 256 (four 64-row passes) — 1,024 left cfg4's 21,504 stacked
+// rows to 21 workgroups on 256 CUs (174 us per call); 128 moved the time into the serial slice sums
+constexpr long long kRootSliceRows = 256;
+
 extern "C" size_t mdno_nnconv_bwd_root_workspace_bytes(int64_t rows) {
-    const long long blocks = (rows + 1023) / 1024;
+    const long long blocks = (rows + kRootSliceRows - 1) / kRootSliceRows;
     return align_up((size_t)blocks * (4096 + 64) * sizeof(float), 256);
 }
 
@@ -539,7 +543,7 @@ extern "C" int mdno_nnconv_bwd_root(const float* x, const float* gz, int64_t row
     MDNO_REQUIRE(workspace_bytes >= mdno_nnconv_bwd_root_workspace_bytes(rows), MDNO_EWORKSPACE,
                  "mdno_nnconv_bwd_root: workspace");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const long long slice_rows = 1024;
+    const long long slice_rows = kRootSliceRows;
     const int blocks = (int)((rows + slice_rows - 1) / slice_rows);
     float* part_root = static_cast<float*>(workspace);
     float* part_bias = part_root + (size_t)blocks * 4096;

@@ -43,6 +43,72 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
     out[i] = pack4_bf16(v.x, v.y, v.z, v.w);
 }
 
+// ---------------------------------------------------------------- first layer: K <= 8, bf16 out
+// c[r][n] = bf16(act(sum_k a[r][k] w[n][k] + b[n])), a fp32 [rows,K] (the edge attributes), w fp32 [n,K].
+// A store with a few FMAs in front: thread = (row, 8 consecutive columns) -> one 16-B store; the sums are
+// the fmaf chains of linear_generic_kernel (k ascending, bias added last), so the result is the one the
+// fp32 kernel followed by mdno_cast_bf16 gave — without the fp32 round trip (200 + 12 us -> 2x us at cfg4).
+// Workgroup = SK_ROWS rows x all columns, in passes of 128 column groups (1,024 columns); thread = (group,
+// row parity).  The weights of the pass sit in LDS as [k][j][group] (group = 8 consecutive columns, j =
+// column inside it), so the lanes of a wave — consecutive groups — read consecutive words.  (With every
+// thread fetching its 48 weights from global memory, 192 B apart from its neighbour's, the kernel took
+// 531 us; the fp32 kernel 200.)
+constexpr int SK_ROWS = 32, SK_GROUPS = 128;
+template <bool RELU>
+__global__ __launch_bounds__(256) void linear_smallk_bf16_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                                 const float* __restrict__ bias, long long rows, int N,
+                                                                 int K, uint4* __restrict__ C) {
+    __shared__ float wt[8 * 8 * SK_GROUPS];       // [k][j][group], 32 KiB
+    __shared__ float bs[8 * SK_GROUPS];           // [j][group]
+    __shared__ float as[SK_ROWS * 8];
+    const int tid = threadIdx.x, groups = N >> 3;
+    const int grp = tid & (SK_GROUPS - 1), par = tid / SK_GROUPS;      // 128 groups x 2 row parities
+    const long long r0 = (long long)blockIdx.x * SK_ROWS;
+    for (int t = tid; t < SK_ROWS * 8; t += 256) {
+        const long long r = r0 + (t >> 3);
+        const int k = t & 7;
+        as[t] = (r < rows && k < K) ? A[r * K + k] : 0.f;
+    }
+    for (int g0 = 0; g0 < groups; g0 += SK_GROUPS) {
+        const int ng = groups - g0 < SK_GROUPS ? groups - g0 : SK_GROUPS;
+        __syncthreads();
+        for (int t = tid; t < ng * 8 * K; t += 256) {       // coalesced over (column, k)
+            const int col = t / K, k = t - col * K;
+            wt[(k * 8 + (col & 7)) * SK_GROUPS + (col >> 3)] = W[(size_t)g0 * 8 * K + t];
+        }
+        for (int t = tid; t < ng * 8; t += 256) bs[(t & 7) * SK_GROUPS + (t >> 3)] = bias ? bias[g0 * 8 + t] : 0.f;
+        __syncthreads();
+        if (grp < ng) {
+            float wr[8][8], br[8];      // the thread's 8 columns x K weights stay in registers across the rows
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                br[j] = bs[j * SK_GROUPS + grp];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) wr[k][j] = k < K ? wt[(k * 8 + j) * SK_GROUPS + grp] : 0.f;
+            }
+            for (int rr = par; rr < SK_ROWS; rr += 2) {
+                const long long r = r0 + rr;
+                if (r >= rows) break;
+                float av[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) av[k] = as[rr * 8 + k];
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (k < K) s = fmaf(av[k], wr[k][j], s);
+                    s += br[j];
+                    v[j] = RELU ? fmaxf(s, 0.f) : s;
+                }
+                const uint2 lo = pack4_bf16(v[0], v[1], v[2], v[3]), hi = pack4_bf16(v[4], v[5], v[6], v[7]);
+                C[(size_t)r * groups + g0 + grp] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- C = act(A . W^T + b)
 // 128 x 128 block tile, 4 waves of 64 x 64 (2 x 2 v_mfma_f32_32x32x16_bf16), 32 k per stage, register
 // staging into double-buffered LDS.  Rows of 32 bf16 are padded to 80 B: 16-B aligned fragment reads,
@@ -492,6 +558,22 @@ extern "C" int mdno_linear_bf16_fwd(const void* a, const float* w, const float* 
     else      { if (out_bf16) MDNO_GO(false, true); else MDNO_GO(false, false); }
 #undef MDNO_GO
     return check_launch("gemm_nt_bf16_kernel");
+}
+
+extern "C" int mdno_linear_smallk_bf16_fwd(const float* a, const float* w, const float* bias, int64_t rows, int n, int k,
+                                           int relu, void* c, void* stream) {
+    MDNO_REQUIRE(a && w && c && rows > 0, MDNO_EINVAL, "mdno_linear_smallk_bf16_fwd: bad arguments");
+    MDNO_REQUIRE(k >= 1 && k <= 8 && n % 8 == 0 && (reinterpret_cast<uintptr_t>(c) & 15) == 0, MDNO_EUNSUPPORTED,
+                 "mdno_linear_smallk_bf16_fwd: k=%d (1..8) n=%d (x8), c 16-byte aligned", k, n);
+    const long long blocks = (rows + SK_ROWS - 1) / SK_ROWS;
+    MDNO_REQUIRE(blocks < (1ll << 31), MDNO_EUNSUPPORTED, "mdno_linear_smallk_bf16_fwd: too many rows");
+    const dim3 grid((unsigned)blocks);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (relu) hipLaunchKernelGGL(linear_smallk_bf16_kernel<true>, grid, dim3(256), 0, s, a, w, bias, (long long)rows, n, k,
+                                 static_cast<uint4*>(c));
+    else hipLaunchKernelGGL(linear_smallk_bf16_kernel<false>, grid, dim3(256), 0, s, a, w, bias, (long long)rows, n, k,
+                            static_cast<uint4*>(c));
+    return check_launch("linear_smallk_bf16_kernel");
 }
 
 extern "C" size_t mdno_gemm_atb_bf16_workspace_bytes(int n1, int n2) {

@@ -396,6 +396,20 @@ def cast_bf16(a: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def linear_smallk_bf16(a: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], relu: bool = False) -> torch.Tensor:
+    """bf16(act(a . w^T + b)) for the first edge-MLP layer: a fp32 [rows,k<=8] (edge attributes), w fp32 [n,k]."""
+    lib = _lib.load()
+    a, w = f32(a), f32(w)
+    rows, k = a.shape
+    n = w.shape[0]
+    if not (1 <= k <= 8 and n % 8 == 0):        # (other shapes: the fp32 kernel, then the cast)
+        return cast_bf16(linear(a, w, b, relu=relu))
+    c = torch.empty((rows, n), dtype=torch.bfloat16, device=a.device)
+    check(lib.mdno_linear_smallk_bf16_fwd(ptr(a), ptr(w), ptr(f32(b)) if b is not None else None, rows, n, k, int(relu),
+                                          ptr(c), stream_ptr(a.device)), "mdno_linear_smallk_bf16_fwd")
+    return c
+
+
 def linear_bf16(a: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], relu: bool = False,
                 out_bf16: bool = True) -> torch.Tensor:
     """act(a . w^T + b): a bf16 [rows,k], w fp32 master [n,k] (cast per call), fp32 accumulation."""

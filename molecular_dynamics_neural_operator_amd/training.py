@@ -61,7 +61,7 @@ class KernelIntegralBlock(torch.autograd.Function):
     @staticmethod
     def _forward_bf16(ctx, x0, ea, graph, depth, w0, b0, w1, b1, w2, b2, root1, bias1, root2, bias2):
         R = x0.shape[0]
-        h1 = ops.cast_bf16(ops.linear(ea, w0, b0, relu=True))            # K = 6: fp32 kernel, stored bf16
+        h1 = ops.linear_smallk_bf16(ea, w0, b0, relu=True)               # K = 6: fp32 fmaf chains, stored bf16
         h2 = ops.linear_bf16(h1, w1, b1, relu=True, out_bf16=True)
         w_e = ops.linear_bf16(h2, w2, b2, relu=False, out_bf16=True)     # [E, 4096] bf16: 8 KiB per edge
         L = 2 * depth

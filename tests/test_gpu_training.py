@@ -203,6 +203,12 @@ def test_bf16_ops_against_fp64_of_the_rounded_operands(dev, O):
         assert rel_err(got, bf(a).double().t() @ bf(b).double()) < 3e-6
         assert torch.equal(got, ops.gemm_atb_bf16(bf(a).to(dev), bf(b).to(dev)))        # fixed-order slices
         assert rel_err(ops.colsum_bf16(bf(a).to(dev)), bf(a).double().sum(0)) < 3e-6
+    # first edge-MLP layer (K = 6 edge attributes, bf16 out in one kernel) == fp32 kernel, then the cast, bit for bit
+    for rows, n, k, relu in ((1001, 1024, 6, True), (77, 128, 6, False), (300, 64, 8, True), (5, 8, 1, True)):
+        a, w, b = torch.randn(rows, k, generator=g).to(dev), torch.randn(n, k, generator=g).to(dev), torch.randn(n, generator=g).to(dev)
+        got = ops.linear_smallk_bf16(a, w, b, relu=relu)
+        assert got.dtype == torch.bfloat16 and torch.equal(got, ops.cast_bf16(ops.linear(a, w, b, relu=relu)))
+        assert torch.equal(ops.linear_smallk_bf16(a, w, None, relu=relu), ops.cast_bf16(ops.linear(a, w, None, relu=relu)))
     gq, y = torch.randn(40, 64, generator=g), torch.randn(40, 64, generator=g)
     assert torch.equal(ops.relu_bwd_bf16(gq.to(dev), bf(y).to(dev), out_bf16=False).cpu(), gq * (bf(y).float() > 0))
     assert torch.equal(ops.relu_bwd_bf16(gq.to(dev), bf(y).to(dev), out_bf16=True).cpu(), bf(gq * (bf(y).float() > 0)))

@@ -593,3 +593,38 @@ def test_untied_conv2_kernel_is_evaluated_separately(dev, O):
         model.conv_mode = conv
         eng = RolloutEngine(model, 1, N, W, 8.0, max_steps=steps, device=dev)
         close(eng.run(torch.from_numpy(win), aa, steps)[:, 0], ref, name=f"untied conv2, rollout {conv}")
+
+
+# ------------------------------------------------------------------------------- ragged sizes
+@pytest.mark.parametrize("gemm_mode", ["split_f16", "split_bf16"])
+@pytest.mark.parametrize("conv_mode", ["factored", "materialized"])
+def test_ragged_member_sizes_free_run_vs_oracle(dev, O, conv_mode, gemm_mode):
+    """Member sizes that are no multiple of any tile (1 atom, 2, 31, 65, 129 and 200 atoms — the last with
+    sources of more than 128 edges, i.e. a second row tile in the factored conv), one and two members: three
+    free-running steps at width 64 against the oracle's host loop, member by member, with the edge counts of
+    every step."""
+    from molecular_dynamics_neural_operator_amd import synthetic as syn
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN
+    from molecular_dynamics_neural_operator_amd.rollout import RolloutEngine
+    from molecular_dynamics_neural_operator_amd.weights import near_identity_state_dict
+    W, steps = 4, 3
+    sd = near_identity_state_dict(64, 128, seed=21, kernel_gain=1e-2, feature_gain=0.1, kernel_to_coords=1.0)
+    model = KernelNN(64, 128, 2, 6, 7, 3, 20, 4)
+    model.load_state_dict(sd)
+    model.eval().to(dev)
+    model.gemm_mode, model.conv_mode = gemm_mode, conv_mode
+    for N, M in ((1, 1), (2, 2), (31, 1), (65, 2), (129, 1), (200, 2)):
+        base = syn.jitter_window(syn.box_frame(N, seed=30 + N), W, seed=30 + N)
+        wins = syn.ensemble_windows(base, M, sigma=0.2, seed0=500 + N)                 # [M, W, N, 3]
+        aa = torch.from_numpy(syn.amino_acids(N, seed=N))
+        eng = RolloutEngine(model, M, N, W, 8.0, max_steps=steps, device=dev)
+        traj = eng.run(torch.from_numpy(np.ascontiguousarray(wins.transpose(1, 0, 2, 3))), aa, steps).cpu().numpy()
+        edges = np.zeros(steps, dtype=np.int64)
+        for m in range(M):
+            s0 = O.construct_pairdata(wins[m], aa, 8.0)
+            fc = O.recursive_propagation(sd, 2, s0, steps, 8.0, hoist=True)
+            ref = np.stack([f["x_position"][-1].numpy() for f in fc])
+            np.testing.assert_allclose(traj[:, m], ref, rtol=1e-4, atol=1e-4 * max(np.abs(ref).max(), 1.0),
+                                       err_msg=f"N={N} member {m}")
+            edges += np.array([s0["edge_index"].shape[1]] + [f["edge_index"].shape[1] for f in fc[:-1]])
+        assert eng.edges_per_step.cpu().tolist() == edges.tolist(), (N, M)

@@ -58,10 +58,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-// flags[0]: a weight is out of fp16 range (set when the weight planes are built);
-// flags[1]: an activation of the current forward is.  Either one sends the chunk down the bf16 path.
-__device__ __forceinline__ bool f16_blocked(const int* __restrict__ flags) {
-    return (__builtin_nontemporal_load(flags) | __builtin_nontemporal_load(flags + 1)) != 0;
+// flags[0]: a weight is not finite (set when the weight planes are built); flags[1]: an activation of the
+// current forward is out of fp16 range; flags[2], flags[3]: h1 / h2 of the current forward hold at least one
+// value >= F16_ACT_MIN (split_layout.h: below that the two-plane form has only an absolute error bound).
+// `need`: which of flags[2], flags[3] (bit 0, bit 1) the product's operands depend on.  Any failure sends
+// the chunk down the bf16 path.
+__device__ __forceinline__ bool f16_blocked(const int* __restrict__ flags, int need) {
+    bool b = (__builtin_nontemporal_load(flags) | __builtin_nontemporal_load(flags + 1)) != 0;
+    if (need & 1) b |= __builtin_nontemporal_load(flags + 2) == 0;
+    if (need & 2) b |= __builtin_nontemporal_load(flags + 3) == 0;
+    return b;
 }
 
 constexpr int TN = 128, TK = 16;               // block tile is TM x 128 (TM = 128 or 256); one MFMA k-step per stage
@@ -93,28 +99,46 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
         *reinterpret_cast<uint4*>(planes + tiled_off(row, k0, nkt, p)) = *reinterpret_cast<const uint4*>(o[p]);
 }
 
+// One wave per row: the row's largest magnitude, then the power of two that lifts it to [2^13, 2^14)
+// (f16_row_scale; exact), then the two-plane split of the scaled row.  unscale[row] = 1/scale is what the
+// GEMM epilogue multiplies the row's output column by.  Lane = 16-B chunks lane, lane+64, ... (8 k each).
 __global__ __launch_bounds__(256) void split_planes_f16_kernel(const float* __restrict__ w, int rows, int K,
                                                                unsigned char* __restrict__ planes,
+                                                               float* __restrict__ unscale,
                                                                int* __restrict__ range_flag) {
-    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
-    const int chunks_per_row = K >> 3;
-    if (id >= (long long)rows * chunks_per_row) return;
-    const int row = (int)(id / chunks_per_row), k0 = (int)(id % chunks_per_row) * 8;
-    const float4 v0 = *reinterpret_cast<const float4*>(w + (size_t)row * K + k0);
-    const float4 v1 = *reinterpret_cast<const float4*>(w + (size_t)row * K + k0 + 4);
-    const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-    _Float16 o[2][8];
-    bool bad = false;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;                      // (wave-uniform)
+    const float* wr = w + (size_t)row * K;
+    const int chunks = K >> 3;
+    float mx = 0.f;
+    for (int c = lane; c < chunks; c += 64) {
+        const float4 v0 = *reinterpret_cast<const float4*>(wr + 8 * c);
+        const float4 v1 = *reinterpret_cast<const float4*>(wr + 8 * c + 4);
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v0.z), fabsf(v0.w))));
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v1.x), fabsf(v1.y)), fmaxf(fabsf(v1.z), fabsf(v1.w))));
+    }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        bad |= !(fabsf(x[j]) < F16_MAX);
-        split2h(x[j], o[0][j], o[1][j]);
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    const float sc = f16_row_scale(mx);
+    if (lane == 0) unscale[row] = 1.f / sc;       // (power of two: exact)
+    const int nkt = K >> 4;
+    bool bad = false;
+    for (int c = lane; c < chunks; c += 64) {
+        const float4 v0 = *reinterpret_cast<const float4*>(wr + 8 * c);
+        const float4 v1 = *reinterpret_cast<const float4*>(wr + 8 * c + 4);
+        const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        _Float16 o[2][8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xs = x[j] * sc;
+            bad |= !(fabsf(xs) < F16_MAX);        // (inf / NaN only: the row's max sits below 2^14)
+            split2h(xs, o[0][j], o[1][j]);
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+            *reinterpret_cast<uint4*>(planes + tiled_off2(row, 8 * c, nkt, p)) = *reinterpret_cast<const uint4*>(o[p]);
     }
     if (bad) atomicOr(range_flag, 1);
-    const int nkt = K >> 4;
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-        *reinterpret_cast<uint4*>(planes + tiled_off2(row, k0, nkt, p)) = *reinterpret_cast<const uint4*>(o[p]);
 }
 
 // ---------------------------------------------------------------- x [rows,64] -> planes, + q = x . B
@@ -143,13 +167,15 @@ __global__ __launch_bounds__(256) void split_bias64_kernel(const float* __restri
             *reinterpret_cast<uint4*>(planes + tiled_off(row, 8 * o, 4, p)) = *reinterpret_cast<const uint4*>(pl[p]);
         if (planes_h != nullptr) {
             _Float16 ph[2][8];
-            bool bad = false;
+            bool bad = false, seen = false;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 bad |= !(fabsf(xv[j]) < F16_MAX);
+                seen |= fabsf(xv[j]) >= F16_ACT_MIN;
                 split2h(xv[j], ph[0][j], ph[1][j]);
             }
             if (bad) atomicOr(range_flag, 1);
+            if (seen) range_flag[F16_SEEN_OFF] = 1;      // (same value from every thread that stores it: no atomic)
 #pragma unroll
             for (int p = 0; p < 2; ++p)
                 *reinterpret_cast<uint4*>(planes_h + tiled_off2(row, 8 * o, 4, p)) = *reinterpret_cast<const uint4*>(ph[p]);
@@ -176,10 +202,10 @@ __global__ __launch_bounds__(256) void edge_l0_split_kernel(
     const int* __restrict__ src, const int* __restrict__ dst, const float* __restrict__ edge_attr,
     const int* __restrict__ perm, const int* __restrict__ num_edges, long long e_begin, int e_count, int F, int k,
     const float* __restrict__ w0, const float* __restrict__ b0, unsigned char* __restrict__ hp,
-    int* __restrict__ f16_flags) {
+    int* __restrict__ f16_flags, int f16_need) {
     __shared__ __attribute__((aligned(16))) float wsh[L0_UNITS * MAX_F];
     __shared__ __attribute__((aligned(16))) float bsh[L0_UNITS];
-    if (!F16 && f16_flags != nullptr && !f16_blocked(f16_flags)) return;   // fallback launch, not needed
+    if (!F16 && f16_flags != nullptr && !f16_blocked(f16_flags, f16_need)) return;   // fallback launch, not needed
     const int Fn = FT ? FT : F;
     const long long E = *num_edges;
     const long long tile0 = (long long)blockIdx.x * L0_ROWS;   // first row of this tile inside the chunk
@@ -210,7 +236,7 @@ __global__ __launch_bounds__(256) void edge_l0_split_kernel(
     __syncthreads();
     if (!valid) return;
     const int nkt = k >> 4;
-    bool bad = false;
+    bool bad = false, seen = false;
 #pragma unroll 2
     for (int t = 0; t < L0_UNITS / 16; ++t) {
         const int c = t * 16 + half * 8;       // this thread's 8 hidden units, relative to u0
@@ -225,6 +251,7 @@ __global__ __launch_bounds__(256) void edge_l0_split_kernel(
             const float v = fmaxf(sum + bsh[c + j], 0.f);
             if (F16) {
                 bad |= !(v < F16_MAX);
+                seen |= v >= F16_ACT_MIN;
                 split2h(v, oh[0][j], oh[1][j]);
             } else {
                 split3(v, o[0][j], o[1][j], o[2][j]);
@@ -241,17 +268,19 @@ __global__ __launch_bounds__(256) void edge_l0_split_kernel(
         }
     }
     if (F16 && bad) atomicOr(f16_flags + 1, 1);
+    if (F16 && seen) f16_flags[2] = 1;      // (the same value from whoever stores it: no atomic)
 }
 
 // f16 = true: fp16 planes + range flag; f16 = false with flags: the bf16 fallback (runs if a flag is up)
 static int launch_edge_l0_split(const float* pos_mode, int frame, const int* t_dev, int rows_per_frame, const int* src,
                                 const int* dst, const float* edge_attr, const int* perm, const int* num_edges,
                                 long long e0, int cnt, int F, int k, const float* w0, const float* b0,
-                                unsigned char* hp, hipStream_t s, bool f16 = false, int* f16_flags = nullptr) {
+                                unsigned char* hp, hipStream_t s, bool f16 = false, int* f16_flags = nullptr,
+                                int f16_need = 0) {
     const dim3 grid((cnt + L0_ROWS - 1) / L0_ROWS, k / L0_UNITS);
 #define MDNO_L0(FT, H)                                                                                             \
     hipLaunchKernelGGL((edge_l0_split_kernel<FT, H>), grid, dim3(256), 0, s, pos_mode, frame, t_dev, rows_per_frame, \
-                       src, dst, edge_attr, perm, num_edges, e0, cnt, F, k, w0, b0, hp, f16_flags)
+                       src, dst, edge_attr, perm, num_edges, e0, cnt, F, k, w0, b0, hp, f16_flags, f16_need)
     if (F == 6) { if (f16) MDNO_L0(6, true); else MDNO_L0(6, false); }
     else        { if (f16) MDNO_L0(0, true); else MDNO_L0(0, false); }
 #undef MDNO_L0
@@ -273,6 +302,8 @@ struct SplitGemmArgs {
     int m_fastest;             // tile order: 0 = n fastest (neighbours share the A row-panel), 1 = m fastest (share B)
     const int* f16_flags = nullptr;   // SPLIT_F16: the fp16 kernel runs while no flag is up, the bf16 one (given
                                       // the flags) only when one is; NULL: unconditional
+    int f16_need = 0;                 // which "seen" words the operands depend on (f16_blocked)
+    const float* b_unscale = nullptr; // fp16 kernel: per-column factor undoing the weight rows' power-of-two scale
 };
 
 // One stage (k-step of 16) for a wave: (2x2 tiles) x 6 plane products = 24 MFMAs, 12 fragment reads.
@@ -312,7 +343,7 @@ __global__ __launch_bounds__(TM * 2, 2) void gemm_split_bf16_kernel(SplitGemmArg
     constexpr int A_PIECES = PIECES - 12;
     constexpr int PPW = (PIECES + WAVES - 1) / WAVES;    // pieces per wave: 6 or 5
 
-    if (g.f16_flags != nullptr && !f16_blocked(g.f16_flags)) return;   // bf16 fallback launch, not needed
+    if (g.f16_flags != nullptr && !f16_blocked(g.f16_flags, g.f16_need)) return;   // bf16 fallback launch, not needed
     long long valid = g.num_edges ? (long long)(*g.num_edges) - g.row_begin : (long long)g.rows_valid;
     if (valid > g.rows) valid = g.rows;
     if (valid <= 0) return;
@@ -508,7 +539,7 @@ __global__ __launch_bounds__(1024 / MI) void gemm_split_f16_kernel(SplitGemmArgs
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int TM = F16_TM, WAVES = 16 / MI;
     constexpr int PPW = F16_STAGE_BYTES / 1024 / WAVES;   // one-KiB DMA pieces per wave per stage: 6 or 12
-    if (g.f16_flags != nullptr && f16_blocked(g.f16_flags)) return;   // out of fp16 range: the bf16 launch behind us runs
+    if (g.f16_flags != nullptr && f16_blocked(g.f16_flags, g.f16_need)) return;   // out of fp16 range: the bf16 launch behind us runs
     long long valid = g.num_edges ? (long long)(*g.num_edges) - g.row_begin : (long long)g.rows_valid;
     if (valid > g.rows) valid = g.rows;
     if (valid <= 0) return;
@@ -560,11 +591,16 @@ __global__ __launch_bounds__(1024 / MI) void gemm_split_f16_kernel(SplitGemmArgs
 #pragma unroll
             for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.f; accx[i][j][e] = 0.f; }
     float bv0 = 0.f, bv1 = 0.f;      // fetched before the K loop and pinned (see gemm_split_bf16_kernel)
+    float us0 = 1.f, us1 = 1.f;      // undo the power-of-two scale of the weight rows behind these two columns
     if (g.bias) {
         bv0 = g.bias[bn + wn * 64 + l31];
         bv1 = g.bias[bn + wn * 64 + 32 + l31];
     }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bv0), "+v"(bv1));   // the counted waits below must see DMA pieces only
+    if (g.b_unscale) {
+        us0 = g.b_unscale[bn + wn * 64 + l31];
+        us1 = g.b_unscale[bn + wn * 64 + 32 + l31];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bv0), "+v"(bv1), "+v"(us0), "+v"(us1));   // the counted waits below must see DMA pieces only
 
     MDNO_DMA_STAGE(0, 0)
     if (nst > 1) MDNO_DMA_STAGE(1, 1)
@@ -598,23 +634,24 @@ __global__ __launch_bounds__(1024 / MI) void gemm_split_f16_kernel(SplitGemmArgs
     }
 #undef MDNO_DMA_STAGE
 
-    bool bad = false;
+    bool bad = false, seen = false;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = bn + wn * 64 + j * 32 + l31;
-        const float bv = j ? bv1 : bv0;
+        const float bv = j ? bv1 : bv0, us = j ? us1 : us0;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = bm + wm * (MI * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (m < valid) {
-                    const float v = (acc[i][j][e] + accx[i][j][e] * F16_LO_UNSCALE) + bv;
+                    const float v = (acc[i][j][e] + accx[i][j][e] * F16_LO_UNSCALE) * us + bv;
                     if (OUT == 2) {
                         g.C[((size_t)(m >> 7) * (g.N >> 5) + (n >> 5)) * 4096 + (m & 127) * 32 + (n & 31)] = fmaxf(v, 0.f);
                     } else if (OUT == 4) {
                         const float rv = fmaxf(v, 0.f);
                         bad |= !(rv < F16_MAX);
+                        seen |= rv >= F16_ACT_MIN;
                         _Float16 ph, pl;
                         split2h(rv, ph, pl);
                         const size_t o = tiled_off2(m, n, g.N >> 4, 0);
@@ -628,6 +665,7 @@ __global__ __launch_bounds__(1024 / MI) void gemm_split_f16_kernel(SplitGemmArgs
         }
     }
     if (OUT == 4 && bad) atomicOr(const_cast<int*>(g.f16_flags) + 1, 1);
+    if (OUT == 4 && seen) const_cast<int*>(g.f16_flags)[3] = 1;
 }
 
 template <int OUT, int MI>
@@ -666,15 +704,19 @@ __global__ __launch_bounds__(256, 2) void gemm_k64_f16_kernel(const unsigned cha
                                                            const unsigned char* __restrict__ Ab,
                                                            const unsigned char* __restrict__ Bb,
                                                            const int* __restrict__ flag_w,
-                                                           const int* __restrict__ flag_x, float* __restrict__ C,
-                                                           int rows_valid, int N, int tiles_m) {
+                                                           const int* __restrict__ flag_x,
+                                                           const float* __restrict__ b_unscale,
+                                                           float* __restrict__ C, int rows_valid, int N, int tiles_m) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tn = blockIdx.x, bn = tn * TN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
-    const bool blocked = (__builtin_nontemporal_load(flag_w) | __builtin_nontemporal_load(flag_x)) != 0;
+    // fp16 planes only for node features that are in range AND hold a value >= F16_ACT_MIN (split_layout.h)
+    const bool blocked = (__builtin_nontemporal_load(flag_w) | __builtin_nontemporal_load(flag_x)) != 0 ||
+                         __builtin_nontemporal_load(flag_x + F16_SEEN_OFF) == 0;
     f32x16 acc[2][2], accx[2][2];
+    float us0 = 1.f, us1 = 1.f;      // per-column undo of the W3T rows' power-of-two scale (fp16 path only)
     const int hsw = (h ^ ((l31 >> 3) & 1)) << 4;
     const int a_rd = (wm * 64 + l31) * 32 + hsw, b_rd = 32768 + (wn * 64 + l31) * 32 + hsw;
     // (fallback: accx stays zero and the sum below is acc itself, bit for bit)
@@ -684,7 +726,7 @@ __global__ __launch_bounds__(256, 2) void gemm_k64_f16_kernel(const unsigned cha
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                    \
             _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                             \
                 const int m = (TM_) * 128 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;           \
-                if (COND) C[(size_t)m * N + n] = acc[i][j][e] + accx[i][j][e] * F16_LO_UNSCALE;          \
+                if (COND) C[(size_t)m * N + n] = (acc[i][j][e] + accx[i][j][e] * F16_LO_UNSCALE) * (j ? us1 : us0); \
             }                                                                                            \
     }
     // (a full tile stores without the 64 per-row tests; only a launch's last tile can be ragged)
@@ -697,13 +739,15 @@ __global__ __launch_bounds__(256, 2) void gemm_k64_f16_kernel(const unsigned cha
     if (!blocked) {
         const unsigned char* a_src = Ah + lane * 16;                            // 32 KiB per 128-row tile
         const unsigned char* b_src = Bh + ((size_t)tn << 15) + lane * 16;
+        us0 = b_unscale[bn + wn * 64 + l31];
+        us1 = b_unscale[bn + wn * 64 + 32 + l31];
 #pragma unroll
         for (int t = 0; t < 8; ++t) {       // wave w moves KiB w, w+4, ... of B and of the first A tile
             const int piece = wave + 4 * t;
             __builtin_amdgcn_global_load_lds((glb_u8*)(b_src + piece * 1024), (lds_u8*)(lds + 32768 + piece * 1024), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((glb_u8*)(a_src + piece * 1024), (lds_u8*)(lds + piece * 1024), 16, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(us0), "+v"(us1) : : "memory");   // (pinned here: see the bias note above)
         for (int tm = 0; tm < tiles_m; ++tm) {
             // everybody's pieces of this tile's A (and of B) have landed.  Bare barrier instructions:
             // __syncthreads() carries a fence the compiler lowers to vmcnt(0), i.e. a wait for the stores
@@ -819,18 +863,18 @@ size_t split_planes_f16_bytes(long long rows, int K) {
     return (size_t)2 * ((rows + 255) / 256 * 256) * K * sizeof(_Float16);
 }
 
-int split_planes_f16(const float* a, int rows, int K, void* planes, int* range_flag, hipStream_t s) {
-    MDNO_REQUIRE(K % 16 == 0 && (reinterpret_cast<uintptr_t>(a) & 15) == 0 && range_flag, MDNO_EINVAL,
+int split_planes_f16(const float* a, int rows, int K, void* planes, float* unscale, int* range_flag, hipStream_t s) {
+    MDNO_REQUIRE(K % 16 == 0 && (reinterpret_cast<uintptr_t>(a) & 15) == 0 && range_flag && unscale, MDNO_EINVAL,
                  "split_planes_f16: K=%d", K);
-    const long long chunks = (long long)rows * (K / 8);
-    hipLaunchKernelGGL(split_planes_f16_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, s, a, rows, K,
-                       static_cast<unsigned char*>(planes), range_flag);
+    hipLaunchKernelGGL(split_planes_f16_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, a, rows, K,
+                       static_cast<unsigned char*>(planes), unscale, range_flag);
     return check_launch("split_planes_f16_kernel");
 }
 
 int split_gemm_rows_k64_f16(const void* a_planes, const void* b_planes, const void* a_bf16, const void* b_bf16,
-                            const int* flag_w, const int* flag_x, int rows, int N, float* C, hipStream_t s) {
-    MDNO_REQUIRE(N % TN == 0 && rows > 0 && a_bf16 && b_bf16 && flag_w && flag_x, MDNO_EUNSUPPORTED,
+                            const int* flag_w, const int* flag_x, const float* b_unscale, int rows, int N, float* C,
+                            hipStream_t s) {
+    MDNO_REQUIRE(N % TN == 0 && rows > 0 && a_bf16 && b_bf16 && flag_w && flag_x && b_unscale, MDNO_EUNSUPPORTED,
                  "split_gemm_rows_k64_f16: rows=%d N=%d", rows, N);
     static std::atomic<unsigned long long> lds_raised{0};
     MDNO_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(&gemm_k64_f16_kernel), K64_LDS_BYTES, lds_raised));
@@ -838,7 +882,7 @@ int split_gemm_rows_k64_f16(const void* a_planes, const void* b_planes, const vo
     hipLaunchKernelGGL(gemm_k64_f16_kernel, dim3(tiles_n), dim3(256), K64_LDS_BYTES, s,
                        static_cast<const unsigned char*>(a_planes), static_cast<const unsigned char*>(b_planes),
                        static_cast<const unsigned char*>(a_bf16), static_cast<const unsigned char*>(b_bf16), flag_w, flag_x,
-                       C, rows, N, tiles_m);
+                       b_unscale, C, rows, N, tiles_m);
     return check_launch("gemm_k64_f16_kernel");
 }
 
@@ -880,6 +924,7 @@ bool edge_mlp_split_supported(int ker_width, int out_dim) {
 // One layout for both entry points: [h1 planes][h2 planes][W1 planes][W2 planes][W1 fp16 planes][flags][W2 fp16 planes]
 struct SplitWs {
     unsigned char *h1p, *h2p, *w1p, *w2p, *w1h, *w2h;
+    float *w1us, *w2us;      // per-row unscale factors of the fp16 weight images
     int* f16_flags;
     size_t total;
 };
@@ -894,6 +939,8 @@ static SplitWs carve_split(void* ws, int k, int out_dim, long long chunk) {
     w.w1h = reinterpret_cast<unsigned char*>(cv.take<_Float16>(2 * (size_t)k * k));
     w.f16_flags = cv.take<int>(64);
     w.w2h = reinterpret_cast<unsigned char*>(cv.take<_Float16>(2 * (size_t)out_dim * k));
+    w.w1us = cv.take<float>((size_t)k);
+    w.w2us = cv.take<float>((size_t)out_dim);
     w.total = cv.used();
     return w;
 }
@@ -920,16 +967,14 @@ int edge_mlp_split(const float* frames, int frame, const int* t_dev, int rows_pe
                            w2p);
         if (f16) {   // fp16 images of W1, W2 + their range flag (flags[0]); the bf16 images serve the fallback
             MDNO_TRY(fill_ints(sw.f16_flags, 1, 0, s));
-            hipLaunchKernelGGL(split_planes_f16_kernel, dim3((unsigned)((c1 + 255) / 256)), dim3(256), 0, s, w.w1, k, k,
-                               sw.w1h, sw.f16_flags);
-            hipLaunchKernelGGL(split_planes_f16_kernel, dim3((unsigned)((c2 + 255) / 256)), dim3(256), 0, s, w.w2,
-                               out_dim, k, sw.w2h, sw.f16_flags);
+            MDNO_TRY(split_planes_f16(w.w1, k, k, sw.w1h, sw.w1us, sw.f16_flags, s));
+            MDNO_TRY(split_planes_f16(w.w2, out_dim, k, sw.w2h, sw.w2us, sw.f16_flags, s));
         }
     }
     MDNO_TRY(check_launch("split_planes_kernel"));
     if (phase == WP_PREPARE_ONLY) return MDNO_OK;
     const float* pos_mode = edge_attr ? nullptr : frames;
-    if (f16) MDNO_TRY(fill_ints(sw.f16_flags + 1, 1, 0, s));   // activation flag of THIS forward
+    if (f16) MDNO_TRY(fill_ints(sw.f16_flags + 1, 3, 0, s));   // activation flags of THIS forward (range, h1 seen, h2 seen)
     for (long long e0 = 0; e0 < edge_cap; e0 += chunk) {
         const int cnt = (int)((edge_cap - e0) < chunk ? (edge_cap - e0) : chunk);
         if (f16) {
@@ -942,21 +987,23 @@ int edge_mlp_split(const float* frames, int frame, const int* t_dev, int rows_pe
                                               e0, cnt, ker_in, k, w.w0, w.b0, h1p, s, true, sw.f16_flags));
             }
             {
-                TimedSection ts(KID_GEMM_L1, s);
-                SplitGemmArgs gh{h1p, sw.w1h, w.b1, nullptr, h2p, num_edges, e0, (int)chunk, k, k, 0, 0, 0, 0, sw.f16_flags};
+                TimedSection ts(KID_GEMM_L1, s);   // reads h1 (need 1), writes h2 planes + their range / "seen" words
+                SplitGemmArgs gh{h1p, sw.w1h, w.b1, nullptr, h2p, num_edges, e0, (int)chunk, k, k, 0, 0, 0, 0, sw.f16_flags,
+                                 1, sw.w1us};
                 MDNO_TRY((launch_split_f16_gemm<4, 2>(gh, s)));
             }
             {
-                TimedSection ts(KID_GEMM_L2, s);
+                TimedSection ts(KID_GEMM_L2, s);   // reads h2 (need 3: h1 and h2 both fit fp16)
                 SplitGemmArgs gh{h2p, sw.w2h, w.b2, w_e + (size_t)e0 * out_dim, nullptr, num_edges, e0, (int)chunk, out_dim,
-                                 k, 0, 0, 0, 0, sw.f16_flags};
+                                 k, 0, 0, 0, 0, sw.f16_flags, 3, sw.w2us};
                 MDNO_TRY((launch_split_f16_gemm<0, 2>(gh, s)));
+                // the bf16 trio runs iff the fp16 chain did not go all the way through (same test: need 3)
                 MDNO_TRY(launch_edge_l0_split(pos_mode, frame, t_dev, rows_per_frame, src, dst, edge_attr, perm, num_edges,
-                                              e0, cnt, ker_in, k, w.w0, w.b0, h1p, s, false, sw.f16_flags));
-                SplitGemmArgs g1{h1p, w1p, w.b1, nullptr, h2p, num_edges, e0, (int)chunk, k, k, 0, 0, 0, 0, sw.f16_flags};
+                                              e0, cnt, ker_in, k, w.w0, w.b0, h1p, s, false, sw.f16_flags, 3));
+                SplitGemmArgs g1{h1p, w1p, w.b1, nullptr, h2p, num_edges, e0, (int)chunk, k, k, 0, 0, 0, 0, sw.f16_flags, 3};
                 MDNO_TRY((launch_split_gemm_tm<128, 1>(g1, s)));
                 SplitGemmArgs g2{h2p, w2p, w.b2, w_e + (size_t)e0 * out_dim, nullptr, num_edges, e0, (int)chunk, out_dim, k,
-                                 0, 0, 0, 0, sw.f16_flags};
+                                 0, 0, 0, 0, sw.f16_flags, 3};
                 if (out_dim >= 2048) MDNO_TRY((launch_split_gemm_tm<256, 0>(g2, s)));
                 else MDNO_TRY((launch_split_gemm_tm<128, 0>(g2, s)));
             }
@@ -992,14 +1039,13 @@ int edge_mlp_split_hidden(const float* frames, int frame, const int* t_dev, int 
         hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((c1 + 255) / 256)), dim3(256), 0, s, w.w1, k, k, w1p);
         if (f16) {   // fp16 image of W1 + its range flag (flags[0]); the bf16 image above serves the fallback
             MDNO_TRY(fill_ints(sw.f16_flags, 1, 0, s));
-            hipLaunchKernelGGL(split_planes_f16_kernel, dim3((unsigned)((c1 + 255) / 256)), dim3(256), 0, s, w.w1, k, k,
-                               sw.w1h, sw.f16_flags);
+            MDNO_TRY(split_planes_f16(w.w1, k, k, sw.w1h, sw.w1us, sw.f16_flags, s));
         }
     }
     MDNO_TRY(check_launch("split_planes_kernel"));
     if (phase == WP_PREPARE_ONLY) return MDNO_OK;
     const float* pos_mode = edge_attr ? nullptr : frames;
-    if (f16) MDNO_TRY(fill_ints(sw.f16_flags + 1, 1, 0, s));   // activation flag of THIS forward
+    if (f16) MDNO_TRY(fill_ints(sw.f16_flags + 1, 3, 0, s));   // activation flags of THIS forward (range, h1 seen, h2 seen)
     for (long long e0 = 0; e0 < edge_cap; e0 += chunk) {
         const int cnt = (int)((edge_cap - e0) < chunk ? (edge_cap - e0) : chunk);
         float* out = h_out + (size_t)e0 * k;      // chunk % 128 == 0: the k-tiled tile index continues across chunks
@@ -1010,12 +1056,13 @@ int edge_mlp_split_hidden(const float* frames, int frame, const int* t_dev, int 
                                               e0, cnt, ker_in, k, w.w0, w.b0, h1p, s, true, sw.f16_flags));
             }
             TimedSection ts(KID_GEMM_L1, s);
-            SplitGemmArgs gh{h1p, sw.w1h, w.b1, out, nullptr, num_edges, e0, (int)chunk, k, k, 0, 0, 0, 0, sw.f16_flags};
+            SplitGemmArgs gh{h1p, sw.w1h, w.b1, out, nullptr, num_edges, e0, (int)chunk, k, k, 0, 0, 0, 0, sw.f16_flags, 1,
+                             sw.w1us};
             MDNO_TRY((launch_split_f16_gemm<2, 2>(gh, s)));
             // the same chunk on the bf16 kernels: both exit at their first instruction unless a range flag is up
             MDNO_TRY(launch_edge_l0_split(pos_mode, frame, t_dev, rows_per_frame, src, dst, edge_attr, perm, num_edges,
-                                          e0, cnt, ker_in, k, w.w0, w.b0, h1p, s, false, sw.f16_flags));
-            SplitGemmArgs g1{h1p, w1p, w.b1, out, nullptr, num_edges, e0, (int)chunk, k, k, 0, 0, 0, 0, sw.f16_flags};
+                                          e0, cnt, ker_in, k, w.w0, w.b0, h1p, s, false, sw.f16_flags, 1));
+            SplitGemmArgs g1{h1p, w1p, w.b1, out, nullptr, num_edges, e0, (int)chunk, k, k, 0, 0, 0, 0, sw.f16_flags, 1};
             MDNO_TRY((launch_split_gemm_tm<128, 2>(g1, s)));
             continue;
         }

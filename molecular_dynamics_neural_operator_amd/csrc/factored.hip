@@ -478,7 +478,10 @@ __global__ __launch_bounds__(256) void reverse_edges_kernel(const int* __restric
                                                             int tail_planes, int* __restrict__ f16_x_flags) {
     // once per forward, before any conv application: no node feature has been seen out of fp16 range
     // yet (a kernel's stores rather than a memset node: the captured step stays a chain of kernels)
-    if (blockIdx.x == 0 && threadIdx.x <= kMaxF16Applications) f16_x_flags[threadIdx.x] = 0;
+    if (blockIdx.x == 0 && threadIdx.x <= kMaxF16Applications) {
+        f16_x_flags[threadIdx.x] = 0;
+        f16_x_flags[F16_SEEN_OFF + threadIdx.x] = 0;
+    }
     const int E = row_ptr[num_rows];
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= E) return;
@@ -674,13 +677,15 @@ __global__ __launch_bounds__(AGG_CHAINS * 16) void aggregate_rev_kernel(const fl
                 *reinterpret_cast<uint4*>(next_xp + tiled_off(t, 8 * c, 4, p)) = *reinterpret_cast<const uint4*>(pl[p]);
             if (next_xh != nullptr) {
                 _Float16 ph[2][8];
-                bool bad = false;
+                bool bad = false, seen = false;
 #pragma unroll
                 for (int j2 = 0; j2 < 8; ++j2) {
                     bad |= !(fabsf(row[8 * c + j2]) < F16_MAX);
+                    seen |= fabsf(row[8 * c + j2]) >= F16_ACT_MIN;
                     split2h(row[8 * c + j2], ph[0][j2], ph[1][j2]);
                 }
                 if (bad) atomicOr(next_flag, 1);
+                if (seen) next_flag[F16_SEEN_OFF] = 1;
 #pragma unroll
                 for (int p = 0; p < 2; ++p)
                     *reinterpret_cast<uint4*>(next_xh + tiled_off2(t, 8 * c, 4, p)) = *reinterpret_cast<const uint4*>(ph[p]);
@@ -714,7 +719,8 @@ size_t factored_workspace_bytes(int num_rows, int ker_width, long long edge_cap)
     cv.take<char>(split_planes_bytes(num_rows, 64));                    // X as bf16 planes
     cv.take<char>(split_planes_f16_bytes((long long)64 * ker_width, 64));   // W3T as fp16 planes
     cv.take<char>(split_planes_f16_bytes(num_rows, 64));                    // X as fp16 planes
-    cv.take<int>(64);                                                   // fp16 range flags
+    cv.take<int>(128);                                                  // fp16 range flags + "seen" words
+    cv.take<float>((size_t)64 * ker_width);                             // unscale factors of the fp16 W3T rows
     cv.take<int>((size_t)num_rows);                                     // sources of each Y chunk by decreasing degree
     return cv.used();
 }
@@ -732,7 +738,8 @@ FactoredWs factored_carve(void* ws, int num_rows, int ker_width, long long edge_
     f.xp = cv.take<char>(split_planes_bytes(num_rows, 64));
     f.w3th = cv.take<char>(split_planes_f16_bytes((long long)64 * ker_width, 64));
     f.xh = cv.take<char>(split_planes_f16_bytes(num_rows, 64));
-    f.f16_flags = cv.take<int>(64);
+    f.f16_flags = cv.take<int>(128);
+    f.w3tus = cv.take<float>((size_t)64 * ker_width);
     f.order = cv.take<int>((size_t)num_rows);
     return f;
 }
@@ -745,7 +752,7 @@ int factored_prepare_weights(const float* w3, int ker_width, int gemm_mode, cons
     if (gemm_mode == MDNO_GEMM_SPLIT_BF16) {
         MDNO_TRY(split_planes(f.w3t, 64 * ker_width, 64, f.w3tp, s));
         MDNO_TRY(fill_ints(f.f16_flags, 1, 0, s));
-        MDNO_TRY(split_planes_f16(f.w3t, 64 * ker_width, 64, f.w3th, f.f16_flags, s));
+        MDNO_TRY(split_planes_f16(f.w3t, 64 * ker_width, 64, f.w3th, f.w3tus, f.f16_flags, s));
     }
     return MDNO_OK;
 }
@@ -806,7 +813,7 @@ int factored_conv(const float* x, const float* h2, const int* row_ptr, int num_r
                 const unsigned char* xp = static_cast<const unsigned char*>(f.xp) + (size_t)(r0 >> 7) * 4 * 3 * 4096;
                 if (y_f16) {   // two fp16 planes, 32 KiB per 128-row tile (bf16 images ride along for the fallback)
                     const unsigned char* xh = static_cast<const unsigned char*>(f.xh) + ((size_t)(r0 >> 7) << 15);
-                    MDNO_TRY(split_gemm_rows_k64_f16(xh, f.w3th, xp, f.w3tp, f.f16_flags, flag_x, cnt, ncols, f.y, s));
+                    MDNO_TRY(split_gemm_rows_k64_f16(xh, f.w3th, xp, f.w3tp, f.f16_flags, flag_x, f.w3tus, cnt, ncols, f.y, s));
                 } else {
                     MDNO_TRY(split_gemm_rows(xp, f.w3tp, cnt, ncols, 64, f.y, s));
                 }

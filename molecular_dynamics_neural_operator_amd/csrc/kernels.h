@@ -73,10 +73,12 @@ int split_planes_bias64(const float* x, int rows, const float* b, float* q, void
 int fill_ints(int* p, int n, int value, hipStream_t s);     // n <= 256, by a kernel
 // two-plane fp16 images (SPLIT_F16) and the K = 64 GEMM on them (the factored conv's Y = X . W3T)
 size_t split_planes_f16_bytes(long long rows, int K);
-int split_planes_f16(const float* a, int rows, int K, void* planes, int* range_flag, hipStream_t s);
+// (each row scaled by a power of two into fp16's upper binades; unscale[row] = the factor that undoes it)
+int split_planes_f16(const float* a, int rows, int K, void* planes, float* unscale, int* range_flag, hipStream_t s);
 // (bf16 images of the same operands + the two range flags: the kernel multiplies those when a flag is up)
 int split_gemm_rows_k64_f16(const void* a_planes, const void* b_planes, const void* a_bf16, const void* b_bf16,
-                            const int* flag_w, const int* flag_x, int rows, int N, float* C, hipStream_t s);
+                            const int* flag_w, const int* flag_x, const float* b_unscale, int rows, int N, float* C,
+                            hipStream_t s);
 int split_gemm_rows(const void* a_planes, const void* b_planes, int rows, int N, int K, float* C, hipStream_t s);
 // C = act(A . W^T + b) with both operands split on the way in (training ops)
 size_t split_linear_workspace_bytes(long long rows, int N, int K);
@@ -89,7 +91,9 @@ struct FactoredWs {
     float *w3t, *y, *m, *q;
     void *w3tp, *xp;          // split-bf16 images of W3T and of the current node features
     void *w3th, *xh;          // the same as two fp16 planes (SPLIT_F16)
-    int* f16_flags;           // [0]: W3T out of fp16 range; [1 + a]: the node features entering application a are
+    float* w3tus;             // per-row unscale factors of the fp16 image of W3T
+    int* f16_flags;           // [0]: W3T not finite; [1 + a]: the node features entering application a are out of
+                              // fp16 range; [64 + 1 + a]: they hold a value >= F16_ACT_MIN (split_layout.h)
     int* rev;
     int* order;               // sources of each Y chunk by decreasing degree (factored_prepare_graph)
     long long part_stride;

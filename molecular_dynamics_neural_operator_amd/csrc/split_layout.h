@@ -24,6 +24,24 @@ __device__ __forceinline__ size_t tiled_off(long long row, int kcol, int nkt, in
 
 // ---- two fp16 planes (SPLIT_F16, see edge_mlp_split.hip): x = hi + 2^-11 lo', exact for |x| < 65504
 constexpr float F16_LO_SCALE = 2048.f, F16_LO_UNSCALE = 1.f / 2048.f, F16_MAX = 65504.f;
+// fp16 has 30 binades.  Error of the two-plane form: |x - (hi + 2^-11 lo')| <= max(2^-23 |x|, 2^-36) — relative
+// down to |x| = 2^-13, ABSOLUTE below (hi, then lo', go subnormal).  Two rules keep the absolute floor out of
+// sight: (a) a WEIGHT row (one output unit) is multiplied by a power of two that puts its largest entry in
+// [2^13, 2^14) before the split, and the product's column is multiplied back in the GEMM epilogue — exact
+// both ways, so inside a row the floor sits 2^-50 below the largest weight; (b) an ACTIVATION tensor is
+// accepted only if it holds at least one value >= F16_ACT_MIN = 2^-10 (floor <= 2^-26 of the tensor's
+// largest value); otherwise — and on |x| >= 65504 — the product runs on the bf16 planes.
+constexpr float F16_ACT_MIN = 1.f / 1024.f;
+constexpr int F16_SEEN_OFF = 64;      // node features (factored conv): "seen" word = range word + 64 ints
+
+// power of two s with max*s in [2^13, 2^14); 1 for a zero / subnormal / non-finite max
+__device__ __forceinline__ float f16_row_scale(float row_max) {
+    const int ex = (int)((__builtin_bit_cast(unsigned, row_max) >> 23) & 0xffu);
+    if (ex == 0 || ex == 255) return 1.f;
+    int e = (127 + 13) - ex;
+    e = e < -126 ? -126 : (e > 126 ? 126 : e);      // s and 1/s both normal floats
+    return __builtin_bit_cast(float, (unsigned)(127 + e) << 23);
+}
 
 __device__ __forceinline__ void split2h(float x, _Float16& h, _Float16& l) {
     h = (_Float16)x;

@@ -381,7 +381,7 @@ extern "C" int mdno_fc_out_bwd(const float* x, const float* w, const float* g, i
     hipLaunchKernelGGL(fc_out_bwd_kernel, dim3(blocks), dim3(ROWS), 0, s, x, w, g, rows, width, out_width, dx, part, stride);
     hipLaunchKernelGGL(reduce_blocks_kernel, dim3((out_width * width + 255) / 256), dim3(256), 0, s, (const float*)part,
                        blocks, stride, out_width * width, d_w);
-    hipLaunchKernelGGL(reduce_blocks_kernel, dim3(1), dim3(256), 0, s, (const float*)part + out_width * width, blocks,
-                       stride, out_width, d_b);
+    hipLaunchKernelGGL(reduce_blocks_kernel, dim3((out_width + 255) / 256), dim3(256), 0, s,
+                       (const float*)part + out_width * width, blocks, stride, out_width, d_b);
     return check_launch("fc_out_bwd");
 }

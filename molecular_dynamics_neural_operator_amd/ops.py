@@ -339,7 +339,7 @@ def source_sorted(graph: CSRGraph, num_nodes: int) -> CSRGraph:
     out-edge, `perm` = the edge's position in the destination-sorted arrays (and in W_e)."""
     e = graph.edge_count()
     swapped = torch.stack([graph.dst[:e], graph.src[:e]]).to(torch.long)   # "target" := source
-    return coo_to_csr(swapped, num_nodes)
+    return coo_to_csr(swapped, num_nodes, validate=False)     # (ids come from a CSR that was validated when built)
 
 
 def nnconv_bwd_x(gz: torch.Tensor, gs: torch.Tensor, by_src: CSRGraph, w_e: torch.Tensor,
@@ -540,7 +540,11 @@ def node_prologue_bwd(pack: ParamPack, frames: torch.Tensor, x_aminoacid: torch.
                                      ws.numel(), stream_ptr(dev)), "mdno_node_prologue_bwd")
     out = {"emb.weight": d_emb, "fc1.weight": d_w, "fc1.bias": d_b}
     if has_lstm:
-        out.update({"lstm.weight_ih_l0": d_lstm[0:36].reshape(12, 3), "lstm.weight_hh_l0": d_lstm[36:72].reshape(12, 3),
-                    "lstm.bias_ih_l0": d_lstm[72:84], "lstm.bias_hh_l0": d_lstm[72:84],
-                    "lstm_fc.weight": d_lstm[84:93].reshape(3, 3), "lstm_fc.bias": d_lstm[93:96]})
+        # every gradient owns its storage: autograd's AccumulateGrad keeps the tensor it is handed, so
+        # views of one buffer (bias_ih and bias_hh have the SAME gradient) would alias .grad tensors —
+        # clip_grad_norm_ and a second backward without zero_grad(set_to_none=True) then count it twice
+        out.update({"lstm.weight_ih_l0": d_lstm[0:36].reshape(12, 3).clone(),
+                    "lstm.weight_hh_l0": d_lstm[36:72].reshape(12, 3).clone(),
+                    "lstm.bias_ih_l0": d_lstm[72:84].clone(), "lstm.bias_hh_l0": d_lstm[72:84].clone(),
+                    "lstm_fc.weight": d_lstm[84:93].reshape(3, 3).clone(), "lstm_fc.bias": d_lstm[93:96].clone()})
     return out

@@ -58,9 +58,11 @@ def test_abi_version_struct_layout_and_error_string(lib):
     assert rc == _lib.EINVAL and b"null pointer" in lib.mdno_last_error()
     assert lib.mdno_edge_mlp_workspace_bytes(1024, 4096, 1000, _lib.GEMM_MODES["f32"]) == 2 * 1024 * 1024 * 4 + 512
     # split mode: 2 x 3 bf16 activation planes + the split weights; untileable shapes fall back to fp32 sizing
-    # (+ the two fp16 planes of W1 and of W2 and a 256-B line of range flags, used by SPLIT_F16)
+    # (+ the two fp16 planes of W1 and of W2, a 256-B line of range flags and one fp32 unscale factor per
+    # weight row, used by SPLIT_F16)
     assert lib.mdno_edge_mlp_workspace_bytes(1024, 4096, 1000, 0) == (2 * 3 * 1024 * 1024 * 2 + 3 * 2 * (1024 + 4096) * 1024
-                                                                      + 2 * 2 * (1024 + 4096) * 1024 + 256)
+                                                                      + 2 * 2 * (1024 + 4096) * 1024 + 256
+                                                                      + 4 * (1024 + 4096))
     assert lib.mdno_edge_mlp_workspace_bytes(1024, 4096, 1000, _lib.GEMM_MODES["split_f16"]) == \
         lib.mdno_edge_mlp_workspace_bytes(1024, 4096, 1000, 0)
     assert lib.mdno_edge_mlp_workspace_bytes(16, 64, 1000, 0) == 2 * 1024 * 16 * 4 + 512

@@ -178,22 +178,45 @@ def test_split_f16_hidden_gemm_accuracy_and_range_fallback(dev, live504):
     gb = ops.radius_graph(big_pos, first.shape[0], float(z["threshold"]) * 3.0e5)
     a, b = latent("split_f16", big_frames, big_pos, gb), latent("split_bf16", big_frames, big_pos, gb)
     assert bool(torch.isfinite(a).all()) and rel(a, b) < 1e-6
-    # (2b) one hidden-layer weight out of range
+    # (2b) one hidden-layer weight above fp16's range: its ROW is scaled down by a power of two before the
+    # split (split_layout.h) and the product's column scaled back — still the fp16 planes, still fp32-accurate
     with torch.no_grad():
         model.conv1.net.layers[2].weight[5, 7] = 1.0e5
     a, b = latent("split_f16"), latent("split_bf16")
-    assert bool(torch.isfinite(a).all()) and rel(a, b) < 1e-6
-    # (2c) ... and node features out of range as well (fc1 scaled up: |x| ~ 1e5-1e6 from the first conv
-    # application on): the Y = X.W3T GEMM of SPLIT_F16 then multiplies the bf16 planes inside the same
-    # launch; with the hidden GEMM on its fallback too, the whole forward equals split_bf16 bit for bit
+    assert bool(torch.isfinite(a).all()) and rel(a, b) < 1e-6 and not torch.equal(a, b)
+    # (2c) node features out of range (fc1 scaled up: |x| ~ 1e5-1e6 from the first conv application on): the
+    # Y = X.W3T GEMM of SPLIT_F16 then multiplies the bf16 planes inside the same launch; with the hidden
+    # GEMM on its fallback too (the activations of (2a)), the whole forward equals split_bf16 bit for bit
     with torch.no_grad():
         model.fc1.weight.mul_(3.0e4)
         model.fc1.bias.mul_(3.0e4)
     a, b = latent("split_f16"), latent("split_bf16")
+    assert float(b.abs().max()) > 65504.0 and bool(torch.isfinite(a).all()) and rel(a, b) < 1e-6
+    # every flag up — activations of (2a) AND node features above 65504 in every application (fc1 x 20 on the
+    # saturated LSTM output ~7.6e3; the kernel integral damped so that 12 layers stay finite): bit-identical
+    model.load_state_dict(sd)
+    model.to(dev)
+    with torch.no_grad():
+        model.fc1.weight.mul_(20.0)
+        model.fc1.bias.mul_(20.0)
+        model.conv1.net.layers[4].weight.mul_(1.0e-4)
+        model.conv1.net.layers[4].bias.mul_(1.0e-4)
+    a, b = latent("split_f16", big_frames, big_pos, gb), latent("split_bf16", big_frames, big_pos, gb)
     assert float(b.abs().max()) > 65504.0 and bool(torch.isfinite(a).all()) and torch.equal(a, b)
+    # (2d) node features BELOW what two fp16 planes resolve (every |x| < 2^-10; here ~1e-7, where fp16's grid is
+    # 6e-8): Y = X.W3T must take the bf16 planes — on the fp16 planes the latent would be off by percents
+    model.load_state_dict(sd)
+    model.to(dev)
+    with torch.no_grad():
+        model.fc1.weight.mul_(1.0e-8)
+        model.fc1.bias.mul_(1.0e-8)
+        model.conv1.bias.mul_(1.0e-8)
+        model.conv2.bias.mul_(1.0e-8)
+    a, b = latent("split_f16"), latent("f32")
+    assert 0.0 < float(b.abs().max()) < 2.0 ** -10 and rel(a, b) < 1e-6
     # (3) the materialized path (model(data) with the sample's own edge list): both edge-MLP GEMMs run on fp16
-    # planes; a last-layer weight out of range, or activations out of range, send all of it through the bf16
-    # kernels -> bit-identical to split_bf16
+    # planes; activations out of range send all of it through the bf16 kernels -> bit-identical to split_bf16;
+    # a last-layer weight above 65504 only changes that row's power-of-two scale
     model.load_state_dict(sd)
     model.to(dev)
 
@@ -209,7 +232,11 @@ def test_split_f16_hidden_gemm_accuracy_and_range_fallback(dev, live504):
     assert torch.equal(forward("split_f16", big), forward("split_bf16", big))
     with torch.no_grad():
         model.conv1.net.layers[4].weight[3, 9] = 1.0e5
-    assert torch.equal(forward("split_f16", s), forward("split_bf16", s))
+    # (the 1e5 entry makes the forward ill-conditioned — |out| ~ 1e6 from cancelling terms —, so the three
+    # modes are held against each other: the fp16 planes are as close to exact-fp32 MFMA as the bf16 planes are)
+    a, b, c = forward("split_f16", s), forward("split_bf16", s), forward("f32", s)
+    assert bool(torch.isfinite(a).all()) and not torch.equal(a, b)
+    assert rel(a, c) < 3 * max(rel(b, c), 1e-6) and rel(a, c) < 1e-5, (rel(a, c), rel(b, c))
 
 
 # ------------------------------------------------------------------------------- propogate (nb:336-358)

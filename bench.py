@@ -170,7 +170,7 @@ def _cores() -> int:
     return n
 
 
-def cpu_baseline(sd, depth, window, aa, threshold, budget_s):
+def cpu_baseline(sd, depth, window, aa, threshold, budget_s, first_frame_gpu=None):
     """Reference-faithful CPU step on this host (graph_kernel.py:396-413): forward with the edge-MLP
     evaluated in every conv application (hoist=False) + scipy graph rebuild.  Legs:
       value      shape B (this workload), all host cores: ONE full rollout step, timed (estimated from one
@@ -201,9 +201,10 @@ def cpu_baseline(sd, depth, window, aa, threshold, budget_s):
     del w_e
     est = 2 * depth * t_conv + t_graph
     note(f"cpu baseline: one conv application {t_conv:.2f}s, graph {t_graph:.3f}s -> full step ~{est:.0f}s")
+    first_frame_cpu = None
     if est <= budget_s:
         t0 = time.perf_counter()
-        O.recursive_propagation(sd_cpu, depth, s, 1, threshold, hoist=False)
+        first_frame_cpu = O.recursive_propagation(sd_cpu, depth, s, 1, threshold, hoist=False)[0]["x_position"][-1].numpy()
         t_step = time.perf_counter() - t0
         sample = (f"1 full rollout step, timed: forward with the edge-MLP evaluated {2 * depth}x as the reference does "
                   f"+ scipy graph rebuild, N={N}, E={E} ({cores} threads)")
@@ -217,6 +218,26 @@ def cpu_baseline(sd, depth, window, aa, threshold, budget_s):
     out = {"value": 1.0 / t_step, "unit": "frames/s", "cores": cores, "kind": "port", "sample": sample,
            "seconds_per_frame": t_step, "full_step_measured": measured,
            "one_conv_application_s": t_conv, "graph_rebuild_s": t_graph}
+    # parity at the bench's own weights and start window: the oracle's first frame (the step just timed; or,
+    # when that was only estimated, one step with the shared edge-MLP evaluated once — the same values) against
+    # frame W of the timed engine's trajectory
+    if first_frame_gpu is not None:
+        if first_frame_cpu is None and est / (2 * depth) * 1.5 <= budget_s:
+            first_frame_cpu = O.recursive_propagation(sd_cpu, depth, s, 1, threshold, hoist=True)[0]["x_position"][-1].numpy()
+        if first_frame_cpu is not None:
+            d = first_frame_gpu.astype(np.float64) - first_frame_cpu.astype(np.float64)
+            # what the model computes is the displacement from the last window frame: the error relative to
+            # THAT (a near-identity model would make any error look small against |coordinates| ~ 10 A)
+            disp = first_frame_cpu.astype(np.float64) - np.asarray(window[-1], dtype=np.float64)
+            out["parity_first_frame"] = {
+                "rel_l2": float(np.linalg.norm(d) / np.linalg.norm(first_frame_cpu)),
+                "max_abs_A": float(np.abs(d).max()),
+                "rel_l2_of_displacement": float(np.linalg.norm(d) / max(np.linalg.norm(disp), 1e-300)),
+                "mean_displacement_A": float(np.linalg.norm(disp, axis=1).mean()),
+                "tolerance_rel_l2": 1e-5,
+                "what": "frame W of the timed rollout vs the oracle's first step from the same window and weights "
+                        "(reference-faithful CPU forward + scipy graph)"}
+            out["parity_first_frame_rel_l2"] = out["parity_first_frame"]["rel_l2"]
 
     # ---- one thread, shape B: one conv application on an edge slice, scaled
     note(f"cpu baseline: full step {t_step:.1f}s ({'timed' if measured else 'estimated'}); one-thread leg")
@@ -351,6 +372,8 @@ def worker(a):
     # ---- warm-up (untimed): the step graph was captured in reset()
     eng.step(a.warmup)
     eng.synchronize()
+    # first produced frame of member 0 (kept for the cpu_baseline leg's parity figure)
+    first_frame_gpu = eng.traj[W, 0].detach().cpu().numpy() if (a.warmup > 0 and total_members == 1) else None
     m_max = -(-total_members // world)
     if world > 1:    # the collective of the timed region, once, untimed: communicator set-up and buffers
         gather_trajectories(torch.zeros((a.steps, M, N, 3), dtype=torch.float32, device=dev), total_members)
@@ -531,7 +554,13 @@ def worker(a):
 
     cpu = None
     if rank == 0 and world == 1 and not a.skip_cpu_baseline and a.variant == "intree":
-        cpu = cpu_baseline(sd, a.depth, base, aa, a.threshold, a.cpu_budget_s)
+        cpu = cpu_baseline(sd, a.depth, base, aa, a.threshold, a.cpu_budget_s, first_frame_gpu)
+        if cpu.get("parity_first_frame"):
+            pf = cpu["parity_first_frame"]
+            note(f"parity, first frame vs the oracle: rel L2 {pf['rel_l2']:.2e} (of the displacement "
+                 f"{pf['rel_l2_of_displacement']:.2e}), max |err| {pf['max_abs_A']:.2e} A")
+            if not pf["rel_l2"] <= pf["tolerance_rel_l2"]:
+                raise SystemExit(f"bench.py: first-frame parity {pf['rel_l2']:.3e} exceeds {pf['tolerance_rel_l2']:.0e}")
 
     if rank == 0:
         cfg = "configs[1]" if total_members == 1 else ("configs[2]" if total_members == ENSEMBLE_MEMBERS else "ensemble")

@@ -15,7 +15,7 @@ Two things are patched at run time, nothing in the reference is edited:
 The reference itself never travels: only the data written here is committed.
 
 Usage:  python oracle/gen_golden.py [--out tests/golden] [--skip-large] [--only NAME[,NAME]]
-        (sections: base, live504, checkpoint; every section seeds itself, so any subset
+        (sections: base, live504, checkpoint, train; every section seeds itself, so any subset
         reproduces the same files)
 """
 from __future__ import annotations
@@ -158,11 +158,81 @@ def gen_checkpoint(gk, out: Path):
     print("checkpoint_best_pt: ok;", len(arrays), "tensors, |out| max", float(np.abs(out_ref).max()))
 
 
+def gen_train_step(gk, ds, out: Path):
+    """One iteration of the reference's own `train()` (graph_kernel.py:445-474) at batch size 1 — the only
+    batch size at which its forward is well defined without torch_geometric's DataParallel collation
+    (SURVEY.md §3.3): zero_grad, forward, `LpLoss(size_average=False)` (:547), backward, Adam step
+    (lr 0.01, weight_decay 5e-4, :541-543).  Stored: the sample, the loss `train()` returns, every
+    parameter's gradient as left in `.grad`, and the parameters after the step.  Two sizes: width 8 /
+    k 16 (weights stored) and width 64 / k 128 (the HIP training kernels' width; weights regenerated from
+    the seed by the test, checksums stored)."""
+    from molecular_dynamics_neural_operator_amd import synthetic as syn
+    THR, N, W = 8.0, 28, 10
+    base = syn.chain_frame(N, seed=0)
+    T = 40
+    traj = syn.ou_trajectory(base, T, sigma=0.15, theta=0.2, seed=2)
+    aa = torch.from_numpy(syn.amino_acids(N, seed=0))
+    gk.args = Namespace(window_size=W, num_residues=N, batch_size=1)
+    cms = np.empty(T, dtype=object)
+    for t in range(T):
+        cms[t] = _flat_contact_map(gk.construct_pairdata(traj[t:t + 1], aa, threshold=THR))
+
+    class OneSampleBatch(torch.nn.Module):      # stands in for DataParallel's collation of a 1-element list
+        def __init__(self, module):
+            super().__init__()
+            self.module = module
+
+        def forward(self, batch):
+            assert len(batch) == 1
+            return self.module(batch[0])
+
+    arrays = {}
+    with tempfile.TemporaryDirectory() as td:
+        h5 = Path(td) / "synthetic.h5"
+        with open(h5, "wb") as fh:
+            np.savez(fh, contact_map=cms, point_cloud=np.transpose(traj, (0, 2, 1)).copy(),
+                     rmsd=np.zeros(T, np.float32), amino_acids=aa.numpy())
+        dset = ds.ContactMapDataset(str(h5), window_size=W, horizon=1, node_feature_dset_path=str(h5))
+        idx = 5
+        sample = dset[idx]
+        for tag, ctor, seed in (("s8", (8, 16, 2, 6, 7, 3, 20, 4), 21), ("w64", (64, 128, 2, 6, 7, 3, 20, 4), 31)):
+            torch.manual_seed(seed)
+            model = gk.KernelNN(*ctor)
+            with torch.no_grad():                  # keep activations O(1) through the random-init layers
+                for p_ in model.conv1.net.layers[4].parameters():
+                    p_.mul_(0.2)
+            before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+            wrapped = OneSampleBatch(model)
+            optimizer = torch.optim.Adam(wrapped.parameters(), lr=0.01, weight_decay=5e-4)
+            avg_loss, avg_mse = gk.train(wrapped, [[sample]], optimizer, gk.LpLoss(size_average=False), "cpu")
+            grads = {k: p_.grad.detach().clone() for k, p_ in model.named_parameters()}
+            after = {k: v.detach().clone() for k, v in model.state_dict().items()}
+            names, sums, asums = _checksums(before)
+            arrays.update({f"{tag}.ctor": np.array(ctor), f"{tag}.seed": seed, f"{tag}.last_layer_scale": 0.2,
+                           f"{tag}.loss": avg_loss, f"{tag}.mse": avg_mse,
+                           f"{tag}.param_names": names, f"{tag}.param_sum": sums, f"{tag}.param_abs_sum": asums})
+            arrays.update(_sd_np(grads, f"{tag}.g."))
+            if tag == "s8":
+                arrays.update(_sd_np(before, f"{tag}.p."))
+                arrays.update(_sd_np(after, f"{tag}.a."))
+            else:       # after-step values of the small tensors only (the wide ones follow from their gradients)
+                arrays.update(_sd_np({k: v for k, v in after.items() if v.numel() <= 4096}, f"{tag}.a."))
+            print(f"train_step {tag}: loss {avg_loss:.6f} mse {avg_mse:.6f}; |grad| max "
+                  f"{max(float(g.abs().max()) for g in grads.values()):.3e}")
+    np.savez_compressed(
+        out / "train_step_b1.npz", sample_index=idx, window=W, threshold=THR, lr=0.01, weight_decay=5e-4,
+        point_cloud=np.transpose(traj, (0, 2, 1)).copy(), contact_map=cms, amino_acids=aa.numpy(),
+        rmsd=np.zeros(T, np.float32),
+        x_position=sample.x_position.numpy(), x_aminoacid=sample.x_aminoacid.numpy(), y=sample.y.numpy(),
+        edge_index=sample.edge_index.numpy(), edge_attr=sample.edge_attr.numpy(), **arrays)
+    print("train_step_b1: ok")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", type=Path, default=REPO / "tests" / "golden")
     ap.add_argument("--skip-large", action="store_true", help="skip the N=504 full-size forwards (minutes of CPU)")
-    ap.add_argument("--only", default="", help="comma-separated sections: base, live504, checkpoint (default: all)")
+    ap.add_argument("--only", default="", help="comma-separated sections: base, live504, checkpoint, train (default: all)")
     a = ap.parse_args()
     a.out.mkdir(parents=True, exist_ok=True)
     torch.set_num_threads(8)
@@ -172,6 +242,8 @@ def main():
     from molecular_dynamics_neural_operator_amd import synthetic as syn
     if not only or "checkpoint" in only:
         gen_checkpoint(gk, a.out)
+    if not only or "train" in only:
+        gen_train_step(gk, ds, a.out)
     if (not only and not a.skip_large) or "live504" in only:
         gen_live504(gk, ds, a.out)
     if only and "base" not in only:

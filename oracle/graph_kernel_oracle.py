@@ -18,6 +18,8 @@ What it restates (plain ``torch`` CPU fp32 + scipy, no torch_geometric), functio
   recursive_propagation graph_kernel.py:396-413
   dataset_sample        dataset.py:180-227 (ContactMapDataset.__getitem__)
   lp_loss_rel           graph_kernel.py:105-119
+  train_step            graph_kernel.py:453-463 (forward, LpLoss(size_average=False), backward) — autograd over
+                        the functions above, B=1 per sample
 
 Pinning: the reference ships no tests, goldens or KATs for this path.  The
 oracle is pinned against outputs of the reference's own code run in the build container by
@@ -137,6 +139,66 @@ def kernelnn_notebook_forward(sd: StateDict, x_position: Tensor, x_aminoacid: Te
                 w_e = edge_mlp(edge_attr, sd, "conv1.net.")
             x = F.relu(nnconv_apply(x, edge_index, w_e, sd["conv1.root"], sd["conv1.bias"], "mean"))
         return F.linear(x, sd["fc2.weight"], sd["fc2.bias"])
+
+
+# --------------------------------------------------------------------------- differentiable forward + train step
+def lstm_last_hidden_functional(x_position: Tensor, sd: StateDict) -> Tensor:
+    """The same W sequential LSTM steps as `_lstm_last_hidden` (graph_kernel.py:279-284; torch.nn.LSTM cell,
+    gate order i, f, g, o; zero initial state; batch = atoms), written out so that autograd sees the
+    parameters of `sd` and any dtype works."""
+    w, n, d = x_position.shape
+    w_ih, w_hh = sd["lstm.weight_ih_l0"], sd["lstm.weight_hh_l0"]
+    b = sd["lstm.bias_ih_l0"] + sd["lstm.bias_hh_l0"]
+    h = torch.zeros(n, d, dtype=w_ih.dtype)
+    c = torch.zeros(n, d, dtype=w_ih.dtype)
+    for t in range(w):
+        gates = x_position[t].to(w_ih.dtype) @ w_ih.t() + h @ w_hh.t() + b
+        i, f, g, o = gates.chunk(4, dim=1)
+        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+        h = torch.sigmoid(o) * torch.tanh(c)
+    return h
+
+
+def kernelnn_forward_autograd(sd: StateDict, x_position: Tensor, x_aminoacid: Tensor, edge_index: Tensor,
+                              edge_attr: Tensor, depth: int) -> Tensor:
+    """`kernelnn_forward` (graph_kernel.py:277-309, B=1) with autograd left on and in the dtype of `sd`
+    (the shared edge-MLP evaluated once: identical values, graph_kernel.py:271-273)."""
+    dt = sd["fc1.weight"].dtype
+    x = lstm_last_hidden_functional(x_position, sd)
+    x = F.linear(x, sd["lstm_fc.weight"], sd["lstm_fc.bias"])
+    emb = F.embedding(x_aminoacid, sd["emb.weight"])
+    x = F.relu(F.linear(torch.cat((emb, x), dim=1), sd["fc1.weight"], sd["fc1.bias"]))
+    w_e = edge_mlp(edge_attr.to(dt), sd, "conv1.net.")
+    for conv in ("conv1", "conv2"):
+        for _ in range(depth):
+            x = F.relu(nnconv_apply(x, edge_index, w_e, sd[conv + ".root"], sd[conv + ".bias"], "mean"))
+    return F.linear(x, sd["fc2.weight"], sd["fc2.bias"])
+
+
+def train_step(sd: StateDict, samples: Sequence[dict], depth: int, dtype=torch.float64):
+    """Loss and gradients of one `train` iteration (graph_kernel.py:453-467 with
+    `LpLoss(size_average=False)`, :547) up to `l2.backward()`: every sample is an independent B=1 forward
+    (the only batch size at which the reference's forward is well defined), the loss is the
+    sum over samples of ||out_b - y_b|| / ||y_b||.  conv1.net and conv2.net are ONE module in the reference
+    (:271-273): `sd`'s conv2.net.* entries are ignored and both key sets receive the shared gradient.
+    Returns (loss, out [B*N, out_width], {name: grad})."""
+    shared = {k: v for k, v in sd.items() if not k.startswith("conv2.net.")}
+    params = {k: v.detach().to(dtype).clone().requires_grad_(True) for k, v in shared.items()}
+    outs, ys = [], []
+    for s in samples:
+        outs.append(kernelnn_forward_autograd(params, s["x_position"], s["x_aminoacid"], s["edge_index"],
+                                              s["edge_attr"], depth))
+        ys.append(s["y"].to(dtype))
+    out, y = torch.cat(outs), torch.cat(ys)
+    b = len(samples)
+    loss = lp_loss_rel(out.view(b, -1), y.view(b, -1), size_average=False)
+    names = list(params)
+    grads = torch.autograd.grad(loss, [params[n] for n in names])
+    g = dict(zip(names, grads))
+    for k in list(g):
+        if k.startswith("conv1.net."):
+            g["conv2.net." + k[len("conv1.net."):]] = g[k]
+    return float(loss.detach()), out.detach(), g
 
 
 # --------------------------------------------------------------------------- graph

@@ -30,6 +30,20 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+def host_cores():
+    """CPUs this process may really use: the affinity mask capped by the cgroup quota (a GPU box shows 256
+    host threads in the mask and grants 16 CPUs; 256 torch threads on that quota crawl)."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def load_golden(name):
     return np.load(GOLDEN / name, allow_pickle=True)
 

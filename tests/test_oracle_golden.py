@@ -142,3 +142,53 @@ def test_checkpoint_fixture_forward():
     out = O.kernelnn_forward(sd, t(z["x_position"]), t(z["x_aminoacid"]), t(z["edge_index"]), t(z["edge_attr"]),
                              int(z["ctor"][2]))
     torch.testing.assert_close(out, t(z["out"]), rtol=1e-6, atol=1e-6)
+
+
+def _train_step_case(z, tag):
+    """(state_dict before the step, sample, depth) of one case of train_step_b1.npz."""
+    ctor = [int(v) for v in z[f"{tag}.ctor"]]
+    if f"{tag}.p.fc1.weight" in z.files:
+        sd = golden_state_dict(z, f"{tag}.p.")
+    else:       # regenerated from the seed in the reference's RNG-draw order, then checked against the checksums
+        sd = O.reference_init_state_dict(*ctor, seed=int(z[f"{tag}.seed"]))
+        for k in list(sd):
+            if k.endswith("net.layers.4.weight") or k.endswith("net.layers.4.bias"):
+                sd[k] = sd[k] * float(z[f"{tag}.last_layer_scale"])
+        for n, s_, a_ in zip([str(x) for x in z[f"{tag}.param_names"]], z[f"{tag}.param_sum"], z[f"{tag}.param_abs_sum"]):
+            assert float(sd[n].double().sum()) == pytest.approx(float(s_), rel=1e-12, abs=1e-12), n
+            assert float(sd[n].double().abs().sum()) == pytest.approx(float(a_), rel=1e-12), n
+    sample = dict(x_position=t(z["x_position"]), x_aminoacid=t(z["x_aminoacid"]), y=t(z["y"]),
+                  edge_index=t(z["edge_index"]), edge_attr=t(z["edge_attr"]))
+    return sd, sample, ctor[2]
+
+
+@pytest.mark.parametrize("tag", ["s8", "w64"])
+def test_train_step_reference_golden(tag):
+    """Loss and every parameter gradient of the oracle's train_step against ONE iteration of the reference's
+    own train() at batch size 1 (oracle/gen_golden.py gen_train_step; graph_kernel.py:445-474): in fp32 (the
+    reference's arithmetic) and in fp64 (what the GPU tests use as the exact answer): rel. L2 <= 2e-6 per
+    parameter either way (measured 1-4e-7: fp32 rounding of the reference's own run).  The Adam update (:541-543) applied to the
+    golden gradients reproduces the reference's parameters after the step."""
+    z = load_golden("train_step_b1.npz")
+    sd, sample, depth = _train_step_case(z, tag)
+    want = golden_state_dict(z, f"{tag}.g.")
+    assert set(want) == {k for k in sd if not k.startswith("conv2.net.")}      # (named_parameters lists a shared module once)
+    for dtype, tol in ((torch.float32, 2e-6), (torch.float64, 2e-6)):
+        loss, out, grads = O.train_step(sd, [sample], depth, dtype=dtype)
+        assert loss == pytest.approx(float(z[f"{tag}.loss"]), rel=1e-5)
+        worst = {}
+        for n, g in want.items():
+            worst[n] = float((grads[n].double() - g.double()).norm() / g.double().norm().clamp_min(1e-30))
+        print(tag, dtype, {k: f"{v:.1e}" for k, v in worst.items()})
+        assert max(worst.values()) < tol, worst
+    # one Adam step with the reference's settings on the golden gradients -> the reference's updated parameters
+    # (conv1.net / conv2.net are one module there: one parameter, one update)
+    after = golden_state_dict(z, f"{tag}.a.")
+    params = {k: torch.nn.Parameter(v.clone()) for k, v in sd.items() if not k.startswith("conv2.net.")}
+    opt = torch.optim.Adam(params.values(), lr=float(z["lr"]), weight_decay=float(z["weight_decay"]))
+    for k, p_ in params.items():
+        p_.grad = want[k].clone()
+    opt.step()
+    for k, v in after.items():
+        src = params[k.replace("conv2.net.", "conv1.net.")]
+        torch.testing.assert_close(src.detach(), v, rtol=1e-6, atol=1e-7)

@@ -157,8 +157,9 @@ def _train_step_case(z, tag):
         for n, s_, a_ in zip([str(x) for x in z[f"{tag}.param_names"]], z[f"{tag}.param_sum"], z[f"{tag}.param_abs_sum"]):
             assert float(sd[n].double().sum()) == pytest.approx(float(s_), rel=1e-12, abs=1e-12), n
             assert float(sd[n].double().abs().sum()) == pytest.approx(float(a_), rel=1e-12), n
-    sample = dict(x_position=t(z["x_position"]), x_aminoacid=t(z["x_aminoacid"]), y=t(z["y"]),
-                  edge_index=t(z["edge_index"]), edge_attr=t(z["edge_attr"]))
+    c = lambda a: torch.from_numpy(np.ascontiguousarray(a))      # (dataset.py hands out transposed views; C order here)
+    sample = dict(x_position=c(z["x_position"]), x_aminoacid=c(z["x_aminoacid"]), y=c(z["y"]),
+                  edge_index=c(z["edge_index"]), edge_attr=c(z["edge_attr"]))
     return sd, sample, ctor[2]
 
 

@@ -97,12 +97,42 @@ def parse(argv=None):
     ap.add_argument("--skip-roofline", action="store_true")
     ap.add_argument("--skip-ensemble-leg", action="store_true",
                     help="N=1 default run: skip the 64-member single-GPU leg (cfg3's like-for-like baseline)")
+    ap.add_argument("--skip-config-legs", action="store_true",
+                    help="N=1 default run: skip the cfg4 (training), cfg5 (50k-atom box) and shape-A (N=28) legs")
     ap.add_argument("--cpu-budget-s", type=float, default=120.0,
                     help="bound on the full reference-faithful CPU step; estimated first from one conv application")
     return ap.parse_args(argv)
 
 
 # ----------------------------------------------------------------------------------------------- launcher
+def visible_gpus() -> int:
+    """GPUs the workers will see, found WITHOUT a HIP call in this (launcher) process — torch.cuda.device_count()
+    falls back to hipGetDeviceCount on builds without amdsmi, which opens the runtime here.  The visibility
+    variables if one is set; else a short-lived child asks the runtime (a container can expose fewer devices
+    than the KFD topology lists, so sysfs alone is not trusted); the topology count only if that child fails."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    try:
+        r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                           capture_output=True, text=True, timeout=300)
+        if r.returncode == 0:
+            return int(r.stdout.strip().splitlines()[-1])
+    except (OSError, ValueError, IndexError, subprocess.TimeoutExpired):
+        pass
+    n = 0
+    for prop in Path("/sys/class/kfd/kfd/topology/nodes").glob("*/properties"):
+        try:
+            for line in prop.read_text().splitlines():
+                k, _, val = line.partition(" ")
+                if k == "simd_count" and int(val) > 0:
+                    n += 1
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def launch_workers(a) -> int:
     """`python bench.py --gpus N` with no launcher around it: start N fresh worker processes (this
     process has made no GPU call and makes none), relay rank 0's JSON line, return the worst exit code."""
@@ -113,7 +143,7 @@ def launch_workers(a) -> int:
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this driver (RCCL needs it)
     env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
-    ndev = torch.cuda.device_count()                        # counts devices without initialising HIP
+    ndev = visible_gpus()                                   # no HIP call in this process (see there)
     if ndev < n and "MDNO_BENCH_BACKEND" not in env:
         print(f"bench.py: {n} ranks on {ndev} visible GPU(s): ranks share cards, collective over gloo "
               "(rehearsal only — RCCL needs one GPU per rank)", file=sys.stderr)
@@ -282,6 +312,220 @@ def cpu_baseline(sd, depth, window, aa, threshold, budget_s, first_frame_gpu=Non
     return out
 
 
+# ----------------------------------------------------------------------------------------------- extra legs
+def _event_ms(fn, reps, warm=2):
+    """Mean milliseconds of fn() over `reps` calls, HIP events on torch's current stream (the stream the
+    training ops launch on)."""
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def leg_cfg4_training(dev, frames=10000, batch=128, kernel_width=1024, depth=6, cpu_samples=8):
+    """BASELINE configs[3]: operator training on a synthetic preprocessed-BBA-layout trajectory (N=28 C-alpha
+    chain, Ornstein-Uhlenbeck jitter, contact maps at 8 A; SURVEY.md §8d cfg4: T=10,000 frames, batch 128), the
+    reference's model / optimiser / loss (graph_kernel.py:528-547), ONE timed epoch per precision after a
+    two-batch warm-up, batches built on the device from the resident trajectory.  Also: the dominant GEMM and
+    conv kernels of the bf16 step timed alone at the batch's shapes (HIP events), and the same step in torch
+    autograd over the oracle's formulas on the host as the CPU baseline."""
+    import tempfile
+    from molecular_dynamics_neural_operator_amd import ops, synthetic as syn
+    from molecular_dynamics_neural_operator_amd.dataset import ContactMapDataset, write_trajectory_npz
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN, LpLoss
+    from molecular_dynamics_neural_operator_amd.training import DeviceTrajectory, train_epoch
+    N, W = 28, 10
+    traj = syn.ou_trajectory(syn.chain_frame(N, seed=0), frames, sigma=0.3, theta=0.1, seed=2)
+    cms = [syn.contact_map(f, 8.0) for f in traj]
+    with tempfile.TemporaryDirectory() as td:
+        path = Path(td) / "synthetic_bba.npz"
+        write_trajectory_npz(path, traj, cms, syn.amino_acids(N, seed=0))
+        dset = ContactMapDataset(str(path), window_size=W, horizon=1)
+    dtraj = DeviceTrajectory(dset, dev)
+    n_train = int(len(dset) * 0.8)                                      # partition split 0.8 (graph_kernel.py:509-520)
+    idx = [list(range(s, s + batch)) for s in range(0, n_train - batch + 1, batch)]      # drop_last
+    out = {"frames": frames, "atoms": N, "window": W, "batch_size": batch, "train_batches": len(idx),
+           "kernel_width": kernel_width, "depth": depth, "collate": "device (mdno_collate_samples)",
+           "optimizer": "torch.optim.Adam(lr=1e-4, weight_decay=5e-4)"}
+    E0 = None
+    for precision in ("bf16", "fp32"):
+        torch.manual_seed(0)
+        model = KernelNN(64, kernel_width, depth, 6, 7, 3, 20, 4)
+        with torch.no_grad():     # the reference's init explodes through 12 layers at k=1024: damp the kernel's last layer
+            for p_ in model.conv1.net.layers[4].parameters():
+                p_.mul_(0.05)
+        model.to(dev)
+        model.train_precision = precision
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=5e-4)
+        loss_fn = LpLoss(size_average=False)
+        train_epoch(model, (dtraj.batch(i) for i in idx[:2]), opt, loss_fn)              # warm-up
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        t0 = time.perf_counter()
+        tl, mse = train_epoch(model, (dtraj.batch(i) for i in idx), opt, loss_fn)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[precision] = {"samples_per_s": len(idx) * batch / dt, "ms_per_batch": dt / len(idx) * 1e3, "epoch_s": dt,
+                          "train_loss": tl, "train_mse": mse, "peak_memory_MiB": torch.cuda.max_memory_allocated() / 2**20}
+        note(f"cfg4 {precision}: {out[precision]['samples_per_s']:.0f} samples/s, {out[precision]['ms_per_batch']:.2f} ms/batch")
+        if precision == "bf16":
+            b0 = dtraj.batch(idx[0])
+            E0 = int(b0.edge_index.shape[1])
+            # the step's dominant kernels, alone, at this batch's shapes
+            h2 = torch.randn(E0, kernel_width, device=dev).to(torch.bfloat16)
+            w2, bb2 = model.conv1.net.layers[4].weight.detach(), model.conv1.net.layers[4].bias.detach()
+            ms = _event_ms(lambda: ops.linear_bf16(h2, w2, bb2, relu=False, out_bf16=True), 10)
+            fl = 2.0 * E0 * kernel_width * 4096
+            roofs = {"gemm_last_layer_fwd": {"bound": "mfma", "kernel": "bf16 A.W^T [E,k]x[k,4096] -> bf16", "ms": ms,
+                                             "achieved": fl / ms / 1e9, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                             "frac": fl / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS}}
+            dwe = torch.randn(E0, 4096, device=dev).to(torch.bfloat16)
+            ms = _event_ms(lambda: ops.gemm_atb_bf16(dwe, h2), 10)
+            roofs["gemm_weight_grad"] = {"bound": "mfma", "kernel": "bf16 A^T.B [E,4096]^T x [E,k]", "ms": ms,
+                                         "achieved": fl / ms / 1e9, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                         "frac": fl / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS}
+            g = ops.coo_to_csr(b0.edge_index, batch * N, validate=False)
+            x = torch.randn(batch * N, 64, device=dev)
+            root, cb = model.conv1.root.detach(), model.conv1.bias.detach()
+            ms = _event_ms(lambda: ops.nnconv_bf16w(x, g, dwe, root, cb, "mean", relu=True), 20)
+            byts = E0 * (64 * 64 * 2 + 4) + (batch * N + 1) * 4 + 2 * batch * N * 64 * 4
+            roofs["conv_fwd_bf16_We"] = {"bound": "hbm", "kernel": "nnconv64_bf16w_kernel", "ms": ms, "achieved": byts / ms / 1e6,
+                                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": byts / ms / 1e6 / HBM_PEAK_GBS,
+                                         "algorithmic_bytes_per_launch": byts}
+            out["rooflines"] = roofs
+            out["edges_per_batch"] = E0
+            del h2, dwe, x
+        del model, opt
+        torch.cuda.empty_cache()
+    # CPU baseline: the same step (forward, LpLoss, backward) in torch autograd over the oracle's formulas
+    from oracle import graph_kernel_oracle as O
+    torch.set_num_threads(_cores())
+    torch.manual_seed(0)
+    ref = KernelNN(64, kernel_width, depth, 6, 7, 3, 20, 4)
+    sd = {k: v.detach() for k, v in ref.state_dict().items()}
+    samples = [dset[i] for i in range(cpu_samples)]
+    dicts = [dict(x_position=s_.x_position, x_aminoacid=s_.x_aminoacid, y=s_.y, edge_index=s_.edge_index,
+                  edge_attr=s_.edge_attr) for s_ in samples]
+    O.train_step(sd, dicts[:1], depth, dtype=torch.float32)
+    t0 = time.perf_counter()
+    O.train_step(sd, dicts, depth, dtype=torch.float32)
+    dt = time.perf_counter() - t0
+    out["cpu_baseline"] = {"value": cpu_samples / dt, "unit": "samples/s", "cores": _cores(), "kind": "port",
+                           "sample": f"forward + LpLoss + backward of {cpu_samples} samples, torch autograd over the oracle's "
+                                     "formulas (edge-MLP evaluated once per sample, not 12x), no optimizer step"}
+    return out
+
+
+def leg_cfg5_shape_c(dev, atoms=50000, cutoff=10.0, steps=2):
+    """BASELINE configs[4] (SURVEY.md §8 shape C): synthetic 50k-atom box, 10 A cutoff, the full model, factored
+    conv (the materialised W_e would be 298 GB): `steps` timed rollout steps issued as plain launches with the
+    per-kernel HIP-event timer attached (graph build on the device included)."""
+    from molecular_dynamics_neural_operator_amd import ops, synthetic as syn
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN
+    from molecular_dynamics_neural_operator_amd.rollout import RolloutEngine
+    from molecular_dynamics_neural_operator_amd.weights import near_identity_state_dict
+    N, W, KW, C = atoms, 10, 1024, 64
+    frame = syn.box_frame(N, seed=3)
+    win = syn.jitter_window(frame, W, sigma=0.01, seed=3)
+    aa = torch.from_numpy(syn.amino_acids(N, seed=3))
+    g = ops.radius_graph(torch.from_numpy(frame).to(dev), N, cutoff, edge_cap=int(N * 500))
+    E = g.edge_count()
+    deg_max = int((g.row_ptr[1:] - g.row_ptr[:-1]).max().item())
+    del g
+    torch.cuda.empty_cache()
+    sd = near_identity_state_dict(64, KW, seed=0, kernel_gain=1e-3, feature_gain=0.1)
+    model = KernelNN(64, KW, 6, 6, 7, 3, 20, 4)
+    model.load_state_dict(sd)
+    model.eval().to(dev)
+    model.conv_mode = "factored"
+    eng = RolloutEngine(model, 1, N, W, cutoff, max_steps=steps + 1, edge_cap=int(E * 1.05), device=dev,
+                        max_degree=(deg_max + 127) // 128 * 128 + 128)
+    ws_gib = eng.workspace.numel() / 2**30
+    eng.reset(torch.from_numpy(win), aa)
+    eng.step(1)
+    eng.synchronize()
+    eng.attach_timer(steps * 4000)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.step(steps)
+    eng.stream.synchronize()
+    dt = time.perf_counter() - t0
+    tm = eng.read_timer()
+    eng.detach_timer()
+    eng.synchronize()
+    e_mean = float(eng.edges_per_step[1:1 + steps].double().mean().item())
+    ks = {k: {"ms_per_step": ms / steps, "launches": int(n)} for k, (ms, n) in tm.items() if n}
+    app_s = ks["nnconv"]["ms_per_step"] * 1e-3 / 12            # all launches of one conv application
+    alg = e_mean * KW * 4 + N * C * KW * 4 + 2 * e_mean * C * 4 + (N + 1) * 4
+    out = {"atoms": N, "cutoff_A": cutoff, "edges": E, "mean_degree": E / N, "max_degree": deg_max, "steps": steps,
+           "ms_per_step": dt / steps * 1e3, "frames_per_s": steps / dt, "workspace_GiB": ws_gib, "conv_mode": eng.conv_mode,
+           "kernels_ms_per_step": {k: round(v["ms_per_step"], 3) for k, v in ks.items()},
+           "roofline": {"bound": "hbm", "kernel": "gemm_per_source_split_kernel", "achieved": alg / app_s / 1e9,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / app_s / 1e9 / HBM_PEAK_GBS,
+                        "algorithmic_bytes_per_application": alg, "ms_per_application": app_s * 1e3, "traffic": None},
+           "launch": "plain launches (event timer attached)"}
+    eng.close()
+    del eng
+    torch.cuda.empty_cache()
+    return out
+
+
+def leg_shape_a(dev, a):
+    """SURVEY.md §8 shape A — the reference's actual BBA (N=28 C-alpha, bba_analysis.ipynb:1034): the in-tree model
+    with 1 and with 64 members, and the notebook-era model (window 1, conv1 only, kernel_width 512) whose rollout
+    the notebook timed at 80.56 it/s on unknown hardware (nb:370)."""
+    from molecular_dynamics_neural_operator_amd import synthetic as syn
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN, KernelNNNotebook
+    from molecular_dynamics_neural_operator_amd.rollout import RolloutEngine
+    from molecular_dynamics_neural_operator_amd.weights import near_identity_state_dict
+    N = 28
+    frame0 = syn.chain_frame(N, seed=1)
+    aa = torch.from_numpy(syn.amino_acids(N, seed=1))
+    out = {"atoms": N, "reference_notebook_it_per_s": 80.56,
+           "reference_note": "bba_analysis.ipynb:370 — notebook-era model, device unknown, incl. host graph rebuild"}
+
+    def run(model, M, W, steps, warm):
+        base = syn.jitter_window(frame0, W, seed=1)
+        wins = np.stack([syn.ensemble_windows(base, 1, sigma=0.1, seed0=100 + m)[0] if M > 1 else base for m in range(M)], axis=1)
+        eng = RolloutEngine(model, M, N, W, a.threshold, max_steps=warm + steps, device=dev)
+        eng.reset(torch.from_numpy(wins), aa)
+        eng.step(warm)
+        eng.synchronize()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.step(steps)
+        eng.stream.synchronize()
+        dt = time.perf_counter() - t0
+        eng.synchronize()
+        r = {"members": M, "steps": steps, "frames_per_s": steps * M / dt, "ms_per_step": dt / steps * 1e3, "conv_mode": eng.conv_mode,
+             "edges_per_member": float(eng.edges_per_step[warm:warm + steps].double().mean().item()) / M}
+        eng.close()
+        return r
+
+    sd = near_identity_state_dict(64, 1024, seed=0, kernel_gain=1e-3, feature_gain=0.1)
+    model = KernelNN(64, 1024, 6, 6, 7, 3, 20, 4)
+    model.load_state_dict(sd)
+    model.eval().to(dev)
+    model.gemm_mode = a.gemm_mode
+    out["intree_1_member"] = run(model, 1, 10, 500, 50)
+    out["intree_64_members"] = run(model, 64, 10, 100, 10)
+    sdn = {k: v for k, v in near_identity_state_dict(64, 512, seed=0, kernel_gain=1e-3, feature_gain=0.1).items()
+           if not k.startswith(("lstm", "conv2"))}
+    nb = KernelNNNotebook(64, 512, 6, 6, 7, 3, 20, 4)
+    nb.load_state_dict(sdn)
+    nb.eval().to(dev)
+    nb.gemm_mode = a.gemm_mode
+    out["notebook_era_k512_window1"] = run(nb, 1, 1, 500, 50)
+    out["notebook_era_k512_window1"]["vs_reference_notebook"] = out["notebook_era_k512_window1"]["frames_per_s"] / 80.56
+    return out
+
+
 # ----------------------------------------------------------------------------------------------- worker
 def profiled_traffic(kernel: str, atoms: int, members: int, conv_mode: str, gemm_mode: str):
     """PMC HBM bytes per launch from profiles/roofline_traffic.json — only for the configuration the
@@ -386,12 +630,14 @@ def worker(a):
     t0 = time.perf_counter()
     eng.step(a.steps)
     eng.stream.synchronize()
+    t_steps = time.perf_counter() - t0                                             # this rank's K steps alone
     produced = eng.traj[W + a.warmup:W + a.warmup + a.steps]                       # [K,M,N,3]
     if world > 1:
         full = gather_trajectories(produced, total_members)
     else:
         full = produced
     torch.cuda.synchronize()
+    t_gather = time.perf_counter() - t0 - t_steps                                  # incl. waiting for the slowest rank
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -399,6 +645,15 @@ def worker(a):
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    mg_timing = None
+    if world > 1:    # per-rank step time and the collective, separately (outside the timed region)
+        tt = torch.tensor([t_steps, t_gather], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        allt = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(allt, tt)
+        mg_timing = {"per_rank_steps_ms": [float(x[0]) * 1e3 for x in allt],
+                     "per_rank_gather_ms": [float(x[1]) * 1e3 for x in allt],
+                     "note": "gather_ms of a rank includes its wait for the slowest rank's steps; the collective "
+                             "itself is the smallest entry", "gathered_bytes_per_rank": int(produced.numel() * 4)}
     eng.synchronize()   # raises on edge overflow / bad input
     assert full.shape == (a.steps, total_members, N, 3) and bool(torch.isfinite(full).all())
     eps = eng.edges_per_step[a.warmup:a.warmup + a.steps].double()
@@ -552,6 +807,26 @@ def worker(a):
         del enge
         eng = None
 
+    # ---- the other BASELINE configurations on the same clock (default N=1 run only; each leg is bounded and a
+    # failure in one is recorded, not fatal to the headline)
+    config_legs = {}
+    if default_single and not a.skip_config_legs:
+        if eng is not None:
+            eng.close()
+            eng = None
+        torch.cuda.empty_cache()
+        for name, fn in (("shape_A", lambda: leg_shape_a(dev, a)), ("cfg4_training", lambda: leg_cfg4_training(dev)),
+                         ("cfg5_shape_c", lambda: leg_cfg5_shape_c(dev))):
+            t0 = time.perf_counter()
+            note(f"{name} leg")
+            try:
+                config_legs[name] = fn()
+                config_legs[name]["leg_seconds"] = time.perf_counter() - t0
+            except Exception as e:     # noqa: BLE001 — recorded in the line
+                config_legs[name] = {"error": f"{type(e).__name__}: {e}"}
+                note(f"{name} leg FAILED: {config_legs[name]['error']}")
+            torch.cuda.empty_cache()
+
     cpu = None
     if rank == 0 and world == 1 and not a.skip_cpu_baseline and a.variant == "intree":
         cpu = cpu_baseline(sd, a.depth, base, aa, a.threshold, a.cpu_budget_s, first_frame_gpu)
@@ -580,7 +855,15 @@ def worker(a):
                        "launch": "plain" if a.no_graph else "hipGraph replay", "edge_mlp_gemm": a.gemm_mode,
                        "variant": a.variant, "conv_mode": mode, "conv_mode_requested": a.conv_mode},
             "roofline": dominant, "rooflines": roofs, "other_conv_mode": other_mode,
-            "ensemble64_single_gpu": ensemble_leg, "cpu_baseline": cpu, "kernels": kernels,
+            "ensemble64_single_gpu": ensemble_leg,
+            # the like-for-like 1-GPU point of the N > 1 series (same 64-member workload): divide an N-GPU
+            # `value` by THIS, not by the 1-member headline above
+            "baseline_1gpu_same_workload": ({"workload": "BASELINE configs[2]: 64-member ensemble on one GPU",
+                                             "value": ensemble_leg["frames_per_s"], "unit": "frames/s"}
+                                            if ensemble_leg else None),
+            "cfg4_training": config_legs.get("cfg4_training"), "cfg5_shape_c": config_legs.get("cfg5_shape_c"),
+            "shape_A": config_legs.get("shape_A"),
+            "cpu_baseline": cpu, "kernels": kernels, "multi_gpu_timing": mg_timing,
         }
         print(json.dumps(line), flush=True)
     if eng is not None:

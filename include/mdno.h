@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDNO_ABI_VERSION 9
+#define MDNO_ABI_VERSION 10
 
 #define MDNO_OK            0
 #define MDNO_EINVAL       -1   /* bad argument (null pointer, non-positive size, unsupported dim) */
@@ -340,6 +340,22 @@ int mdno_relu_bwd_bf16(const float* g, const void* y, int64_t rows, int n, int o
 size_t mdno_colsum_bf16_workspace_bytes(int n);
 int mdno_colsum_bf16(const void* a, int64_t rows, int n, float* out, void* workspace, size_t workspace_bytes,
                      void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Training: batch assembly on the device (csrc/collate.hip) — replaces, for a trajectory resident in HBM,
+ * ContactMapDataset.__getitem__ per sample (dataset.py:180-227, incl. the per-edge attribute loop :194-201)
+ * and torch_geometric's DataListLoader / Batch.from_data_list collation (graph_kernel.py:513-519, :454;
+ * offset rule PairData.__inc__, dataset.py:41-45).
+ *   pos   f32 [T,N,3]; rows, cols i32: the flat contact maps of all frames (dataset.py:114, 189)
+ *   meta  i64 [3*B+1] (device): {first window frame of sample b} {first edge of that frame in rows/cols}
+ *         {first edge of sample b in the batch; entry B = E}
+ *   ->    x_position f32 [W,B*N,3] (time-major), y f32 [B*N,3] (frame idx+W+horizon-1),
+ *         edge_index i64 [2,E] (sample b shifted by b*N), edge_attr f32 [E,6] = [pos[idx][row], pos[idx][col]]
+ *   max_edges_per_sample only sizes the launch.
+ * ---------------------------------------------------------------------------------------- */
+int mdno_collate_samples(const float* pos, const int32_t* rows, const int32_t* cols, const int64_t* meta,
+                         int B, int N, int W, int horizon, int max_edges_per_sample, float* x_position, float* y,
+                         int64_t* edge_index, float* edge_attr, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Training: backward of the per-atom ends (csrc/train_nodes.hip) — the node prologue (graph_kernel.py:279-298;

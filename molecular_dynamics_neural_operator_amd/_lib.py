@@ -14,7 +14,7 @@ LIB_PATH = Path(os.environ.get("MDNO_LIB", _HERE / "libmdno.so"))
 OK, EINVAL, ELAUNCH, EWORKSPACE, EUNSUPPORTED = 0, -1, -2, -3, -4
 AGGR = {"add": 0, "mean": 1}
 STATUS_EDGE_OVERFLOW, STATUS_BAD_AMINOACID = 1, 2
-ABI_VERSION = 9
+ABI_VERSION = 10
 GEMM_MODES = {"split_bf16": 0, "f32": 1, "split_f16": 2}
 CONV_MODES = {"materialized": 0, "factored": 1, "auto": 2}
 STATUS_ASYMMETRIC_GRAPH = 4
@@ -103,6 +103,7 @@ SIGNATURES = {
                                     _P]),
     "mdno_fc_out_bwd_workspace_bytes": (_SZ, [_I, _I, _I]),
     "mdno_fc_out_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _SZ, _P]),
+    "mdno_collate_samples": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
 }
 
 _lib = None

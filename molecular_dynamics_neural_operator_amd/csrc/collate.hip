@@ -1,0 +1,83 @@
+// Device-side batch assembly for training (BASELINE configs[3]).
+//
+// Replaces, for a trajectory that is resident in HBM, what the reference does on the host for every
+// batch: ContactMapDataset.__getitem__ per sample (dataset.py:180-227: window slice, the first window
+// frame's contact map, the per-edge Python attribute loop :194-201) and torch_geometric's
+// DataListLoader + Batch.from_data_list collation (graph_kernel.py:513-519, invoked :454; the
+// edge_index offset rule is PairData.__inc__, dataset.py:41-45).  One launch pair builds the
+// block-diagonal batch of B independent samples:
+//     x_position f32 [W, B*N, 3]   time-major: frame w of every sample is one contiguous block
+//     y          f32 [B*N, 3]      frame idx_b + W + horizon - 1
+//     edge_index i64 [2, E]        sample b's contact map (frame idx_b) shifted by b*N, samples in order
+//     edge_attr  f32 [E, 6]        [pos[idx_b][row], pos[idx_b][col]]   (dataset.py:194-201)
+// from pos f32 [T,N,3], the flat contact maps (rows / cols of all frames, i32) and a small per-batch
+// table meta i64 [3*B + 1] = {frame idx_b} {first edge of that frame in the flat arrays} {first edge of
+// sample b in the batch; entry B = E}, which the host fills from the dataset's offsets (it owns them:
+// no device->host read is needed to size the batch).
+#include "kernels.h"
+
+namespace mdno {
+namespace {
+
+__global__ __launch_bounds__(256) void collate_positions_kernel(const float* __restrict__ pos,
+                                                                const long long* __restrict__ meta, int B, int N,
+                                                                int W, int horizon, float* __restrict__ x_position,
+                                                                float* __restrict__ y) {
+    // one thread per output float; frames W..W (index W) is the target
+    const long long per_frame = (long long)B * N * 3;
+    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= per_frame * (W + 1)) return;
+    const int w = (int)(id / per_frame);
+    const long long r = id - (long long)w * per_frame;
+    const int b = (int)(r / (N * 3));
+    const int nd = (int)(r - (long long)b * N * 3);
+    const long long frame = meta[b] + (w < W ? w : W + horizon - 1);
+    const float v = pos[frame * N * 3 + nd];
+    if (w < W) x_position[id] = v;
+    else y[r] = v;
+}
+
+__global__ __launch_bounds__(256) void collate_edges_kernel(const float* __restrict__ pos,
+                                                            const int* __restrict__ rows, const int* __restrict__ cols,
+                                                            const long long* __restrict__ meta, int B, int N,
+                                                            long long* __restrict__ edge_index,
+                                                            float* __restrict__ edge_attr) {
+    const int b = blockIdx.x;
+    const long long frame = meta[b], in0 = meta[B + b], out0 = meta[2 * B + b], E = meta[3 * B];
+    const long long cnt = meta[2 * B + b + 1] - out0;
+    const float* p = pos + frame * N * 3;
+    const long long off = (long long)b * N;
+    for (long long e = (long long)blockIdx.y * 256 + threadIdx.x; e < cnt; e += (long long)gridDim.y * 256) {
+        const int r = rows[in0 + e], c = cols[in0 + e];
+        edge_index[out0 + e] = r + off;
+        edge_index[E + out0 + e] = c + off;
+        float* a = edge_attr + (out0 + e) * 6;
+        a[0] = p[r * 3]; a[1] = p[r * 3 + 1]; a[2] = p[r * 3 + 2];
+        a[3] = p[c * 3]; a[4] = p[c * 3 + 1]; a[5] = p[c * 3 + 2];
+    }
+}
+
+}  // namespace
+}  // namespace mdno
+
+using namespace mdno;
+
+extern "C" int mdno_collate_samples(const float* pos, const int32_t* rows, const int32_t* cols, const int64_t* meta,
+                                    int B, int N, int W, int horizon, int max_edges_per_sample, float* x_position,
+                                    float* y, int64_t* edge_index, float* edge_attr, void* stream) {
+    MDNO_REQUIRE(pos && rows && cols && meta && x_position && y && edge_index && edge_attr, MDNO_EINVAL,
+                 "mdno_collate_samples: null pointer");
+    MDNO_REQUIRE(B > 0 && N > 0 && W > 0 && horizon > 0 && max_edges_per_sample >= 0, MDNO_EINVAL,
+                 "mdno_collate_samples: B=%d N=%d W=%d horizon=%d", B, N, W, horizon);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long long n = (long long)B * N * 3 * (W + 1);
+    hipLaunchKernelGGL(collate_positions_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pos,
+                       (const long long*)meta, B, N, W, horizon, x_position, y);
+    if (max_edges_per_sample > 0) {
+        int gy = (max_edges_per_sample + 255) / 256;
+        if (gy > 64) gy = 64;
+        hipLaunchKernelGGL(collate_edges_kernel, dim3(B, gy), dim3(256), 0, s, pos, rows, cols, (const long long*)meta, B,
+                           N, (long long*)edge_index, edge_attr);
+    }
+    return check_launch("collate_samples");
+}

@@ -228,7 +228,12 @@ class KernelNN(nn.Module):
         device = require_gpu(device)
         conv_mode = conv_mode or self.conv_mode
         params = list(self.parameters())
-        key = (str(device), self.gemm_mode, conv_mode) + tuple((p.data_ptr(), p._version) for p in params)
+        # fp32 contiguous parameters on `device` are VIEWED by the pack (device pointers to their storage), so an
+        # in-place update (an optimizer step) needs no new pack; anything the pack had to copy is keyed by version
+        viewed = all(p.dtype == torch.float32 and p.is_contiguous() and p.device.type == device.type and
+                     (device.index is None or p.device.index == device.index) for p in params)
+        key = (str(device), self.gemm_mode, conv_mode) + tuple(
+            (p.data_ptr(), 0 if viewed else p._version) for p in params)
         if self._pack is None or self._pack_key != key:
             self._pack = ops.ParamPack(self.state_dict(), self.depth, device, self.gemm_mode, conv_mode)
             self._pack_key = key

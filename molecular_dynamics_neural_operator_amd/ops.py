@@ -24,9 +24,10 @@ class CSRGraph:
     perm: Optional[torch.Tensor] = None   # i32 [E]: CSR position p holds input edge perm[p]
     status: Optional[torch.Tensor] = None
     max_degree: int = 0                   # bound on any node's degree for the factored conv (0 = N)
+    n_edges: Optional[int] = None         # the edge count when the host knows it (COO input): no device read
 
     def edge_count(self) -> int:
-        return int(self.num_edges.item())
+        return self.n_edges if self.n_edges is not None else int(self.num_edges.item())
 
     def to_edge_index(self) -> torch.Tensor:
         """Reference-order COO `[rows; cols]` (graph_kernel.py:368) — valid for radius graphs, whose
@@ -56,10 +57,12 @@ def radius_graph(pos: torch.Tensor, n_atoms: int, cutoff: float = 8.0, edge_cap:
     return CSRGraph(row_ptr, src, dst, ne, cap, None, status)
 
 
-def coo_to_csr(edge_index: torch.Tensor, num_nodes: int, validate: bool = True) -> CSRGraph:
+def coo_to_csr(edge_index: torch.Tensor, num_nodes: int, validate: bool = True,
+               status: Optional[torch.Tensor] = None) -> CSRGraph:
     """edge_index i64 [2,E] (row 0 = source, row 1 = target) -> CSRGraph with `perm`.  A node id
     outside [0, num_nodes) raises (as the reference's gather / scatter do); `validate=False` defers
-    that check: the bit stays in `graph.status` for the caller to read after its own work."""
+    that check: the bit stays in `graph.status` (`status` if given: a device word the kernels OR into)
+    for the caller to read after its own work — no host synchronisation here."""
     lib = _lib.load()
     if edge_index.dim() != 2 or edge_index.shape[0] != 2:
         raise MdnoError(f"edge_index must be [2,E], got {tuple(edge_index.shape)}")
@@ -73,13 +76,14 @@ def coo_to_csr(edge_index: torch.Tensor, num_nodes: int, validate: bool = True) 
     perm = torch.empty(cap, dtype=torch.int32, device=dev)
     nbytes = lib.mdno_coo_to_csr_workspace_bytes(E, num_nodes)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    if status is None:
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
     check(lib.mdno_coo_to_csr(ptr(ei), E, num_nodes, ptr(row_ptr), ptr(src), ptr(dst), ptr(perm), ptr(status),
                               ptr(ws), nbytes, stream_ptr(dev)), "mdno_coo_to_csr")
     if validate:
         raise_on_status(status.item(), "coo_to_csr")
     ne = torch.full((1,), E, dtype=torch.int32, device=dev)
-    return CSRGraph(row_ptr, src, dst, ne, cap, perm, status)
+    return CSRGraph(row_ptr, src, dst, ne, cap, perm, status, 0, E)
 
 
 def edge_mlp(weights, ker_in: int, ker_width: int, out_dim: int, graph: CSRGraph,
@@ -105,14 +109,15 @@ def edge_mlp(weights, ker_in: int, ker_width: int, out_dim: int, graph: CSRGraph
 
 
 def nnconv(x: torch.Tensor, graph: CSRGraph, w_e: torch.Tensor, root: Optional[torch.Tensor],
-           bias: Optional[torch.Tensor], aggr: str = "mean", relu: bool = False) -> torch.Tensor:
+           bias: Optional[torch.Tensor], aggr: str = "mean", relu: bool = False,
+           out: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = _lib.load()
     if aggr not in AGGR:
         raise MdnoError(f"aggr={aggr!r} is not implemented by the HIP path (add, mean)")
     x = f32(x)
     R, cin = x.shape
     cout = w_e.shape[1] // cin
-    y = torch.empty((R, cout), dtype=torch.float32, device=x.device)
+    y = out if out is not None else torch.empty((R, cout), dtype=torch.float32, device=x.device)
     root_c = f32(root) if root is not None else None
     bias_c = f32(bias) if bias is not None else None
     check(lib.mdno_nnconv_fwd(ptr(x), ptr(graph.row_ptr), ptr(graph.src), R, ptr(w_e), ptr(root_c), ptr(bias_c),
@@ -193,9 +198,12 @@ class ParamPack:
         return C.byref(self.struct)
 
 
-def node_prologue(pack: ParamPack, frames: torch.Tensor, x_aminoacid: torch.Tensor) -> torch.Tensor:
+def node_prologue(pack: ParamPack, frames: torch.Tensor, x_aminoacid: torch.Tensor,
+                  status: Optional[torch.Tensor] = None) -> torch.Tensor:
     """frames f32 [W,M,N,3] -> x0 f32 [M*N,width]: LSTM over the window, lstm_fc, Embedding, concat, fc1,
-    ReLU (graph_kernel.py:279-298).  Raises on an amino-acid id outside [0, num_embeddings)."""
+    ReLU (graph_kernel.py:279-298).  Raises on an amino-acid id outside [0, num_embeddings) — unless the
+    caller passes its own `status` word (int32 [1] on the device): the bit is then left there for it to
+    read later and this call does not synchronise."""
     lib = _lib.load()
     frames = f32(frames)
     if frames.dim() == 3:
@@ -206,10 +214,13 @@ def node_prologue(pack: ParamPack, frames: torch.Tensor, x_aminoacid: torch.Tens
     if aa.numel() not in (N, M * N):
         raise MdnoError(f"x_aminoacid has {aa.numel()} entries, expected {N} or {M * N}")
     x0 = torch.empty((M * N, pack.struct.width), dtype=torch.float32, device=dev)
-    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    deferred = status is not None
+    if not deferred:
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
     check(lib.mdno_node_prologue_fwd(pack.ref, ptr(frames), M, W, N, ptr(aa), int(aa.numel() == M * N and M > 1),
                                      ptr(x0), ptr(status), stream_ptr(dev)), "mdno_node_prologue_fwd")
-    raise_on_status(status.item(), "node_prologue")
+    if not deferred:
+        raise_on_status(status.item(), "node_prologue")
     return x0
 
 
@@ -437,12 +448,12 @@ def gemm_atb_bf16(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 
 
 def nnconv_bf16w(x: torch.Tensor, graph: CSRGraph, w_e: torch.Tensor, root, bias, aggr: str = "mean",
-                 relu: bool = False) -> torch.Tensor:
+                 relu: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = _lib.load()
     x, w_e = f32(x), _bf16(w_e)
     if x.shape[1] != 64 or w_e.shape[1] != 4096:
         raise MdnoError("nnconv_bf16w: width 64 only")
-    y = torch.empty_like(x)
+    y = out if out is not None else torch.empty_like(x)
     check(lib.mdno_nnconv_bf16w_fwd(ptr(x), ptr(graph.row_ptr), ptr(graph.src), x.shape[0], ptr(w_e),
                                     ptr(f32(root)) if root is not None else None,
                                     ptr(f32(bias)) if bias is not None else None, AGGR[aggr], int(relu), ptr(y),
@@ -548,3 +559,20 @@ def node_prologue_bwd(pack: ParamPack, frames: torch.Tensor, x_aminoacid: torch.
                     "lstm.bias_ih_l0": d_lstm[72:84].clone(), "lstm.bias_hh_l0": d_lstm[72:84].clone(),
                     "lstm_fc.weight": d_lstm[84:93].reshape(3, 3).clone(), "lstm_fc.bias": d_lstm[93:96].clone()})
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+def collate_samples(pos: torch.Tensor, rows: torch.Tensor, cols: torch.Tensor, meta: torch.Tensor, B: int, N: int,
+                    W: int, horizon: int, n_edges: int, max_edges_per_sample: int):
+    """Block-diagonal training batch built on the device (include/mdno.h mdno_collate_samples).
+    -> (x_position [W,B*N,3], y [B*N,3], edge_index i64 [2,E], edge_attr [E,6])"""
+    lib = _lib.load()
+    dev = pos.device
+    x_position = torch.empty((W, B * N, 3), dtype=torch.float32, device=dev)
+    y = torch.empty((B * N, 3), dtype=torch.float32, device=dev)
+    edge_index = torch.empty((2, n_edges), dtype=torch.long, device=dev)
+    edge_attr = torch.empty((n_edges, 6), dtype=torch.float32, device=dev)
+    check(lib.mdno_collate_samples(ptr(pos), ptr(rows), ptr(cols), ptr(meta), B, N, W, horizon, max_edges_per_sample,
+                                   ptr(x_position), ptr(y), ptr(edge_index), ptr(edge_attr), stream_ptr(dev)),
+          "mdno_collate_samples")
+    return x_position, y, edge_index, edge_attr

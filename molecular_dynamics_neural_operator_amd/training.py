@@ -20,6 +20,7 @@ from __future__ import annotations
 
 from typing import List, Optional, Sequence
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -53,7 +54,7 @@ class KernelIntegralBlock(torch.autograd.Function):
         X[0].copy_(x0)
         for a in range(1, L + 1):
             root, bias = (root1, bias1) if a <= depth else (root2, bias2)
-            X[a].copy_(ops.nnconv(X[a - 1], graph, w_e, root, bias, "mean", relu=True))
+            ops.nnconv(X[a - 1], graph, w_e, root, bias, "mean", relu=True, out=X[a])
         ctx.graph, ctx.depth, ctx.gemm_mode = graph, depth, gemm_mode
         ctx.save_for_backward(ea, h1, h2, w_e, X, w0, w1, w2, root1, root2)
         return X[L].clone()
@@ -69,7 +70,7 @@ class KernelIntegralBlock(torch.autograd.Function):
         X[0].copy_(x0)
         for a in range(1, L + 1):
             root, bias = (root1, bias1) if a <= depth else (root2, bias2)
-            X[a].copy_(ops.nnconv_bf16w(X[a - 1], graph, w_e, root, bias, "mean", relu=True))
+            ops.nnconv_bf16w(X[a - 1], graph, w_e, root, bias, "mean", relu=True, out=X[a])
         ctx.graph, ctx.depth, ctx.gemm_mode = graph, depth, "bf16"
         ctx.save_for_backward(ea, h1, h2, w_e, X, w0, w1, w2, root1, root2)
         return X[L].clone()
@@ -79,7 +80,7 @@ class KernelIntegralBlock(torch.autograd.Function):
         ea, h1, h2, w_e, X, w0, w1, w2, root1, root2 = ctx.saved_tensors
         graph, depth = ctx.graph, ctx.depth
         L, R = 2 * depth, X.shape[1]
-        by_src = ops.source_sorted(graph, R)
+        by_src = getattr(graph, "by_src", None) or ops.source_sorted(graph, R)
         inv = ops.inv_degree(graph, "mean")
         GZ = torch.empty((L, R, 64), dtype=torch.float32, device=X.device)
         GS = torch.empty((L, R, 64), dtype=torch.float32, device=X.device)
@@ -114,7 +115,7 @@ class KernelIntegralBlock(torch.autograd.Function):
         ea, h1, h2, w_e, X, w0, w1, w2, root1, root2 = ctx.saved_tensors
         graph, depth, gemm_mode = ctx.graph, ctx.depth, ctx.gemm_mode
         L, R = 2 * depth, X.shape[1]
-        by_src = ops.source_sorted(graph, R)
+        by_src = getattr(graph, "by_src", None) or ops.source_sorted(graph, R)
         inv = ops.inv_degree(graph, "mean")
         GZ = torch.empty((L, R, 64), dtype=torch.float32, device=X.device)
         GS = torch.empty((L, R, 64), dtype=torch.float32, device=X.device)
@@ -146,7 +147,7 @@ class NodePrologue(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pack, frames, aa, *params):
-        x0 = ops.node_prologue(pack, frames, aa)
+        x0 = ops.node_prologue(pack, frames, aa, status=pack.train_status)
         ctx.pack, ctx.names = pack, pack.prologue_names
         ctx.save_for_backward(frames, aa, x0)
         return x0
@@ -186,11 +187,67 @@ def collate(samples: Sequence[PairData]) -> PairData:
     b.x_position = torch.cat([s.x_position for s in samples], dim=1) if samples[0].x_position.dim() == 3 else \
         torch.cat([s.x_position.unsqueeze(0) for s in samples], dim=1)
     assert b.x_position.shape[0] == W or samples[0].x_position.dim() == 2
+    b.num_graphs = len(samples)
     return b
 
 
+class DeviceTrajectory:
+    """A `ContactMapDataset` resident in HBM, handing out training batches built ON the device
+    (include/mdno.h mdno_collate_samples).  Stands in for the reference's `DataListLoader` + torch_geometric
+    collation (graph_kernel.py:513-519; `model(batch)` at :454 collates per step on the host): per batch the
+    host only fills a 3*B+1 word table from the dataset's offsets — no per-sample Python, no per-sample H2D
+    copies, no device->host read.  `batch(indices)` returns a collated `PairData` (time-major x_position
+    [W,B*N,3], y, edge_index, edge_attr, x_aminoacid tiled) whose samples are `dataset[i]` for i in indices,
+    in that order — the same tensors `collate([dataset[i] ...])` builds on the host (tested bitwise)."""
+
+    def __init__(self, dataset, device):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise MdnoError("DeviceTrajectory needs a GPU device (no CPU fallback)")
+        self.W, self.horizon = int(dataset.window_size), int(dataset.horizon)
+        self.length = len(dataset)
+        pos = np.ascontiguousarray(dataset.edge_attrs, dtype=np.float32)                  # [T,N,3]
+        self.N = int(pos.shape[1])
+        cms = [np.asarray(c).reshape(2, -1) for c in dataset.edge_indices]
+        counts = np.array([c.shape[1] for c in cms], dtype=np.int64)
+        self.counts = counts
+        self.offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        self.pos = torch.from_numpy(pos).to(self.device)
+        self.rows = torch.from_numpy(np.concatenate([c[0] for c in cms]).astype(np.int32)).to(self.device)
+        self.cols = torch.from_numpy(np.concatenate([c[1] for c in cms]).astype(np.int32)).to(self.device)
+        self.x_aminoacid = dataset.x_aminoacid.to(self.device)
+        self._aa_tiled = {}
+
+    def __len__(self) -> int:
+        return self.length
+
+    def batch(self, indices) -> PairData:
+        idx = np.asarray(indices, dtype=np.int64).reshape(-1)
+        if idx.size == 0 or idx.min() < 0 or idx.max() >= self.length:
+            raise IndexError(f"sample indices must lie in [0, {self.length})")
+        B = int(idx.size)
+        cnt = self.counts[idx]
+        meta = np.empty(3 * B + 1, dtype=np.int64)
+        meta[:B] = idx
+        meta[B:2 * B] = self.offsets[idx]
+        meta[2 * B] = 0
+        np.cumsum(cnt, out=meta[2 * B + 1:])
+        E = int(meta[3 * B])
+        meta_d = torch.from_numpy(meta).to(self.device, non_blocking=True)
+        xp, y, ei, ea = ops.collate_samples(self.pos, self.rows, self.cols, meta_d, B, self.N, self.W, self.horizon, E,
+                                            int(cnt.max()))
+        if B not in self._aa_tiled:
+            self._aa_tiled[B] = self.x_aminoacid.repeat(B)
+        out = PairData(x_aminoacid=self._aa_tiled[B], x_position=xp, y=y, edge_attr=ea, edge_index=ei)
+        out.num_graphs = B
+        return out
+
+
 def train_forward(model, data) -> torch.Tensor:
-    """Differentiable forward of `KernelNN` for one sample or a list/batch of samples -> [B*N, out]."""
+    """Differentiable forward of `KernelNN` for one sample, a list of samples, or an already collated batch
+    (`collate`, `DeviceTrajectory.batch`) -> [B*N, out].  Nothing here waits for the device: index errors
+    (amino-acid id or node id out of range — IndexError in the reference) are left in `model`'s training
+    status word and raised by `check_train_status(model)`, which `train_epoch` calls once per epoch."""
     batch = collate(data) if not isinstance(data, PairData) else data
     dev = next(model.parameters()).device
     if dev.type != "cuda":
@@ -200,7 +257,7 @@ def train_forward(model, data) -> torch.Tensor:
         xp = xp.unsqueeze(0)
     W, R, _ = xp.shape
     aa = batch.x_aminoacid.to(dev)
-    if model.conv1.net is not model.conv2.net:
+    if getattr(model, "conv2", None) is not None and model.conv1.net is not model.conv2.net:
         raise NotImplementedError("training assumes the reference's single shared edge-MLP (graph_kernel.py:271-273)")
     # per-atom prologue (graph_kernel.py:279-298 with B=1 semantics per sample): HIP forward + backward.
     # The ParamPack holds device pointers to the parameters' CURRENT storage (fp32 contiguous parameters
@@ -209,8 +266,18 @@ def train_forward(model, data) -> torch.Tensor:
     names = tuple(k for k in _PROLOGUE_KEYS if k in sd)
     pack = model.param_pack(dev, conv_mode="materialized")
     pack.prologue_names = names
+    status = getattr(model, "_train_status", None)
+    if status is None or status.device != dev:
+        status = model._train_status = torch.zeros(1, dtype=torch.int32, device=dev)
+    pack.train_status = status
     x0 = NodePrologue.apply(pack, xp.unsqueeze(1).contiguous(), aa, *[sd[k] for k in names])
-    graph = ops.coo_to_csr(batch.edge_index.to(dev), R)
+    ei = batch.edge_index.to(dev)
+    graph = ops.coo_to_csr(ei, R, validate=False, status=status)
+    # the same edges grouped by source, for the input-gradient kernel: built now, next to the forward's sort
+    # (ids already validated by it), so that the backward starts with everything in place
+    E = graph.n_edges
+    graph.by_src = ops.coo_to_csr(torch.stack([graph.dst[:E], graph.src[:E]]).to(torch.long), R, validate=False,
+                                  status=status) if torch.is_grad_enabled() else None
     net = model.conv1.net
     w0, b0, w1, b1, w2, b2 = net.hip_weights()
     conv2 = getattr(model, "conv2", None)
@@ -230,20 +297,43 @@ def train_forward(model, data) -> torch.Tensor:
     return FcOut.apply(x, model.fc2.weight, model.fc2.bias)
 
 
+def check_train_status(model) -> None:
+    """Read (one device->host word) and clear the status the training forwards since the last call left
+    behind; raises what the reference's nn.Embedding / index_select would have raised in that forward."""
+    from ._lib import raise_on_status
+    st = getattr(model, "_train_status", None)
+    if st is None:
+        return
+    word = int(st.item())
+    st.zero_()
+    raise_on_status(word, "training forward")
+
+
 def train_epoch(model, batches, optimizer, loss_fn, batch_size: Optional[int] = None):
-    """One pass over `batches` (an iterable of lists of PairData, as the reference's DataListLoader
-    yields): returns (avg relative-L2 loss, avg MSE) like train() (graph_kernel.py:445-474)."""
+    """One pass over `batches` — an iterable of lists of PairData (as the reference's DataListLoader yields)
+    or of collated batches (`DeviceTrajectory.batch`): returns (avg relative-L2 loss, avg MSE) like train()
+    (graph_kernel.py:445-474).  The per-batch losses stay on the device until the pass is over (the
+    reference's `l2.item()` per batch would stall the GPU once per step); they are then added on the host in
+    double precision in batch order, which is what `avg_loss += l2.item()` does."""
     model.train()
-    tot, tot_mse, n = 0.0, 0.0, 0
+    losses, mses = [], []
     for batch in batches:
-        B = len(batch) if not isinstance(batch, PairData) else (batch_size or 1)
+        if isinstance(batch, PairData):
+            B = batch_size or getattr(batch, "num_graphs", 1)
+        else:
+            B = len(batch)
         optimizer.zero_grad()
         out = train_forward(model, batch)
         y = torch.cat([s.y for s in batch]).to(out.device) if not isinstance(batch, PairData) else batch.y.to(out.device)
         l2 = loss_fn(out.view(B, -1), y.view(B, -1))
         l2.backward()
         optimizer.step()
-        tot += float(l2.item())
-        tot_mse += float(F.mse_loss(out.detach(), y).item())
-        n += 1
-    return tot / max(n, 1), tot_mse / max(n, 1)
+        losses.append(l2.detach())
+        mses.append(F.mse_loss(out.detach(), y))
+    check_train_status(model)
+    n = len(losses)
+    if n == 0:
+        return 0.0, 0.0
+    tot = float(torch.stack(losses).double().cpu().sum())
+    tot_mse = float(torch.stack(mses).double().cpu().sum())
+    return tot / n, tot_mse / n

@@ -23,7 +23,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from molecular_dynamics_neural_operator_amd import synthetic as syn  # noqa: E402
 from molecular_dynamics_neural_operator_amd.dataset import ContactMapDataset, write_trajectory_npz  # noqa: E402
 from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN, LpLoss  # noqa: E402
-from molecular_dynamics_neural_operator_amd.training import collate, train_epoch, train_forward  # noqa: E402
+from molecular_dynamics_neural_operator_amd.training import DeviceTrajectory, collate, train_epoch, train_forward  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, default=2000)
@@ -36,6 +36,9 @@ ap.add_argument("--cpu-batches", type=int, default=0)
 ap.add_argument("--precision", choices=["fp32", "bf16"], default="bf16",
                 help="bf16 (BASELINE configs[3]): h1, h2, W_e, dW_e stored in bf16, single-product bf16 GEMMs with "
                      "fp32 accumulation, fp32 master weights; fp32: split-bf16 GEMMs at fp32-level accuracy")
+ap.add_argument("--host-collate", action="store_true",
+                help="collate every batch on the host from ContactMapDataset samples (what the reference's "
+                     "DataListLoader does) instead of on the device from the resident trajectory")
 ap.add_argument("--workdir", default="/tmp/mdno_train")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -51,8 +54,32 @@ dset = ContactMapDataset(str(path), window_size=W, horizon=1)
 n_train = int(len(dset) * 0.8)                                    # partition split (graph_kernel.py:509-520)
 train_idx, valid_idx = list(range(n_train)), list(range(n_train, len(dset)))
 B = a.batch_size
-batches = [[dset[i] for i in train_idx[s:s + B]] for s in range(0, len(train_idx) - B + 1, B)]   # drop_last
-vbatches = [[dset[i] for i in valid_idx[s:s + B]] for s in range(0, len(valid_idx) - B + 1, B)]
+traj_dev = None if a.host_collate else DeviceTrajectory(dset, dev)
+
+
+class Batches:
+    """drop_last batches over an index list; device mode builds each batch on the GPU when it is asked for
+    (as a loader would), host mode hands out lists of samples for `collate`."""
+
+    def __init__(self, idx):
+        self.idx = [idx[s:s + B] for s in range(0, len(idx) - B + 1, B)]
+        self.host = [[dset[i] for i in b] for b in self.idx] if traj_dev is None else None
+
+    def __len__(self):
+        return len(self.idx)
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            out = Batches([])
+            out.idx, out.host = self.idx[k], (self.host[k] if self.host is not None else None)
+            return out
+        return self.host[k] if self.host is not None else traj_dev.batch(self.idx[k])
+
+    def __iter__(self):
+        return (self[k] for k in range(len(self)))
+
+
+batches, vbatches = Batches(train_idx), Batches(valid_idx)
 
 torch.manual_seed(0)
 model = KernelNN(64, a.kernel_width, a.depth, 6, 7, 3, 20, 4)
@@ -73,13 +100,14 @@ def validate():
     with torch.enable_grad():
         for vb in vbatches:
             out = train_forward(model, vb)
-            y = torch.cat([s.y for s in vb]).to(dev)
+            y = vb.y if traj_dev is not None else torch.cat([s.y for s in vb]).to(dev)
             tot += float(loss_fn(out.view(B, -1), y.view(B, -1)).item())
     return tot / max(len(vbatches), 1)
 
 
 summary = {"frames": a.frames, "batch_size": B, "train_batches": len(batches), "edges_per_batch":
-           int(sum(s.edge_index.shape[1] for s in batches[0])), "kernel_width": a.kernel_width, "depth": a.depth}
+           int(sum(dset[i].edge_index.shape[1] for i in batches.idx[0])), "kernel_width": a.kernel_width,
+           "depth": a.depth, "collate": "host" if a.host_collate else "device"}
 summary["precision"] = a.precision
 train_epoch(model, batches[:1], opt, loss_fn)          # warm-up (allocator, kernels)
 torch.cuda.synchronize()
@@ -104,8 +132,8 @@ if a.cpu_batches:
     sd = dict(ref.named_parameters())
     copt = torch.optim.Adam(ref.parameters(), lr=a.lr, weight_decay=5e-4)
     t0 = time.perf_counter()
-    for b in batches[:a.cpu_batches]:
-        cb = collate(b)
+    for bi in batches.idx[:a.cpu_batches]:
+        cb = collate([dset[i] for i in bi])
         copt.zero_grad()
         xp = cb.x_position
         R = xp.shape[1]

@@ -427,3 +427,71 @@ def test_node_prologue_and_fc2_backward_vs_autograd(dev, variant):
     assert rel_err(dx, g.double().cpu() @ w.double().cpu()) < 1e-6
     assert rel_err(d_w, g.double().cpu().t() @ x.double().cpu()) < 1e-6
     assert rel_err(d_b, g.double().cpu().sum(0)) < 1e-6
+
+
+# ------------------------------------------------------------------------------- device-side batches
+def test_device_trajectory_batches_equal_host_collation(dev, tmp_path):
+    """DeviceTrajectory.batch(indices) — the batch built on the device from the resident trajectory
+    (mdno_collate_samples) — holds bit for bit the tensors `collate([dataset[i] ...])` builds on the host from
+    ContactMapDataset.__getitem__ (dataset.py:180-227) and the PairData batching rule (dataset.py:41-45):
+    unordered, repeated and boundary indices; and a training step on it gives the same loss and gradients."""
+    from molecular_dynamics_neural_operator_amd.dataset import ContactMapDataset
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN, LpLoss
+    from molecular_dynamics_neural_operator_amd.training import DeviceTrajectory, collate
+    z = load_golden("rollout_20.npz")
+    path = tmp_path / "traj.npz"
+    write_golden_trajectory(path, z)
+    for W, h in ((int(z["window"]), 1), (1, 1), (4, 3)):
+        dset = ContactMapDataset(str(path), window_size=W, horizon=h)
+        traj = DeviceTrajectory(dset, dev)
+        assert len(traj) == len(dset)
+        idx = [len(dset) - 1, 0, 7, 7, 3]
+        got = traj.batch(idx)
+        want = collate([dset[i] for i in idx])
+        assert got.num_graphs == len(idx)
+        for f in ("x_position", "y", "edge_index", "edge_attr", "x_aminoacid"):
+            assert torch.equal(getattr(got, f).cpu(), getattr(want, f)), (W, h, f)
+        with pytest.raises(IndexError):
+            traj.batch([len(dset)])
+    dset = ContactMapDataset(str(path), window_size=int(z["window"]), horizon=1)
+    traj = DeviceTrajectory(dset, dev)
+    idx = [0, 7, 19]
+    torch.manual_seed(3)
+    model = KernelNN(64, 128, 2, 6, 7, 3, 20, 4)
+    with torch.no_grad():
+        for p_ in model.conv1.net.layers[4].parameters():
+            p_.mul_(0.2)
+    model.to(dev).train()
+    res = []
+    for batch in (traj.batch(idx), [dset[i] for i in idx]):
+        model.zero_grad(set_to_none=True)
+        out = model(batch)
+        y = batch.y if not isinstance(batch, list) else torch.cat([s.y for s in batch]).to(dev)
+        loss = LpLoss(size_average=False)(out.view(3, -1), y.view(3, -1))
+        loss.backward()
+        res.append((loss.detach().clone(), {n: p_.grad.clone() for n, p_ in model.named_parameters()}))
+    assert torch.equal(res[0][0], res[1][0])
+    for n in res[0][1]:
+        assert torch.equal(res[0][1][n], res[1][1][n]), n
+
+
+def test_training_index_errors_are_deferred_not_lost(dev, tmp_path):
+    """The training forward does not wait for the device; an amino-acid id outside the embedding table (the
+    reference: IndexError from nn.Embedding inside that forward) is raised by check_train_status / at the end
+    of train_epoch, and the status word is cleared afterwards."""
+    from molecular_dynamics_neural_operator_amd.dataset import ContactMapDataset
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN, LpLoss
+    from molecular_dynamics_neural_operator_amd.training import check_train_status, train_epoch
+    z = load_golden("rollout_20.npz")
+    path = tmp_path / "traj.npz"
+    write_golden_trajectory(path, z)
+    dset = ContactMapDataset(str(path), window_size=int(z["window"]), horizon=1)
+    model = KernelNN(64, 128, 2, 6, 7, 3, 20, 4).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    bad = dset[0]
+    bad.x_aminoacid = bad.x_aminoacid.clone()
+    bad.x_aminoacid[3] = 20
+    with pytest.raises(IndexError):
+        train_epoch(model, [[dset[1], bad]], opt, LpLoss(size_average=False))
+    check_train_status(model)                          # cleared: nothing left to raise
+    train_epoch(model, [[dset[1], dset[2]]], opt, LpLoss(size_average=False))

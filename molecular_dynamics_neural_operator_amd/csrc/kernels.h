@@ -115,6 +115,12 @@ constexpr int kMaxF16Applications = 62;
 // x_prepared: the bf16 image of x and q = x.B3 are already in f.xp / f.q (left there by the previous
 // application, which was given this application's b3 as next_b3); next_b3 NULL: nothing follows.
 
+// bf16 training GEMMs (gemm_bf16.hip): C = act(A . W^T + b), A bf16 [rows,K], W bf16 [N,K], C bf16 or fp32;
+// 256 x 256 tiles, two wave groups one phase apart (N % 256 == 0, K % 32 == 0, K >= 64)
+bool gemm_nt_pp_supported(long long rows, int N, int K);
+int gemm_nt_pp(const void* A, const void* W, const float* bias, long long rows, int N, int K, int relu, int out_bf16,
+               void* C, hipStream_t s);
+
 int nnconv(const float* x, const int* row_ptr, const int* src, int num_rows, const float* w_e, const float* root,
            const float* bias, int Cin, int Cout, int aggr, int relu, float* y, hipStream_t s);
 

@@ -548,6 +548,8 @@ extern "C" int mdno_linear_bf16_fwd(const void* a, const float* w, const float* 
                  "mdno_linear_bf16_fwd: workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
     MDNO_TRY(mdno_cast_bf16(w, (int64_t)n * k, workspace, stream));      // master weights -> bf16, every call
+    if (gemm_nt_pp_supported(rows, n, k))      // 256 x 256 tiles, LDS-DMA ring, two wave groups a phase apart
+        return gemm_nt_pp(a, workspace, bias, (long long)rows, n, k, relu, out_bf16, c, s);
     const __bf16* A = static_cast<const __bf16*>(a);
     const __bf16* W = static_cast<const __bf16*>(workspace);
     // (an XCD-aware order — all column tiles of a row tile on one XCD — was measured: 617 -> 640 us on the

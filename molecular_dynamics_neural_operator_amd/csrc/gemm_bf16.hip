@@ -103,10 +103,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NtArgs g) {
     auto piece_off = [&](int t) { return (wave + 8 * t) * 1024; };      // (pieces 16.. are B: 16 KiB + ...: same formula)
 #define MDNO_PP_DMA(ST)                                                                                         \
     {                                                                                                           \
-        const int slot_ = (ST) % PP_RING;                                                                       \
-        _Pragma("unroll") for (int t = 0; t < PP_PIECES_PER_WAVE; ++t)                                          \
-            __builtin_amdgcn_global_load_lds((glb_u8*)(psrc[t] + (size_t)(ST) * PP_ROW_BYTES),                  \
-                                             (lds_u8*)(lds + slot_ * PP_STAGE_BYTES + piece_off(t)), 16, 0, 0); \
+        const int st_ = (ST), slot_ = st_ % PP_RING;       /* (ST may name the caller's loop variable) */       \
+        _Pragma("unroll") for (int pi_ = 0; pi_ < PP_PIECES_PER_WAVE; ++pi_)                                    \
+            __builtin_amdgcn_global_load_lds((glb_u8*)(psrc[pi_] + (size_t)st_ * PP_ROW_BYTES),                \
+                                             (lds_u8*)(lds + slot_ * PP_STAGE_BYTES + piece_off(pi_)), 16, 0, 0); \
     }
 
     // ---- fragment read offsets (row-swizzled 16-B chunks)
@@ -187,31 +187,51 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NtArgs g) {
         MDNO_PP_BARRIER()
         // ---- multiply phase of stage t
         MDNO_PP_MMA()
-        MDNO_PP_BARRIER()
+        // (the last barrier of waves 4-7 — the one the stagger added to their count — is left out: nothing follows
+        // it but the epilogue, which waves 0-3 then start while waves 4-7 are still multiplying)
+        if (grp == 0 || t + 1 < T) { MDNO_PP_BARRIER() }
     }
-    if (grp == 0) { MDNO_PP_BARRIER() }          // pairs with the stagger barrier of waves 4-7
 #undef MDNO_PP_DMA
 #undef MDNO_PP_LOAD
 #undef MDNO_PP_MMA
 #undef MDNO_PP_BARRIER
 
-    // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5): a lane holds
+    // ONE column of 16 rows, so storing from the accumulators is 2-byte (or 4-byte) pieces 2*N apart — 128 store
+    // instructions per lane and 16.7 us per tile, a third of the K = 1024 products.  Instead every wave turns its
+    // tile through a private LDS patch (the ring is idle now: 8 KiB per wave), 32 rows at a time: bias / ReLU /
+    // rounding on the way in (one element per ds_write), whole rows on the way out — 16 B per lane, a 128-B line
+    // per 8 (bf16) or 4 (fp32) lanes.  LDS operations of one wave execute in order: no wait between the two.
+    constexpr int ESZ = OUT_BF16 ? 2 : 4;
+    constexpr int PATCH_ROW = 64 * ESZ;                    // bytes per patch row (the wave's 64 columns)
+    unsigned char* patch = lds + wave * (32 * 64 * 4);    // 8 KiB apart (fp32 size) for either type
+    const size_t ldc = (size_t)g.N * ESZ;
+    unsigned char* cbase = static_cast<unsigned char*>(g.C) + (size_t)(bn + wn * 64) * ESZ;
+    constexpr int LANES_PER_ROW = PATCH_ROW / 16;          // 8 or 16
+    constexpr int ROWS_PER_INSTR = 64 / LANES_PER_ROW;     // 8 or 4
+    const int orow = lane / LANES_PER_ROW, ochunk = lane % LANES_PER_ROW;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = bn + wn * 64 + j * 32 + l31;
-        const float bv = j ? bv1 : bv0;
+    for (int i = 0; i < 4; ++i) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 2; ++j) {
+            const float bv = j ? bv1 : bv0;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const long long m = bm + grp * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (m < g.rows) {
-                    float v = acc[i][j][e] + bv;
-                    if (RELU) v = fmaxf(v, 0.f);
-                    if (OUT_BF16) static_cast<__bf16*>(g.C)[(size_t)m * g.N + n] = (__bf16)v;
-                    else static_cast<float*>(g.C)[(size_t)m * g.N + n] = v;
-                }
+                const int r = (e & 3) + 8 * (e >> 2) + 4 * h;
+                float v = acc[i][j][e] + bv;
+                if (RELU) v = fmaxf(v, 0.f);
+                unsigned char* dst = patch + r * PATCH_ROW + (j * 32 + l31) * ESZ;
+                if (OUT_BF16) *reinterpret_cast<__bf16*>(dst) = (__bf16)v;
+                else *reinterpret_cast<float*>(dst) = v;
             }
+        }
+        const long long m0 = bm + grp * 128 + i * 32;
+#pragma unroll
+        for (int rr = 0; rr < 32; rr += ROWS_PER_INSTR) {
+            const uint4 v = *reinterpret_cast<const uint4*>(patch + (rr + orow) * PATCH_ROW + ochunk * 16);
+            const long long m = m0 + rr + orow;
+            if (m < g.rows) *reinterpret_cast<uint4*>(cbase + (size_t)m * ldc + ochunk * 16) = v;
+        }
     }
 }
 

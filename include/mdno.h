@@ -312,8 +312,12 @@ int mdno_nnconv_bwd_we(const float* x, const float* gs, const int32_t* src, cons
  *                           as mdno_linear_fwd's generic kernel, rounded once to bf16
  *   mdno_linear_bf16_fwd    c = act(a . w^T + b): a bf16 [rows,k], w fp32 [n,k]; c bf16 (out_bf16) or fp32;
  *                           n % 128 == 0, k % 32 == 0; workspace mdno_linear_bf16_workspace_bytes(n, k)
+ *   mdno_linear_bf16_masked c bf16 [rows,n] = (y > 0) ? a . w^T : 0 — the input gradient of a Linear+ReLU layer whose
+ *                           stored output is y bf16 [rows,n] (graph_kernel.py:239-242 differentiated), mask fused
+ *                           into the GEMM's epilogue; n % 256 == 0, k % 32 == 0, k >= 64
+ *                           (mdno_linear_bf16_masked_supported); workspace mdno_linear_bf16_workspace_bytes(n, k)
  *   mdno_gemm_atb_bf16      c [n1,n2] fp32 = a^T . b over rows, a bf16 [rows,n1], b bf16 [rows,n2], n1, n2 % 128 == 0;
- *                           16 fixed row slices added in order; workspace mdno_gemm_atb_bf16_workspace_bytes
+ *                           fixed row slices added in order; workspace mdno_gemm_atb_bf16_workspace_bytes
  *   mdno_nnconv_bf16w_fwd   mdno_nnconv_fwd at 64x64 with w_e bf16 [E,4096]
  *   mdno_nnconv_bwd_x_bf16w mdno_nnconv_bwd_x with w_e bf16
  *   mdno_nnconv_bwd_we_bf16 d_we bf16 [E,4096] = sum_l x_l[src p] (x) gs_l[dst p] (rounded once, at the end)
@@ -326,6 +330,9 @@ int mdno_linear_smallk_bf16_fwd(const float* a, const float* w, const float* bia
 size_t mdno_linear_bf16_workspace_bytes(int n, int k);
 int mdno_linear_bf16_fwd(const void* a, const float* w, const float* bias, int64_t rows, int n, int k, int relu,
                          int out_bf16, void* c, void* workspace, size_t workspace_bytes, void* stream);
+int mdno_linear_bf16_masked_supported(int64_t rows, int n, int k);
+int mdno_linear_bf16_masked(const void* a, const float* w, const void* y, int64_t rows, int n, int k, void* c,
+                            void* workspace, size_t workspace_bytes, void* stream);
 size_t mdno_gemm_atb_bf16_workspace_bytes(int n1, int n2);
 int mdno_gemm_atb_bf16(const void* a, const void* b, int64_t rows, int n1, int n2, float* c,
                        void* workspace, size_t workspace_bytes, void* stream);

@@ -90,6 +90,8 @@ SIGNATURES = {
     "mdno_linear_smallk_bf16_fwd": (_I, [_P, _P, _P, _L, _I, _I, _I, _P, _P]),
     "mdno_linear_bf16_workspace_bytes": (_SZ, [_I, _I]),
     "mdno_linear_bf16_fwd": (_I, [_P, _P, _P, _L, _I, _I, _I, _I, _P, _P, _SZ, _P]),
+    "mdno_linear_bf16_masked_supported": (_I, [_L, _I, _I]),
+    "mdno_linear_bf16_masked": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _SZ, _P]),
     "mdno_gemm_atb_bf16_workspace_bytes": (_SZ, [_I, _I]),
     "mdno_gemm_atb_bf16": (_I, [_P, _P, _L, _I, _I, _P, _P, _SZ, _P]),
     "mdno_nnconv_bf16w_fwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P]),

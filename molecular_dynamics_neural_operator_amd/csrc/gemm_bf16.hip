@@ -53,19 +53,33 @@ constexpr int PP_RING = 3;
 constexpr int PP_LDS_BYTES = PP_RING * PP_STAGE_BYTES;    // 96 KiB
 constexpr int PP_PIECES_PER_WAVE = PP_STAGE_BYTES / 1024 / 8;   // 4
 
-struct NtArgs {
-    const __bf16* A;      // [rows, K]
-    const __bf16* W;      // [N, K]
-    const float* bias;    // [N] or null
-    void* C;              // [rows, N] bf16 or fp32
-    long long rows;
-    int N, K;
+// EPI_BIAS: C = act(acc + bias) as bf16 or fp32.  EPI_MASK: C = bf16(Y > 0 ? acc : 0) — the ReLU backward of the
+// layer whose stored output is Y, fused (graph_kernel.py:239-242 differentiated: d pre = d h * (h > 0)).
+// EPI_SLAB: fp32 partial products of a K slice into slab z (the A^T.B products; added in slice order afterwards).
+enum { EPI_BIAS = 0, EPI_MASK = 1, EPI_SLAB = 2 };
+
+struct PpArgs {
+    const __bf16* A;      // NT: [rows, K] row-major.   TN: [rows, n1]
+    const __bf16* W;      // NT: [N, K] row-major.      TN: [rows, n2]
+    const float* bias;    // EPI_BIAS: [N] or null
+    const __bf16* Y;      // EPI_MASK: [rows, N]
+    void* C;              // NT: [rows, N] bf16 or fp32.  TN: slabs [slices][n1][n2] fp32
+    const unsigned char* zeros;   // TN: 512 zero bytes (rows past the end of the contraction read these)
+    long long rows;       // NT: output rows.  TN: contraction length
+    int N, K;             // NT: output columns, contraction length.  TN: n2, n1
     int tiles_n;
     long long tiles_m;
+    long long slice_rows; // TN: rows per K slice (multiple of 32)
 };
 
-template <bool RELU, bool OUT_BF16>
-__global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NtArgs g) {
+// TN = false: C = A . W^T (contraction index fastest in both operands: LDS rows of 32 k, ds_read_b128 fragments).
+// TN = true:  C = A^T . B over rows (contraction index SLOWEST in both operands): a stage is 32 rows of 256
+//   columns per operand, copied as it lies — LDS rows of 512 B, the 16-B chunks XOR-swizzled by ((row & 3) << 2) —
+//   and the fragments come out of gfx950's transposing read ds_read_b64_tr_b16 (a 16-lane group gets a 4-row x
+//   16-column block column-major: 4 consecutive k of its own m; two reads make the 8-k MFMA operand).  The four
+//   rows of a block sit in four different 64-B quarters of the 256-B bank row: conflict free.
+template <bool TN, int EPI, bool RELU, bool OUT_BF16>
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PpArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     // XCD-aware tile order (blocks b, b+8, ... share an XCD): each XCD gets a contiguous range of tiles, n
     // fastest, so that the tiles sharing an A row panel run on one L2.  Bijective for any count.
@@ -82,47 +96,93 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NtArgs g) {
     const int wn = wave & 3;                    // 64-column strip
     const int l31 = lane & 31, h = lane >> 5;
 
-    // ---- LDS-DMA: wave w moves pieces w, w+8 (A rows 16w.., 128+16w..) and w+16, w+24 (B rows likewise)
-    const int pr = lane >> 2;                                   // row inside a piece
-    const int pc = (lane & 3) ^ ((lane >> 4) & 3);              // global chunk fetched into LDS chunk lane&3
-    const size_t ldk = (size_t)g.K * 2;                         // bytes per operand row
+    // ---- contraction range and stage count
+    long long k0 = 0, k1 = g.K;                 // NT: k; TN: rows of this slice
+    if (TN) {
+        k0 = (long long)blockIdx.y * g.slice_rows;
+        k1 = k0 + g.slice_rows;
+        if (k1 > g.rows) k1 = g.rows;
+    }
+    const int T = (int)((k1 - k0 + PP_BK - 1) / PP_BK);
+
+    // ---- LDS-DMA sources.  Wave w moves pieces w, w+8 (operand A) and w+16, w+24 (operand B) of every stage.
+    //   NT: a piece is 16 rows x 64 B; lane l -> row l>>2, LDS chunk l&3 <- global chunk (l&3) ^ ((l>>4)&3)
+    //   TN: a piece is 2 rows x 512 B; lane l -> row l>>5, LDS chunk l&31 <- global chunk (l&31) ^ ((row&3)<<2)
     const unsigned char* psrc[PP_PIECES_PER_WAVE];
+    size_t stage_stride;                        // bytes from one stage's source to the next
+    int tn_row[PP_PIECES_PER_WAVE];             // TN: row of this lane's piece inside the stage (to test against k1)
+    if (!TN) {
+        const int pr = lane >> 2, pc = (lane & 3) ^ ((lane >> 4) & 3);
+        const size_t ldk = (size_t)g.K * 2;
+        stage_stride = PP_ROW_BYTES;
 #pragma unroll
-    for (int t = 0; t < PP_PIECES_PER_WAVE; ++t) {
-        const int piece = wave + 8 * t;                          // 0..31; < 16: A, else B
-        const int row = (piece & 15) * 16 + pr;
-        if (piece < 16) {
-            long long ar = bm + row;
-            if (ar >= g.rows) ar = g.rows - 1;                   // past the end: re-read the last row (never stored)
-            psrc[t] = reinterpret_cast<const unsigned char*>(g.A) + (size_t)ar * ldk + pc * 16;
-        } else {
-            psrc[t] = reinterpret_cast<const unsigned char*>(g.W) + (size_t)(bn + row) * ldk + pc * 16;
+        for (int t = 0; t < PP_PIECES_PER_WAVE; ++t) {
+            const int piece = wave + 8 * t;                      // 0..31; < 16: A, else B
+            const int row = (piece & 15) * 16 + pr;
+            tn_row[t] = 0;
+            if (piece < 16) {
+                long long ar = bm + row;
+                if (ar >= g.rows) ar = g.rows - 1;               // past the end: re-read the last row (never stored)
+                psrc[t] = reinterpret_cast<const unsigned char*>(g.A) + (size_t)ar * ldk + pc * 16;
+            } else {
+                psrc[t] = reinterpret_cast<const unsigned char*>(g.W) + (size_t)(bn + row) * ldk + pc * 16;
+            }
+        }
+    } else {
+        stage_stride = 0;                        // (computed per operand below: PP_BK rows of n1 or n2 elements)
+#pragma unroll
+        for (int t = 0; t < PP_PIECES_PER_WAVE; ++t) {
+            const int piece = wave + 8 * t;
+            const int row = (piece & 15) * 2 + (lane >> 5);      // 0..31
+            const int pc = (lane & 31) ^ ((row & 3) << 2);
+            tn_row[t] = row;
+            if (piece < 16) psrc[t] = reinterpret_cast<const unsigned char*>(g.A) + ((size_t)(k0 + row) * g.K + bm) * 2 + pc * 16;
+            else psrc[t] = reinterpret_cast<const unsigned char*>(g.W) + ((size_t)(k0 + row) * g.N + bn) * 2 + pc * 16;
         }
     }
-    // LDS offset of piece t inside a slot: A pieces at piece*1024, B pieces behind the A operand
-    auto piece_off = [&](int t) { return (wave + 8 * t) * 1024; };      // (pieces 16.. are B: 16 KiB + ...: same formula)
+    const size_t tn_stride_a = (size_t)PP_BK * g.K * 2, tn_stride_b = (size_t)PP_BK * g.N * 2;
+    const unsigned char* zsrc = TN ? g.zeros + (lane & 31) * 16 : nullptr;
+    const int piece_base = wave * 1024;          // piece t of this wave sits at piece_base + t * 8 KiB inside a slot
 #define MDNO_PP_DMA(ST)                                                                                         \
     {                                                                                                           \
         const int st_ = (ST), slot_ = st_ % PP_RING;       /* (ST may name the caller's loop variable) */       \
-        _Pragma("unroll") for (int pi_ = 0; pi_ < PP_PIECES_PER_WAVE; ++pi_)                                    \
-            __builtin_amdgcn_global_load_lds((glb_u8*)(psrc[pi_] + (size_t)st_ * PP_ROW_BYTES),                \
-                                             (lds_u8*)(lds + slot_ * PP_STAGE_BYTES + piece_off(pi_)), 16, 0, 0); \
+        _Pragma("unroll") for (int pi_ = 0; pi_ < PP_PIECES_PER_WAVE; ++pi_) {                                  \
+            const unsigned char* src_;                                                                          \
+            if (!TN) src_ = psrc[pi_] + (size_t)st_ * stage_stride;                                             \
+            else {                                                                                              \
+                src_ = psrc[pi_] + (size_t)st_ * (pi_ < 2 ? tn_stride_a : tn_stride_b);                         \
+                if (k0 + (long long)st_ * PP_BK + tn_row[pi_] >= k1) src_ = zsrc;   /* past the contraction: zeros */ \
+            }                                                                                                   \
+            __builtin_amdgcn_global_load_lds((glb_u8*)src_,                                                     \
+                                             (lds_u8*)(lds + slot_ * PP_STAGE_BYTES + piece_base + pi_ * 8192), 16, 0, 0); \
+        }                                                                                                       \
     }
 
-    // ---- fragment read offsets (row-swizzled 16-B chunks)
+    // ---- fragment read offsets
     int a_off[4], b_off[2];
+    int c0 = 0, c1 = 0;
+    if (!TN) {       // rows of 64 B, 16-B chunks swizzled by (row >> 2) & 3; lane = (row l31, k-half h)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = grp * 128 + i * 32 + l31;
-        a_off[i] = row * PP_ROW_BYTES;
-    }
+        for (int i = 0; i < 4; ++i) a_off[i] = (grp * 128 + i * 32 + l31) * PP_ROW_BYTES;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row = wn * 64 + j * 32 + l31;
-        b_off[j] = PP_OPERAND_BYTES + row * PP_ROW_BYTES;
+        for (int j = 0; j < 2; ++j) b_off[j] = PP_OPERAND_BYTES + (wn * 64 + j * 32 + l31) * PP_ROW_BYTES;
+        const int sw = (l31 >> 2) & 3;
+        c0 = ((0 + h) ^ sw) << 4;
+        c1 = ((2 + h) ^ sw) << 4;
+    } else {         // rows of 512 B (k index), chunk ^= (row & 3) << 2; 16-lane group gq = lane>>4, lane = 4q+p in it
+        const int gq = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+        const int rowb = (8 * (gq >> 1) + qq) * 512 + 8 * (pp & 1);          // + kk*16 rows + r*4 rows as immediates
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ch = (grp * 128 + i * 32 + 16 * (gq & 1)) / 8 + (pp >> 1);
+            a_off[i] = rowb + ((ch ^ (qq << 2)) << 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ch = (wn * 64 + j * 32 + 16 * (gq & 1)) / 8 + (pp >> 1);
+            b_off[j] = PP_OPERAND_BYTES + rowb + ((ch ^ (qq << 2)) << 4);
+        }
     }
-    const int sw = (l31 >> 2) & 3;              // (row >> 2) & 3: every row above is l31 plus a multiple of 32
-    const int c0 = ((0 + h) ^ sw) << 4, c1 = ((2 + h) ^ sw) << 4;     // k-step 0: chunks h, k-step 1: chunks 2 + h
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -132,24 +192,41 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NtArgs g) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     float bv0 = 0.f, bv1 = 0.f;      // fetched before the K loop and pinned (edge_mlp_split.hip, epilogue stores)
-    if (g.bias) {
+    if (EPI == EPI_BIAS && g.bias) {
         bv0 = g.bias[bn + wn * 64 + l31];
         bv1 = g.bias[bn + wn * 64 + 32 + l31];
     }
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(bv0), "+v"(bv1));      // the counted waits below must see DMA pieces only
 
-    const int T = g.K / PP_BK;
     bf16x8 fa[2][4], fb[2][2];
+    auto tr_frag = [&](const unsigned char* p_) {       // two transposing reads: k rows +0..3 and +4..7
+        typedef short s16x4 __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p_));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p_ + 4 * 512));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
 #define MDNO_PP_LOAD(ST)                                                                          \
     {                                                                                             \
         const unsigned char* sb_ = lds + ((ST) % PP_RING) * PP_STAGE_BYTES;                       \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
-            fa[0][i] = *reinterpret_cast<const bf16x8*>(sb_ + a_off[i] + c0);                     \
-            fa[1][i] = *reinterpret_cast<const bf16x8*>(sb_ + a_off[i] + c1);                     \
-        }                                                                                         \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                           \
-            fb[0][j] = *reinterpret_cast<const bf16x8*>(sb_ + b_off[j] + c0);                     \
-            fb[1][j] = *reinterpret_cast<const bf16x8*>(sb_ + b_off[j] + c1);                     \
+        if (!TN) {                                                                                \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                       \
+                fa[0][i] = *reinterpret_cast<const bf16x8*>(sb_ + a_off[i] + c0);                 \
+                fa[1][i] = *reinterpret_cast<const bf16x8*>(sb_ + a_off[i] + c1);                 \
+            }                                                                                     \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                       \
+                fb[0][j] = *reinterpret_cast<const bf16x8*>(sb_ + b_off[j] + c0);                 \
+                fb[1][j] = *reinterpret_cast<const bf16x8*>(sb_ + b_off[j] + c1);                 \
+            }                                                                                     \
+        } else {                                                                                  \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                       \
+                fa[0][i] = tr_frag(sb_ + a_off[i]);                                               \
+                fa[1][i] = tr_frag(sb_ + a_off[i] + 16 * 512);                                    \
+            }                                                                                     \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                       \
+                fb[0][j] = tr_frag(sb_ + b_off[j]);                                               \
+                fb[1][j] = tr_frag(sb_ + b_off[j] + 16 * 512);                                    \
+            }                                                                                     \
         }                                                                                         \
     }
 #define MDNO_PP_MMA()                                                                             \
@@ -168,7 +245,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NtArgs g) {
     __builtin_amdgcn_sched_barrier(0);
 
     // prologue: stages 0 and 1 in flight, stage 0 landed for everybody
-    MDNO_PP_DMA(0)
+    if (T > 0) { MDNO_PP_DMA(0) }
     if (T > 1) { MDNO_PP_DMA(1) }
     if (T > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -191,6 +268,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NtArgs g) {
         // it but the epilogue, which waves 0-3 then start while waves 4-7 are still multiplying)
         if (grp == 0 || t + 1 < T) { MDNO_PP_BARRIER() }
     }
+    if (T == 0 && grp == 0) { MDNO_PP_BARRIER() }   // (an empty slice: pair the stagger barrier)
 #undef MDNO_PP_DMA
 #undef MDNO_PP_LOAD
 #undef MDNO_PP_MMA
@@ -202,16 +280,31 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NtArgs g) {
     // tile through a private LDS patch (the ring is idle now: 8 KiB per wave), 32 rows at a time: bias / ReLU /
     // rounding on the way in (one element per ds_write), whole rows on the way out — 16 B per lane, a 128-B line
     // per 8 (bf16) or 4 (fp32) lanes.  LDS operations of one wave execute in order: no wait between the two.
-    constexpr int ESZ = OUT_BF16 ? 2 : 4;
+    constexpr bool OBF = OUT_BF16 && EPI != EPI_SLAB;
+    constexpr int ESZ = OBF ? 2 : 4;
     constexpr int PATCH_ROW = 64 * ESZ;                    // bytes per patch row (the wave's 64 columns)
     unsigned char* patch = lds + wave * (32 * 64 * 4);    // 8 KiB apart (fp32 size) for either type
     const size_t ldc = (size_t)g.N * ESZ;
     unsigned char* cbase = static_cast<unsigned char*>(g.C) + (size_t)(bn + wn * 64) * ESZ;
+    if (EPI == EPI_SLAB) cbase += (size_t)blockIdx.y * (size_t)g.K * g.N * 4;      // slab z = [n1 = K][n2 = N] fp32
+    const long long out_rows = TN ? (long long)g.K : g.rows;
     constexpr int LANES_PER_ROW = PATCH_ROW / 16;          // 8 or 16
     constexpr int ROWS_PER_INSTR = 64 / LANES_PER_ROW;     // 8 or 4
     const int orow = lane / LANES_PER_ROW, ochunk = lane % LANES_PER_ROW;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+        const long long m0 = bm + grp * 128 + i * 32;
+        // EPI_MASK: this lane's 16 B of the stored activation Y, one load per output store, issued first
+        uint4 yv[32 / ROWS_PER_INSTR];
+        if (EPI == EPI_MASK) {
+#pragma unroll
+            for (int rr = 0; rr < 32; rr += ROWS_PER_INSTR) {
+                long long m = m0 + rr + orow;
+                if (m >= out_rows) m = out_rows - 1;
+                yv[rr / ROWS_PER_INSTR] = *reinterpret_cast<const uint4*>(
+                    reinterpret_cast<const unsigned char*>(g.Y) + ((size_t)m * g.N + bn + wn * 64) * 2 + ochunk * 16);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const float bv = j ? bv1 : bv0;
@@ -221,18 +314,40 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NtArgs g) {
                 float v = acc[i][j][e] + bv;
                 if (RELU) v = fmaxf(v, 0.f);
                 unsigned char* dst = patch + r * PATCH_ROW + (j * 32 + l31) * ESZ;
-                if (OUT_BF16) *reinterpret_cast<__bf16*>(dst) = (__bf16)v;
+                if (OBF) *reinterpret_cast<__bf16*>(dst) = (__bf16)v;
                 else *reinterpret_cast<float*>(dst) = v;
             }
         }
-        const long long m0 = bm + grp * 128 + i * 32;
 #pragma unroll
         for (int rr = 0; rr < 32; rr += ROWS_PER_INSTR) {
-            const uint4 v = *reinterpret_cast<const uint4*>(patch + (rr + orow) * PATCH_ROW + ochunk * 16);
+            uint4 v = *reinterpret_cast<const uint4*>(patch + (rr + orow) * PATCH_ROW + ochunk * 16);
+            if (EPI == EPI_MASK) {      // eight bf16 per lane: keep where the stored activation is positive
+                const uint4 y = yv[rr / ROWS_PER_INSTR];
+                auto keep = [](unsigned vv, unsigned yy) {
+                    // bf16 > 0  <=>  sign clear and not zero (NaN activations cannot come out of a ReLU)
+                    const unsigned lo = ((yy & 0x8000u) == 0 && (yy & 0x7fffu) != 0) ? (vv & 0xffffu) : 0u;
+                    const unsigned hi = ((yy & 0x80000000u) == 0 && (yy & 0x7fff0000u) != 0) ? (vv & 0xffff0000u) : 0u;
+                    return lo | hi;
+                };
+                v.x = keep(v.x, y.x); v.y = keep(v.y, y.y); v.z = keep(v.z, y.z); v.w = keep(v.w, y.w);
+            }
             const long long m = m0 + rr + orow;
-            if (m < g.rows) *reinterpret_cast<uint4*>(cbase + (size_t)m * ldc + ochunk * 16) = v;
+            if (m < out_rows) *reinterpret_cast<uint4*>(cbase + (size_t)m * ldc + ochunk * 16) = v;
         }
     }
+}
+
+// out[i] = sum over slices (in order) of slab[z][i]
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slab, int slices, long long count,
+                                                           float* __restrict__ out) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= count) return;
+    float4 s = *reinterpret_cast<const float4*>(slab + i);
+    for (int z = 1; z < slices; ++z) {
+        const float4 v = *reinterpret_cast<const float4*>(slab + (size_t)z * count + i);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + i) = s;
 }
 
 }  // namespace
@@ -241,24 +356,69 @@ bool gemm_nt_pp_supported(long long rows, int N, int K) {
     return rows > 0 && N % PP_T == 0 && K % PP_BK == 0 && K >= 2 * PP_BK;
 }
 
+template <bool TN, int EPI, bool RELU, bool OUT_BF16>
+static int launch_pp(const PpArgs& g, unsigned slices, hipStream_t s) {
+    static std::atomic<unsigned long long> raised{0};
+    MDNO_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(&gemm_pp_kernel<TN, EPI, RELU, OUT_BF16>), PP_LDS_BYTES, raised));
+    const long long nwg = g.tiles_m * g.tiles_n;
+    MDNO_REQUIRE(nwg < (1ll << 31), MDNO_EUNSUPPORTED, "gemm_pp: too many tiles");
+    hipLaunchKernelGGL((gemm_pp_kernel<TN, EPI, RELU, OUT_BF16>), dim3((unsigned)nwg, slices), dim3(512), PP_LDS_BYTES, s, g);
+    return check_launch("gemm_pp_kernel");
+}
+
 // C = act(A . W^T + b): A bf16 [rows,K], W bf16 [N,K] (both row-major), C bf16 or fp32 [rows,N]
 int gemm_nt_pp(const void* A, const void* W, const float* bias, long long rows, int N, int K, int relu, int out_bf16,
                void* C, hipStream_t s) {
     MDNO_REQUIRE(gemm_nt_pp_supported(rows, N, K), MDNO_EUNSUPPORTED, "gemm_nt_pp: rows=%lld N=%d K=%d", rows, N, K);
-    NtArgs g{static_cast<const __bf16*>(A), static_cast<const __bf16*>(W), bias, C, rows, N, K, N / PP_T,
-             (rows + PP_T - 1) / PP_T};
-    const long long nwg = g.tiles_m * g.tiles_n;
-    MDNO_REQUIRE(nwg < (1ll << 31), MDNO_EUNSUPPORTED, "gemm_nt_pp: too many tiles");
-    static std::atomic<unsigned long long> raised[4] = {};
-#define MDNO_GO(R, O, IDX)                                                                                         \
-    {                                                                                                              \
-        MDNO_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(&gemm_nt_pp_kernel<R, O>), PP_LDS_BYTES, raised[IDX])); \
-        hipLaunchKernelGGL((gemm_nt_pp_kernel<R, O>), dim3((unsigned)nwg), dim3(512), PP_LDS_BYTES, s, g);          \
+    PpArgs g{static_cast<const __bf16*>(A), static_cast<const __bf16*>(W), bias, nullptr, C, nullptr, rows, N, K, N / PP_T,
+             (rows + PP_T - 1) / PP_T, 0};
+    if (relu) return out_bf16 ? launch_pp<false, EPI_BIAS, true, true>(g, 1, s) : launch_pp<false, EPI_BIAS, true, false>(g, 1, s);
+    return out_bf16 ? launch_pp<false, EPI_BIAS, false, true>(g, 1, s) : launch_pp<false, EPI_BIAS, false, false>(g, 1, s);
+}
+
+// C bf16 [rows,N] = (Y > 0) ? A . W^T : 0 — the input gradient of a Linear+ReLU layer whose stored output is Y
+int gemm_nt_pp_masked(const void* A, const void* W, const void* Y, long long rows, int N, int K, void* C, hipStream_t s) {
+    MDNO_REQUIRE(gemm_nt_pp_supported(rows, N, K) && Y, MDNO_EUNSUPPORTED, "gemm_nt_pp_masked: rows=%lld N=%d K=%d", rows, N, K);
+    PpArgs g{static_cast<const __bf16*>(A), static_cast<const __bf16*>(W), nullptr, static_cast<const __bf16*>(Y), C, nullptr,
+             rows, N, K, N / PP_T, (rows + PP_T - 1) / PP_T, 0};
+    return launch_pp<false, EPI_MASK, false, true>(g, 1, s);
+}
+
+// ---- C [n1,n2] fp32 = A^T . B over rows: A bf16 [rows,n1], B bf16 [rows,n2]
+bool gemm_tn_pp_supported(long long rows, int n1, int n2) { return rows > 0 && n1 % PP_T == 0 && n2 % PP_T == 0; }
+
+static int tn_slices(long long rows, int n1, int n2) {
+    const long long tiles = (long long)(n1 / PP_T) * (n2 / PP_T);
+    long long sl = 256 / tiles;                    // one workgroup per CU when the tiles alone do not fill the chip
+    if (sl < 1) sl = 1;
+    if (sl > 32) sl = 32;
+    const long long max_sl = (rows + 4 * PP_BK - 1) / (4 * PP_BK);      // at least a few stages per slice
+    if (sl > max_sl) sl = max_sl;
+    return (int)sl;
+}
+
+size_t gemm_tn_pp_workspace_bytes(long long rows, int n1, int n2) {
+    // slabs (none when one slice writes C directly) + the 512 zero bytes; sized for the largest slice count
+    return align_up((size_t)32 * n1 * n2 * sizeof(float), 256) + 1024;
+}
+
+int gemm_tn_pp(const void* A, const void* B, long long rows, int n1, int n2, float* C, void* workspace, hipStream_t s) {
+    MDNO_REQUIRE(gemm_tn_pp_supported(rows, n1, n2), MDNO_EUNSUPPORTED, "gemm_tn_pp: rows=%lld n1=%d n2=%d", rows, n1, n2);
+    const int slices = tn_slices(rows, n1, n2);
+    const long long slice_rows = ((rows + slices - 1) / slices + PP_BK - 1) / PP_BK * PP_BK;
+    const size_t slab_bytes = align_up((size_t)32 * n1 * n2 * sizeof(float), 256);
+    unsigned char* zeros = static_cast<unsigned char*>(workspace) + slab_bytes;
+    MDNO_TRY(fill_ints(reinterpret_cast<int*>(zeros), 128, 0, s));
+    float* slabs = slices == 1 ? C : static_cast<float*>(workspace);
+    PpArgs g{static_cast<const __bf16*>(A), static_cast<const __bf16*>(B), nullptr, nullptr, slabs, zeros, rows, n2, n1,
+             n2 / PP_T, n1 / PP_T, slice_rows};
+    MDNO_TRY((launch_pp<true, EPI_SLAB, false, false>(g, (unsigned)slices, s)));
+    if (slices > 1) {
+        const long long count = (long long)n1 * n2;
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((count / 4 + 255) / 256)), dim3(256), 0, s,
+                           static_cast<const float*>(workspace), slices, count, C);
     }
-    if (relu) { if (out_bf16) MDNO_GO(true, true, 0) else MDNO_GO(true, false, 1) }
-    else      { if (out_bf16) MDNO_GO(false, true, 2) else MDNO_GO(false, false, 3) }
-#undef MDNO_GO
-    return check_launch("gemm_nt_pp_kernel");
+    return check_launch("gemm_tn_pp");
 }
 
 }  // namespace mdno

@@ -115,11 +115,18 @@ constexpr int kMaxF16Applications = 62;
 // x_prepared: the bf16 image of x and q = x.B3 are already in f.xp / f.q (left there by the previous
 // application, which was given this application's b3 as next_b3); next_b3 NULL: nothing follows.
 
-// bf16 training GEMMs (gemm_bf16.hip): C = act(A . W^T + b), A bf16 [rows,K], W bf16 [N,K], C bf16 or fp32;
-// 256 x 256 tiles, two wave groups one phase apart (N % 256 == 0, K % 32 == 0, K >= 64)
+// bf16 training GEMMs (gemm_bf16.hip): 256 x 256 tiles, 8 waves, two wave groups one phase apart over an
+// LDS-DMA ring of 32-k stages.
+//   gemm_nt_pp         C = act(A . W^T + b), A bf16 [rows,K], W bf16 [N,K], C bf16 or fp32 (N % 256 == 0, K % 32 == 0, K >= 64)
+//   gemm_nt_pp_masked  C bf16 = (Y > 0) ? A . W^T : 0 — Linear+ReLU input gradient with the mask fused (Y bf16 [rows,N])
+//   gemm_tn_pp         C fp32 [n1,n2] = A^T . B over rows (n1, n2 % 256 == 0); K slices added in fixed order
 bool gemm_nt_pp_supported(long long rows, int N, int K);
 int gemm_nt_pp(const void* A, const void* W, const float* bias, long long rows, int N, int K, int relu, int out_bf16,
                void* C, hipStream_t s);
+int gemm_nt_pp_masked(const void* A, const void* W, const void* Y, long long rows, int N, int K, void* C, hipStream_t s);
+bool gemm_tn_pp_supported(long long rows, int n1, int n2);
+size_t gemm_tn_pp_workspace_bytes(long long rows, int n1, int n2);
+int gemm_tn_pp(const void* A, const void* B, long long rows, int n1, int n2, float* C, void* workspace, hipStream_t s);
 
 int nnconv(const float* x, const int* row_ptr, const int* src, int num_rows, const float* w_e, const float* root,
            const float* bias, int Cin, int Cout, int aggr, int relu, float* y, hipStream_t s);

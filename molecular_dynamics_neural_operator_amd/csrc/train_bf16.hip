@@ -579,7 +579,22 @@ extern "C" int mdno_linear_smallk_bf16_fwd(const float* a, const float* w, const
 }
 
 extern "C" size_t mdno_gemm_atb_bf16_workspace_bytes(int n1, int n2) {
-    return align_up((size_t)kTnSlices * n1 * n2 * sizeof(float), 256);
+    const size_t old_path = align_up((size_t)kTnSlices * n1 * n2 * sizeof(float), 256);
+    if (!gemm_tn_pp_supported(1, n1, n2)) return old_path;
+    const size_t pp = gemm_tn_pp_workspace_bytes(1, n1, n2);
+    return pp > old_path ? pp : old_path;
+}
+
+extern "C" int mdno_linear_bf16_masked_supported(int64_t rows, int n, int k) { return gemm_nt_pp_supported(rows, n, k) ? 1 : 0; }
+
+extern "C" int mdno_linear_bf16_masked(const void* a, const float* w, const void* y, int64_t rows, int n, int k, void* c,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
+    MDNO_REQUIRE(a && w && y && c && workspace && rows > 0, MDNO_EINVAL, "mdno_linear_bf16_masked: bad arguments");
+    MDNO_REQUIRE(gemm_nt_pp_supported(rows, n, k), MDNO_EUNSUPPORTED, "mdno_linear_bf16_masked: n=%d (x256) k=%d (x32, >= 64)", n, k);
+    MDNO_REQUIRE(workspace_bytes >= mdno_linear_bf16_workspace_bytes(n, k), MDNO_EWORKSPACE,
+                 "mdno_linear_bf16_masked: workspace too small");
+    MDNO_TRY(mdno_cast_bf16(w, (int64_t)n * k, workspace, stream));      // master weights -> bf16, every call
+    return gemm_nt_pp_masked(a, workspace, y, (long long)rows, n, k, c, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int mdno_gemm_atb_bf16(const void* a, const void* b, int64_t rows, int n1, int n2, float* c,
@@ -589,6 +604,7 @@ extern "C" int mdno_gemm_atb_bf16(const void* a, const void* b, int64_t rows, in
     MDNO_REQUIRE(workspace_bytes >= mdno_gemm_atb_bf16_workspace_bytes(n1, n2), MDNO_EWORKSPACE,
                  "mdno_gemm_atb_bf16: workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (gemm_tn_pp_supported(rows, n1, n2)) return gemm_tn_pp(a, b, (long long)rows, n1, n2, c, workspace, s);
     const long long slice_rows = ((rows + kTnSlices - 1) / kTnSlices + 31) / 32 * 32;
     hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(n2 / 128, n1 / 128, kTnSlices), dim3(256), 0, s,
                        static_cast<const __bf16*>(a), static_cast<const __bf16*>(b), static_cast<float*>(workspace),

@@ -435,6 +435,24 @@ def linear_bf16(a: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], rel
     return c
 
 
+def linear_bf16_relu_bwd(g: torch.Tensor, w_t: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """bf16((y > 0) * (g . w_t^T)): the input gradient of a Linear + ReLU layer whose stored (bf16) output is y —
+    g bf16 [rows,k], w_t fp32 [n,k] (the layer's weight, transposed), y bf16 [rows,n].  One GEMM with the mask in its
+    epilogue where the shape tiles (n % 256 == 0, k % 32 == 0); otherwise the GEMM, then mdno_relu_bwd_bf16 —
+    the same fp32 accumulation, mask and single rounding either way."""
+    lib = _lib.load()
+    g, w_t, y = _bf16(g), f32(w_t), _bf16(y)
+    rows, k = g.shape
+    n = w_t.shape[0]
+    if not lib.mdno_linear_bf16_masked_supported(rows, n, k):
+        return relu_bwd_bf16(linear_bf16(g, w_t, None, out_bf16=False), y, out_bf16=True)
+    c = torch.empty((rows, n), dtype=torch.bfloat16, device=g.device)
+    ws = _ws(lib.mdno_linear_bf16_workspace_bytes(n, k), g.device)
+    check(lib.mdno_linear_bf16_masked(ptr(g), ptr(w_t), ptr(y), rows, n, k, ptr(c), ptr(ws), ws.numel(),
+                                      stream_ptr(g.device)), "mdno_linear_bf16_masked")
+    return c
+
+
 def gemm_atb_bf16(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
     a, b = _bf16(a), _bf16(b)

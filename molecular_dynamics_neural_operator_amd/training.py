@@ -95,11 +95,11 @@ class KernelIntegralBlock(torch.autograd.Function):
         del GZ, GS
         d_b2 = ops.colsum_bf16(d_we)
         d_w2 = ops.gemm_atb_bf16(d_we, h2)
-        gz2 = ops.relu_bwd_bf16(ops.linear_bf16(d_we, ops.transpose(w2), None, out_bf16=False), h2, out_bf16=True)
+        gz2 = ops.linear_bf16_relu_bwd(d_we, ops.transpose(w2), h2)        # bf16((h2 > 0) * (dW_e . W2))
         del d_we
         d_b1 = ops.colsum_bf16(gz2)
         d_w1 = ops.gemm_atb_bf16(gz2, h1)
-        gz1 = ops.relu_bwd_bf16(ops.linear_bf16(gz2, ops.transpose(w1), None, out_bf16=False), h1, out_bf16=True)
+        gz1 = ops.linear_bf16_relu_bwd(gz2, ops.transpose(w1), h1)
         d_b0 = ops.colsum_bf16(gz1)
         # d_w0 = gz1^T . ea with ea [E, 6]: the six attribute columns ride in a zero-padded 128-column bf16
         # operand of the same A^T.B kernel (the generic fp32 kernel took as long as the big products)

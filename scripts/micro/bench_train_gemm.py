@@ -30,7 +30,17 @@ for rows, n, k in ((300, 256, 64), (1000, 256, 1024), (517, 4096, 128), (257, 51
     good = e1 < 3e-6 and e2 < 4e-3 and e3 < 3e-6
     ok &= good
     print(f"NT rows={rows} n={n} k={k}: fp32-out {e1:.2e}  bf16-out+relu {e2:.2e}  no-bias {e3:.2e}  {'ok' if good else 'FAIL'}", flush=True)
-for rows, n1, n2 in ((5000, 128, 256), (333, 1024, 128), (4097, 256, 4096), (31, 128, 128), (70000, 512, 256)):
+# masked variant: bf16((y > 0) * (g . w_t^T)) == the two-step path, bit for bit
+for rows, n, k in ((300, 256, 64), (1000, 256, 1024), (517, 1024, 4096)):
+    gq, w, yv = torch.randn(rows, k, generator=g), torch.randn(n, k, generator=g) / k ** 0.5, torch.randn(rows, n, generator=g)
+    yv = bf(torch.relu(yv)).to(dev)
+    two = ops.relu_bwd_bf16(ops.linear_bf16(bf(gq).to(dev), w.to(dev), None, out_bf16=False), yv, out_bf16=True)
+    one = ops.linear_bf16_relu_bwd(bf(gq).to(dev), w.to(dev), yv)
+    good = torch.equal(one, two)
+    ok &= good
+    print(f"NT masked rows={rows} n={n} k={k}: equal to GEMM + relu_bwd: {good}", flush=True)
+for rows, n1, n2 in ((5000, 128, 256), (333, 1024, 128), (4097, 256, 4096), (31, 256, 256), (70000, 512, 256), (1000, 4096, 1024),
+                     (43712, 1024, 1024)):
     a, b = torch.randn(rows, n1, generator=g), torch.randn(rows, n2, generator=g)
     got = ops.gemm_atb_bf16(bf(a).to(dev), bf(b).to(dev))
     e = rel(got, bf(a).double().t() @ bf(b).double())
@@ -68,6 +78,7 @@ for name, fn, fl in (
         ("NT h2.W2^T   [E,1024]x[1024,4096]      bf16-out", lambda: ops.linear_bf16(h, w2, b2, relu=False, out_bf16=True), 2.0 * E * k * 4096),
         ("NT dWe.W2    [E,4096]x[4096,1024]      fp32-out", lambda: ops.linear_bf16(big, w2t, None, relu=False, out_bf16=False), 2.0 * E * k * 4096),
         ("NT gz2.W1    [E,1024]x[1024,1024]      fp32-out", lambda: ops.linear_bf16(h, w1, None, relu=False, out_bf16=False), 2.0 * E * k * k),
+        ("NT dWe.W2 masked [E,4096]x[4096,1024] bf16-out", lambda: ops.linear_bf16_relu_bwd(big, w2t, h), 2.0 * E * k * 4096),
         ("TN dWe^T.h2  [E,4096]^T x [E,1024]", lambda: ops.gemm_atb_bf16(big, h), 2.0 * E * k * 4096),
         ("TN gz2^T.h1  [E,1024]^T x [E,1024]", lambda: ops.gemm_atb_bf16(h, h), 2.0 * E * k * k)):
     ms = timeit(fn)

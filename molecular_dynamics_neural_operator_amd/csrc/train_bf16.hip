@@ -501,21 +501,39 @@ __global__ __launch_bounds__(256) void relu_bwd_bf16_kernel(const float* __restr
     else static_cast<float4*>(out)[i] = r;
 }
 
-// column sums of a bf16 matrix: block (column group of 64, row slice) -> part[slice][n]; reduced in slice order
+// column sums of a bf16 matrix: block = (512 columns, row slice); thread = 8 consecutive columns (one 16-B load per
+// row: a wave reads a contiguous KiB) x one of four row phases -> part[slice][n]; phases added in order, slices
+// reduced in slice order.  (One 2-byte load per thread and row, 128 B per wave-load, took 94 us for the
+// 358 MB of dW_e; this shape streams.)
 __global__ __launch_bounds__(256) void colsum_bf16_kernel(const __bf16* __restrict__ a, float* __restrict__ part,
                                                           long long rows, int n, long long slice_rows) {
-    __shared__ float red[4][64];
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    __shared__ float red[4][64][8];
+    const int cg = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int col = blockIdx.x * 512 + cg * 8;
     const long long r0 = (long long)blockIdx.y * slice_rows;
     long long r1 = r0 + slice_rows;
     if (r1 > rows) r1 = rows;
-    float s = 0.f;
+    float s[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = 0.f;
     if (col < n)
-        for (long long r = r0 + rl; r < r1; r += 4) s += bf2f(reinterpret_cast<const unsigned short*>(a)[(size_t)r * n + col]);
-    red[rl][threadIdx.x & 63] = s;
+        for (long long r = r0 + rl; r < r1; r += 4) {
+            const uint4 u = *reinterpret_cast<const uint4*>(a + (size_t)r * n + col);
+            const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s[2 * j] += __builtin_bit_cast(float, w[j] << 16);
+                s[2 * j + 1] += __builtin_bit_cast(float, w[j] & 0xffff0000u);
+            }
+        }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[rl][cg][j] = s[j];
     __syncthreads();
-    if (rl == 0 && col < n)
-        part[(size_t)blockIdx.y * n + col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (rl == 0 && col < n) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            part[(size_t)blockIdx.y * n + col + j] = (red[0][cg][j] + red[1][cg][j]) + (red[2][cg][j] + red[3][cg][j]);
+    }
 }
 
 constexpr int kTnSlices = 16, kColSlicesB = 128;
@@ -669,7 +687,8 @@ extern "C" int mdno_colsum_bf16(const void* a, int64_t rows, int n, float* out, 
     MDNO_REQUIRE(workspace_bytes >= mdno_colsum_bf16_workspace_bytes(n), MDNO_EWORKSPACE, "mdno_colsum_bf16: workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long long slice_rows = (rows + kColSlicesB - 1) / kColSlicesB;
-    hipLaunchKernelGGL(colsum_bf16_kernel, dim3((n + 63) / 64, kColSlicesB), dim3(256), 0, s, static_cast<const __bf16*>(a),
+    MDNO_REQUIRE(n % 8 == 0 && (reinterpret_cast<uintptr_t>(a) & 15) == 0, MDNO_EUNSUPPORTED, "mdno_colsum_bf16: n=%d (x8)", n);
+    hipLaunchKernelGGL(colsum_bf16_kernel, dim3((n + 511) / 512, kColSlicesB), dim3(256), 0, s, static_cast<const __bf16*>(a),
                        static_cast<float*>(workspace), (long long)rows, n, slice_rows);
     hipLaunchKernelGGL(reduce_slices_bf16path_kernel, dim3((n + 255) / 256), dim3(256), 0, s,
                        static_cast<const float*>(workspace), kColSlicesB, (long long)n, out);

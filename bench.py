@@ -362,7 +362,10 @@ def leg_cfg4_training(dev, frames=10000, batch=128, kernel_width=1024, depth=6, 
                 p_.mul_(0.05)
         model.to(dev)
         model.train_precision = precision
-        opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=5e-4)
+        try:      # torch's single-kernel Adam where the build has it (same update rule)
+            opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=5e-4, fused=True)
+        except (RuntimeError, TypeError):
+            opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=5e-4)
         loss_fn = LpLoss(size_average=False)
         train_epoch(model, (dtraj.batch(i) for i in idx[:2]), opt, loss_fn)              # warm-up
         torch.cuda.synchronize()

@@ -266,6 +266,7 @@ int mdno_rollout_plan_timer_detach(mdno_rollout_plan* plan);
  *   mdno_gemm_atb         C (+)= A^T . B             A [rows,n1], B [rows,n2] -> C [n1,n2] (weight grads)
  *   mdno_colsum           out (+)= column sums of A [rows,n]                       (bias grads)
  *   mdno_relu_bwd         out = g * (y > 0) [* row_scale[row]]
+ *   mdno_relu_bwd2        gz = g * (y > 0) and gs = gz * row_scale[row] in one pass (same values as two calls)
  *   mdno_transpose        At [cols,rows] = A [rows,cols]^T
  *   mdno_inv_degree       inv[r] = 1/max(deg_r,1) (mean) or 1 (add)
  *   mdno_nnconv_bwd_x     g_prev[r] = gz[r].root^T + sum_{e: src e = r} W_e . gs[dst e]; edges grouped by
@@ -286,6 +287,8 @@ int mdno_gemm_atb(const float* a, const float* b, int64_t rows, int n1, int n2, 
                   void* workspace, size_t workspace_bytes, void* stream);
 int mdno_colsum(const float* a, int64_t rows, int n, float* out, int accumulate,
                 void* workspace, size_t workspace_bytes, void* stream);
+int mdno_relu_bwd2(const float* g, const float* y, const float* row_scale, int64_t rows, int n, float* gz, float* gs,
+                   void* stream);
 int mdno_relu_bwd(const float* g, const float* y, const float* row_scale, int64_t rows, int n, float* out,
                   void* stream);
 int mdno_transpose(const float* a, int rows, int cols, float* at, void* stream);

@@ -80,6 +80,7 @@ SIGNATURES = {
     "mdno_gemm_atb": (_I, [_P, _P, _L, _I, _I, _P, _I, _P, _SZ, _P]),
     "mdno_colsum": (_I, [_P, _L, _I, _P, _I, _P, _SZ, _P]),
     "mdno_relu_bwd": (_I, [_P, _P, _P, _L, _I, _P, _P]),
+    "mdno_relu_bwd2": (_I, [_P, _P, _P, _L, _I, _P, _P, _P]),
     "mdno_transpose": (_I, [_P, _I, _I, _P, _P]),
     "mdno_inv_degree": (_I, [_P, _I, _I, _P, _P]),
     "mdno_nnconv_bwd_x": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P, _P]),

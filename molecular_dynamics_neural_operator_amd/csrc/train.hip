@@ -252,6 +252,25 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__
     *reinterpret_cast<float4*>(out + id) = o;
 }
 
+// both at once: gz = g * (y > 0) and gs = gz * scale[row] — what the conv backward needs of one application
+// (d root, d bias read gz; the input and edge-weight gradients read gs = gz / max(deg,1)); same arithmetic as two calls
+__global__ __launch_bounds__(256) void relu_bwd2_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                        const float* __restrict__ row_scale, float* __restrict__ gz,
+                                                        float* __restrict__ gs, long long rows, int N) {
+    const long long id = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (id >= rows * N) return;
+    const float4 gv = *reinterpret_cast<const float4*>(g + id);
+    const float4 yv = *reinterpret_cast<const float4*>(y + id);
+    const float sc = row_scale[id / N];
+    float4 a, b;
+    a.x = yv.x > 0.f ? gv.x : 0.f; b.x = yv.x > 0.f ? gv.x * sc : 0.f;
+    a.y = yv.y > 0.f ? gv.y : 0.f; b.y = yv.y > 0.f ? gv.y * sc : 0.f;
+    a.z = yv.z > 0.f ? gv.z : 0.f; b.z = yv.z > 0.f ? gv.z * sc : 0.f;
+    a.w = yv.w > 0.f ? gv.w : 0.f; b.w = yv.w > 0.f ? gv.w * sc : 0.f;
+    *reinterpret_cast<float4*>(gz + id) = a;
+    *reinterpret_cast<float4*>(gs + id) = b;
+}
+
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ A, float* __restrict__ At, int R, int Cc) {
     __shared__ float tile[32][33];
     const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
@@ -499,6 +518,16 @@ extern "C" int mdno_relu_bwd(const float* g, const float* y, const float* row_sc
     hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), g, y, row_scale, out, (long long)rows, n);
     return check_launch("mdno_relu_bwd");
+}
+
+extern "C" int mdno_relu_bwd2(const float* g, const float* y, const float* row_scale, int64_t rows, int n, float* gz,
+                              float* gs, void* stream) {
+    MDNO_REQUIRE(g && y && row_scale && gz && gs && rows > 0 && n > 0 && n % 4 == 0, MDNO_EINVAL,
+                 "mdno_relu_bwd2: bad arguments (n % 4)");
+    const long long quads = rows * n / 4;
+    hipLaunchKernelGGL(relu_bwd2_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), g, y, row_scale, gz, gs, (long long)rows, n);
+    return check_launch("mdno_relu_bwd2");
 }
 
 extern "C" int mdno_transpose(const float* a, int rows, int cols, float* at, void* stream) {

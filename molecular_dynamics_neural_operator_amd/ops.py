@@ -328,6 +328,15 @@ def relu_bwd(g: torch.Tensor, y: torch.Tensor, row_scale: Optional[torch.Tensor]
     return out
 
 
+def relu_bwd2(g: torch.Tensor, y: torch.Tensor, row_scale: torch.Tensor, gz: torch.Tensor, gs: torch.Tensor) -> None:
+    """gz = g * (y > 0), gs = gz * row_scale[row] (both written in place)."""
+    lib = _lib.load()
+    g, y = f32(g), f32(y)
+    rows, n = g.shape
+    check(lib.mdno_relu_bwd2(ptr(g), ptr(y), ptr(row_scale), rows, n, ptr(gz), ptr(gs), stream_ptr(g.device)),
+          "mdno_relu_bwd2")
+
+
 def transpose(a: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
     a = f32(a)

@@ -86,8 +86,7 @@ class KernelIntegralBlock(torch.autograd.Function):
         GS = torch.empty((L, R, 64), dtype=torch.float32, device=X.device)
         g = ops.f32(g_out)
         for a in range(L, 0, -1):
-            ops.relu_bwd(g, X[a], None, out=GZ[a - 1])
-            ops.relu_bwd(g, X[a], inv, out=GS[a - 1])
+            ops.relu_bwd2(g, X[a], inv, GZ[a - 1], GS[a - 1])
             g = ops.nnconv_bwd_x_bf16w(GZ[a - 1], GS[a - 1], by_src, w_e, root1 if a <= depth else root2)
         d_root1, d_bias1 = ops.nnconv_bwd_root(X[0:depth].reshape(-1, 64), GZ[0:depth].reshape(-1, 64))
         d_root2, d_bias2 = ops.nnconv_bwd_root(X[depth:L].reshape(-1, 64), GZ[depth:L].reshape(-1, 64))
@@ -121,8 +120,7 @@ class KernelIntegralBlock(torch.autograd.Function):
         GS = torch.empty((L, R, 64), dtype=torch.float32, device=X.device)
         g = ops.f32(g_out)
         for a in range(L, 0, -1):
-            ops.relu_bwd(g, X[a], None, out=GZ[a - 1])
-            ops.relu_bwd(g, X[a], inv, out=GS[a - 1])
+            ops.relu_bwd2(g, X[a], inv, GZ[a - 1], GS[a - 1])
             g = ops.nnconv_bwd_x(GZ[a - 1], GS[a - 1], by_src, w_e, root1 if a <= depth else root2)
         d_root1, d_bias1 = ops.nnconv_bwd_root(X[0:depth].reshape(-1, 64), GZ[0:depth].reshape(-1, 64))
         d_root2, d_bias2 = ops.nnconv_bwd_root(X[depth:L].reshape(-1, 64), GZ[depth:L].reshape(-1, 64))

@@ -89,7 +89,10 @@ with torch.no_grad():     # the reference's init makes activations explode throu
 cpu_model = copy.deepcopy(model)
 model.to(dev)
 model.train_precision = a.precision
-opt = torch.optim.Adam(model.parameters(), lr=a.lr, weight_decay=5e-4)
+try:      # torch's single-kernel Adam where the build has it (same update rule; graph_kernel.py:541-543)
+    opt = torch.optim.Adam(model.parameters(), lr=a.lr, weight_decay=5e-4, fused=True)
+except (RuntimeError, TypeError):
+    opt = torch.optim.Adam(model.parameters(), lr=a.lr, weight_decay=5e-4)
 sched = torch.optim.lr_scheduler.StepLR(opt, step_size=50, gamma=0.8)
 loss_fn = LpLoss(size_average=False)
 

@@ -53,6 +53,9 @@ def test_linear_atb_colsum_transpose_relu(dev):
     gq, y, sc = torch.randn(40, 64, generator=g), torch.randn(40, 64, generator=g), torch.rand(40, generator=g)
     assert torch.equal(ops.relu_bwd(gq.to(dev), y.to(dev)).cpu(), gq * (y > 0))
     torch.testing.assert_close(ops.relu_bwd(gq.to(dev), y.to(dev), sc.to(dev)).cpu(), gq * (y > 0) * sc[:, None])
+    gz, gs = torch.empty(40, 64, device=dev), torch.empty(40, 64, device=dev)       # both outputs in one pass
+    ops.relu_bwd2(gq.to(dev), y.to(dev), sc.to(dev), gz, gs)
+    assert torch.equal(gz, ops.relu_bwd(gq.to(dev), y.to(dev))) and torch.equal(gs, ops.relu_bwd(gq.to(dev), y.to(dev), sc.to(dev)))
 
 
 def test_nnconv_backward_ops_vs_autograd(dev, O):

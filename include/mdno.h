@@ -79,8 +79,6 @@ extern "C" {
 #define MDNO_STATUS_BAD_AMINOACID 2   /* x_aminoacid outside [0, num_embeddings) */
 #define MDNO_STATUS_ASYMMETRIC_GRAPH 4 /* factored conv: an edge has no reverse edge */
 #define MDNO_STATUS_DEGREE_OVERFLOW  8 /* factored conv: a node has more edges than the max_degree bound */
-#define MDNO_STATUS_FUSED_TIMEOUT   32 /* the one-launch conv path for small graphs waited ~1 s for a row another
-                                          workgroup should have published (a workgroup not resident): results invalid */
 #define MDNO_STATUS_BAD_EDGE_INDEX  16 /* mdno_coo_to_csr: a node id outside [0, num_nodes) (clamped in bounds;
                                           the reference's index_select / scatter raise IndexError there) */
 

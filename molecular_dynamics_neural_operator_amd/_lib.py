@@ -20,7 +20,6 @@ CONV_MODES = {"materialized": 0, "factored": 1, "auto": 2}
 STATUS_ASYMMETRIC_GRAPH = 4
 STATUS_DEGREE_OVERFLOW = 8
 STATUS_BAD_EDGE_INDEX = 16
-STATUS_FUSED_TIMEOUT = 32
 
 
 class MdnoError(RuntimeError):
@@ -182,8 +181,6 @@ def raise_on_status(status_word: int, what: str = "") -> None:
         raise MdnoError(pre + "radius graph exceeded edge_cap; use a larger capacity")
     if st & STATUS_DEGREE_OVERFLOW:
         raise MdnoError(pre + "a node has more edges than max_degree; raise the bound (0 = n_atoms)")
-    if st & STATUS_FUSED_TIMEOUT:
-        raise MdnoError(pre + "the one-launch conv path timed out waiting for another workgroup's rows")
     if st & STATUS_ASYMMETRIC_GRAPH:
         raise MdnoError(pre + "factored conv met an edge without a reverse edge (graph not symmetric)")
     raise MdnoError(pre + f"device status {st:#x}")

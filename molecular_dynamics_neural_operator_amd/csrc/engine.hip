@@ -76,7 +76,7 @@ bool separate_conv2_kernel(const mdno_kernelnn_params* p) {
 
 struct FwdWs {
     float *xa, *xb, *w_e, *h2;
-    void *mlp, *fact, *fused;
+    void *mlp, *fact;
     size_t mlp_bytes, total;
     bool factored;
 };
@@ -114,12 +114,6 @@ FwdWs carve_fwd(void* ws, const mdno_kernelnn_params* p, int M, int N, long long
     // the materialised path also serves explicit-edge_attr calls when conv_mode asks for factored
     f.w_e = cv.take<float>(f.factored ? 0 : (size_t)edge_cap * p->width * p->width);
     f.mlp = cv.take<char>(f.mlp_bytes);
-    // small graphs, materialised: all conv applications + fc2 in one launch (nnconv.hip)
-    f.fused = nullptr;
-    if (!f.factored && nnconv_fused_applicable((int)R, edge_cap, p->width)) {
-        char* base = cv.take<char>(nnconv_fused_workspace_bytes((int)R, 2 * p->depth));
-        f.fused = ws ? (void*)base : (void*)1;      // (sizing pass: non-null marker)
-    }
     f.total = cv.used();
     return f;
 }
@@ -174,16 +168,6 @@ int forward_impl(const mdno_kernelnn_params* p, const float* frames, int t0, con
             }
         }
     } else {
-        // small graph with the reference's single shared kernel: edge-MLP once, then every conv application and fc2
-        // in ONE launch (an application here is ~2 us of work behind a ~9 us launch: nnconv.hip)
-        if (ws.fused && !separate_conv2_kernel(p) && p->depth > 0 && !prep_only && phase != WP_PREPARE_ONLY) {
-            EdgeMlpWeights w{p->k_w0, p->k_b0, p->k_w1, p->k_b1, p->k_w2, p->k_b2};
-            MDNO_TRY(edge_mlp(edge_frames, edge_frame, t_dev, R, src, dst, edge_attr, perm, num_edges, edge_cap, p->ker_in,
-                              p->ker_width, C * C, p->gemm_mode, w, ws.w_e, ws.mlp, ws.mlp_bytes, s, phase));
-            return nnconv_fused(cur, row_ptr, src, R, ws.w_e, p->conv1_root, p->conv1_bias, p->conv2_root, p->conv2_bias,
-                                p->depth, blocks, p->fc2_w, p->fc2_b, p->out_width, out_frames, t_out, t_dev, latent,
-                                ws.fused, status, s);
-        }
         for (int block = 0; block < blocks; ++block) {
             if (block == 0 || separate_conv2_kernel(p)) {
                 EdgeMlpWeights w = (block == 0)

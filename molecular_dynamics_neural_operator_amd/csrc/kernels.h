@@ -131,17 +131,6 @@ int gemm_tn_pp(const void* A, const void* B, long long rows, int n1, int n2, flo
 int nnconv(const float* x, const int* row_ptr, const int* src, int num_rows, const float* w_e, const float* root,
            const float* bias, int Cin, int Cout, int aggr, int relu, float* y, hipStream_t s);
 
-// All 2*depth conv applications + fc2 of a small graph in ONE launch (nnconv.hip): rows travel between the
-// workgroups as flag-guarded write-through stores; bit-identical to the launch-per-application path.
-// The generation word inside `workspace` must be zero-initialised once (any value works: tags only need to differ
-// from the previous launch's).
-size_t nnconv_fused_workspace_bytes(int R, int applications);
-bool nnconv_fused_applicable(int R, long long edge_cap, int width);
-int nnconv_fused(const float* x0, const int* row_ptr, const int* src, int R, const float* w_e, const float* root1,
-                 const float* bias1, const float* root2, const float* bias2, int depth, int blocks, const float* fc2_w,
-                 const float* fc2_b, int out_width, float* out_frames, int t_out, const int* t_dev, float* latent,
-                 void* workspace, int* status, hipStream_t s);
-
 int node_prologue(const mdno_kernelnn_params* p, const float* frames, int t0, const int* t_dev, int M, int W, int N,
                   const long long* aa, int aa_per_member, float* x0, int* status, hipStream_t s);
 

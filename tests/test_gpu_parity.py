@@ -764,57 +764,3 @@ def test_errors_are_loud(dev):
     eng = RolloutEngine(model8, 1, 28, 10, 8.0, max_steps=1, device=dev)
     with pytest.raises(MdnoError):
         eng.run(t(z["x_position"]), torch.full((28,), 25, dtype=torch.long), 1)
-
-
-# ------------------------------------------------------------------------------- one-launch conv path (small graphs)
-def test_fused_small_graph_path_is_bitwise_the_per_application_path(dev):
-    """Graphs of at most 2,048 rows / 8,192 edges (the reference's own BBA, N = 28) run all 2*depth conv applications
-    and fc2 in ONE launch whose workgroups hand rows to each other through flag-guarded write-through stores
-    (csrc/nnconv.hip nnconv64_fused_kernel).  Same arithmetic in the same order: the forward (output AND latent)
-    equals, bit for bit, the same forward composed from the per-application kernels through the op-level C ABI —
-    at N = 28 (one row per workgroup) and for a 10-member batch of 280 rows (more rows than the 256 workgroups:
-    several rows per workgroup), where every member also equals its solo run; repeated runs are identical."""
-    from molecular_dynamics_neural_operator_amd import ops, synthetic as syn
-    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN
-    from molecular_dynamics_neural_operator_amd.rollout import RolloutEngine
-    from molecular_dynamics_neural_operator_amd.weights import near_identity_state_dict
-    N, W = 28, 10
-    sd = near_identity_state_dict(64, 128, seed=3, kernel_gain=2e-2, feature_gain=0.2, kernel_to_coords=1.0)
-    model = KernelNN(64, 128, 6, 6, 7, 3, 20, 4)
-    model.load_state_dict(sd)
-    model.eval().to(dev)
-    aa = torch.from_numpy(syn.amino_acids(N, seed=2)).to(dev)
-
-    def composed(frames, M):
-        """node prologue -> edge-MLP -> 12 x nnconv -> fc2, one C-ABI call per step (the launch-per-application kernels)"""
-        pack = model.param_pack(dev, conv_mode="materialized")
-        last = frames[-1].reshape(M * N, 3).contiguous()
-        g = ops.radius_graph(last, N, 8.0)
-        x = ops.node_prologue(pack, frames, aa)
-        net = model.conv1.net
-        w_e = ops.edge_mlp(net.hip_weights(), 6, 128, 4096, g, edge_pos=last, gemm_mode=model.gemm_mode)
-        for conv in (model.conv1, model.conv2):
-            for _ in range(model.depth):
-                x = ops.nnconv(x, g, w_e, conv.root, conv.bias, "mean", relu=True)
-        return ops.fc_out(x, model.fc2.weight, model.fc2.bias), x, g
-
-    for M in (1, 10):
-        base = syn.jitter_window(syn.chain_frame(N, seed=5), W, seed=5)
-        wins = syn.ensemble_windows(base, M, sigma=0.2, seed0=40) if M > 1 else base[None]
-        frames = torch.from_numpy(np.ascontiguousarray(wins.transpose(1, 0, 2, 3))).to(dev)      # [W,M,N,3]
-        want_out, want_lat, g = composed(frames, M)
-        assert M * N * N <= 8192 and g.edge_count() > 0                                           # the fused regime
-        got_out, got_lat = ops.kernelnn_forward(model.param_pack(dev, conv_mode="materialized"), frames, aa,
-                                                ops.radius_graph(frames[-1].reshape(M * N, 3).contiguous(), N, 8.0),
-                                                edge_pos=frames[-1].reshape(M * N, 3).contiguous(), return_latent=True)
-        assert torch.equal(got_lat, want_lat) and torch.equal(got_out, want_out), M
-        # the rollout engine (captured step) takes the same path: first frame == the forward above; replays repeat
-        eng = RolloutEngine(model, M, N, W, 8.0, max_steps=4, device=dev)
-        assert eng.conv_mode == "materialized"
-        tr = eng.run(frames, aa, 4).clone()
-        assert torch.equal(tr[0].reshape(M * N, 3), want_out)
-        assert torch.equal(eng.run(frames, aa, 4), tr)
-        if M > 1:
-            solo = RolloutEngine(model, 1, N, W, 8.0, max_steps=4, device=dev)
-            for m in (0, 7):
-                assert torch.equal(solo.run(frames[:, m:m + 1].contiguous(), aa, 4)[:, 0], tr[:, m]), m

@@ -9,7 +9,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python3 $ROOT/bench.py --skip-cpu-baseline --skip-ensemble-leg"
+B="python3 $ROOT/bench.py --skip-cpu-baseline --skip-ensemble-leg --skip-config-legs"
 for M in 1 8; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_m$M -- $B --steps 50 --warmup 5 --total-members $M > $OUT/bench_m$M.json 2> $OUT/trace_m$M.err
   echo "trace m$M done"
@@ -18,6 +18,11 @@ for M in 1 8; do
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_m$M -- $B --steps 3 --warmup 1 --no-graph --total-members $M > $OUT/pmc_write_m$M.json 2> $OUT/pmc_write_m$M.err
   echo "write m$M done"
 done
-# training step (cfg4 stand-in): kernel trace only
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train_trace -- python3 $ROOT/scripts/train_synthetic.py > $OUT/train.json 2> $OUT/train.err
+# matrix-pipe occupancy of the MFMA kernels of the timed path (1 member): its own counter pass
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_mfma_m1 -- $B --single-mode --steps 3 --warmup 1 --no-graph --total-members 1 > $OUT/pmc_mfma_m1.json 2> $OUT/pmc_mfma_m1.err
+echo "mfma m1 done"
+# training (cfg4: N=28, batch 128, k=1024, depth 6, bf16): kernel trace, then the same counters for its GEMMs
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train_trace -- python3 $ROOT/scripts/train_synthetic.py --frames 4000 > $OUT/train.json 2> $OUT/train.err
 echo "train trace done"
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_mfma_train -- python3 $ROOT/scripts/train_synthetic.py --frames 600 > $OUT/pmc_mfma_train.json 2> $OUT/pmc_mfma_train.err
+echo "mfma train done"

@@ -20,7 +20,7 @@ from collections import defaultdict
 from pathlib import Path
 
 src = Path(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof")
-tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
 out = Path("profiles")
 out.mkdir(exist_ok=True)
 
@@ -100,6 +100,38 @@ for M in (1, 8):
         traffic.append({"kernel": kernel, "atoms": c["atoms"], "members": c["members_this_rank"], "conv_mode": conv_mode,
                         "gemm_mode": c["edge_mlp_gemm"], "hbm_bytes_per_launch": per_launch * launches_per_app,
                         "launches_per_application": launches_per_app, "source": f"profiles/{tag}_m{M}_pmc.json"})
+
+
+def mfma_summary(sub, dest, what, keep):
+    """GRBM_GUI_ACTIVE / SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES per launch -> kernel cycles and matrix-pipe occupancy"""
+    files = glob.glob(str(src / sub / "*" / "*_counter_collection.csv"))
+    if not files:
+        return
+    agg = defaultdict(lambda: defaultdict(list))
+    for r in csv.DictReader(open(newest(files))):
+        agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    ks = {}
+    for k, d in agg.items():
+        if not any(k.startswith(p_) for p_ in keep) or "GRBM_GUI_ACTIVE" not in d:
+            continue
+        gui = sum(d["GRBM_GUI_ACTIVE"]) / len(d["GRBM_GUI_ACTIVE"])
+        mf = sum(d.get("SQ_VALU_MFMA_BUSY_CYCLES", [0.0])) / max(len(d.get("SQ_VALU_MFMA_BUSY_CYCLES", [])), 1)
+        sq = sum(d.get("SQ_BUSY_CYCLES", [0.0])) / max(len(d.get("SQ_BUSY_CYCLES", [])), 1)
+        ks[k] = {"launches": len(d["GRBM_GUI_ACTIVE"]), "GRBM_GUI_ACTIVE": gui, "kernel_cycles": gui / 8,
+                 "SQ_VALU_MFMA_BUSY_CYCLES": mf, "SQ_BUSY_CYCLES": sq, "mfma_busy_frac": mf / (1024 * gui / 8) if gui else None}
+    dest.write_text(json.dumps({
+        "note": f"rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -- {what}; averages per launch. "
+                "GRBM_GUI_ACTIVE is summed over the 8 XCDs: kernel cycles = GUI/8. SQ_VALU_MFMA_BUSY_CYCLES is summed over the "
+                "1,024 SIMDs and equals 32 cycles x the number of v_mfma_f32_32x32x16 issued. mfma_busy_frac = MFMA_BUSY / "
+                "(1024 * GUI/8).", "kernels": ks}, indent=1))
+    print("wrote", dest)
+
+
+mfma_summary("pmc_mfma_m1", out / f"{tag}_m1_pmc_mfma.json",
+             "python3 bench.py --skip-cpu-baseline --skip-ensemble-leg --single-mode --steps 3 --warmup 1 --no-graph "
+             "(1 member, N=504, split_f16)", ("gemm_split_f16_kernel", "gemm_per_source_split_kernel", "gemm_k64_f16_kernel"))
+mfma_summary("pmc_mfma_train", out / f"{tag}_train_pmc_mfma.json",
+             "python3 scripts/train_synthetic.py --frames 600 (cfg4 batch: 43.7k edges, k=1024, bf16)", ("gemm_pp_kernel",))
 kernel_stats("train_trace", out / f"{tag}_train_kernel_stats.csv")
 tj = last_json_line(src / "train.json")
 if tj is not None:

@@ -64,7 +64,6 @@ struct PpArgs {
     const float* bias;    // EPI_BIAS: [N] or null
     const __bf16* Y;      // EPI_MASK: [rows, N]
     void* C;              // NT: [rows, N] bf16 or fp32.  TN: slabs [slices][n1][n2] fp32
-    const unsigned char* zeros;   // TN: 512 zero bytes (rows past the end of the contraction read these)
     long long rows;       // NT: output rows.  TN: contraction length
     int N, K;             // NT: output columns, contraction length.  TN: n2, n1
     int tiles_n;
@@ -108,54 +107,53 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PpArgs g) {
     // ---- LDS-DMA sources.  Wave w moves pieces w, w+8 (operand A) and w+16, w+24 (operand B) of every stage.
     //   NT: a piece is 16 rows x 64 B; lane l -> row l>>2, LDS chunk l&3 <- global chunk (l&3) ^ ((l>>4)&3)
     //   TN: a piece is 2 rows x 512 B; lane l -> row l>>5, LDS chunk l&31 <- global chunk (l&31) ^ ((row&3)<<2)
-    const unsigned char* psrc[PP_PIECES_PER_WAVE];
-    size_t stage_stride;                        // bytes from one stage's source to the next
-    int tn_row[PP_PIECES_PER_WAVE];             // TN: row of this lane's piece inside the stage (to test against k1)
+    // Issued as buffer loads (buffer_load_dwordx4 ... offen lds): one descriptor per operand whose base is this
+    // tile's (and, TN, this K slice's) first byte, a per-lane 32-bit offset that never changes, and the stage as
+    // the scalar offset — no 64-bit address arithmetic per piece, and whatever lies past the descriptor's size
+    // reads as ZERO: the rows of A past the end of the matrix (NT; their outputs are never stored) and the rows
+    // of the last stage past the end of the contraction (TN; they must contribute nothing).
+    unsigned voff[PP_PIECES_PER_WAVE];
+    unsigned stride_a, stride_b;                 // bytes from one stage to the next, per operand
+    __amdgpu_buffer_rsrc_t rsrc_a, rsrc_b;
     if (!TN) {
         const int pr = lane >> 2, pc = (lane & 3) ^ ((lane >> 4) & 3);
         const size_t ldk = (size_t)g.K * 2;
-        stage_stride = PP_ROW_BYTES;
+        stride_a = stride_b = PP_ROW_BYTES;
+        long long live = g.rows - bm;
+        if (live > PP_T) live = PP_T;
+        rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const unsigned char*>(g.A) + (size_t)bm * ldk), 0,
+                                                   (int)(live * (long long)ldk), 0x00020000);
+        rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const unsigned char*>(g.W) + (size_t)bn * ldk), 0,
+                                                   (int)(PP_T * ldk), 0x00020000);
 #pragma unroll
         for (int t = 0; t < PP_PIECES_PER_WAVE; ++t) {
             const int piece = wave + 8 * t;                      // 0..31; < 16: A, else B
-            const int row = (piece & 15) * 16 + pr;
-            tn_row[t] = 0;
-            if (piece < 16) {
-                long long ar = bm + row;
-                if (ar >= g.rows) ar = g.rows - 1;               // past the end: re-read the last row (never stored)
-                psrc[t] = reinterpret_cast<const unsigned char*>(g.A) + (size_t)ar * ldk + pc * 16;
-            } else {
-                psrc[t] = reinterpret_cast<const unsigned char*>(g.W) + (size_t)(bn + row) * ldk + pc * 16;
-            }
+            voff[t] = (unsigned)(((piece & 15) * 16 + pr) * ldk + pc * 16);
         }
     } else {
-        stage_stride = 0;                        // (computed per operand below: PP_BK rows of n1 or n2 elements)
+        stride_a = (unsigned)((size_t)PP_BK * g.K * 2);
+        stride_b = (unsigned)((size_t)PP_BK * g.N * 2);
+        const long long live = k1 - k0;          // rows of this slice
+        rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const unsigned char*>(g.A) + ((size_t)k0 * g.K + bm) * 2), 0,
+                                                   live > 0 ? (unsigned)(((live - 1) * g.K + PP_T) * 2) : 0, 0x00020000);
+        rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const unsigned char*>(g.W) + ((size_t)k0 * g.N + bn) * 2), 0,
+                                                   live > 0 ? (unsigned)(((live - 1) * g.N + PP_T) * 2) : 0, 0x00020000);
 #pragma unroll
         for (int t = 0; t < PP_PIECES_PER_WAVE; ++t) {
             const int piece = wave + 8 * t;
             const int row = (piece & 15) * 2 + (lane >> 5);      // 0..31
             const int pc = (lane & 31) ^ ((row & 3) << 2);
-            tn_row[t] = row;
-            if (piece < 16) psrc[t] = reinterpret_cast<const unsigned char*>(g.A) + ((size_t)(k0 + row) * g.K + bm) * 2 + pc * 16;
-            else psrc[t] = reinterpret_cast<const unsigned char*>(g.W) + ((size_t)(k0 + row) * g.N + bn) * 2 + pc * 16;
+            voff[t] = (unsigned)((size_t)row * (piece < 16 ? g.K : g.N) * 2 + pc * 16);
         }
     }
-    const size_t tn_stride_a = (size_t)PP_BK * g.K * 2, tn_stride_b = (size_t)PP_BK * g.N * 2;
-    const unsigned char* zsrc = TN ? g.zeros + (lane & 31) * 16 : nullptr;
     const int piece_base = wave * 1024;          // piece t of this wave sits at piece_base + t * 8 KiB inside a slot
 #define MDNO_PP_DMA(ST)                                                                                         \
     {                                                                                                           \
         const int st_ = (ST), slot_ = st_ % PP_RING;       /* (ST may name the caller's loop variable) */       \
-        _Pragma("unroll") for (int pi_ = 0; pi_ < PP_PIECES_PER_WAVE; ++pi_) {                                  \
-            const unsigned char* src_;                                                                          \
-            if (!TN) src_ = psrc[pi_] + (size_t)st_ * stage_stride;                                             \
-            else {                                                                                              \
-                src_ = psrc[pi_] + (size_t)st_ * (pi_ < 2 ? tn_stride_a : tn_stride_b);                         \
-                if (k0 + (long long)st_ * PP_BK + tn_row[pi_] >= k1) src_ = zsrc;   /* past the contraction: zeros */ \
-            }                                                                                                   \
-            __builtin_amdgcn_global_load_lds((glb_u8*)src_,                                                     \
-                                             (lds_u8*)(lds + slot_ * PP_STAGE_BYTES + piece_base + pi_ * 8192), 16, 0, 0); \
-        }                                                                                                       \
+        _Pragma("unroll") for (int pi_ = 0; pi_ < PP_PIECES_PER_WAVE; ++pi_)                                    \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(pi_ < 2 ? rsrc_a : rsrc_b,                                 \
+                                                     (lds_u8*)(lds + slot_ * PP_STAGE_BYTES + piece_base + pi_ * 8192), 16, \
+                                                     voff[pi_], (unsigned)st_ * (pi_ < 2 ? stride_a : stride_b), 0, 0); \
     }
 
     // ---- fragment read offsets
@@ -370,7 +368,7 @@ static int launch_pp(const PpArgs& g, unsigned slices, hipStream_t s) {
 int gemm_nt_pp(const void* A, const void* W, const float* bias, long long rows, int N, int K, int relu, int out_bf16,
                void* C, hipStream_t s) {
     MDNO_REQUIRE(gemm_nt_pp_supported(rows, N, K), MDNO_EUNSUPPORTED, "gemm_nt_pp: rows=%lld N=%d K=%d", rows, N, K);
-    PpArgs g{static_cast<const __bf16*>(A), static_cast<const __bf16*>(W), bias, nullptr, C, nullptr, rows, N, K, N / PP_T,
+    PpArgs g{static_cast<const __bf16*>(A), static_cast<const __bf16*>(W), bias, nullptr, C, rows, N, K, N / PP_T,
              (rows + PP_T - 1) / PP_T, 0};
     if (relu) return out_bf16 ? launch_pp<false, EPI_BIAS, true, true>(g, 1, s) : launch_pp<false, EPI_BIAS, true, false>(g, 1, s);
     return out_bf16 ? launch_pp<false, EPI_BIAS, false, true>(g, 1, s) : launch_pp<false, EPI_BIAS, false, false>(g, 1, s);
@@ -379,7 +377,7 @@ int gemm_nt_pp(const void* A, const void* W, const float* bias, long long rows, 
 // C bf16 [rows,N] = (Y > 0) ? A . W^T : 0 — the input gradient of a Linear+ReLU layer whose stored output is Y
 int gemm_nt_pp_masked(const void* A, const void* W, const void* Y, long long rows, int N, int K, void* C, hipStream_t s) {
     MDNO_REQUIRE(gemm_nt_pp_supported(rows, N, K) && Y, MDNO_EUNSUPPORTED, "gemm_nt_pp_masked: rows=%lld N=%d K=%d", rows, N, K);
-    PpArgs g{static_cast<const __bf16*>(A), static_cast<const __bf16*>(W), nullptr, static_cast<const __bf16*>(Y), C, nullptr,
+    PpArgs g{static_cast<const __bf16*>(A), static_cast<const __bf16*>(W), nullptr, static_cast<const __bf16*>(Y), C,
              rows, N, K, N / PP_T, (rows + PP_T - 1) / PP_T, 0};
     return launch_pp<false, EPI_MASK, false, true>(g, 1, s);
 }
@@ -394,23 +392,25 @@ static int tn_slices(long long rows, int n1, int n2) {
     if (sl > 32) sl = 32;
     const long long max_sl = (rows + 4 * PP_BK - 1) / (4 * PP_BK);      // at least a few stages per slice
     if (sl > max_sl) sl = max_sl;
+    // a slice's operand panels are addressed through 32-bit buffer offsets: keep them under 2 GiB
+    const long long widest = n1 > n2 ? n1 : n2;
+    while ((rows + sl - 1) / sl * widest * 2 >= (1ll << 31)) ++sl;
     return (int)sl;
 }
 
 size_t gemm_tn_pp_workspace_bytes(long long rows, int n1, int n2) {
-    // slabs (none when one slice writes C directly) + the 512 zero bytes; sized for the largest slice count
-    return align_up((size_t)32 * n1 * n2 * sizeof(float), 256) + 1024;
+    // slabs (none when one slice writes C directly), sized for the largest slice count the rule above picks
+    long long sl = tn_slices(rows, n1, n2);
+    if (sl < 32) sl = 32;
+    return align_up((size_t)sl * n1 * n2 * sizeof(float), 256);
 }
 
 int gemm_tn_pp(const void* A, const void* B, long long rows, int n1, int n2, float* C, void* workspace, hipStream_t s) {
     MDNO_REQUIRE(gemm_tn_pp_supported(rows, n1, n2), MDNO_EUNSUPPORTED, "gemm_tn_pp: rows=%lld n1=%d n2=%d", rows, n1, n2);
     const int slices = tn_slices(rows, n1, n2);
     const long long slice_rows = ((rows + slices - 1) / slices + PP_BK - 1) / PP_BK * PP_BK;
-    const size_t slab_bytes = align_up((size_t)32 * n1 * n2 * sizeof(float), 256);
-    unsigned char* zeros = static_cast<unsigned char*>(workspace) + slab_bytes;
-    MDNO_TRY(fill_ints(reinterpret_cast<int*>(zeros), 128, 0, s));
     float* slabs = slices == 1 ? C : static_cast<float*>(workspace);
-    PpArgs g{static_cast<const __bf16*>(A), static_cast<const __bf16*>(B), nullptr, nullptr, slabs, zeros, rows, n2, n1,
+    PpArgs g{static_cast<const __bf16*>(A), static_cast<const __bf16*>(B), nullptr, nullptr, slabs, rows, n2, n1,
              n2 / PP_T, n1 / PP_T, slice_rows};
     MDNO_TRY((launch_pp<true, EPI_SLAB, false, false>(g, (unsigned)slices, s)));
     if (slices > 1) {

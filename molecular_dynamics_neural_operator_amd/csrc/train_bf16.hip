@@ -599,7 +599,7 @@ extern "C" int mdno_linear_smallk_bf16_fwd(const float* a, const float* w, const
 extern "C" size_t mdno_gemm_atb_bf16_workspace_bytes(int n1, int n2) {
     const size_t old_path = align_up((size_t)kTnSlices * n1 * n2 * sizeof(float), 256);
     if (!gemm_tn_pp_supported(1, n1, n2)) return old_path;
-    const size_t pp = gemm_tn_pp_workspace_bytes(1, n1, n2);
+    const size_t pp = gemm_tn_pp_workspace_bytes(1, n1, n2);      // (32 slabs: what any row count up to 2^31 / widest * 32 needs)
     return pp > old_path ? pp : old_path;
 }
 

@@ -523,6 +523,13 @@ __device__ __forceinline__ void mma_f16_kstep_fill(f32x16 (&acc)[MI][2], f32x16 
         }
 }
 
+// one LDS-DMA piece (64 lanes x 16 B) as a buffer load: descriptor {base, bytes}, per-lane offset, scalar offset
+__device__ __forceinline__ void dma_piece_buffer(const unsigned char* base, int bytes, lds_u8* dst, unsigned voffset,
+                                                 unsigned soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000), dst, 16,
+                                             voffset, soffset, 0, 0);
+}
+
 constexpr int F16_TM = 256, F16_RING = 3;
 constexpr int F16_TILE_BYTES = 2 * 2 * PLANE_BYTES;       // one 128-row tile: two k-steps x two planes = 16 KiB
 constexpr int F16_STAGE_BYTES = 3 * F16_TILE_BYTES;       // A tile 0 | A tile 1 | B = 48 KiB
@@ -560,22 +567,30 @@ __global__ __launch_bounds__(1024 / MI) void gemm_split_f16_kernel(SplitGemmArgs
     // piece qq of a stage: block qq/16 (A row tile 0, A row tile 1, B), KiB qq%16 of that block's 16 KiB;
     // in HBM a row tile's k-steps are contiguous (8 KiB each), so a stage is one 16 KiB run per block
     const int nkt = g.K / TK, nst = g.K / 32;
+    // pieces go out as buffer loads (buffer_load_dwordx4 ... offen lds): one descriptor per operand panel based at
+    // this tile's first byte, a per-lane 32-bit offset that never changes, the stage as the scalar offset — no
+    // 64-bit address arithmetic per piece (gemm_bf16.hip measured 8 % on its DMA-bound loop)
     const size_t a_tile_stride = (size_t)nkt * 2 << 12;
-    const unsigned char* a_base = g.Ap + (size_t)(bm >> 7) * a_tile_stride;
-    const unsigned char* b_base = g.Bp + (size_t)(bn >> 7) * a_tile_stride;
-    const unsigned char* psrc[PPW];
+    const unsigned char* const a_panel = g.Ap + (size_t)(bm >> 7) * a_tile_stride;      // two row tiles
+    const unsigned char* const b_panel = g.Bp + (size_t)(bn >> 7) * a_tile_stride;
+    const int a_bytes = (int)(2 * a_tile_stride), b_bytes = (int)a_tile_stride;
+    unsigned voff[PPW];
 #pragma unroll
     for (int t = 0; t < PPW; ++t) {
         const int qq = wave + t * WAVES, blk = qq >> 4;
-        psrc[t] = (blk < 2 ? a_base + (size_t)blk * a_tile_stride : b_base) + (qq & 15) * 1024 + lane * 16;
+        voff[t] = (unsigned)((blk == 1 ? a_tile_stride : 0) + (qq & 15) * 1024 + lane * 16);
     }
+    // (piece t of a wave belongs to block (wave + t * WAVES) >> 4: with 8 waves, t = 0, 1 -> A tile 0, t = 2, 3 -> A tile 1,
+    // t = 4, 5 -> B; with 4 waves twice as many each)
+#define MDNO_PIECE_DMA(T, DST, KO)                                                              \
+    dma_piece_buffer((((T) * WAVES) >> 4) < 2 ? a_panel : b_panel, (((T) * WAVES) >> 4) < 2 ? a_bytes : b_bytes, DST, voff[T], KO)
     const int d0 = wave * 1024;
 #define MDNO_DMA_STAGE(ST, SLOT)                                                                       \
     {                                                                                                  \
-        const size_t ko = (size_t)(ST) * F16_TILE_BYTES;                                               \
+        const unsigned ko = (unsigned)(ST) * F16_TILE_BYTES;                                           \
         lds_u8* ldst = (lds_u8*)(lds + (SLOT) * F16_STAGE_BYTES + d0);                                 \
         _Pragma("unroll") for (int t = 0; t < PPW; ++t)                                                \
-            __builtin_amdgcn_global_load_lds((glb_u8*)(psrc[t] + ko), ldst + t * WAVES * 1024, 16, 0, 0); \
+            MDNO_PIECE_DMA(t, ldst + t * WAVES * 1024, ko);                                        \
     }
 
     const int hsw = (h ^ ((l31 >> 3) & 1)) << 4;
@@ -617,22 +632,40 @@ __global__ __launch_bounds__(1024 / MI) void gemm_split_f16_kernel(SplitGemmArgs
         asm volatile("" ::: "memory");
         const unsigned char* sb = lds + slot * F16_STAGE_BYTES;
         const bool more = st + 2 < nst;
-        const size_t ko = (size_t)(st + 2) * F16_TILE_BYTES;
+        const unsigned ko = (unsigned)(st + 2) * F16_TILE_BYTES;
         lds_u8* ldst = (lds_u8*)(lds + slot_in * F16_STAGE_BYTES + d0);
         // pieces of stage st+2: PPW / 2 behind the groups of each k-step (MI = 2: 3 + 3 of the 4 + 4 groups)
         constexpr int HALF = (PPW + 1) / 2;
-        mma_f16_kstep_fill<MI>(acc, accx, sb, a_rd, b_rd, [&](int grp) {
-            if (more && grp < HALF)
-                __builtin_amdgcn_global_load_lds((glb_u8*)(psrc[grp] + ko), ldst + grp * WAVES * 1024, 16, 0, 0);
-        });
-        mma_f16_kstep_fill<MI>(acc, accx, sb + 2 * PLANE_BYTES, a_rd, b_rd, [&](int grp) {
-            if (more && grp < PPW - HALF)
-                __builtin_amdgcn_global_load_lds((glb_u8*)(psrc[HALF + grp] + ko), ldst + (HALF + grp) * WAVES * 1024, 16, 0, 0);
-        });
+        // (written out rather than passed as a functor to mma_f16_kstep_fill: a lambda that touches a buffer
+        // descriptor makes the host pass drop this kernel's stub)
+#define MDNO_F16_KSTEP_DMA(SB, P0, NP)                                                                                \
+        {                                                                                                                 \
+            f16x8 a_[MI][2], b_[2][2];                                                                                    \
+            _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                                               \
+                _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                            \
+                    a_[i][p] = *reinterpret_cast<const f16x8*>((SB) + p * PLANE_BYTES + a_rd + i * 32 * 32);              \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                             \
+                    b_[j][p] = *reinterpret_cast<const f16x8*>((SB) + p * PLANE_BYTES + b_rd + j * 32 * 32);              \
+            }                                                                                                             \
+            _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                                \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                           \
+                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_[i][1], b_[j][0], accx[i][j], 0, 0, 0);         \
+                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_[i][0], b_[j][1], accx[i][j], 0, 0, 0);         \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_[i][0], b_[j][0], acc[i][j], 0, 0, 0);           \
+                    __builtin_amdgcn_sched_barrier(0);                                                                    \
+                    if (more && i * 2 + j < (NP))                                                                         \
+                        MDNO_PIECE_DMA((P0) + i * 2 + j, ldst + ((P0) + i * 2 + j) * WAVES * 1024, ko);                   \
+                    __builtin_amdgcn_sched_barrier(0);                                                                    \
+                }                                                                                                         \
+        }
+        MDNO_F16_KSTEP_DMA(sb, 0, HALF)
+        MDNO_F16_KSTEP_DMA(sb + 2 * PLANE_BYTES, HALF, PPW - HALF)
+#undef MDNO_F16_KSTEP_DMA
         slot = slot == F16_RING - 1 ? 0 : slot + 1;
         slot_in = slot_in == F16_RING - 1 ? 0 : slot_in + 1;
     }
 #undef MDNO_DMA_STAGE
+#undef MDNO_PIECE_DMA
 
     bool bad = false, seen = false;
 #pragma unroll

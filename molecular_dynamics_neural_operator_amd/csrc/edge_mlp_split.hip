@@ -701,6 +701,140 @@ __global__ __launch_bounds__(1024 / MI) void gemm_split_f16_kernel(SplitGemmArgs
     if (OUT == 4 && seen) const_cast<int*>(g.f16_flags)[3] = 1;
 }
 
+// ---- the same product for a FEW rows (a 28-atom chain has 330 edges): 128 x 64 tiles, 8 waves of 32 x 32.
+// At E = 330 the kernel above launches 2 x 8 (hidden layer) or 2 x 32 (last layer) workgroups whose K loops
+// take 35-40 us whatever the row count — 24 MFMAs per wave per stage, 32 stages.  Here a wave has 6 MFMAs per
+// stage and the launch has 3 x 16 / 3 x 64 workgroups, so the K loop is as long as the 768 KiB of operand
+// planes take to reach one CU (64 B/clk: ~5 us).  The stages (A: one 128-row tile = 16 KiB, B: half a tile =
+// 4 runs of 2 KiB) sit in a ring of six with five in flight: a CU's share of the L2 bandwidth times the L2
+// latency is ~50 KiB, the ring holds 120.  Per output element the MFMAs are the same instructions in the
+// same order as in gemm_split_f16_kernel (k-steps ascending; cross terms a_lo b_hi, a_hi b_lo, then
+// a_hi b_hi), so both kernels give the same bits and the choice between them — made from the launch's row
+// capacity — never shows in a result (an ensemble member's trajectory is the same alone and in a batch).
+constexpr int F16S_TM = 128, F16S_TN = 64, F16S_RING = 6;
+constexpr int F16S_STAGE_BYTES = F16_TILE_BYTES + F16_TILE_BYTES / 2;       // 24 KiB
+constexpr int F16S_LDS_BYTES = F16S_RING * F16S_STAGE_BYTES;               // 144 KiB
+
+template <int OUT>
+__global__ __launch_bounds__(512) void gemm_split_f16_small_kernel(SplitGemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    if (g.f16_flags != nullptr && f16_blocked(g.f16_flags, g.f16_need)) return;
+    long long valid = g.num_edges ? (long long)(*g.num_edges) - g.row_begin : (long long)g.rows_valid;
+    if (valid > g.rows) valid = g.rows;
+    if (valid <= 0) return;
+    const int tiles_mv = (int)((valid + F16S_TM - 1) / F16S_TM);
+    const int nwg = g.tiles_n * tiles_mv;
+    const int orig = blockIdx.x;
+    if (orig >= nwg) return;
+    // XCD x owns a contiguous run of tiles, row tiles fastest: the row tiles of one B panel are neighbours
+    const int xcd = orig & 7, q = nwg >> 3, r8 = nwg & 7;
+    const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
+    const int bm = (tile % tiles_mv) * F16S_TM, bn = (tile / tiles_mv) * F16S_TN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;              // 4 x 2 waves of 32 x 32
+    const int l31 = lane & 31, h = lane >> 5;
+    const int nkt = g.K / TK, nst = g.K / 32;
+    const size_t tile_stride = (size_t)nkt * 2 << 12;     // bytes of one 128-row tile of an operand image
+    const unsigned char* const a_panel = g.Ap + (size_t)(bm >> 7) * tile_stride;
+    const unsigned char* const b_panel = g.Bp + (size_t)(bn >> 7) * tile_stride;
+    const int panel_bytes = (int)tile_stride;
+    // piece w + 8t of a stage: t = 0, 1 -> KiB w, w + 8 of the A tile's 16 KiB run; t = 2 -> B piece w: run
+    // w >> 1 (k-step, plane) of 4 KiB in HBM, of which this tile's 64 columns are one 2 KiB half
+    const unsigned v_a0 = (unsigned)(wave * 1024 + lane * 16), v_a1 = v_a0 + 8192;
+    const unsigned v_b = (unsigned)((wave >> 1) * 4096 + ((bn >> 6) & 1) * 2048 + (wave & 1) * 1024 + lane * 16);
+#define MDNO_DMA_STAGE(ST, SLOT)                                                                         \
+    {                                                                                                    \
+        const unsigned ko = (unsigned)(ST) * F16_TILE_BYTES;                                             \
+        lds_u8* ldst = (lds_u8*)(lds + (SLOT) * F16S_STAGE_BYTES + wave * 1024);                          \
+        dma_piece_buffer(a_panel, panel_bytes, ldst, v_a0, ko);                                          \
+        dma_piece_buffer(a_panel, panel_bytes, ldst + 8192, v_a1, ko);                                   \
+        dma_piece_buffer(b_panel, panel_bytes, ldst + 16384, v_b, ko);                                   \
+    }
+    const int hsw = (h ^ ((l31 >> 3) & 1)) << 4;
+    const int a_rd = (wm * 32 + l31) * 32 + hsw;                          // + ks * 8192 + p * 4096
+    const int b_rd = F16_TILE_BYTES + (wn * 32 + l31) * 32 + hsw;         // + (ks * 2 + p) * 2048
+
+    f32x16 acc, accx;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc[e] = 0.f; accx[e] = 0.f; }
+    float bv = 0.f, us = 1.f;
+    if (g.bias) bv = g.bias[bn + wn * 32 + l31];
+    if (g.b_unscale) us = g.b_unscale[bn + wn * 32 + l31];
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bv), "+v"(us));   // the counted waits below must see DMA pieces only
+
+#pragma unroll
+    for (int t = 0; t < F16S_RING - 1; ++t)
+        if (t < nst) MDNO_DMA_STAGE(t, t)
+    int slot = 0, slot_in = F16S_RING - 1;
+    for (int st = 0; st < nst; ++st) {
+        // stages still in flight behind stage st: min(RING - 2, nst - 1 - st) groups of three pieces
+        const int behind = nst - 1 - st;
+        if (behind >= 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (behind == 3) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        else if (behind == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (behind == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // everybody's pieces of stage st have landed, and nobody still reads the slot multiplied at st - 1
+        // (a wave's fragment reads feed its MFMAs, so they have returned before it gets here)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (st + F16S_RING - 1 < nst) MDNO_DMA_STAGE(st + F16S_RING - 1, slot_in)
+        const unsigned char* sb = lds + slot * F16S_STAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const f16x8 a0 = *reinterpret_cast<const f16x8*>(sb + ks * 8192 + a_rd);
+            const f16x8 a1 = *reinterpret_cast<const f16x8*>(sb + ks * 8192 + 4096 + a_rd);
+            const f16x8 b0 = *reinterpret_cast<const f16x8*>(sb + ks * 4096 + b_rd);
+            const f16x8 b1 = *reinterpret_cast<const f16x8*>(sb + ks * 4096 + 2048 + b_rd);
+            accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, accx, 0, 0, 0);
+            accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, accx, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc, 0, 0, 0);
+        }
+        slot = slot == F16S_RING - 1 ? 0 : slot + 1;
+        slot_in = slot_in == F16S_RING - 1 ? 0 : slot_in + 1;
+    }
+#undef MDNO_DMA_STAGE
+
+    bool bad = false, seen = false;
+    const int n = bn + wn * 32 + l31;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int m = bm + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (m < valid) {
+            const float v = (acc[e] + accx[e] * F16_LO_UNSCALE) * us + bv;
+            if (OUT == 4) {
+                const float rv = fmaxf(v, 0.f);
+                bad |= !(rv < F16_MAX);
+                seen |= rv >= F16_ACT_MIN;
+                _Float16 ph, pl;
+                split2h(rv, ph, pl);
+                const size_t o = tiled_off2(m, n, g.N >> 4, 0);
+                *reinterpret_cast<_Float16*>(g.Cp + o) = ph;
+                *reinterpret_cast<_Float16*>(g.Cp + o + PLANE_BYTES) = pl;
+            } else {
+                g.C[(size_t)m * g.N + n] = OUT == 3 ? fmaxf(v, 0.f) : v;
+            }
+        }
+    }
+    if (OUT == 4 && bad) atomicOr(const_cast<int*>(g.f16_flags) + 1, 1);
+    if (OUT == 4 && seen) const_cast<int*>(g.f16_flags)[3] = 1;
+}
+
+// few rows: the 256-row kernel would leave more than half of the CUs without a tile
+constexpr int F16S_MAX_BIG_TILES = 128;
+
+template <int OUT>
+int launch_split_f16_gemm_small(SplitGemmArgs g, hipStream_t s) {
+    static std::atomic<unsigned long long> lds_raised{0};
+    MDNO_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(&gemm_split_f16_small_kernel<OUT>), F16S_LDS_BYTES, lds_raised));
+    g.tiles_n = g.N / F16S_TN;
+    g.tiles_m = g.rows / F16S_TM;
+    hipLaunchKernelGGL((gemm_split_f16_small_kernel<OUT>), dim3(g.tiles_n * g.tiles_m), dim3(512), F16S_LDS_BYTES, s, g);
+    return check_launch("split-f16 GEMM (few rows)");
+}
+
 template <int OUT, int MI>
 int launch_split_f16_gemm(SplitGemmArgs g, hipStream_t s) {
     constexpr int lds_bytes = F16_RING * F16_STAGE_BYTES;     // 147,456 B: one workgroup per CU
@@ -708,6 +842,7 @@ int launch_split_f16_gemm(SplitGemmArgs g, hipStream_t s) {
     MDNO_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(&gemm_split_f16_kernel<OUT, MI>), lds_bytes, lds_raised));
     MDNO_REQUIRE(g.K % 32 == 0 && g.N % TN == 0 && g.rows % F16_TM == 0, MDNO_EUNSUPPORTED,
                  "split-f16 GEMM: rows=%d N=%d K=%d", g.rows, g.N, g.K);
+    if (OUT != 2 && (g.N / TN) * (g.rows / F16_TM) <= F16S_MAX_BIG_TILES) return launch_split_f16_gemm_small<OUT>(g, s);
     g.tiles_n = g.N / TN;
     g.tiles_m = g.rows / F16_TM;
     hipLaunchKernelGGL((gemm_split_f16_kernel<OUT, MI>), dim3(g.tiles_n * g.tiles_m), dim3(1024 / MI), lds_bytes, s, g);

@@ -271,6 +271,13 @@ extern "C" size_t mdno_edge_mlp_workspace_bytes(int ker_width, int out_dim, int6
     return align_up(2 * (size_t)chunk * (size_t)ker_width * sizeof(float) + 512, 256);
 }
 
+int* mdno::edge_mlp_activation_flags(void* workspace, int ker_width, int out_dim, long long edge_cap, int gemm_mode) {
+    if (gemm_mode != MDNO_GEMM_SPLIT_F16 || !edge_mlp_split_supported(ker_width, out_dim) || ker_width % 32 != 0 ||
+        edge_cap <= 0)
+        return nullptr;
+    return edge_mlp_split_activation_flags(workspace, ker_width, out_dim, chunk_rows_for(edge_cap));
+}
+
 int mdno::edge_mlp(const float* frames, int frame, const int* t_dev, int rows_per_frame, const int* src,
                    const int* dst, const float* edge_attr, const int* perm, const int* num_edges,
                    long long edge_cap, int ker_in, int ker_width, int out_dim, int gemm_mode,
@@ -291,7 +298,7 @@ int mdno::edge_mlp(const float* frames, int frame, const int* t_dev, int rows_pe
         return edge_mlp_split(frames, frame, t_dev, rows_per_frame, src, dst, edge_attr, perm, num_edges, edge_cap,
                               chunk, ker_in, ker_width, out_dim, w, w_e, workspace, s, phase,
                               gemm_mode == MDNO_GEMM_SPLIT_F16 && ker_width % 32 == 0);
-    if (phase == WP_PREPARE_ONLY) return MDNO_OK;   // the fp32 GEMMs read the weights as they are
+    if ((phase & WP_PHASE_MASK) == WP_PREPARE_ONLY) return MDNO_OK;   // the fp32 GEMMs read the weights as they are
     Carver cv(workspace);
     float* h1 = cv.take<float>((size_t)chunk * ker_width);
     float* h2 = cv.take<float>((size_t)chunk * ker_width);
@@ -330,7 +337,7 @@ int mdno::edge_mlp_hidden(const float* frames, int frame, const int* t_dev, int 
         return edge_mlp_split_hidden(frames, frame, t_dev, rows_per_frame, src, dst, edge_attr, perm, num_edges,
                                      edge_cap, chunk, ker_in, ker_width, w, h_out, workspace, s, phase,
                                      gemm_mode == MDNO_GEMM_SPLIT_F16);
-    if (phase == WP_PREPARE_ONLY) return MDNO_OK;
+    if ((phase & WP_PHASE_MASK) == WP_PREPARE_ONLY) return MDNO_OK;
     MDNO_REQUIRE(ker_width % BN == 0 && (reinterpret_cast<uintptr_t>(w.w1) & 15) == 0, MDNO_EUNSUPPORTED,
                  "edge_mlp_hidden: ker_width=%d must be a multiple of %d", ker_width, BN);
     Carver cv(workspace);

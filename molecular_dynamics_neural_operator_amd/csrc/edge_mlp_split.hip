@@ -1117,10 +1117,16 @@ size_t edge_mlp_split_workspace_bytes(int ker_width, int out_dim, long long chun
     return carve_split(nullptr, ker_width, out_dim, chunk).total;
 }
 
+int* edge_mlp_split_activation_flags(void* workspace, int ker_width, int out_dim, long long chunk) {
+    return carve_split(workspace, ker_width, out_dim, chunk).f16_flags + 1;
+}
+
 int edge_mlp_split(const float* frames, int frame, const int* t_dev, int rows_per_frame, const int* src,
                    const int* dst, const float* edge_attr, const int* perm, const int* num_edges,
                    long long edge_cap, long long chunk, int ker_in, int ker_width, int out_dim,
-                   const EdgeMlpWeights& w, float* w_e, void* workspace, hipStream_t s, int phase, bool f16) {
+                   const EdgeMlpWeights& w, float* w_e, void* workspace, hipStream_t s, int phase_in, bool f16) {
+    const int phase = phase_in & WP_PHASE_MASK;
+    const bool flags_zeroed = (phase_in & WP_FLAGS_ZEROED) != 0;
     MDNO_REQUIRE(ker_in > 0 && ker_in <= MAX_F, MDNO_EUNSUPPORTED, "edge_mlp: ker_in=%d (1..%d)", ker_in, MAX_F);
     MDNO_REQUIRE(((reinterpret_cast<uintptr_t>(w.w1) | reinterpret_cast<uintptr_t>(w.w2)) & 15) == 0, MDNO_EINVAL,
                  "edge_mlp: weight pointers must be 16-byte aligned");
@@ -1142,7 +1148,8 @@ int edge_mlp_split(const float* frames, int frame, const int* t_dev, int rows_pe
     MDNO_TRY(check_launch("split_planes_kernel"));
     if (phase == WP_PREPARE_ONLY) return MDNO_OK;
     const float* pos_mode = edge_attr ? nullptr : frames;
-    if (f16) MDNO_TRY(fill_ints(sw.f16_flags + 1, 3, 0, s));   // activation flags of THIS forward (range, h1 seen, h2 seen)
+    // activation flags of THIS forward (range, h1 seen, h2 seen)
+    if (f16 && !flags_zeroed) MDNO_TRY(fill_ints(sw.f16_flags + 1, kEdgeMlpActivationFlags, 0, s));
     for (long long e0 = 0; e0 < edge_cap; e0 += chunk) {
         const int cnt = (int)((edge_cap - e0) < chunk ? (edge_cap - e0) : chunk);
         if (f16) {
@@ -1194,7 +1201,9 @@ int edge_mlp_split(const float* frames, int frame, const int* t_dev, int rows_pe
 int edge_mlp_split_hidden(const float* frames, int frame, const int* t_dev, int rows_per_frame, const int* src,
                           const int* dst, const float* edge_attr, const int* perm, const int* num_edges,
                           long long edge_cap, long long chunk, int ker_in, int ker_width, const EdgeMlpWeights& w,
-                          float* h_out, void* workspace, hipStream_t s, int phase, bool f16) {
+                          float* h_out, void* workspace, hipStream_t s, int phase_in, bool f16) {
+    const int phase = phase_in & WP_PHASE_MASK;
+    const bool flags_zeroed = (phase_in & WP_FLAGS_ZEROED) != 0;
     MDNO_REQUIRE(ker_in > 0 && ker_in <= MAX_F, MDNO_EUNSUPPORTED, "edge_mlp: ker_in=%d (1..%d)", ker_in, MAX_F);
     MDNO_REQUIRE((reinterpret_cast<uintptr_t>(w.w1) & 15) == 0, MDNO_EINVAL,
                  "edge_mlp: weight pointers must be 16-byte aligned");
@@ -1213,7 +1222,8 @@ int edge_mlp_split_hidden(const float* frames, int frame, const int* t_dev, int 
     MDNO_TRY(check_launch("split_planes_kernel"));
     if (phase == WP_PREPARE_ONLY) return MDNO_OK;
     const float* pos_mode = edge_attr ? nullptr : frames;
-    if (f16) MDNO_TRY(fill_ints(sw.f16_flags + 1, 3, 0, s));   // activation flags of THIS forward (range, h1 seen, h2 seen)
+    // activation flags of THIS forward (range, h1 seen, h2 seen)
+    if (f16 && !flags_zeroed) MDNO_TRY(fill_ints(sw.f16_flags + 1, kEdgeMlpActivationFlags, 0, s));
     for (long long e0 = 0; e0 < edge_cap; e0 += chunk) {
         const int cnt = (int)((edge_cap - e0) < chunk ? (edge_cap - e0) : chunk);
         float* out = h_out + (size_t)e0 * k;      // chunk % 128 == 0: the k-tiled tile index continues across chunks

@@ -123,10 +123,10 @@ int forward_impl(const mdno_kernelnn_params* p, const float* frames, int t0, con
                  const long long* aa, int aa_per_member, const int* row_ptr, const int* src, const int* dst,
                  const int* num_edges, long long edge_cap, int max_degree, const float* edge_frames, int edge_frame,
                  const float* edge_attr, const int* perm, float* out_frames, int t_out, float* latent,
-                 const FwdWs& ws, int* status, hipStream_t s, int phase = WP_BOTH) {
+                 const FwdWs& ws, int* status, hipStream_t s, int phase = WP_BOTH, const StepTail* tail = nullptr) {
     const int R = M * N, C = p->width;
     // WP_PREPARE_ONLY: just the weight-derived operands of the (single, shared) edge-MLP
-    const bool prep_only = phase == WP_PREPARE_ONLY;
+    const bool prep_only = (phase & WP_PHASE_MASK) == WP_PREPARE_ONLY;
     if (!prep_only) MDNO_TRY(node_prologue(p, frames, t0, t_dev, M, W, N, aa, aa_per_member, ws.xa, status, s));
     float* cur = ws.xa;
     float* nxt = ws.xb;
@@ -147,8 +147,8 @@ int forward_impl(const mdno_kernelnn_params* p, const float* frames, int t0, con
                 // attr = [pos[source], pos[destination]] = [pos[row], pos[col]]: pass (dst, src) swapped
                 MDNO_TRY(edge_mlp_hidden(edge_frames, edge_frame, t_dev, R, /*src=*/dst, /*dst=*/src, nullptr, nullptr,
                                          num_edges, edge_cap, p->ker_in, p->ker_width, p->gemm_mode, w, ws.h2, ws.mlp,
-                                         ws.mlp_bytes, s, phase));
-                if (phase != WP_RUN_ONLY) MDNO_TRY(factored_prepare_weights(w.w2, p->ker_width, cgm, fw, s));
+                                         ws.mlp_bytes, s, block == 0 ? phase : (phase & ~WP_FLAGS_ZEROED)));
+                if ((phase & WP_PHASE_MASK) != WP_RUN_ONLY) MDNO_TRY(factored_prepare_weights(w.w2, p->ker_width, cgm, fw, s));
             }
             if (prep_only) return MDNO_OK;
             const float* b3 = (block == 1 && separate_conv2_kernel(p)) ? p->k2_b2 : p->k_b2;
@@ -175,7 +175,7 @@ int forward_impl(const mdno_kernelnn_params* p, const float* frames, int t0, con
                                        : EdgeMlpWeights{p->k2_w0, p->k2_b0, p->k2_w1, p->k2_b1, p->k2_w2, p->k2_b2};
                 MDNO_TRY(edge_mlp(edge_frames, edge_frame, t_dev, R, src, dst, edge_attr, perm, num_edges, edge_cap,
                                   p->ker_in, p->ker_width, C * C, p->gemm_mode, w, ws.w_e, ws.mlp, ws.mlp_bytes, s,
-                                  phase));
+                                  block == 0 ? phase : (phase & ~WP_FLAGS_ZEROED)));   // (the caller zeroed the flags once)
             }
             if (prep_only) return MDNO_OK;
             const float* root = block == 0 ? p->conv1_root : p->conv2_root;
@@ -187,14 +187,8 @@ int forward_impl(const mdno_kernelnn_params* p, const float* frames, int t0, con
         }
     }
     if (latent) MDNO_HIP(hipMemcpyAsync(latent, cur, sizeof(float) * (size_t)R * C, hipMemcpyDeviceToDevice, s));
-    MDNO_TRY(fc_out(cur, p->fc2_w, p->fc2_b, R, C, p->out_width, out_frames, t_out, t_dev, s));
+    MDNO_TRY(fc_out(cur, p->fc2_w, p->fc2_b, R, C, p->out_width, out_frames, t_out, t_dev, s, tail));
     return MDNO_OK;
-}
-
-__global__ void advance_step_kernel(int* t_dev, const int* num_edges, int* edges_per_step) {
-    const int t = *t_dev;
-    if (edges_per_step) edges_per_step[t] = *num_edges;
-    *t_dev = t + 1;
 }
 
 struct RolloutWs {
@@ -211,7 +205,7 @@ RolloutWs carve_rollout(void* ws, const mdno_kernelnn_params* p, int M, int N, l
     r.src = cv.take<int>((size_t)edge_cap);
     r.dst = cv.take<int>((size_t)edge_cap);
     r.num_edges = cv.take<int>(64);   // counters on their own 256-B line
-    r.t_dev = r.num_edges + 1;
+    r.t_dev = r.num_edges + 1;        // (+2: finished workgroups of the step's last kernel, StepTail::done)
     r.fwd_bytes = carve_fwd(nullptr, p, M, N, edge_cap, use_factored(p, M, edge_cap, true)).total;
     r.fwd = cv.take<char>(r.fwd_bytes);
     r.total = cv.used();
@@ -265,7 +259,10 @@ extern "C" size_t mdno_rollout_workspace_bytes(const mdno_kernelnn_params* p, in
 
 namespace mdno {
 namespace {
-__global__ void set_step_kernel(int* t_dev, int v) { *t_dev = v; }
+__global__ void set_step_kernel(int* t_dev, int v) {
+    t_dev[0] = v;
+    t_dev[1] = 0;      // StepTail::done
+}
 }  // namespace
 }  // namespace mdno
 
@@ -300,15 +297,19 @@ static int plan_prepare_weights(mdno_rollout_plan* pl, hipStream_t s) {
 static int plan_enqueue_step(mdno_rollout_plan* pl, hipStream_t s) {
     const int W = pl->W;
     // graph + edge attributes of the LAST window frame (graph_kernel.py:363, :375): frame W-1+t
+    // the graph kernels also clear the activation flags of this step's edge-MLP, and the step's last kernel
+    // moves the step counter on: two launches fewer per step (a launch is ~4 us; a 28-atom step is ~30 of them)
+    int* act_flags = edge_mlp_activation_flags(pl->fw.mlp, pl->p.ker_width,
+                                               pl->fw.factored ? pl->p.ker_width : pl->p.width * pl->p.width,
+                                               pl->edge_cap, pl->p.gemm_mode);
     MDNO_TRY(radius_graph(pl->traj, W - 1, pl->r.t_dev, pl->M, pl->N, pl->threshold, pl->r.row_ptr, pl->r.src,
-                          pl->r.dst, pl->edge_cap, pl->r.num_edges, pl->status, s));
-    MDNO_TRY(forward_impl(&pl->p, pl->traj, 0, pl->r.t_dev, pl->M, W, pl->N, pl->aa, pl->aa_per_member, pl->r.row_ptr,
-                          pl->r.src, pl->r.dst, pl->r.num_edges, pl->edge_cap, pl->max_degree, pl->traj, W - 1, nullptr,
-                          nullptr, pl->traj, W, nullptr, pl->fw, pl->status, s,
-                          pl->weights_cached ? WP_RUN_ONLY : WP_BOTH));
-    hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(1), 0, s, pl->r.t_dev, (const int*)pl->r.num_edges,
-                       pl->edges_per_step);
-    return check_launch("advance_step");
+                          pl->r.dst, pl->edge_cap, pl->r.num_edges, pl->status, s, act_flags,
+                          act_flags ? kEdgeMlpActivationFlags : 0));
+    const StepTail tail{pl->r.t_dev, pl->r.num_edges, pl->edges_per_step, pl->r.t_dev + 1};
+    return forward_impl(&pl->p, pl->traj, 0, pl->r.t_dev, pl->M, W, pl->N, pl->aa, pl->aa_per_member, pl->r.row_ptr,
+                        pl->r.src, pl->r.dst, pl->r.num_edges, pl->edge_cap, pl->max_degree, pl->traj, W - 1, nullptr,
+                        nullptr, pl->traj, W, nullptr, pl->fw, pl->status, s,
+                        (pl->weights_cached ? WP_RUN_ONLY : WP_BOTH) | (act_flags ? WP_FLAGS_ZEROED : 0), &tail);
 }
 
 extern "C" int mdno_rollout_plan_create(mdno_rollout_plan** plan, const mdno_kernelnn_params* p, float* traj, int M,

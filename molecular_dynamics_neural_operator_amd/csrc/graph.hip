@@ -47,10 +47,12 @@ __global__ __launch_bounds__(256) void radius_count_kernel(const float* __restri
 // next to the per-edge work that follows).
 __global__ __launch_bounds__(1024) void scan_rows_kernel(const int* __restrict__ deg, int R, long long cap,
                                                          int* __restrict__ row_ptr, int* __restrict__ num_edges,
-                                                         int* __restrict__ status) {
+                                                         int* __restrict__ status, int* __restrict__ zero_words,
+                                                         int n_zero) {
     __shared__ long long wsum[16];
     __shared__ long long carry_s;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid < n_zero) zero_words[tid] = 0;
     if (tid == 0) carry_s = 0;
     __syncthreads();
     for (int base = 0; base < R; base += 1024) {
@@ -110,6 +112,76 @@ __global__ __launch_bounds__(256) void radius_fill_kernel(const float* __restric
             }
         }
         base += __popcll(mask);
+    }
+}
+
+// The three passes in ONE workgroup for a short chain (R <= 128 rows, N <= 128 atoms per member — the reference's
+// 28-residue BBA): at that size a launch costs more than the pass it carries.  Same tests, same order: a row's
+// neighbour masks are kept in LDS between the count and the fill.
+constexpr int kSmallGraphRows = 128;
+
+__global__ __launch_bounds__(1024) void radius_graph_small_kernel(const float* __restrict__ frames, int frame,
+                                                                  const int* __restrict__ t_dev, int N, int R,
+                                                                  double cutoff, long long cap,
+                                                                  int* __restrict__ row_ptr, int* __restrict__ src,
+                                                                  int* __restrict__ dst, int* __restrict__ num_edges,
+                                                                  int* __restrict__ status, int* __restrict__ zero_words,
+                                                                  int n_zero) {
+    __shared__ unsigned long long mask_s[kSmallGraphRows][2];
+    __shared__ int excl_s[kSmallGraphRows + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < n_zero) zero_words[tid] = 0;
+    const float* pos = frames + (size_t)(frame + (t_dev ? *t_dev : 0)) * R * 3;
+    for (int r = wave; r < R; r += 16) {
+        const int m = r / N;
+        const float* pm = pos + (size_t)m * N * 3;
+        const float* pi = pos + (size_t)r * 3;
+        const double xi = pi[0], yi = pi[1], zi = pi[2];
+        for (int jb = 0; jb < 2; ++jb) {
+            const int j = jb * 64 + lane;
+            const bool in = (j < N) && within(xi, yi, zi, pm + (size_t)j * 3, cutoff);
+            const unsigned long long mask = __ballot(in);
+            if (lane == 0) mask_s[r][jb] = mask;
+        }
+    }
+    __syncthreads();
+    if (tid < 128) {      // exclusive scan of the in-degrees over two waves
+        const int v = tid < R ? __popcll(mask_s[tid][0]) + __popcll(mask_s[tid][1]) : 0;
+        int incl = v;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        if (tid == 63) excl_s[kSmallGraphRows] = incl;      // total of the first wave
+        excl_s[tid] = incl - v;
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const int e = excl_s[tid] + (tid >= 64 ? excl_s[kSmallGraphRows] : 0);
+        if (tid < R) row_ptr[tid] = (int)(e < cap ? e : cap);
+        if (tid == R - 1) {
+            const long long total = (long long)e + __popcll(mask_s[tid][0]) + __popcll(mask_s[tid][1]);
+            const long long ec = total < cap ? total : cap;
+            row_ptr[R] = (int)ec;
+            *num_edges = (int)ec;
+            if (total > cap && status) atomicOr(status, MDNO_STATUS_EDGE_OVERFLOW);
+        }
+    }
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int r = wave; r < R; r += 16) {
+        const int m = r / N;
+        long long base = excl_s[r] + (r >= 64 ? excl_s[kSmallGraphRows] : 0);
+        for (int jb = 0; jb < 2; ++jb) {
+            const unsigned long long mask = mask_s[r][jb];
+            if ((mask >> lane) & 1ull) {
+                const long long p = base + __popcll(mask & lt);
+                if (p < cap) {
+                    src[p] = m * N + jb * 64 + lane;
+                    if (dst) dst[p] = r;
+                }
+            }
+            base += __popcll(mask);
+        }
     }
 }
 
@@ -223,7 +295,8 @@ CooWs carve_coo(void* ws, long long E, int num_nodes) {
 }  // namespace mdno
 
 int mdno::radius_graph(const float* frames, int frame, const int* t_dev, int M, int N, double cutoff, int* row_ptr,
-                       int* src, int* dst, long long edge_cap, int* num_edges, int* status, hipStream_t s) {
+                       int* src, int* dst, long long edge_cap, int* num_edges, int* status, hipStream_t s,
+                       int* zero_words, int n_zero) {
     MDNO_REQUIRE(frames && row_ptr && src && num_edges, MDNO_EINVAL, "radius_graph: null pointer");
     MDNO_REQUIRE(M > 0 && N > 0 && edge_cap > 0 && frame >= 0, MDNO_EINVAL, "radius_graph: M=%d N=%d cap=%lld", M, N,
                  edge_cap);
@@ -233,10 +306,16 @@ int mdno::radius_graph(const float* frames, int frame, const int* t_dev, int M, 
     const int blocks = (R + kRowsPerBlock - 1) / kRowsPerBlock;
     // The in-degrees are staged in src[0..R) (needs edge_cap >= R); the fill pass overwrites them.
     MDNO_REQUIRE(edge_cap >= R, MDNO_EINVAL, "radius_graph: edge_cap (%lld) < rows (%d)", edge_cap, R);
+    MDNO_REQUIRE(n_zero >= 0 && n_zero <= 64 && (n_zero == 0 || zero_words), MDNO_EINVAL, "radius_graph: n_zero=%d", n_zero);
     TimedSection ts(KID_GRAPH, s);
+    if (R <= kSmallGraphRows && N <= 128) {
+        hipLaunchKernelGGL(radius_graph_small_kernel, dim3(1), dim3(1024), 0, s, frames, frame, t_dev, N, R, cutoff,
+                           edge_cap, row_ptr, src, dst, num_edges, status, zero_words, n_zero);
+        return check_launch("radius_graph");
+    }
     hipLaunchKernelGGL(radius_count_kernel, dim3(blocks), dim3(256), 0, s, frames, frame, t_dev, N, R, cutoff, src);
     hipLaunchKernelGGL(scan_rows_kernel, dim3(1), dim3(1024), 0, s, (const int*)src, R, edge_cap, row_ptr,
-                       num_edges, status);
+                       num_edges, status, zero_words, n_zero);
     hipLaunchKernelGGL(radius_fill_kernel, dim3(blocks), dim3(256), 0, s, frames, frame, t_dev, N, R, cutoff,
                        (const int*)row_ptr, edge_cap, src, dst);
     return check_launch("radius_graph");
@@ -275,7 +354,7 @@ extern "C" int mdno_coo_to_csr(const int64_t* edge_index, int64_t E, int num_nod
     MDNO_HIP(hipMemsetAsync(c.deg, 0, sizeof(int) * 2 * (size_t)num_nodes, s));
     hipLaunchKernelGGL(coo_count_kernel, dim3(nb), dim3(256), 0, s, ei, (long long)E, num_nodes, c.deg, status);
     hipLaunchKernelGGL(scan_rows_kernel, dim3(1), dim3(1024), 0, s, (const int*)c.deg, num_nodes, (long long)E,
-                       row_ptr, c.scratch, (int*)nullptr);
+                       row_ptr, c.scratch, (int*)nullptr, (int*)nullptr, 0);
     hipLaunchKernelGGL(coo_slot_kernel, dim3(nb), dim3(256), 0, s, ei, (long long)E, num_nodes, (const int*)row_ptr,
                        c.cursor, c.ids);
     hipLaunchKernelGGL(coo_row_sort_kernel, dim3((num_nodes + 3) / 4), dim3(256), 0, s, ei, num_nodes,

@@ -22,8 +22,11 @@ struct TimedSection {
     ~TimedSection() { if (on) timer_mark(kid, false, s); }
 };
 
+// zero_words / n_zero (<= 64): ints the graph kernels also reset — a rollout step clears the edge-MLP's
+// activation flags here instead of with a launch of its own
 int radius_graph(const float* frames, int frame, const int* t_dev, int M, int N, double cutoff, int* row_ptr,
-                 int* src, int* dst, long long edge_cap, int* num_edges, int* status, hipStream_t s);
+                 int* src, int* dst, long long edge_cap, int* num_edges, int* status, hipStream_t s,
+                 int* zero_words = nullptr, int n_zero = 0);
 
 struct EdgeMlpWeights {
     const float *w0, *b0, *w1, *b1, *w2, *b2;
@@ -32,7 +35,14 @@ struct EdgeMlpWeights {
 // Weight-derived operands (bf16 plane images, W3T) live in the caller's workspace.  A rollout plan
 // builds them once per mdno_rollout_plan_run (WP_PREPARE_ONLY) and its steps reuse them (WP_RUN_ONLY);
 // one-off calls do both (WP_BOTH).
-enum WeightPhase { WP_BOTH = 0, WP_PREPARE_ONLY = 1, WP_RUN_ONLY = 2 };
+// WP_FLAGS_ZEROED (OR-ed in): the caller has already reset the activation flags of this forward
+// (edge_mlp_activation_flags), the edge-MLP launches no kernel for it.
+enum WeightPhase { WP_BOTH = 0, WP_PREPARE_ONLY = 1, WP_RUN_ONLY = 2, WP_PHASE_MASK = 3, WP_FLAGS_ZEROED = 4 };
+constexpr int kEdgeMlpActivationFlags = 3;
+// the three per-forward flag words of the SPLIT_F16 edge-MLP inside `workspace` (NULL in the other modes);
+// out_dim = ker_width for edge_mlp_hidden
+int* edge_mlp_activation_flags(void* workspace, int ker_width, int out_dim, long long edge_cap, int gemm_mode);
+int* edge_mlp_split_activation_flags(void* workspace, int ker_width, int out_dim, long long chunk);
 
 // gemm_mode: MDNO_GEMM_SPLIT_BF16 (default; falls back to exact fp32 when the shape is not tileable)
 // or MDNO_GEMM_F32.
@@ -134,7 +144,15 @@ int nnconv(const float* x, const int* row_ptr, const int* src, int num_rows, con
 int node_prologue(const mdno_kernelnn_params* p, const float* frames, int t0, const int* t_dev, int M, int W, int N,
                   const long long* aa, int aa_per_member, float* x0, int* status, hipStream_t s);
 
+// End of a rollout step, done by the workgroup of fc_out that finishes last (every workgroup has read *t_dev
+// by then): edges_per_step[t] = *num_edges, *t_dev = t + 1.  `done` counts finished workgroups and is left at 0.
+struct StepTail {
+    int* t_dev;
+    const int* num_edges;
+    int* edges_per_step;
+    int* done;
+};
 int fc_out(const float* x, const float* w, const float* b, int rows, int width, int out_width, float* out_frames,
-           int t_out, const int* t_dev, hipStream_t s);
+           int t_out, const int* t_dev, hipStream_t s, const StepTail* tail = nullptr);
 
 }  // namespace mdno

@@ -45,12 +45,16 @@ __device__ __forceinline__ void fma4(float4& a, float s, const float4& w) {
 // acc += x[16g..16g+15] . Wblk[16g..16g+15][4q..4q+3]
 __device__ __forceinline__ void edge_accumulate64(float4& acc, const float* __restrict__ xrow,
                                                   const float* __restrict__ wmat, int g, int q) {
-    const float* xp = xrow + 16 * g;
-    const float4 x0 = ld4(xp), x1 = ld4(xp + 4), x2 = ld4(xp + 8), x3 = ld4(xp + 12);
+    // the 16 KiB of W first: their address does not wait for src[p], which the x row's does
     const float* wp = wmat + (16 * g) * 64 + 4 * q;
     float4 w[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) w[r] = ld4_stream(wp + r * 64);
+    const float* xp = xrow + 16 * g;
+    const float4 x0 = ld4(xp), x1 = ld4(xp + 4), x2 = ld4(xp + 8), x3 = ld4(xp + 12);
+    // all twenty loads in flight before the first FMA waits for one (left alone, the scheduler waits for the
+    // x row after nine of them and issues the rest behind that round trip)
+    __builtin_amdgcn_sched_barrier(0);
     fma4(acc, x0.x, w[0]);  fma4(acc, x0.y, w[1]);  fma4(acc, x0.z, w[2]);  fma4(acc, x0.w, w[3]);
     fma4(acc, x1.x, w[4]);  fma4(acc, x1.y, w[5]);  fma4(acc, x1.z, w[6]);  fma4(acc, x1.w, w[7]);
     fma4(acc, x2.x, w[8]);  fma4(acc, x2.y, w[9]);  fma4(acc, x2.z, w[10]); fma4(acc, x2.w, w[11]);

@@ -121,19 +121,29 @@ __global__ __launch_bounds__(256) void node_prologue_kernel(PrologueArgs a) {
 __global__ __launch_bounds__(256) void fc_out_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ b, int R, int width,
                                                      int out_width, float* __restrict__ out, int t_out,
-                                                     const int* __restrict__ t_dev) {
+                                                     const int* __restrict__ t_dev, StepTail tail) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= R) return;
-    const int t = t_out + (t_dev ? *t_dev : 0);
-    float* o_ptr = out + ((size_t)t * R + r) * out_width;
-    const float* xr = x + (size_t)r * width;
-    for (int o = 0; o < out_width; ++o) {
-        float s = 0.f;
-        for (int c = lane; c < width; c += 64) s = fmaf(xr[c], w[(size_t)o * width + c], s);
+    const int step = t_dev ? *t_dev : 0;
+    if (r < R) {
+        float* o_ptr = out + ((size_t)(t_out + step) * R + r) * out_width;
+        const float* xr = x + (size_t)r * width;
+        for (int o = 0; o < out_width; ++o) {
+            float s = 0.f;
+            for (int c = lane; c < width; c += 64) s = fmaf(xr[c], w[(size_t)o * width + c], s);
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-        if (lane == 0) o_ptr[o] = s + (b ? b[o] : 0.f);
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+            if (lane == 0) o_ptr[o] = s + (b ? b[o] : 0.f);
+        }
+    }
+    if (tail.done == nullptr) return;
+    // the step counter moves on once every workgroup is past its read of it (each has `step` in a register
+    // before it gets here; the next kernel of the stream starts after this one has drained)
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(tail.done, 1) == (int)gridDim.x - 1) {
+        *tail.done = 0;
+        if (tail.edges_per_step) tail.edges_per_step[step] = *tail.num_edges;
+        *tail.t_dev = step + 1;
     }
 }
 
@@ -164,12 +174,14 @@ int mdno::node_prologue(const mdno_kernelnn_params* p, const float* frames, int 
 }
 
 int mdno::fc_out(const float* x, const float* w, const float* b, int rows, int width, int out_width,
-                 float* out_frames, int t_out, const int* t_dev, hipStream_t s) {
+                 float* out_frames, int t_out, const int* t_dev, hipStream_t s, const StepTail* tail) {
     MDNO_REQUIRE(x && w && out_frames, MDNO_EINVAL, "fc_out: null pointer");
     MDNO_REQUIRE(rows > 0 && width > 0 && out_width > 0 && t_out >= 0, MDNO_EINVAL, "fc_out: bad sizes");
+    MDNO_REQUIRE(!tail || (tail->t_dev && tail->t_dev == t_dev && tail->num_edges && tail->done), MDNO_EINVAL,
+                 "fc_out: incomplete step tail");
     TimedSection ts(KID_FC_OUT, s);
     hipLaunchKernelGGL(fc_out_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, b, rows, width, out_width,
-                       out_frames, t_out, t_dev);
+                       out_frames, t_out, t_dev, tail ? *tail : StepTail{nullptr, nullptr, nullptr, nullptr});
     return check_launch("fc_out");
 }
 

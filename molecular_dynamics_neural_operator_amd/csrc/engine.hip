@@ -127,9 +127,11 @@ int forward_impl(const mdno_kernelnn_params* p, const float* frames, int t0, con
     const int R = M * N, C = p->width;
     // WP_PREPARE_ONLY: just the weight-derived operands of the (single, shared) edge-MLP
     const bool prep_only = (phase & WP_PHASE_MASK) == WP_PREPARE_ONLY;
-    if (!prep_only) MDNO_TRY(node_prologue(p, frames, t0, t_dev, M, W, N, aa, aa_per_member, ws.xa, status, s));
+    if (!prep_only && !(phase & WP_PROLOGUE_DONE))
+        MDNO_TRY(node_prologue(p, frames, t0, t_dev, M, W, N, aa, aa_per_member, ws.xa, status, s));
     float* cur = ws.xa;
     float* nxt = ws.xb;
+    bool fc_done = false;      // the output layer went out with the last conv application
     const int blocks = p->conv2_root ? 2 : 1;   // notebook-era model: conv1 only (lstm_* NULL as well)
     if (ws.factored) {
         // symmetric radius graph, attributes from positions: row r = SOURCE r -> destinations src[p]
@@ -181,13 +183,19 @@ int forward_impl(const mdno_kernelnn_params* p, const float* frames, int t0, con
             const float* root = block == 0 ? p->conv1_root : p->conv2_root;
             const float* bias = block == 0 ? p->conv1_bias : p->conv2_bias;
             for (int d = 0; d < p->depth; ++d) {
-                MDNO_TRY(nnconv(cur, row_ptr, src, R, ws.w_e, root, bias, C, C, MDNO_AGGR_MEAN, /*relu=*/1, nxt, s));
+                // the forward's last application also applies the output layer to its rows (and ends the step)
+                const bool last = block + 1 == blocks && d + 1 == p->depth;
+                const FcTail fc{p->fc2_w, p->fc2_b, p->out_width, out_frames, t_out, t_dev,
+                                tail ? *tail : StepTail{nullptr, nullptr, nullptr, nullptr}};
+                MDNO_TRY(nnconv(cur, row_ptr, src, R, ws.w_e, root, bias, C, C, MDNO_AGGR_MEAN, /*relu=*/1, nxt, s,
+                                last ? &fc : nullptr));
+                fc_done = last;
                 float* t = cur; cur = nxt; nxt = t;
             }
         }
     }
     if (latent) MDNO_HIP(hipMemcpyAsync(latent, cur, sizeof(float) * (size_t)R * C, hipMemcpyDeviceToDevice, s));
-    MDNO_TRY(fc_out(cur, p->fc2_w, p->fc2_b, R, C, p->out_width, out_frames, t_out, t_dev, s, tail));
+    if (!fc_done) MDNO_TRY(fc_out(cur, p->fc2_w, p->fc2_b, R, C, p->out_width, out_frames, t_out, t_dev, s, tail));
     return MDNO_OK;
 }
 
@@ -302,14 +310,22 @@ static int plan_enqueue_step(mdno_rollout_plan* pl, hipStream_t s) {
     int* act_flags = edge_mlp_activation_flags(pl->fw.mlp, pl->p.ker_width,
                                                pl->fw.factored ? pl->p.ker_width : pl->p.width * pl->p.width,
                                                pl->edge_cap, pl->p.gemm_mode);
-    MDNO_TRY(radius_graph(pl->traj, W - 1, pl->r.t_dev, pl->M, pl->N, pl->threshold, pl->r.row_ptr, pl->r.src,
-                          pl->r.dst, pl->edge_cap, pl->r.num_edges, pl->status, s, act_flags,
-                          act_flags ? kEdgeMlpActivationFlags : 0));
+    const int n_zero = act_flags ? kEdgeMlpActivationFlags : 0;
+    const bool head = step_head_small_supported(pl->M, pl->N);      // short chain: graph and node prologue in one launch
+    if (head)
+        MDNO_TRY(step_head_small(&pl->p, pl->traj, W, pl->r.t_dev, pl->M, pl->N, pl->aa, pl->aa_per_member, pl->fw.xa,
+                                 pl->threshold, pl->r.row_ptr, pl->r.src, pl->r.dst, pl->edge_cap, pl->r.num_edges,
+                                 pl->status, act_flags, n_zero, s));
+    else
+        MDNO_TRY(radius_graph(pl->traj, W - 1, pl->r.t_dev, pl->M, pl->N, pl->threshold, pl->r.row_ptr, pl->r.src,
+                              pl->r.dst, pl->edge_cap, pl->r.num_edges, pl->status, s, act_flags, n_zero));
     const StepTail tail{pl->r.t_dev, pl->r.num_edges, pl->edges_per_step, pl->r.t_dev + 1};
     return forward_impl(&pl->p, pl->traj, 0, pl->r.t_dev, pl->M, W, pl->N, pl->aa, pl->aa_per_member, pl->r.row_ptr,
                         pl->r.src, pl->r.dst, pl->r.num_edges, pl->edge_cap, pl->max_degree, pl->traj, W - 1, nullptr,
                         nullptr, pl->traj, W, nullptr, pl->fw, pl->status, s,
-                        (pl->weights_cached ? WP_RUN_ONLY : WP_BOTH) | (act_flags ? WP_FLAGS_ZEROED : 0), &tail);
+                        (pl->weights_cached ? WP_RUN_ONLY : WP_BOTH) | (act_flags ? WP_FLAGS_ZEROED : 0) |
+                            (head ? WP_PROLOGUE_DONE : 0),
+                        &tail);
 }
 
 extern "C" int mdno_rollout_plan_create(mdno_rollout_plan** plan, const mdno_kernelnn_params* p, float* traj, int M,

@@ -8,6 +8,7 @@
 // squares and the 3-term sum in f64 (squares of f32 differences are exact in f64, so FMA
 // contraction cannot change the sum), correctly rounded f64 sqrt, strict `<` against the f64 cutoff.
 #include "kernels.h"
+#include "graph_small.h"
 
 namespace mdno {
 
@@ -15,12 +16,6 @@ namespace {
 
 constexpr int kRowsPerBlock = 4;  // one wave per destination row
 
-__device__ __forceinline__ bool within(double xi, double yi, double zi, const float* __restrict__ pj,
-                                       double cutoff) {
-    const double dx = (double)pj[0] - xi, dy = (double)pj[1] - yi, dz = (double)pj[2] - zi;
-    const double s = (dx * dx + dy * dy) + dz * dz;
-    return sqrt(s) < cutoff;
-}
 
 // Pass 1: in-degree of every row.  Lane l tests atoms j = l, l+64, ... of the row's own member.
 __global__ __launch_bounds__(256) void radius_count_kernel(const float* __restrict__ frames, int frame,
@@ -115,75 +110,8 @@ __global__ __launch_bounds__(256) void radius_fill_kernel(const float* __restric
     }
 }
 
-// The three passes in ONE workgroup for a short chain (R <= 128 rows, N <= 128 atoms per member — the reference's
-// 28-residue BBA): at that size a launch costs more than the pass it carries.  Same tests, same order: a row's
-// neighbour masks are kept in LDS between the count and the fill.
-constexpr int kSmallGraphRows = 128;
-
-__global__ __launch_bounds__(1024) void radius_graph_small_kernel(const float* __restrict__ frames, int frame,
-                                                                  const int* __restrict__ t_dev, int N, int R,
-                                                                  double cutoff, long long cap,
-                                                                  int* __restrict__ row_ptr, int* __restrict__ src,
-                                                                  int* __restrict__ dst, int* __restrict__ num_edges,
-                                                                  int* __restrict__ status, int* __restrict__ zero_words,
-                                                                  int n_zero) {
-    __shared__ unsigned long long mask_s[kSmallGraphRows][2];
-    __shared__ int excl_s[kSmallGraphRows + 1];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < n_zero) zero_words[tid] = 0;
-    const float* pos = frames + (size_t)(frame + (t_dev ? *t_dev : 0)) * R * 3;
-    for (int r = wave; r < R; r += 16) {
-        const int m = r / N;
-        const float* pm = pos + (size_t)m * N * 3;
-        const float* pi = pos + (size_t)r * 3;
-        const double xi = pi[0], yi = pi[1], zi = pi[2];
-        for (int jb = 0; jb < 2; ++jb) {
-            const int j = jb * 64 + lane;
-            const bool in = (j < N) && within(xi, yi, zi, pm + (size_t)j * 3, cutoff);
-            const unsigned long long mask = __ballot(in);
-            if (lane == 0) mask_s[r][jb] = mask;
-        }
-    }
-    __syncthreads();
-    if (tid < 128) {      // exclusive scan of the in-degrees over two waves
-        const int v = tid < R ? __popcll(mask_s[tid][0]) + __popcll(mask_s[tid][1]) : 0;
-        int incl = v;
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(incl, o);
-            if (lane >= o) incl += t;
-        }
-        if (tid == 63) excl_s[kSmallGraphRows] = incl;      // total of the first wave
-        excl_s[tid] = incl - v;
-    }
-    __syncthreads();
-    if (tid < 128) {
-        const int e = excl_s[tid] + (tid >= 64 ? excl_s[kSmallGraphRows] : 0);
-        if (tid < R) row_ptr[tid] = (int)(e < cap ? e : cap);
-        if (tid == R - 1) {
-            const long long total = (long long)e + __popcll(mask_s[tid][0]) + __popcll(mask_s[tid][1]);
-            const long long ec = total < cap ? total : cap;
-            row_ptr[R] = (int)ec;
-            *num_edges = (int)ec;
-            if (total > cap && status) atomicOr(status, MDNO_STATUS_EDGE_OVERFLOW);
-        }
-    }
-    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    for (int r = wave; r < R; r += 16) {
-        const int m = r / N;
-        long long base = excl_s[r] + (r >= 64 ? excl_s[kSmallGraphRows] : 0);
-        for (int jb = 0; jb < 2; ++jb) {
-            const unsigned long long mask = mask_s[r][jb];
-            if ((mask >> lane) & 1ull) {
-                const long long p = base + __popcll(mask & lt);
-                if (p < cap) {
-                    src[p] = m * N + jb * 64 + lane;
-                    if (dst) dst[p] = r;
-                }
-            }
-            base += __popcll(mask);
-        }
-    }
-}
+// (the three passes in one workgroup for a short chain: graph_small.h)
+__global__ __launch_bounds__(1024) void radius_graph_small_kernel(SmallGraphArgs a) { radius_graph_small_body(a); }
 
 // ---- COO -> CSR: counting sort by destination (keys are node ids < num_nodes)
 //   count   in-degree of every node (integer atomics: the counts are deterministic); node ids outside
@@ -308,9 +236,10 @@ int mdno::radius_graph(const float* frames, int frame, const int* t_dev, int M, 
     MDNO_REQUIRE(edge_cap >= R, MDNO_EINVAL, "radius_graph: edge_cap (%lld) < rows (%d)", edge_cap, R);
     MDNO_REQUIRE(n_zero >= 0 && n_zero <= 64 && (n_zero == 0 || zero_words), MDNO_EINVAL, "radius_graph: n_zero=%d", n_zero);
     TimedSection ts(KID_GRAPH, s);
-    if (R <= kSmallGraphRows && N <= 128) {
-        hipLaunchKernelGGL(radius_graph_small_kernel, dim3(1), dim3(1024), 0, s, frames, frame, t_dev, N, R, cutoff,
-                           edge_cap, row_ptr, src, dst, num_edges, status, zero_words, n_zero);
+    if (small_graph_supported(M, N)) {
+        hipLaunchKernelGGL(radius_graph_small_kernel, dim3(1), dim3(1024), 0, s,
+                           SmallGraphArgs{frames, frame, t_dev, N, R, cutoff, edge_cap, row_ptr, src, dst, num_edges,
+                                          status, zero_words, n_zero});
         return check_launch("radius_graph");
     }
     hipLaunchKernelGGL(radius_count_kernel, dim3(blocks), dim3(256), 0, s, frames, frame, t_dev, N, R, cutoff, src);

@@ -37,7 +37,9 @@ struct EdgeMlpWeights {
 // one-off calls do both (WP_BOTH).
 // WP_FLAGS_ZEROED (OR-ed in): the caller has already reset the activation flags of this forward
 // (edge_mlp_activation_flags), the edge-MLP launches no kernel for it.
-enum WeightPhase { WP_BOTH = 0, WP_PREPARE_ONLY = 1, WP_RUN_ONLY = 2, WP_PHASE_MASK = 3, WP_FLAGS_ZEROED = 4 };
+// WP_PROLOGUE_DONE (OR-ed in, engine only): the node features of this forward are already in place.
+enum WeightPhase { WP_BOTH = 0, WP_PREPARE_ONLY = 1, WP_RUN_ONLY = 2, WP_PHASE_MASK = 3, WP_FLAGS_ZEROED = 4,
+                   WP_PROLOGUE_DONE = 8 };
 constexpr int kEdgeMlpActivationFlags = 3;
 // the three per-forward flag words of the SPLIT_F16 edge-MLP inside `workspace` (NULL in the other modes);
 // out_dim = ker_width for edge_mlp_hidden
@@ -138,20 +140,40 @@ bool gemm_tn_pp_supported(long long rows, int n1, int n2);
 size_t gemm_tn_pp_workspace_bytes(long long rows, int n1, int n2);
 int gemm_tn_pp(const void* A, const void* B, long long rows, int n1, int n2, float* C, void* workspace, hipStream_t s);
 
-int nnconv(const float* x, const int* row_ptr, const int* src, int num_rows, const float* w_e, const float* root,
-           const float* bias, int Cin, int Cout, int aggr, int relu, float* y, hipStream_t s);
-
-int node_prologue(const mdno_kernelnn_params* p, const float* frames, int t0, const int* t_dev, int M, int W, int N,
-                  const long long* aa, int aa_per_member, float* x0, int* status, hipStream_t s);
-
-// End of a rollout step, done by the workgroup of fc_out that finishes last (every workgroup has read *t_dev
-// by then): edges_per_step[t] = *num_edges, *t_dev = t + 1.  `done` counts finished workgroups and is left at 0.
+// End of a rollout step, done by the workgroup of the step's last kernel that finishes last (every workgroup has
+// read *t_dev by then): edges_per_step[t] = *num_edges, *t_dev = t + 1.  `done` counts finished workgroups and is
+// left at 0.
 struct StepTail {
     int* t_dev;
     const int* num_edges;
     int* edges_per_step;
     int* done;
 };
+// The model's output layer on a conv application's rows (fc_out below, same arithmetic): the last application of a
+// forward writes out[(t_out + *t_dev) * rows + r][0..out_width) = w . y[r] + b next to y itself.
+struct FcTail {
+    const float* w;
+    const float* b;
+    int out_width;
+    float* out;
+    int t_out;
+    const int* t_dev;
+    StepTail step;      // step.done == NULL: none
+};
+int nnconv(const float* x, const int* row_ptr, const int* src, int num_rows, const float* w_e, const float* root,
+           const float* bias, int Cin, int Cout, int aggr, int relu, float* y, hipStream_t s,
+           const FcTail* fc = nullptr);
+
+int node_prologue(const mdno_kernelnn_params* p, const float* frames, int t0, const int* t_dev, int M, int W, int N,
+                  const long long* aa, int aa_per_member, float* x0, int* status, hipStream_t s);
+
+// Head of a rollout step on a short chain (M * N <= 128 rows): radius graph of frame W-1+t and node prologue of the
+// window at frame t in ONE launch (they are independent; each is shorter than a launch).
+bool step_head_small_supported(int M, int N);
+int step_head_small(const mdno_kernelnn_params* p, const float* frames, int W, const int* t_dev, int M, int N,
+                    const long long* aa, int aa_per_member, float* x0, double cutoff, int* row_ptr, int* src, int* dst,
+                    long long edge_cap, int* num_edges, int* status, int* zero_words, int n_zero, hipStream_t s);
+
 int fc_out(const float* x, const float* w, const float* b, int rows, int width, int out_width, float* out_frames,
            int t_out, const int* t_dev, hipStream_t s, const StepTail* tail = nullptr);
 

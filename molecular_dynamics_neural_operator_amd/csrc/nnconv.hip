@@ -82,7 +82,7 @@ template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void nnconv64_row_kernel(
     const float* __restrict__ x, const int* __restrict__ row_ptr, const int* __restrict__ src,
     const float* __restrict__ w_e, const float* __restrict__ root, const float* __restrict__ bias,
-    float* __restrict__ y, int num_rows, int aggr, int relu) {
+    float* __restrict__ y, int num_rows, int aggr, int relu, FcTail fc) {
     constexpr int CPW = CHAINS / WAVES;   // chains per wave
     __shared__ float red[CHAINS][64];
     __shared__ float rootred[64];
@@ -122,6 +122,23 @@ __global__ __launch_bounds__(WAVES * 64) void nnconv64_row_kernel(
         if (bias != nullptr) s += bias[tid];
         if (relu) s = fmaxf(s, 0.f);
         y[(size_t)row * 64 + tid] = s;
+        if (fc.out != nullptr) {
+            // the output layer on this row, as fc_out_kernel computes it (one product per lane, xor tree, bias)
+            const int step = fc.t_dev ? *fc.t_dev : 0;
+            float* o_ptr = fc.out + ((size_t)(fc.t_out + step) * num_rows + row) * fc.out_width;
+            for (int o = 0; o < fc.out_width; ++o) {
+                float v = fmaf(s, fc.w[(size_t)o * 64 + tid], 0.f);
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+                if (tid == 0) o_ptr[o] = v + (fc.b ? fc.b[o] : 0.f);
+            }
+            // (this wave has its copy of the step counter; the last workgroup through here moves it on)
+            if (fc.step.done != nullptr && tid == 0 && atomicAdd(fc.step.done, 1) == num_rows - 1) {
+                *fc.step.done = 0;
+                if (fc.step.edges_per_step) fc.step.edges_per_step[step] = *fc.step.num_edges;
+                *fc.step.t_dev = step + 1;
+            }
+        }
     }
 }
 
@@ -163,7 +180,7 @@ __global__ __launch_bounds__(256) void nnconv_generic_kernel(
 
 int mdno::nnconv(const float* x, const int* row_ptr, const int* src, int num_rows, const float* w_e,
                  const float* root, const float* bias, int Cin, int Cout, int aggr, int relu, float* y,
-                 hipStream_t s) {
+                 hipStream_t s, const FcTail* fc) {
     MDNO_REQUIRE(x && row_ptr && src && w_e && y, MDNO_EINVAL, "nnconv: null pointer");
     MDNO_REQUIRE(num_rows > 0 && Cin > 0 && Cout > 0, MDNO_EINVAL, "nnconv: rows=%d Cin=%d Cout=%d", num_rows, Cin,
                  Cout);
@@ -172,6 +189,15 @@ int mdno::nnconv(const float* x, const int* row_ptr, const int* src, int num_row
     MDNO_REQUIRE(x != y, MDNO_EINVAL, "nnconv: y aliases x");
     const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_e) |
                            reinterpret_cast<uintptr_t>(root)) & 15) == 0;
+    MDNO_REQUIRE(!fc || (fc->w && fc->out && fc->out_width > 0 && fc->t_out >= 0 &&
+                         (!fc->step.done || (fc->step.t_dev && fc->step.t_dev == fc->t_dev && fc->step.num_edges))),
+                 MDNO_EINVAL, "nnconv: incomplete output-layer tail");
+    const FcTail no_tail{};
+    if (fc && !(Cin == 64 && Cout == 64 && aligned)) {      // the generic kernel has no tail: the layer gets its own launch
+        MDNO_TRY(nnconv(x, row_ptr, src, num_rows, w_e, root, bias, Cin, Cout, aggr, relu, y, s, nullptr));
+        return fc_out(y, fc->w, fc->b, num_rows, Cout, fc->out_width, fc->out, fc->t_out, fc->t_dev, s,
+                      fc->step.done ? &fc->step : nullptr);
+    }
     TimedSection ts(KID_NNCONV, s);
     if (Cin == 64 && Cout == 64 && aligned) {
         // waves per destination row: with only a few hundred rows (one ~500-atom trajectory) more
@@ -179,10 +205,10 @@ int mdno::nnconv(const float* x, const int* row_ptr, const int* src, int num_row
         // same 16 chains, so the choice never changes a bit of the result
         if (num_rows >= 4096)
             hipLaunchKernelGGL(nnconv64_row_kernel<4>, dim3(num_rows), dim3(256), 0, s, x, row_ptr, src, w_e, root,
-                               bias, y, num_rows, aggr, relu);
+                               bias, y, num_rows, aggr, relu, fc ? *fc : no_tail);
         else
             hipLaunchKernelGGL(nnconv64_row_kernel<16>, dim3(num_rows), dim3(1024), 0, s, x, row_ptr, src, w_e, root,
-                               bias, y, num_rows, aggr, relu);
+                               bias, y, num_rows, aggr, relu, fc ? *fc : no_tail);
     } else {
         hipLaunchKernelGGL(nnconv_generic_kernel, dim3((num_rows + 3) / 4), dim3(256), 0, s, x, row_ptr, src, w_e,
                            root, bias, y, num_rows, Cin, Cout, aggr, relu);

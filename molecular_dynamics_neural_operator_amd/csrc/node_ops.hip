@@ -8,6 +8,7 @@
 // into the trajectory buffer.  Both are negligible in time (R*~1e3 flop); they exist so that a
 // rollout step never leaves the device.
 #include "kernels.h"
+#include "graph_small.h"
 
 namespace mdno {
 namespace {
@@ -30,9 +31,8 @@ struct PrologueArgs {
     int* status;
 };
 
-__global__ __launch_bounds__(256) void node_prologue_kernel(PrologueArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+// one wave per row r
+__device__ __forceinline__ void node_prologue_row(const PrologueArgs& a, int r, int lane) {
     const int R = a.M * a.N;
     if (r >= R) return;
     const int m = r / a.N, n = r - m * a.N;
@@ -118,6 +118,18 @@ __global__ __launch_bounds__(256) void node_prologue_kernel(PrologueArgs a) {
     }
 }
 
+__global__ __launch_bounds__(256) void node_prologue_kernel(PrologueArgs a) {
+    node_prologue_row(a, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
+}
+
+// Head of a rollout step on a short chain: workgroup 0 builds the radius graph of the newest frame, the others
+// run the node prologue (16 rows each) — the two do not depend on each other, and at this size each is shorter
+// than the launch that would carry it.
+__global__ __launch_bounds__(1024) void step_head_small_kernel(SmallGraphArgs g, PrologueArgs a) {
+    if (blockIdx.x == 0) radius_graph_small_body(g);
+    else node_prologue_row(a, (blockIdx.x - 1) * 16 + (threadIdx.x >> 6), threadIdx.x & 63);
+}
+
 __global__ __launch_bounds__(256) void fc_out_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ b, int R, int width,
                                                      int out_width, float* __restrict__ out, int t_out,
@@ -150,8 +162,10 @@ __global__ __launch_bounds__(256) void fc_out_kernel(const float* __restrict__ x
 }  // namespace
 }  // namespace mdno
 
-int mdno::node_prologue(const mdno_kernelnn_params* p, const float* frames, int t0, const int* t_dev, int M, int W,
-                        int N, const long long* aa, int aa_per_member, float* x0, int* status, hipStream_t s) {
+namespace mdno {
+namespace {
+int prologue_args(const mdno_kernelnn_params* p, const float* frames, int t0, const int* t_dev, int M, int W, int N,
+                  const long long* aa, int aa_per_member, float* x0, int* status, PrologueArgs& a) {
     MDNO_REQUIRE(p && frames && aa && x0, MDNO_EINVAL, "node_prologue: null pointer");
     MDNO_REQUIRE(p->emb_w && p->fc1_w && p->fc1_b, MDNO_EINVAL, "node_prologue: null weight pointer");
     const bool lstm = p->lstm_w_ih != nullptr;
@@ -164,13 +178,42 @@ int mdno::node_prologue(const mdno_kernelnn_params* p, const float* frames, int 
     MDNO_REQUIRE(p->in_width == p->embedding_dim + H, MDNO_EINVAL,
                  "in_width=%d must equal embedding_dim + 3 = %d (graph_kernel.py:296)", p->in_width,
                  p->embedding_dim + H);
-    PrologueArgs a{frames, t0, t_dev, M, W, N, aa, aa_per_member, p->lstm_w_ih, p->lstm_w_hh, p->lstm_b_ih,
-                   p->lstm_b_hh, p->lstm_fc_w, p->lstm_fc_b, p->emb_w, p->fc1_w, p->fc1_b, p->num_embeddings,
-                   p->embedding_dim, p->width, x0, status};
+    a = PrologueArgs{frames, t0, t_dev, M, W, N, aa, aa_per_member, p->lstm_w_ih, p->lstm_w_hh, p->lstm_b_ih,
+                     p->lstm_b_hh, p->lstm_fc_w, p->lstm_fc_b, p->emb_w, p->fc1_w, p->fc1_b, p->num_embeddings,
+                     p->embedding_dim, p->width, x0, status};
+    return MDNO_OK;
+}
+}  // namespace
+}  // namespace mdno
+
+int mdno::node_prologue(const mdno_kernelnn_params* p, const float* frames, int t0, const int* t_dev, int M, int W,
+                        int N, const long long* aa, int aa_per_member, float* x0, int* status, hipStream_t s) {
+    PrologueArgs a;
+    MDNO_TRY(prologue_args(p, frames, t0, t_dev, M, W, N, aa, aa_per_member, x0, status, a));
     const int R = M * N;
     TimedSection ts(KID_PROLOGUE, s);
     hipLaunchKernelGGL(node_prologue_kernel, dim3((R + 3) / 4), dim3(256), 0, s, a);
     return check_launch("node_prologue");
+}
+
+bool mdno::step_head_small_supported(int M, int N) { return small_graph_supported(M, N); }
+
+int mdno::step_head_small(const mdno_kernelnn_params* p, const float* frames, int W, const int* t_dev, int M, int N,
+                          const long long* aa, int aa_per_member, float* x0, double cutoff, int* row_ptr, int* src,
+                          int* dst, long long edge_cap, int* num_edges, int* status, int* zero_words, int n_zero,
+                          hipStream_t s) {
+    MDNO_REQUIRE(step_head_small_supported(M, N), MDNO_EUNSUPPORTED, "step_head_small: M=%d N=%d", M, N);
+    MDNO_REQUIRE(row_ptr && src && num_edges && edge_cap > 0 && t_dev, MDNO_EINVAL, "step_head_small: null pointer");
+    MDNO_REQUIRE(n_zero >= 0 && n_zero <= 64 && (n_zero == 0 || zero_words), MDNO_EINVAL, "step_head_small: n_zero=%d", n_zero);
+    PrologueArgs a;
+    MDNO_TRY(prologue_args(p, frames, 0, t_dev, M, W, N, aa, aa_per_member, x0, status, a));
+    const int R = M * N;
+    // graph of the LAST window frame (W - 1 + t), prologue over the window starting at frame t
+    const SmallGraphArgs g{frames, W - 1, t_dev, N, R, cutoff, edge_cap, row_ptr, src, dst, num_edges, status,
+                           zero_words, n_zero};
+    TimedSection ts(KID_GRAPH, s);
+    hipLaunchKernelGGL(step_head_small_kernel, dim3(1 + (R + 15) / 16), dim3(1024), 0, s, g, a);
+    return check_launch("step_head_small");
 }
 
 int mdno::fc_out(const float* x, const float* w, const float* b, int rows, int width, int out_width,

@@ -194,18 +194,21 @@ __global__ __launch_bounds__(256) void split_bias64_kernel(const float* __restri
 constexpr int MAX_F = 8;
 constexpr int L0_ROWS = 128, L0_UNITS = 128;
 
-// F16: emit the two fp16 planes (and raise f16_flags[1] on a value out of fp16 range) instead of the
-// three bf16 planes; the bf16 instantiation given f16_flags runs only when a flag is up (fallback).
-template <int FT, bool F16>   // FT = compile-time ker_in (6 for position-derived attributes), 0 = run-time F
+// MODE 1: emit the two fp16 planes (and raise f16_flags[1] on a value out of fp16 range) instead of the
+// three bf16 planes; MODE 0 given f16_flags runs only when a flag is up (fallback); MODE 2: both images
+// (launches of a few rows, whose GEMMs pick their operand image themselves: gemm_split_f16_small_kernel).
+template <int FT, int MODE>   // FT = compile-time ker_in (6 for position-derived attributes), 0 = run-time F
 __global__ __launch_bounds__(256) void edge_l0_split_kernel(
     const float* __restrict__ frames, int frame, const int* __restrict__ t_dev, int rows_per_frame,
     const int* __restrict__ src, const int* __restrict__ dst, const float* __restrict__ edge_attr,
     const int* __restrict__ perm, const int* __restrict__ num_edges, long long e_begin, int e_count, int F, int k,
     const float* __restrict__ w0, const float* __restrict__ b0, unsigned char* __restrict__ hp,
-    int* __restrict__ f16_flags, int f16_need) {
+    int* __restrict__ f16_flags, int f16_need, unsigned char* __restrict__ hp_f16) {
+    constexpr bool F16 = MODE != 0, BF16 = MODE != 1;
     __shared__ __attribute__((aligned(16))) float wsh[L0_UNITS * MAX_F];
     __shared__ __attribute__((aligned(16))) float bsh[L0_UNITS];
-    if (!F16 && f16_flags != nullptr && !f16_blocked(f16_flags, f16_need)) return;   // fallback launch, not needed
+    if (MODE == 0 && f16_flags != nullptr && !f16_blocked(f16_flags, f16_need)) return;   // fallback launch, not needed
+    unsigned char* const hph = MODE == 2 ? hp_f16 : hp;
     const int Fn = FT ? FT : F;
     const long long E = *num_edges;
     const long long tile0 = (long long)blockIdx.x * L0_ROWS;   // first row of this tile inside the chunk
@@ -253,15 +256,15 @@ __global__ __launch_bounds__(256) void edge_l0_split_kernel(
                 bad |= !(v < F16_MAX);
                 seen |= v >= F16_ACT_MIN;
                 split2h(v, oh[0][j], oh[1][j]);
-            } else {
-                split3(v, o[0][j], o[1][j], o[2][j]);
             }
+            if (BF16) split3(v, o[0][j], o[1][j], o[2][j]);
         }
         if (F16) {
 #pragma unroll
             for (int p = 0; p < 2; ++p)
-                *reinterpret_cast<uint4*>(hp + tiled_off2(le, u0 + c, nkt, p)) = *reinterpret_cast<const uint4*>(oh[p]);
-        } else {
+                *reinterpret_cast<uint4*>(hph + tiled_off2(le, u0 + c, nkt, p)) = *reinterpret_cast<const uint4*>(oh[p]);
+        }
+        if (BF16) {
 #pragma unroll
             for (int p = 0; p < 3; ++p)
                 *reinterpret_cast<uint4*>(hp + tiled_off(le, u0 + c, nkt, p)) = *reinterpret_cast<const uint4*>(o[p]);
@@ -276,13 +279,14 @@ static int launch_edge_l0_split(const float* pos_mode, int frame, const int* t_d
                                 const int* dst, const float* edge_attr, const int* perm, const int* num_edges,
                                 long long e0, int cnt, int F, int k, const float* w0, const float* b0,
                                 unsigned char* hp, hipStream_t s, bool f16 = false, int* f16_flags = nullptr,
-                                int f16_need = 0) {
+                                int f16_need = 0, unsigned char* hp_f16 = nullptr) {
     const dim3 grid((cnt + L0_ROWS - 1) / L0_ROWS, k / L0_UNITS);
-#define MDNO_L0(FT, H)                                                                                             \
-    hipLaunchKernelGGL((edge_l0_split_kernel<FT, H>), grid, dim3(256), 0, s, pos_mode, frame, t_dev, rows_per_frame, \
-                       src, dst, edge_attr, perm, num_edges, e0, cnt, F, k, w0, b0, hp, f16_flags, f16_need)
-    if (F == 6) { if (f16) MDNO_L0(6, true); else MDNO_L0(6, false); }
-    else        { if (f16) MDNO_L0(0, true); else MDNO_L0(0, false); }
+    // hp_f16 given: both images (bf16 planes -> hp, fp16 planes -> hp_f16)
+#define MDNO_L0(FT, MODE)                                                                                             \
+    hipLaunchKernelGGL((edge_l0_split_kernel<FT, MODE>), grid, dim3(256), 0, s, pos_mode, frame, t_dev, rows_per_frame, \
+                       src, dst, edge_attr, perm, num_edges, e0, cnt, F, k, w0, b0, hp, f16_flags, f16_need, hp_f16)
+    if (F == 6) { if (hp_f16) MDNO_L0(6, 2); else if (f16) MDNO_L0(6, 1); else MDNO_L0(6, 0); }
+    else        { if (hp_f16) MDNO_L0(0, 2); else if (f16) MDNO_L0(0, 1); else MDNO_L0(0, 0); }
 #undef MDNO_L0
     return check_launch("edge_l0_split_kernel");
 }
@@ -304,6 +308,11 @@ struct SplitGemmArgs {
                                       // the flags) only when one is; NULL: unconditional
     int f16_need = 0;                 // which "seen" words the operands depend on (f16_blocked)
     const float* b_unscale = nullptr; // fp16 kernel: per-column factor undoing the weight rows' power-of-two scale
+    // gemm_split_f16_small_kernel only: the bf16 images of the same operands (and of the output, OUT 4).  Given
+    // these the kernel multiplies them itself when a flag is up — no fallback launch behind it
+    const unsigned char* Ap_b = nullptr;
+    const unsigned char* Bp_b = nullptr;
+    unsigned char* Cp_b = nullptr;
 };
 
 // One stage (k-step of 16) for a wave: (2x2 tiles) x 6 plane products = 24 MFMAs, 12 fragment reads.
@@ -718,7 +727,8 @@ constexpr int F16S_LDS_BYTES = F16S_RING * F16S_STAGE_BYTES;               // 14
 template <int OUT>
 __global__ __launch_bounds__(512) void gemm_split_f16_small_kernel(SplitGemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    if (g.f16_flags != nullptr && f16_blocked(g.f16_flags, g.f16_need)) return;
+    const bool blocked = g.f16_flags != nullptr && f16_blocked(g.f16_flags, g.f16_need);
+    if (blocked && g.Ap_b == nullptr) return;      // (the bf16 launch behind this one redoes the chunk)
     long long valid = g.num_edges ? (long long)(*g.num_edges) - g.row_begin : (long long)g.rows_valid;
     if (valid > g.rows) valid = g.rows;
     if (valid <= 0) return;
@@ -764,11 +774,43 @@ __global__ __launch_bounds__(512) void gemm_split_f16_small_kernel(SplitGemmArgs
     if (g.b_unscale) us = g.b_unscale[bn + wn * 32 + l31];
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(bv), "+v"(us));   // the counted waits below must see DMA pieces only
 
+    if (blocked) {
+        // An operand is out of fp16 range (or too small for it): the same tile from the three-plane bf16
+        // images, six products per k-step in gemm_split_bf16_kernel's order.  A rare path (exploding
+        // activations of an untrained net): one k-step at a time, no ring.
+        us = 1.f;
+        const size_t tile_stride_b = (size_t)nkt * 3 << 12;
+        const unsigned char* a_src = g.Ap_b + (size_t)(bm >> 7) * tile_stride_b + lane * 16;
+        const unsigned char* b_src = g.Bp_b + (size_t)(bn >> 7) * tile_stride_b + ((bn >> 6) & 1) * 2048 + lane * 16;
+        const int a_rb = (wm * 32 + l31) * 32 + hsw, b_rb = 3 * PLANE_BYTES + (wn * 32 + l31) * 32 + hsw;
+        for (int kt = 0; kt < nkt; ++kt) {
+            __syncthreads();      // the previous k-step's fragment reads are done
+            for (int q = wave; q < 18; q += 8) {      // A: 12 KiB (three planes), B: three 2 KiB halves
+                const unsigned char* src = q < 12 ? a_src + (size_t)kt * 12288 + q * 1024
+                                                  : b_src + (size_t)kt * 12288 + ((q - 12) >> 1) * 4096 + ((q - 12) & 1) * 1024;
+                __builtin_amdgcn_global_load_lds((glb_u8*)src, (lds_u8*)(lds + q * 1024), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            bf16x8 a[3], b[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                a[p] = *reinterpret_cast<const bf16x8*>(lds + p * PLANE_BYTES + a_rb);
+                b[p] = *reinterpret_cast<const bf16x8*>(lds + p * (PLANE_BYTES / 2) + b_rb);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+        }
+    }
 #pragma unroll
     for (int t = 0; t < F16S_RING - 1; ++t)
-        if (t < nst) MDNO_DMA_STAGE(t, t)
+        if (!blocked && t < nst) MDNO_DMA_STAGE(t, t)
     int slot = 0, slot_in = F16S_RING - 1;
-    for (int st = 0; st < nst; ++st) {
+    for (int st = 0; st < (blocked ? 0 : nst); ++st) {
         // stages still in flight behind stage st: min(RING - 2, nst - 1 - st) groups of three pieces
         const int behind = nst - 1 - st;
         if (behind >= 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
@@ -813,6 +855,14 @@ __global__ __launch_bounds__(512) void gemm_split_f16_small_kernel(SplitGemmArgs
                 const size_t o = tiled_off2(m, n, g.N >> 4, 0);
                 *reinterpret_cast<_Float16*>(g.Cp + o) = ph;
                 *reinterpret_cast<_Float16*>(g.Cp + o + PLANE_BYTES) = pl;
+                if (g.Cp_b != nullptr) {      // and the bf16 image, for a consumer that finds a flag up
+                    __bf16 qh, qm, ql;
+                    split3(rv, qh, qm, ql);
+                    const size_t ob = tiled_off(m, n, g.N >> 4, 0);
+                    *reinterpret_cast<__bf16*>(g.Cp_b + ob) = qh;
+                    *reinterpret_cast<__bf16*>(g.Cp_b + ob + PLANE_BYTES) = qm;
+                    *reinterpret_cast<__bf16*>(g.Cp_b + ob + 2 * PLANE_BYTES) = ql;
+                }
             } else {
                 g.C[(size_t)m * g.N + n] = OUT == 3 ? fmaxf(v, 0.f) : v;
             }
@@ -1090,12 +1140,21 @@ bool edge_mlp_split_supported(int ker_width, int out_dim) {
 }
 
 // One layout for both entry points: [h1 planes][h2 planes][W1 planes][W2 planes][W1 fp16 planes][flags][W2 fp16 planes]
+// [W1, W2 unscale][h1, h2 fp16 planes of a few-row launch]
 struct SplitWs {
     unsigned char *h1p, *h2p, *w1p, *w2p, *w1h, *w2h;
+    unsigned char *h1h, *h2h;   // few rows (both_gemms_small): the fp16 images beside the bf16 ones in h1p, h2p
     float *w1us, *w2us;      // per-row unscale factors of the fp16 weight images
     int* f16_flags;
     size_t total;
 };
+
+// Both GEMMs of the full edge-MLP on the few-rows kernel: then every kernel of the chain carries both operand
+// images and picks one itself, and no fallback launch follows (at that size a launch costs more than a GEMM)
+static bool both_gemms_small(int k, int out_dim, long long chunk) {
+    const long long tm = chunk / F16_TM;
+    return chunk % F16_TM == 0 && (k / TN) * tm <= F16S_MAX_BIG_TILES && (out_dim / TN) * tm <= F16S_MAX_BIG_TILES;
+}
 
 static SplitWs carve_split(void* ws, int k, int out_dim, long long chunk) {
     SplitWs w{};
@@ -1109,6 +1168,9 @@ static SplitWs carve_split(void* ws, int k, int out_dim, long long chunk) {
     w.w2h = reinterpret_cast<unsigned char*>(cv.take<_Float16>(2 * (size_t)out_dim * k));
     w.w1us = cv.take<float>((size_t)k);
     w.w2us = cv.take<float>((size_t)out_dim);
+    const size_t small = both_gemms_small(k, out_dim, chunk) ? 2 * (size_t)chunk * k : 0;
+    w.h1h = reinterpret_cast<unsigned char*>(cv.take<_Float16>(small));
+    w.h2h = reinterpret_cast<unsigned char*>(cv.take<_Float16>(small));
     w.total = cv.used();
     return w;
 }
@@ -1152,6 +1214,28 @@ int edge_mlp_split(const float* frames, int frame, const int* t_dev, int rows_pe
     if (f16 && !flags_zeroed) MDNO_TRY(fill_ints(sw.f16_flags + 1, kEdgeMlpActivationFlags, 0, s));
     for (long long e0 = 0; e0 < edge_cap; e0 += chunk) {
         const int cnt = (int)((edge_cap - e0) < chunk ? (edge_cap - e0) : chunk);
+        if (f16 && both_gemms_small(k, out_dim, chunk)) {
+            // a few hundred rows: three launches — every kernel writes / finds both operand images and the
+            // GEMMs take the bf16 ones themselves when a flag is up (gemm_split_f16_small_kernel)
+            {
+                TimedSection ts(KID_EDGE_L0, s);
+                MDNO_TRY(launch_edge_l0_split(pos_mode, frame, t_dev, rows_per_frame, src, dst, edge_attr, perm, num_edges,
+                                              e0, cnt, ker_in, k, w.w0, w.b0, h1p, s, true, sw.f16_flags, 0, sw.h1h));
+            }
+            {
+                TimedSection ts(KID_GEMM_L1, s);
+                SplitGemmArgs gh{sw.h1h, sw.w1h, w.b1, nullptr, sw.h2h, num_edges, e0, (int)chunk, k, k, 0, 0, 0, 0,
+                                 sw.f16_flags, 1, sw.w1us, h1p, w1p, h2p};
+                MDNO_TRY((launch_split_f16_gemm<4, 2>(gh, s)));
+            }
+            {
+                TimedSection ts(KID_GEMM_L2, s);
+                SplitGemmArgs gh{sw.h2h, sw.w2h, w.b2, w_e + (size_t)e0 * out_dim, nullptr, num_edges, e0, (int)chunk, out_dim,
+                                 k, 0, 0, 0, 0, sw.f16_flags, 3, sw.w2us, h2p, w2p, nullptr};
+                MDNO_TRY((launch_split_f16_gemm<0, 2>(gh, s)));
+            }
+            continue;
+        }
         if (f16) {
             // SPLIT_F16: layer 0 -> fp16 planes, hidden layer -> fp16 planes of h2 (its epilogue checks the
             // range), last layer -> W_e; then the same chunk on the bf16 kernels, which exit at their first

@@ -289,6 +289,8 @@ struct mdno_rollout_plan {
     int* status;
     hipGraph_t graph;
     hipGraphExec_t exec;
+    hipGraph_t graph_n;        // kStepsPerGraph steps in one graph (short chains: a graph launch costs two kernel launches)
+    hipGraphExec_t exec_n;
     Timer* timer;
     bool weights_cached;   // weight-derived operands are rebuilt per plan_run call, not per step
 };
@@ -328,6 +330,32 @@ static int plan_enqueue_step(mdno_rollout_plan* pl, hipStream_t s) {
                         &tail);
 }
 
+constexpr int kStepsPerGraph = 8;
+
+// `n` consecutive steps captured on `s` -> executable graph
+static int capture_steps(mdno_rollout_plan* pl, hipStream_t s, int n, hipGraph_t* graph, hipGraphExec_t* exec) {
+    hipError_t eb = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+    MDNO_REQUIRE(eb == hipSuccess, MDNO_ELAUNCH, "hipStreamBeginCapture: %s", hipGetErrorString(eb));
+    int rc = MDNO_OK;
+    for (int t = 0; t < n && rc == MDNO_OK; ++t) rc = plan_enqueue_step(pl, s);
+    hipError_t ec = hipStreamEndCapture(s, graph);
+    if (rc != MDNO_OK || ec != hipSuccess || !*graph) {
+        if (rc == MDNO_OK) set_error("hipStreamEndCapture: %s", hipGetErrorString(ec));
+        if (*graph) (void)hipGraphDestroy(*graph);
+        *graph = nullptr;
+        return rc != MDNO_OK ? rc : MDNO_ELAUNCH;
+    }
+    hipError_t ei = hipGraphInstantiate(exec, *graph, nullptr, nullptr, 0);
+    if (ei != hipSuccess) {
+        set_error("hipGraphInstantiate: %s", hipGetErrorString(ei));
+        (void)hipGraphDestroy(*graph);
+        *graph = nullptr;
+        *exec = nullptr;
+        return MDNO_ELAUNCH;
+    }
+    return MDNO_OK;
+}
+
 extern "C" int mdno_rollout_plan_create(mdno_rollout_plan** plan, const mdno_kernelnn_params* p, float* traj, int M,
                                         int W, int N, int max_steps, const int64_t* x_aminoacid, int aa_per_member,
                                         double threshold, int64_t edge_cap, int max_degree, void* workspace,
@@ -360,26 +388,13 @@ extern "C" int mdno_rollout_plan_create(mdno_rollout_plan** plan, const mdno_ker
     pl->weights_cached = !separate_conv2_kernel(p);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (use_graph && s != nullptr) {
-        hipError_t eb = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
-        if (eb != hipSuccess) {
-            set_error("hipStreamBeginCapture: %s", hipGetErrorString(eb));
-            delete pl;
-            return MDNO_ELAUNCH;
-        }
-        const int rc = plan_enqueue_step(pl, s);
-        hipError_t ec = hipStreamEndCapture(s, &pl->graph);
-        if (rc != MDNO_OK || ec != hipSuccess || !pl->graph) {
-            if (rc == MDNO_OK) set_error("hipStreamEndCapture: %s", hipGetErrorString(ec));
-            if (pl->graph) (void)hipGraphDestroy(pl->graph);
-            delete pl;
-            return rc != MDNO_OK ? rc : MDNO_ELAUNCH;
-        }
-        hipError_t ei = hipGraphInstantiate(&pl->exec, pl->graph, nullptr, nullptr, 0);
-        if (ei != hipSuccess) {
-            set_error("hipGraphInstantiate: %s", hipGetErrorString(ei));
-            (void)hipGraphDestroy(pl->graph);
-            delete pl;
-            return MDNO_ELAUNCH;
+        int rc = capture_steps(pl, s, 1, &pl->graph, &pl->exec);
+        // a short chain's step is a few dozen launches of a few microseconds: several steps per graph launch
+        if (rc == MDNO_OK && max_steps >= kStepsPerGraph && step_head_small_supported(M, N))
+            rc = capture_steps(pl, s, kStepsPerGraph, &pl->graph_n, &pl->exec_n);
+        if (rc != MDNO_OK) {
+            mdno_rollout_plan_destroy(pl);
+            return rc;
         }
     }
     *plan = pl;
@@ -397,7 +412,11 @@ extern "C" int mdno_rollout_plan_run(mdno_rollout_plan* pl, int start_step, int 
     // the weights may have been updated in place since the last call: refresh their images once
     if (pl->weights_cached) MDNO_TRY(plan_prepare_weights(pl, s));
     for (int t = 0; t < steps; ++t) {
-        if (pl->exec && !pl->timer) {
+        if (pl->exec_n && !pl->timer && steps - t >= kStepsPerGraph) {
+            hipError_t el = hipGraphLaunch(pl->exec_n, s);
+            MDNO_REQUIRE(el == hipSuccess, MDNO_ELAUNCH, "hipGraphLaunch(steps %d..): %s", t, hipGetErrorString(el));
+            t += kStepsPerGraph - 1;
+        } else if (pl->exec && !pl->timer) {
             hipError_t el = hipGraphLaunch(pl->exec, s);
             MDNO_REQUIRE(el == hipSuccess, MDNO_ELAUNCH, "hipGraphLaunch(step %d): %s", t, hipGetErrorString(el));
         } else {  // plain launches (always when a timer is attached: events cannot sit inside a replay)
@@ -462,6 +481,8 @@ extern "C" int mdno_rollout_plan_destroy(mdno_rollout_plan* pl) {
     (void)mdno_rollout_plan_timer_detach(pl);
     if (pl->exec) (void)hipGraphExecDestroy(pl->exec);
     if (pl->graph) (void)hipGraphDestroy(pl->graph);
+    if (pl->exec_n) (void)hipGraphExecDestroy(pl->exec_n);
+    if (pl->graph_n) (void)hipGraphDestroy(pl->graph_n);
     delete pl;
     return MDNO_OK;
 }

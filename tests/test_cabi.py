@@ -59,8 +59,12 @@ def test_abi_version_struct_layout_and_error_string(lib):
     assert lib.mdno_edge_mlp_workspace_bytes(1024, 4096, 1000, _lib.GEMM_MODES["f32"]) == 2 * 1024 * 1024 * 4 + 512
     # split mode: 2 x 3 bf16 activation planes + the split weights; untileable shapes fall back to fp32 sizing
     # (+ the two fp16 planes of W1 and of W2, a 256-B line of range flags and one fp32 unscale factor per
-    # weight row, used by SPLIT_F16)
+    # weight row, used by SPLIT_F16; a launch of <= 1,024 rows also keeps fp16 images of h1 and h2 beside the
+    # bf16 ones: its GEMMs choose between them themselves)
     assert lib.mdno_edge_mlp_workspace_bytes(1024, 4096, 1000, 0) == (2 * 3 * 1024 * 1024 * 2 + 3 * 2 * (1024 + 4096) * 1024
+                                                                      + 2 * 2 * (1024 + 4096) * 1024 + 256
+                                                                      + 4 * (1024 + 4096) + 2 * 2 * 1024 * 1024 * 2)
+    assert lib.mdno_edge_mlp_workspace_bytes(1024, 4096, 2000, 0) == (2 * 3 * 2048 * 1024 * 2 + 3 * 2 * (1024 + 4096) * 1024
                                                                       + 2 * 2 * (1024 + 4096) * 1024 + 256
                                                                       + 4 * (1024 + 4096))
     assert lib.mdno_edge_mlp_workspace_bytes(1024, 4096, 1000, _lib.GEMM_MODES["split_f16"]) == \

@@ -206,6 +206,59 @@ def test_split_f16_row_count_does_not_change_a_bit(dev):
         assert torch.equal(run(E), full[:E]), E
 
 
+def test_few_rows_edge_mlp_takes_the_bf16_images_itself_when_out_of_fp16_range(dev):
+    """A launch of a few hundred rows (both GEMMs on the 128 x 64-tile kernel) has no fallback launches: layer 0 and
+    the hidden GEMM write both operand images, and a GEMM that finds a range flag up multiplies the bf16 one in the
+    same launch.  Layer-0 activations out of range -> every product on the bf16 planes, bit-identical to gemm_mode
+    "split_bf16"; only h2 out of range, or h1 below what fp16 resolves -> mixed, fp32-accurate."""
+    from molecular_dynamics_neural_operator_amd import ops
+    torch.manual_seed(5)
+    E, k = 330, 1024
+    ea = torch.randn(E, 6) * 4
+    lins = [torch.nn.Linear(6, k), torch.nn.Linear(k, k), torch.nn.Linear(k, 4096)]
+    w = [p.data.clone() for lin in lins for p in (lin.weight, lin.bias)]
+    ne = torch.full((1,), E, dtype=torch.int32, device=dev)
+    g = ops.CSRGraph(None, None, None, ne, E, None, None)
+
+    def run(mode, attrs, weights):
+        return ops.edge_mlp([t.to(dev) for t in weights], 6, k, 4096, g, edge_attr=attrs.to(dev), gemm_mode=mode)[:E].cpu()
+
+    def ref64(attrs, weights):
+        h = torch.relu(torch.nn.functional.linear(attrs.double(), weights[0].double(), weights[1].double()))
+        h2 = torch.relu(torch.nn.functional.linear(h, weights[2].double(), weights[3].double()))
+        return h, h2, torch.nn.functional.linear(h2, weights[4].double(), weights[5].double())
+
+    def rel(a, b):
+        return float((a.double() - b).norm() / b.norm())
+
+    # in range: the fp16 planes (not the bf16 kernels' bits), fp32-accurate
+    a, b = run("split_f16", ea, w), run("split_bf16", ea, w)
+    assert not torch.equal(a, b) and rel(a, ref64(ea, w)[2]) < 1e-6
+    # (a) layer-0 activations ~1e6
+    big = ea * 3.0e5
+    h1, _, want = ref64(big, w)
+    assert float(h1.max()) > 65504.0
+    a, b = run("split_f16", big, w), run("split_bf16", big, w)
+    assert torch.isfinite(a).all() and torch.equal(a, b) and rel(a, want) < 1e-6
+    # (b) h1 in range, h2 above 65504 (hidden layer x 2e5): the hidden GEMM runs on fp16 planes, finds h2 out of
+    # range in its epilogue, and the last GEMM takes h2's bf16 image
+    w2 = [t.clone() for t in w]
+    w2[2] *= 2.0e5
+    w2[3] *= 2.0e5
+    h1, h2, want = ref64(ea, w2)
+    assert float(h1.max()) < 65504.0 < float(h2.max())
+    a = run("split_f16", ea, w2)
+    assert torch.isfinite(a).all() and rel(a, want) < 1e-6
+    # (c) every layer-0 activation below 2^-10 (fp16's grid there is 6e-8: two planes no longer carry 22 bits)
+    w3 = [t.clone() for t in w]
+    w3[0] *= 1.0e-8
+    w3[1] *= 1.0e-8
+    h1, _, want = ref64(ea, w3)
+    assert 0.0 < float(h1.max()) < 2.0 ** -10
+    a = run("split_f16", ea, w3)
+    assert rel(a, want) < 1e-6
+
+
 @pytest.mark.parametrize("case", ["small_last_layer", "small_weights", "small_activations", "small_both", "outlier_rows"])
 def test_split_f16_operands_below_fp16_normal_range(dev, case):
     """gemm_mode "split_f16" on operands that sit low in (or below) fp16's range, against fp64.  The scheme

@@ -13,7 +13,8 @@ dev = torch.device("cuda:0")
 lib = _lib.load()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 504
 reps = 40
-for M in (1, 2, 4, 8):
+Ms = [int(v) for v in sys.argv[2].split(',')] if len(sys.argv) > 2 else [1, 2, 4, 8]
+for M in Ms:
     frames = np.concatenate([syn.box_frame(N, seed=1 + m) for m in range(M)])
     g = ops.radius_graph(torch.from_numpy(frames).to(dev), N, 8.0)
     E = g.edge_count()

@@ -26,3 +26,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train_trace -- pyth
 echo "train trace done"
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_mfma_train -- python3 $ROOT/scripts/train_synthetic.py --frames 600 > $OUT/pmc_mfma_train.json 2> $OUT/pmc_mfma_train.err
 echo "mfma train done"
+# the other BASELINE configurations, kernel traces only: training in fp32, shape A (N = 28, one member), shape C (N = 50,000)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train_fp32_trace -- python3 $ROOT/scripts/train_synthetic.py --frames 2000 --precision fp32 > $OUT/train_fp32.json 2> $OUT/train_fp32.err
+echo "train fp32 trace done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/shape_a_trace -- python3 $ROOT/scripts/shape_a_breakdown.py --steps 200 > $OUT/shape_a.json 2> $OUT/shape_a.err
+echo "shape A trace done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/shape_c_trace -- python3 $ROOT/scripts/run_shape_c.py --steps 2 > $OUT/shape_c.json 2> $OUT/shape_c.err
+echo "shape C trace done"

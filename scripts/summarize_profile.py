@@ -141,3 +141,9 @@ if traffic:
         {"note": "2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 read-side correction), separate --pmc passes; bytes per "
                  "conv application (all chunk launches of the per-source GEMM)", "configs": traffic}, indent=1))
     print("wrote profiles/roofline_traffic.json")
+for leg, name in (("train_fp32", "train_fp32"), ("shape_a", "shapeA_m1"), ("shape_c", "shapeC")):
+    if (src / f"{leg}_trace").exists():
+        kernel_stats(f"{leg}_trace", out / f"{tag}_{name}_kernel_stats.csv")
+        text = (src / f"{leg}.json").read_text() if (src / f"{leg}.json").exists() else ""
+        if text.strip():
+            (out / f"{tag}_{name}_under_rocprof.json").write_text(text)

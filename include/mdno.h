@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDNO_ABI_VERSION 10
+#define MDNO_ABI_VERSION 11
 
 #define MDNO_OK            0
 #define MDNO_EINVAL       -1   /* bad argument (null pointer, non-positive size, unsupported dim) */
@@ -263,6 +263,10 @@ int mdno_rollout_plan_timer_detach(mdno_rollout_plan* plan);
  *                         bf16 planes on the way in, 6 plane products, fp32 accumulation (the
  *                         MDNO_GEMM_SPLIT_BF16 arithmetic; needs k % 32 == 0, n % 128 == 0 and a
  *                         workspace of mdno_linear_split_workspace_bytes(rows, n, k))
+ *   mdno_linear_split_f16_fwd  the same on two fp16 planes per operand (3 plane products; the
+ *                         MDNO_GEMM_SPLIT_F16 arithmetic): every row of A and of W is scaled by its own power of
+ *                         two before the split and the output scaled back, so no magnitude leaves fp16's range;
+ *                         same shape rules, workspace mdno_linear_split_f16_workspace_bytes(rows, n, k)
  *   mdno_gemm_atb         C (+)= A^T . B             A [rows,n1], B [rows,n2] -> C [n1,n2] (weight grads)
  *   mdno_colsum           out (+)= column sums of A [rows,n]                       (bias grads)
  *   mdno_relu_bwd         out = g * (y > 0) [* row_scale[row]]
@@ -282,6 +286,9 @@ int mdno_linear_fwd(const float* a, const float* w, const float* bias, int64_t r
 size_t mdno_linear_split_workspace_bytes(int64_t rows, int n, int k);
 int mdno_linear_split_fwd(const float* a, const float* w, const float* bias, int64_t rows, int n, int k, int relu,
                           float* c, void* workspace, size_t workspace_bytes, void* stream);
+size_t mdno_linear_split_f16_workspace_bytes(int64_t rows, int n, int k);
+int mdno_linear_split_f16_fwd(const float* a, const float* w, const float* bias, int64_t rows, int n, int k, int relu,
+                              float* c, void* workspace, size_t workspace_bytes, void* stream);
 size_t mdno_reduce_workspace_bytes(int n1, int n2);
 int mdno_gemm_atb(const float* a, const float* b, int64_t rows, int n1, int n2, float* c, int accumulate,
                   void* workspace, size_t workspace_bytes, void* stream);

@@ -14,7 +14,7 @@ LIB_PATH = Path(os.environ.get("MDNO_LIB", _HERE / "libmdno.so"))
 OK, EINVAL, ELAUNCH, EWORKSPACE, EUNSUPPORTED = 0, -1, -2, -3, -4
 AGGR = {"add": 0, "mean": 1}
 STATUS_EDGE_OVERFLOW, STATUS_BAD_AMINOACID = 1, 2
-ABI_VERSION = 10
+ABI_VERSION = 11
 GEMM_MODES = {"split_bf16": 0, "f32": 1, "split_f16": 2}
 CONV_MODES = {"materialized": 0, "factored": 1, "auto": 2}
 STATUS_ASYMMETRIC_GRAPH = 4
@@ -76,6 +76,8 @@ SIGNATURES = {
     "mdno_linear_fwd": (_I, [_P, _P, _P, _L, _I, _I, _I, _P, _P]),
     "mdno_linear_split_workspace_bytes": (_SZ, [_L, _I, _I]),
     "mdno_linear_split_fwd": (_I, [_P, _P, _P, _L, _I, _I, _I, _P, _P, _SZ, _P]),
+    "mdno_linear_split_f16_workspace_bytes": (_SZ, [_L, _I, _I]),
+    "mdno_linear_split_f16_fwd": (_I, [_P, _P, _P, _L, _I, _I, _I, _P, _P, _SZ, _P]),
     "mdno_reduce_workspace_bytes": (_SZ, [_I, _I]),
     "mdno_gemm_atb": (_I, [_P, _P, _L, _I, _I, _P, _I, _P, _SZ, _P]),
     "mdno_colsum": (_I, [_P, _L, _I, _P, _I, _P, _SZ, _P]),

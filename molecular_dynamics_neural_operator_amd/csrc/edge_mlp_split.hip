@@ -313,6 +313,9 @@ struct SplitGemmArgs {
     const unsigned char* Ap_b = nullptr;
     const unsigned char* Bp_b = nullptr;
     unsigned char* Cp_b = nullptr;
+    // fp16 kernels: per-ROW factor undoing a power-of-two scale of A's rows (split_linear_f16: activations and
+    // gradients of any magnitude, scaled row by row like the weights); [rows] floats, NULL = none
+    const float* a_unscale = nullptr;
 };
 
 // One stage (k-step of 16) for a wave: (2x2 tiles) x 6 plane products = 24 MFMAs, 12 fragment reads.
@@ -676,6 +679,14 @@ __global__ __launch_bounds__(1024 / MI) void gemm_split_f16_kernel(SplitGemmArgs
 #undef MDNO_DMA_STAGE
 #undef MDNO_PIECE_DMA
 
+    // the rows' own scale factors, all fetched before the first store (a load inside the predicated store blocks
+    // would put a full wait in front of every store)
+    float ua[MI][16];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            ua[i][e] = g.a_unscale ? g.a_unscale[bm + wm * (MI * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] : 1.f;
     bool bad = false, seen = false;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -687,7 +698,7 @@ __global__ __launch_bounds__(1024 / MI) void gemm_split_f16_kernel(SplitGemmArgs
             for (int e = 0; e < 16; ++e) {
                 const int m = bm + wm * (MI * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (m < valid) {
-                    const float v = (acc[i][j][e] + accx[i][j][e] * F16_LO_UNSCALE) * us + bv;
+                    const float v = (acc[i][j][e] + accx[i][j][e] * F16_LO_UNSCALE) * us * ua[i][e] + bv;
                     if (OUT == 2) {
                         g.C[((size_t)(m >> 7) * (g.N >> 5) + (n >> 5)) * 4096 + (m & 127) * 32 + (n & 31)] = fmaxf(v, 0.f);
                     } else if (OUT == 4) {
@@ -839,13 +850,17 @@ __global__ __launch_bounds__(512) void gemm_split_f16_small_kernel(SplitGemmArgs
     }
 #undef MDNO_DMA_STAGE
 
+    float ua[16];      // (fetched before the first store: see gemm_split_f16_kernel)
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+        ua[e] = (g.a_unscale && !blocked) ? g.a_unscale[bm + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] : 1.f;
     bool bad = false, seen = false;
     const int n = bn + wn * 32 + l31;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int m = bm + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (m < valid) {
-            const float v = (acc[e] + accx[e] * F16_LO_UNSCALE) * us + bv;
+            const float v = (acc[e] + accx[e] * F16_LO_UNSCALE) * us * ua[e] + bv;
             if (OUT == 4) {
                 const float rv = fmaxf(v, 0.f);
                 bad |= !(rv < F16_MAX);
@@ -1133,6 +1148,46 @@ int split_linear(const float* a, const float* w, const float* bias, long long ro
     SplitGemmArgs g{ap, wp, bias, c, nullptr, nullptr, 0, (int)((rows + 255) / 256 * 256), N, K, 0, 0, (int)rows, 0};
     if (relu) return N >= 2048 ? launch_split_gemm_tm<256, 3>(g, s) : launch_split_gemm_tm<128, 3>(g, s);
     return N >= 2048 ? launch_split_gemm_tm<256, 0>(g, s) : launch_split_gemm_tm<128, 0>(g, s);
+}
+
+// The same product on two fp16 planes per operand (three plane products instead of six): every row of A and of W
+// is multiplied by its own power of two first (f16_row_scale: the row's largest entry lands in [2^13, 2^14), so
+// nothing leaves fp16's range whatever the magnitudes — gradients of 1e-9 as well as activations of 1e6) and the
+// output element (m, n) is multiplied back by both in the epilogue, exactly.  Inside a row, entries more than
+// ~2^29 below the row's largest lose relative accuracy (split_layout.h); their share of a dot product is below
+// fp32 rounding of the sum.
+struct SplitF16Ws {
+    unsigned char *ap, *wp;
+    float *aus, *wus;
+    int* flag;
+    size_t total;
+};
+
+static SplitF16Ws carve_split_f16(void* ws, long long rows, int N, int K) {
+    SplitF16Ws w{};
+    Carver cv(ws);
+    const long long rows_pad = (rows + 255) / 256 * 256;
+    w.ap = reinterpret_cast<unsigned char*>(cv.take<char>(split_planes_f16_bytes(rows, K)));
+    w.wp = reinterpret_cast<unsigned char*>(cv.take<char>(split_planes_f16_bytes(N, K)));
+    w.aus = cv.take<float>((size_t)rows_pad);
+    w.wus = cv.take<float>((size_t)N);
+    w.flag = cv.take<int>(64);
+    w.total = cv.used();
+    return w;
+}
+
+size_t split_linear_f16_workspace_bytes(long long rows, int N, int K) { return carve_split_f16(nullptr, rows, N, K).total; }
+
+int split_linear_f16(const float* a, const float* w, const float* bias, long long rows, int N, int K, int relu, float* c,
+                     void* workspace, hipStream_t s) {
+    const SplitF16Ws sw = carve_split_f16(workspace, rows, N, K);
+    // (the flag word collects "non-finite input": such rows give non-finite outputs, as an fp32 product would)
+    MDNO_TRY(split_planes_f16(a, (int)rows, K, sw.ap, sw.aus, sw.flag, s));
+    MDNO_TRY(split_planes_f16(w, N, K, sw.wp, sw.wus, sw.flag, s));
+    SplitGemmArgs g{sw.ap, sw.wp, bias, c, nullptr, nullptr, 0, (int)((rows + 255) / 256 * 256), N, K, 0, 0, (int)rows, 0};
+    g.b_unscale = sw.wus;
+    g.a_unscale = sw.aus;
+    return relu ? launch_split_f16_gemm<3, 2>(g, s) : launch_split_f16_gemm<0, 2>(g, s);
 }
 
 bool edge_mlp_split_supported(int ker_width, int out_dim) {

@@ -85,6 +85,11 @@ int split_planes_bias64(const float* x, int rows, const float* b, float* q, void
 int fill_ints(int* p, int n, int value, hipStream_t s);     // n <= 256, by a kernel
 // two-plane fp16 images (SPLIT_F16) and the K = 64 GEMM on them (the factored conv's Y = X . W3T)
 size_t split_planes_f16_bytes(long long rows, int K);
+// act(A . W^T + b) on two fp16 planes per operand, rows of both scaled by powers of two (training: split_linear's
+// shapes at half the matrix work)
+size_t split_linear_f16_workspace_bytes(long long rows, int N, int K);
+int split_linear_f16(const float* a, const float* w, const float* bias, long long rows, int N, int K, int relu, float* c,
+                     void* workspace, hipStream_t s);
 // (each row scaled by a power of two into fp16's upper binades; unscale[row] = the factor that undoes it)
 int split_planes_f16(const float* a, int rows, int K, void* planes, float* unscale, int* range_flag, hipStream_t s);
 // (bf16 images of the same operands + the two range flags: the kernel multiplies those when a flag is up)

@@ -470,6 +470,23 @@ extern "C" int mdno_linear_split_fwd(const float* a, const float* w, const float
     return split_linear(a, w, bias, (long long)rows, n, k, relu, c, workspace, static_cast<hipStream_t>(stream));
 }
 
+extern "C" size_t mdno_linear_split_f16_workspace_bytes(int64_t rows, int n, int k) {
+    return rows > 0 && n > 0 && k > 0 ? split_linear_f16_workspace_bytes((long long)rows, n, k) : 0;
+}
+
+extern "C" int mdno_linear_split_f16_fwd(const float* a, const float* w, const float* bias, int64_t rows, int n, int k,
+                                         int relu, float* c, void* workspace, size_t workspace_bytes, void* stream) {
+    MDNO_REQUIRE(a && w && c && workspace && rows > 0 && n > 0 && k > 0, MDNO_EINVAL,
+                 "mdno_linear_split_f16_fwd: bad arguments");
+    MDNO_REQUIRE(split_linear_supported((long long)rows, n, k) &&
+                     ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(w)) & 15) == 0,
+                 MDNO_EUNSUPPORTED, "mdno_linear_split_f16_fwd: needs k %% 32 == 0, n %% 128 == 0, 16-byte aligned "
+                 "operands (rows=%lld n=%d k=%d); use mdno_linear_fwd", (long long)rows, n, k);
+    MDNO_REQUIRE(workspace_bytes >= split_linear_f16_workspace_bytes((long long)rows, n, k), MDNO_EWORKSPACE,
+                 "mdno_linear_split_f16_fwd: workspace");
+    return split_linear_f16(a, w, bias, (long long)rows, n, k, relu, c, workspace, static_cast<hipStream_t>(stream));
+}
+
 extern "C" size_t mdno_reduce_workspace_bytes(int n1, int n2) {
     if (n2 <= 1) return align_up((size_t)kColSlices * (size_t)n1 * sizeof(float), 256);
     return align_up((size_t)kSlices * (size_t)n1 * (size_t)n2 * sizeof(float), 256);

@@ -275,15 +275,21 @@ def _ws(nbytes: int, dev) -> torch.Tensor:
 def linear(a: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], relu: bool = False,
            gemm_mode: str = "f32") -> torch.Tensor:
     """act(a . w^T + b): a [rows,k], w [n,k] (torch Linear layout).  gemm_mode "split_bf16" runs the
-    product on the bf16 matrix pipe with the exact 3-way split (fp32-level error) where the shape
-    tiles (k % 32 == 0, n % 128 == 0); other shapes and "f32" use the fp32 kernels."""
+    product on the bf16 matrix pipe with the exact 3-way split (fp32-level error), "split_f16" on two fp16
+    planes per operand with every row scaled by its own power of two (3 products instead of 6, fp32-level
+    error), where the shape tiles (k % 32 == 0, n % 128 == 0); other shapes and "f32" use the fp32 kernels."""
     lib = _lib.load()
     a, w = f32(a), f32(w)
     rows, k = a.shape
     n = w.shape[0]
     c = torch.empty((rows, n), dtype=torch.float32, device=a.device)
     bb = f32(b) if b is not None else None
-    if gemm_mode != "f32" and k % 32 == 0 and n % 128 == 0 and rows > 0:      # ("split_f16": bf16 planes here)
+    if gemm_mode == "split_f16" and k % 32 == 0 and n % 128 == 0 and rows > 0:
+        ws = _ws(lib.mdno_linear_split_f16_workspace_bytes(rows, n, k), a.device)
+        check(lib.mdno_linear_split_f16_fwd(ptr(a), ptr(w), ptr(bb), rows, n, k, int(relu), ptr(c), ptr(ws), ws.numel(),
+                                            stream_ptr(a.device)), "mdno_linear_split_f16_fwd")
+        return c
+    if gemm_mode != "f32" and k % 32 == 0 and n % 128 == 0 and rows > 0:
         ws = _ws(lib.mdno_linear_split_workspace_bytes(rows, n, k), a.device)
         check(lib.mdno_linear_split_fwd(ptr(a), ptr(w), ptr(bb), rows, n, k, int(relu), ptr(c), ptr(ws), ws.numel(),
                                         stream_ptr(a.device)), "mdno_linear_split_fwd")

@@ -498,3 +498,33 @@ def test_training_index_errors_are_deferred_not_lost(dev, tmp_path):
         train_epoch(model, [[dset[1], bad]], opt, LpLoss(size_average=False))
     check_train_status(model)                          # cleared: nothing left to raise
     train_epoch(model, [[dset[1], dset[2]]], opt, LpLoss(size_average=False))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,n,k", [(700, 256, 1024), (4500, 1024, 256)])      # few-row kernel / 256 x 128 tiles
+def test_linear_split_f16_rows_of_any_magnitude(dev, rows, n, k):
+    """ops.linear(gemm_mode="split_f16") — the fp32 training path's GEMMs: two fp16 planes per operand with every
+    row of A and of W scaled by its own power of two.  Rows spanning 1e-12 .. 1e8 (gradients next to activations)
+    must each come out at fp32 level — worst output row's relative L2 error vs fp64 < 1e-6, and no worse than the
+    bf16 3-way split's worst row."""
+    from molecular_dynamics_neural_operator_amd import ops
+    gen = torch.Generator().manual_seed(rows)
+    a = torch.randn(rows, k, generator=gen) * (10.0 ** (torch.rand(rows, 1, generator=gen) * 20 - 12))
+    w = torch.randn(n, k, generator=gen) * (10.0 ** (torch.rand(n, 1, generator=gen) * 8 - 4))
+    b = torch.randn(n, generator=gen) * 1e-3
+    ref = a.double() @ w.double().t()
+    err = {}
+    for mode in ("split_f16", "split_bf16"):
+        got = ops.linear(a.to(dev), w.to(dev), None, gemm_mode=mode).cpu().double()
+        err[mode] = float(((got - ref).norm(dim=1) / ref.norm(dim=1)).max())
+    print("worst row, rel L2 vs fp64:", {m: f"{e:.2e}" for m, e in err.items()})
+    assert err["split_f16"] < 1e-6 and err["split_f16"] < 2 * err["split_bf16"], err
+    # bias + ReLU epilogue
+    got = ops.linear(a.to(dev), w.to(dev), b.to(dev), relu=True, gemm_mode="split_f16").cpu().double()
+    want = torch.relu(ref + b.double())
+    assert float((got - want).norm() / want.norm()) < 1e-6
+    # a non-finite input row stays that row's problem
+    a2 = a.clone()
+    a2[3, 5] = float("inf")
+    got = ops.linear(a2.to(dev), w.to(dev), None, gemm_mode="split_f16").cpu()
+    assert not torch.isfinite(got[3]).all() and torch.isfinite(got[4:]).all() and torch.isfinite(got[:3]).all()

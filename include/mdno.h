@@ -268,6 +268,10 @@ int mdno_rollout_plan_timer_detach(mdno_rollout_plan* plan);
  *                         two before the split and the output scaled back, so no magnitude leaves fp16's range;
  *                         same shape rules, workspace mdno_linear_split_f16_workspace_bytes(rows, n, k)
  *   mdno_gemm_atb         C (+)= A^T . B             A [rows,n1], B [rows,n2] -> C [n1,n2] (weight grads)
+ *   mdno_gemm_atb_split_f16  the same product on the 16-bit matrix pipe at fp32 accuracy: every column of A and of B
+ *                         scaled by its own power of two, split into two fp16 planes, three plane products, K slices
+ *                         added in a fixed order (needs n1 % 256 == 0, n2 % 256 == 0: _supported; workspace
+ *                         mdno_gemm_atb_split_f16_workspace_bytes(rows, n1, n2))
  *   mdno_colsum           out (+)= column sums of A [rows,n]                       (bias grads)
  *   mdno_relu_bwd         out = g * (y > 0) [* row_scale[row]]
  *   mdno_relu_bwd2        gz = g * (y > 0) and gs = gz * row_scale[row] in one pass (same values as two calls)
@@ -292,6 +296,10 @@ int mdno_linear_split_f16_fwd(const float* a, const float* w, const float* bias,
 size_t mdno_reduce_workspace_bytes(int n1, int n2);
 int mdno_gemm_atb(const float* a, const float* b, int64_t rows, int n1, int n2, float* c, int accumulate,
                   void* workspace, size_t workspace_bytes, void* stream);
+int mdno_gemm_atb_split_f16_supported(int64_t rows, int n1, int n2);
+size_t mdno_gemm_atb_split_f16_workspace_bytes(int64_t rows, int n1, int n2);
+int mdno_gemm_atb_split_f16(const float* a, const float* b, int64_t rows, int n1, int n2, float* c, int accumulate,
+                            void* workspace, size_t workspace_bytes, void* stream);
 int mdno_colsum(const float* a, int64_t rows, int n, float* out, int accumulate,
                 void* workspace, size_t workspace_bytes, void* stream);
 int mdno_relu_bwd2(const float* g, const float* y, const float* row_scale, int64_t rows, int n, float* gz, float* gs,

@@ -76,6 +76,9 @@ SIGNATURES = {
     "mdno_linear_fwd": (_I, [_P, _P, _P, _L, _I, _I, _I, _P, _P]),
     "mdno_linear_split_workspace_bytes": (_SZ, [_L, _I, _I]),
     "mdno_linear_split_fwd": (_I, [_P, _P, _P, _L, _I, _I, _I, _P, _P, _SZ, _P]),
+    "mdno_gemm_atb_split_f16_supported": (_I, [_L, _I, _I]),
+    "mdno_gemm_atb_split_f16_workspace_bytes": (_SZ, [_L, _I, _I]),
+    "mdno_gemm_atb_split_f16": (_I, [_P, _P, _L, _I, _I, _P, _I, _P, _SZ, _P]),
     "mdno_linear_split_f16_workspace_bytes": (_SZ, [_L, _I, _I]),
     "mdno_linear_split_f16_fwd": (_I, [_P, _P, _P, _L, _I, _I, _I, _P, _P, _SZ, _P]),
     "mdno_reduce_workspace_bytes": (_SZ, [_I, _I]),

@@ -34,6 +34,7 @@
 // stage t-1, whose last reads (waves 4-7, load phase t-1) completed — lgkmcnt(0) — before the barrier in
 // front of the earliest DMA issue into it.
 #include "kernels.h"
+#include "split_layout.h"
 
 namespace mdno {
 namespace {
@@ -58,6 +59,16 @@ constexpr int PP_PIECES_PER_WAVE = PP_STAGE_BYTES / 1024 / 8;   // 4
 // EPI_SLAB: fp32 partial products of a K slice into slab z (the A^T.B products; added in slice order afterwards).
 enum { EPI_BIAS = 0, EPI_MASK = 1, EPI_SLAB = 2 };
 
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+// one 32x32x16 MFMA on 16-bit fragments held as bf16x8 registers: bf16, or (F16) the same bits read as fp16
+template <bool F16>
+__device__ __forceinline__ f32x16 mma16(bf16x8 a, bf16x8 b, f32x16 c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
 struct PpArgs {
     const __bf16* A;      // NT: [rows, K] row-major.   TN: [rows, n1]
     const __bf16* W;      // NT: [N, K] row-major.      TN: [rows, n2]
@@ -69,6 +80,10 @@ struct PpArgs {
     int tiles_n;
     long long tiles_m;
     long long slice_rows; // TN: rows per K slice (multiple of 32)
+    // F16 (TN only): the operands are fp16 planes and blockIdx.z picks one of the three plane products of
+    // x = hi + 2^-11 lo' — z = 0: A . W, 1: A2 . W, 2: A . W2 — each into its own set of slabs
+    const __bf16* A2 = nullptr;
+    const __bf16* W2 = nullptr;
 };
 
 // TN = false: C = A . W^T (contraction index fastest in both operands: LDS rows of 32 k, ds_read_b128 fragments).
@@ -77,9 +92,11 @@ struct PpArgs {
 //   and the fragments come out of gfx950's transposing read ds_read_b64_tr_b16 (a 16-lane group gets a 4-row x
 //   16-column block column-major: 4 consecutive k of its own m; two reads make the 8-k MFMA operand).  The four
 //   rows of a block sit in four different 64-B quarters of the 256-B bank row: conflict free.
-template <bool TN, int EPI, bool RELU, bool OUT_BF16>
+template <bool TN, int EPI, bool RELU, bool OUT_BF16, bool F16 = false>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PpArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const __bf16* const opA = (F16 && blockIdx.z == 1) ? g.A2 : g.A;
+    const __bf16* const opW = (F16 && blockIdx.z == 2) ? g.W2 : g.W;
     // XCD-aware tile order (blocks b, b+8, ... share an XCD): each XCD gets a contiguous range of tiles, n
     // fastest, so that the tiles sharing an A row panel run on one L2.  Bijective for any count.
     const long long nwg = g.tiles_m * g.tiles_n;
@@ -134,9 +151,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PpArgs g) {
         stride_a = (unsigned)((size_t)PP_BK * g.K * 2);
         stride_b = (unsigned)((size_t)PP_BK * g.N * 2);
         const long long live = k1 - k0;          // rows of this slice
-        rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const unsigned char*>(g.A) + ((size_t)k0 * g.K + bm) * 2), 0,
+        rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const unsigned char*>(opA) + ((size_t)k0 * g.K + bm) * 2), 0,
                                                    live > 0 ? (unsigned)(((live - 1) * g.K + PP_T) * 2) : 0, 0x00020000);
-        rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const unsigned char*>(g.W) + ((size_t)k0 * g.N + bn) * 2), 0,
+        rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const unsigned char*>(opW) + ((size_t)k0 * g.N + bn) * 2), 0,
                                                    live > 0 ? (unsigned)(((live - 1) * g.N + PP_T) * 2) : 0, 0x00020000);
 #pragma unroll
         for (int t = 0; t < PP_PIECES_PER_WAVE; ++t) {
@@ -233,7 +250,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PpArgs g) {
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                          \
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                                         \
                 _Pragma("unroll") for (int j = 0; j < 2; ++j)                                     \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0); \
+                    acc[i][j] = mma16<F16>(fa[ks][i], fb[ks][j], acc[i][j]);                      \
         __builtin_amdgcn_s_setprio(0);                                                            \
     }
 #define MDNO_PP_BARRIER()                            \
@@ -284,7 +301,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PpArgs g) {
     unsigned char* patch = lds + wave * (32 * 64 * 4);    // 8 KiB apart (fp32 size) for either type
     const size_t ldc = (size_t)g.N * ESZ;
     unsigned char* cbase = static_cast<unsigned char*>(g.C) + (size_t)(bn + wn * 64) * ESZ;
-    if (EPI == EPI_SLAB) cbase += (size_t)blockIdx.y * (size_t)g.K * g.N * 4;      // slab z = [n1 = K][n2 = N] fp32
+    // slab (product z, slice y) = [n1 = K][n2 = N] fp32
+    if (EPI == EPI_SLAB) cbase += ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * (size_t)g.K * g.N * 4;
     const long long out_rows = TN ? (long long)g.K : g.rows;
     constexpr int LANES_PER_ROW = PATCH_ROW / 16;          // 8 or 16
     constexpr int ROWS_PER_INSTR = 64 / LANES_PER_ROW;     // 8 or 4
@@ -354,13 +372,14 @@ bool gemm_nt_pp_supported(long long rows, int N, int K) {
     return rows > 0 && N % PP_T == 0 && K % PP_BK == 0 && K >= 2 * PP_BK;
 }
 
-template <bool TN, int EPI, bool RELU, bool OUT_BF16>
+template <bool TN, int EPI, bool RELU, bool OUT_BF16, bool F16 = false>
 static int launch_pp(const PpArgs& g, unsigned slices, hipStream_t s) {
     static std::atomic<unsigned long long> raised{0};
-    MDNO_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(&gemm_pp_kernel<TN, EPI, RELU, OUT_BF16>), PP_LDS_BYTES, raised));
+    MDNO_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(&gemm_pp_kernel<TN, EPI, RELU, OUT_BF16, F16>), PP_LDS_BYTES, raised));
     const long long nwg = g.tiles_m * g.tiles_n;
     MDNO_REQUIRE(nwg < (1ll << 31), MDNO_EUNSUPPORTED, "gemm_pp: too many tiles");
-    hipLaunchKernelGGL((gemm_pp_kernel<TN, EPI, RELU, OUT_BF16>), dim3((unsigned)nwg, slices), dim3(512), PP_LDS_BYTES, s, g);
+    hipLaunchKernelGGL((gemm_pp_kernel<TN, EPI, RELU, OUT_BF16, F16>), dim3((unsigned)nwg, slices, F16 ? 3 : 1), dim3(512),
+                       PP_LDS_BYTES, s, g);
     return check_launch("gemm_pp_kernel");
 }
 
@@ -419,6 +438,136 @@ int gemm_tn_pp(const void* A, const void* B, long long rows, int n1, int n2, flo
                            static_cast<const float*>(workspace), slices, count, C);
     }
     return check_launch("gemm_tn_pp");
+}
+
+// ---------------------------------------------------------------- fp32 A^T . B on two fp16 planes (fp32 training)
+// C [n1,n2] (+)= A^T . B for fp32 A [rows,n1], B [rows,n2] — the weight gradients of the fp32 training path, which
+// ran on the exact fp32 MFMA (157 TF peak: 2.0 ms for the 4096 x 1024 x 43.7k product).  Here: every COLUMN of A
+// and of B (a row of A^T / B^T) is scaled by its own power of two (largest entry into [2^13, 2^14), as
+// split_layout.h does for weight rows), split into two fp16 planes kept row-major, and the three plane products run
+// on the transposing ping-pong kernel above (blockIdx.z = product), each K slice into its own slab; the slabs are
+// then added in a fixed order, the cross terms scaled by 2^-11 once, and the column scales undone — all exact
+// except the fp32 additions.
+namespace {
+__global__ __launch_bounds__(256) void zero_u32_kernel(unsigned* p, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+
+// bits of max |x[r][c]| over the rows of this block's slice -> atomicMax (non-negative floats order as integers)
+__global__ __launch_bounds__(256) void colmax_kernel(const float* __restrict__ x, long long rows, int n, long long slice_rows,
+                                                     unsigned* __restrict__ maxbits) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n) return;
+    const long long r0 = (long long)blockIdx.y * slice_rows;
+    long long r1 = r0 + slice_rows;
+    if (r1 > rows) r1 = rows;
+    unsigned m = 0u;
+    for (long long r = r0; r < r1; ++r) {
+        const unsigned b = __builtin_bit_cast(unsigned, x[(size_t)r * n + c]) & 0x7fffffffu;
+        m = b > m ? b : m;
+    }
+    if (m) atomicMax(&maxbits[c], m);
+}
+
+// x [rows,n] fp32 -> hi, lo' [rows,n] fp16 of x * scale(column); 8 columns per thread
+__global__ __launch_bounds__(256) void split_cols_f16_kernel(const float* __restrict__ x, long long count8, int n,
+                                                             const unsigned* __restrict__ maxbits,
+                                                             _Float16* __restrict__ hi, _Float16* __restrict__ lo) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count8) return;
+    const int c = (int)((i * 8) % n);
+    const float4 v0 = *reinterpret_cast<const float4*>(x + i * 8), v1 = *reinterpret_cast<const float4*>(x + i * 8 + 4);
+    const float xs[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    _Float16 oh[8], ol[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) split2h(xs[j] * f16_row_scale(__builtin_bit_cast(float, maxbits[c + j])), oh[j], ol[j]);
+    *reinterpret_cast<uint4*>(hi + i * 8) = *reinterpret_cast<const uint4*>(oh);
+    *reinterpret_cast<uint4*>(lo + i * 8) = *reinterpret_cast<const uint4*>(ol);
+}
+
+// out[i][j] (+)= (S0 + 2^-11 (S1 + S2)) / (scale_a[i] scale_b[j]),  S_p = slabs of product p added in slice order
+__global__ __launch_bounds__(256) void reduce_f16_products_kernel(const float* __restrict__ slab, int slices, long long count,
+                                                                  int n2, const unsigned* __restrict__ amax,
+                                                                  const unsigned* __restrict__ bmax, int accumulate,
+                                                                  float* __restrict__ out) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= count) return;
+    float4 sum[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const float* sp = slab + (size_t)p * slices * count + i;
+        float4 s = *reinterpret_cast<const float4*>(sp);
+        for (int z = 1; z < slices; ++z) {
+            const float4 v = *reinterpret_cast<const float4*>(sp + (size_t)z * count);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        sum[p] = s;
+    }
+    const int row = (int)(i / n2), col = (int)(i % n2);
+    const float ua = 1.f / f16_row_scale(__builtin_bit_cast(float, amax[row]));
+    float r[4] = {sum[0].x + (sum[1].x + sum[2].x) * F16_LO_UNSCALE, sum[0].y + (sum[1].y + sum[2].y) * F16_LO_UNSCALE,
+                  sum[0].z + (sum[1].z + sum[2].z) * F16_LO_UNSCALE, sum[0].w + (sum[1].w + sum[2].w) * F16_LO_UNSCALE};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r[j] = r[j] * ua * (1.f / f16_row_scale(__builtin_bit_cast(float, bmax[col + j])));
+        if (accumulate) r[j] += out[i + j];
+    }
+    *reinterpret_cast<float4*>(out + i) = make_float4(r[0], r[1], r[2], r[3]);
+}
+
+struct AtbF16Ws {
+    _Float16 *ah, *al, *bh, *bl;
+    unsigned *amax, *bmax;
+    float* slabs;
+    int slices;
+    size_t total;
+};
+
+AtbF16Ws carve_atb_f16(void* ws, long long rows, int n1, int n2) {
+    AtbF16Ws w{};
+    Carver cv(ws);
+    w.ah = cv.take<_Float16>((size_t)rows * n1);
+    w.al = cv.take<_Float16>((size_t)rows * n1);
+    w.bh = cv.take<_Float16>((size_t)rows * n2);
+    w.bl = cv.take<_Float16>((size_t)rows * n2);
+    w.amax = cv.take<unsigned>((size_t)n1);
+    w.bmax = cv.take<unsigned>((size_t)n2);
+    // three products share the chip: a third of the slices the bf16 product would take, at least one
+    w.slices = (tn_slices(rows, n1, n2) + 2) / 3;
+    w.slabs = cv.take<float>((size_t)3 * w.slices * n1 * n2);
+    w.total = cv.used();
+    return w;
+}
+}  // namespace
+
+bool gemm_atb_f16_supported(long long rows, int n1, int n2) {
+    return gemm_tn_pp_supported(rows, n1, n2) && rows * (long long)(n1 > n2 ? n1 : n2) < (1ll << 40);
+}
+
+size_t gemm_atb_f16_workspace_bytes(long long rows, int n1, int n2) { return carve_atb_f16(nullptr, rows, n1, n2).total; }
+
+int gemm_atb_f16(const float* a, const float* b, long long rows, int n1, int n2, float* c, int accumulate, void* workspace,
+                 hipStream_t s) {
+    MDNO_REQUIRE(gemm_atb_f16_supported(rows, n1, n2), MDNO_EUNSUPPORTED, "gemm_atb_f16: rows=%lld n1=%d n2=%d", rows, n1, n2);
+    const AtbF16Ws w = carve_atb_f16(workspace, rows, n1, n2);
+    hipLaunchKernelGGL(zero_u32_kernel, dim3((n1 + n2 + 255) / 256), dim3(256), 0, s, w.amax, n1 + n2);   // (amax | bmax contiguous)
+    const int cm_slices = 64;
+    const long long cm_rows = (rows + cm_slices - 1) / cm_slices;
+    hipLaunchKernelGGL(colmax_kernel, dim3(n1 / 256, cm_slices), dim3(256), 0, s, a, rows, n1, cm_rows, w.amax);
+    hipLaunchKernelGGL(colmax_kernel, dim3(n2 / 256, cm_slices), dim3(256), 0, s, b, rows, n2, cm_rows, w.bmax);
+    const long long ca = rows * n1 / 8, cb = rows * n2 / 8;
+    hipLaunchKernelGGL(split_cols_f16_kernel, dim3((unsigned)((ca + 255) / 256)), dim3(256), 0, s, a, ca, n1, w.amax, w.ah, w.al);
+    hipLaunchKernelGGL(split_cols_f16_kernel, dim3((unsigned)((cb + 255) / 256)), dim3(256), 0, s, b, cb, n2, w.bmax, w.bh, w.bl);
+    MDNO_TRY(check_launch("gemm_atb_f16: split"));
+    const long long slice_rows = ((rows + w.slices - 1) / w.slices + PP_BK - 1) / PP_BK * PP_BK;
+    PpArgs g{reinterpret_cast<const __bf16*>(w.ah), reinterpret_cast<const __bf16*>(w.bh), nullptr, nullptr, w.slabs, rows, n2, n1,
+             n2 / PP_T, n1 / PP_T, slice_rows, reinterpret_cast<const __bf16*>(w.al), reinterpret_cast<const __bf16*>(w.bl)};
+    MDNO_TRY((launch_pp<true, EPI_SLAB, false, false, true>(g, (unsigned)w.slices, s)));
+    const long long count = (long long)n1 * n2;
+    hipLaunchKernelGGL(reduce_f16_products_kernel, dim3((unsigned)((count / 4 + 255) / 256)), dim3(256), 0, s, w.slabs, w.slices,
+                       count, n2, w.amax, w.bmax, accumulate, c);
+    return check_launch("gemm_atb_f16");
 }
 
 }  // namespace mdno

@@ -85,6 +85,11 @@ int split_planes_bias64(const float* x, int rows, const float* b, float* q, void
 int fill_ints(int* p, int n, int value, hipStream_t s);     // n <= 256, by a kernel
 // two-plane fp16 images (SPLIT_F16) and the K = 64 GEMM on them (the factored conv's Y = X . W3T)
 size_t split_planes_f16_bytes(long long rows, int K);
+// C [n1,n2] (+)= A^T . B for fp32 operands on two fp16 planes each, columns scaled by powers of two (gemm_bf16.hip)
+bool gemm_atb_f16_supported(long long rows, int n1, int n2);
+size_t gemm_atb_f16_workspace_bytes(long long rows, int n1, int n2);
+int gemm_atb_f16(const float* a, const float* b, long long rows, int n1, int n2, float* c, int accumulate, void* workspace,
+                 hipStream_t s);
 // act(A . W^T + b) on two fp16 planes per operand, rows of both scaled by powers of two (training: split_linear's
 // shapes at half the matrix work)
 size_t split_linear_f16_workspace_bytes(long long rows, int N, int K);

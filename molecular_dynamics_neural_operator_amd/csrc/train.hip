@@ -487,6 +487,26 @@ extern "C" int mdno_linear_split_f16_fwd(const float* a, const float* w, const f
     return split_linear_f16(a, w, bias, (long long)rows, n, k, relu, c, workspace, static_cast<hipStream_t>(stream));
 }
 
+extern "C" int mdno_gemm_atb_split_f16_supported(int64_t rows, int n1, int n2) {
+    return gemm_atb_f16_supported((long long)rows, n1, n2) ? 1 : 0;
+}
+
+extern "C" size_t mdno_gemm_atb_split_f16_workspace_bytes(int64_t rows, int n1, int n2) {
+    return gemm_atb_f16_supported((long long)rows, n1, n2) ? gemm_atb_f16_workspace_bytes((long long)rows, n1, n2) : 0;
+}
+
+extern "C" int mdno_gemm_atb_split_f16(const float* a, const float* b, int64_t rows, int n1, int n2, float* c, int accumulate,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
+    MDNO_REQUIRE(a && b && c && workspace && rows > 0, MDNO_EINVAL, "mdno_gemm_atb_split_f16: bad arguments");
+    MDNO_REQUIRE(gemm_atb_f16_supported((long long)rows, n1, n2) &&
+                     ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15) == 0,
+                 MDNO_EUNSUPPORTED, "mdno_gemm_atb_split_f16: needs n1 %% 256 == 0, n2 %% 256 == 0, 16-byte aligned operands "
+                 "(rows=%lld n1=%d n2=%d); use mdno_gemm_atb", (long long)rows, n1, n2);
+    MDNO_REQUIRE(workspace_bytes >= gemm_atb_f16_workspace_bytes((long long)rows, n1, n2), MDNO_EWORKSPACE,
+                 "mdno_gemm_atb_split_f16: workspace");
+    return gemm_atb_f16(a, b, (long long)rows, n1, n2, c, accumulate, workspace, static_cast<hipStream_t>(stream));
+}
+
 extern "C" size_t mdno_reduce_workspace_bytes(int n1, int n2) {
     if (n2 <= 1) return align_up((size_t)kColSlices * (size_t)n1 * sizeof(float), 256);
     return align_up((size_t)kSlices * (size_t)n1 * (size_t)n2 * sizeof(float), 256);

@@ -299,13 +299,20 @@ def linear(a: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], relu: bo
     return c
 
 
-def gemm_atb(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    """a^T . b over rows: a [rows,n1], b [rows,n2] -> [n1,n2] (fixed-order partial sums)."""
+def gemm_atb(a: torch.Tensor, b: torch.Tensor, gemm_mode: str = "f32") -> torch.Tensor:
+    """a^T . b over rows: a [rows,n1], b [rows,n2] -> [n1,n2] (fixed-order partial sums).  gemm_mode "split_f16":
+    on two fp16 planes per operand, columns scaled by powers of two (fp32-level error), where the shape tiles
+    (n1, n2 multiples of 256); otherwise the exact fp32 MFMA."""
     lib = _lib.load()
     a, b = f32(a), f32(b)
     rows, n1 = a.shape
     n2 = b.shape[1]
     c = torch.empty((n1, n2), dtype=torch.float32, device=a.device)
+    if gemm_mode == "split_f16" and lib.mdno_gemm_atb_split_f16_supported(rows, n1, n2):
+        ws = _ws(lib.mdno_gemm_atb_split_f16_workspace_bytes(rows, n1, n2), a.device)
+        check(lib.mdno_gemm_atb_split_f16(ptr(a), ptr(b), rows, n1, n2, ptr(c), 0, ptr(ws), ws.numel(), stream_ptr(a.device)),
+              "mdno_gemm_atb_split_f16")
+        return c
     nb = lib.mdno_reduce_workspace_bytes(n1, n2)
     ws = _ws(nb, a.device)
     check(lib.mdno_gemm_atb(ptr(a), ptr(b), rows, n1, n2, ptr(c), 0, ptr(ws), ws.numel(), stream_ptr(a.device)),

@@ -128,11 +128,11 @@ class KernelIntegralBlock(torch.autograd.Function):
         del GZ, GS
         # edge-MLP backward
         d_b2 = ops.colsum(d_we)
-        d_w2 = ops.gemm_atb(d_we, h2)
+        d_w2 = ops.gemm_atb(d_we, h2, gemm_mode=gemm_mode)
         gz2 = ops.relu_bwd(ops.linear(d_we, ops.transpose(w2), None, gemm_mode=gemm_mode), h2)
         del d_we
         d_b1 = ops.colsum(gz2)
-        d_w1 = ops.gemm_atb(gz2, h1)
+        d_w1 = ops.gemm_atb(gz2, h1, gemm_mode=gemm_mode)
         gz1 = ops.relu_bwd(ops.linear(gz2, ops.transpose(w1), None, gemm_mode=gemm_mode), h1)
         d_b0 = ops.colsum(gz1)
         d_w0 = ops.gemm_atb(gz1, ea)

@@ -528,3 +528,28 @@ def test_linear_split_f16_rows_of_any_magnitude(dev, rows, n, k):
     a2[3, 5] = float("inf")
     got = ops.linear(a2.to(dev), w.to(dev), None, gemm_mode="split_f16").cpu()
     assert not torch.isfinite(got[3]).all() and torch.isfinite(got[4:]).all() and torch.isfinite(got[:3]).all()
+
+
+@pytest.mark.gpu
+def test_gemm_atb_split_f16_columns_of_any_magnitude(dev):
+    """ops.gemm_atb(gemm_mode="split_f16") — the weight gradients of the fp32 training path on two fp16 planes per
+    operand with every column scaled by its own power of two.  Columns spanning 1e-12 .. 1e6: every entry of the
+    product, measured against the norms of its two columns, is as close to fp64 as the exact-fp32-MFMA product."""
+    from molecular_dynamics_neural_operator_amd import ops
+    gen = torch.Generator().manual_seed(9)
+    rows, n1, n2 = 5000, 512, 256
+    a = torch.randn(rows, n1, generator=gen) * (10.0 ** (torch.rand(1, n1, generator=gen) * 18 - 12))
+    b = torch.randn(rows, n2, generator=gen) * (10.0 ** (torch.rand(1, n2, generator=gen) * 12 - 6))
+    a[:, 7] = 0.0                                                      # an all-zero column: scale 1, result 0
+    ref = a.double().t() @ b.double()
+    scale = a.double().norm(dim=0).clamp_min(1e-300)[:, None] * b.double().norm(dim=0)[None, :]
+    err = {}
+    for mode in ("split_f16", "f32"):
+        got = ops.gemm_atb(a.to(dev), b.to(dev), gemm_mode=mode).cpu().double()
+        assert torch.isfinite(got).all()
+        err[mode] = float(((got - ref) / scale).abs().max())
+    print("max |C - fp64| / (|a_i| |b_j|):", {m: f"{e:.2e}" for m, e in err.items()})
+    assert err["split_f16"] < 3e-7 and err["split_f16"] < 3 * err["f32"] + 1e-8, err
+    assert float(ops.gemm_atb(a.to(dev), b.to(dev), gemm_mode="split_f16")[7].abs().max()) == 0.0
+    # two runs, same bits (slabs are added in a fixed order)
+    assert torch.equal(ops.gemm_atb(a.to(dev), b.to(dev), gemm_mode="split_f16"), ops.gemm_atb(a.to(dev), b.to(dev), gemm_mode="split_f16"))

@@ -454,20 +454,36 @@ __global__ __launch_bounds__(256) void zero_u32_kernel(unsigned* p, int n) {
     if (i < n) p[i] = 0u;
 }
 
-// bits of max |x[r][c]| over the rows of this block's slice -> atomicMax (non-negative floats order as integers)
+// bits of max |x[r][c]| over the rows of this block's slice -> atomicMax (non-negative floats order as integers);
+// a thread owns four adjacent columns (16-B loads), four rows in flight
 __global__ __launch_bounds__(256) void colmax_kernel(const float* __restrict__ x, long long rows, int n, long long slice_rows,
                                                      unsigned* __restrict__ maxbits) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (c >= n) return;
     const long long r0 = (long long)blockIdx.y * slice_rows;
     long long r1 = r0 + slice_rows;
     if (r1 > rows) r1 = rows;
-    unsigned m = 0u;
-    for (long long r = r0; r < r1; ++r) {
-        const unsigned b = __builtin_bit_cast(unsigned, x[(size_t)r * n + c]) & 0x7fffffffu;
-        m = b > m ? b : m;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 m = {0u, 0u, 0u, 0u};
+    auto take = [&](const u32x4 v) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned b = v[j] & 0x7fffffffu;
+            m[j] = b > m[j] ? b : m[j];
+        }
+    };
+    long long r = r0;
+    for (; r + 4 <= r1; r += 4) {
+        u32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const u32x4*>(x + (size_t)(r + u) * n + c);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) take(v[u]);
     }
-    if (m) atomicMax(&maxbits[c], m);
+    for (; r < r1; ++r) take(*reinterpret_cast<const u32x4*>(x + (size_t)r * n + c));
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (m[j]) atomicMax(&maxbits[c + j], m[j]);
 }
 
 // x [rows,n] fp32 -> hi, lo' [rows,n] fp16 of x * scale(column); 8 columns per thread
@@ -552,10 +568,10 @@ int gemm_atb_f16(const float* a, const float* b, long long rows, int n1, int n2,
     MDNO_REQUIRE(gemm_atb_f16_supported(rows, n1, n2), MDNO_EUNSUPPORTED, "gemm_atb_f16: rows=%lld n1=%d n2=%d", rows, n1, n2);
     const AtbF16Ws w = carve_atb_f16(workspace, rows, n1, n2);
     hipLaunchKernelGGL(zero_u32_kernel, dim3((n1 + n2 + 255) / 256), dim3(256), 0, s, w.amax, n1 + n2);   // (amax | bmax contiguous)
-    const int cm_slices = 64;
+    const int cm_slices = 512;
     const long long cm_rows = (rows + cm_slices - 1) / cm_slices;
-    hipLaunchKernelGGL(colmax_kernel, dim3(n1 / 256, cm_slices), dim3(256), 0, s, a, rows, n1, cm_rows, w.amax);
-    hipLaunchKernelGGL(colmax_kernel, dim3(n2 / 256, cm_slices), dim3(256), 0, s, b, rows, n2, cm_rows, w.bmax);
+    hipLaunchKernelGGL(colmax_kernel, dim3((n1 + 1023) / 1024, cm_slices), dim3(256), 0, s, a, rows, n1, cm_rows, w.amax);
+    hipLaunchKernelGGL(colmax_kernel, dim3((n2 + 1023) / 1024, cm_slices), dim3(256), 0, s, b, rows, n2, cm_rows, w.bmax);
     const long long ca = rows * n1 / 8, cb = rows * n2 / 8;
     hipLaunchKernelGGL(split_cols_f16_kernel, dim3((unsigned)((ca + 255) / 256)), dim3(256), 0, s, a, ca, n1, w.amax, w.ah, w.al);
     hipLaunchKernelGGL(split_cols_f16_kernel, dim3((unsigned)((cb + 255) / 256)), dim3(256), 0, s, b, cb, n2, w.bmax, w.bh, w.bl);

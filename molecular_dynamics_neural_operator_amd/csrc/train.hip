@@ -212,6 +212,44 @@ __global__ __launch_bounds__(256) void gemm_atb_generic_kernel(const float* __re
     part[(size_t)slice * N1 * N2 + id] = s;
 }
 
+// N2 <= 8 (the first edge-MLP layer's weight gradient: N2 = 6 edge attributes): thread per column of A, so that a
+// row of A is read as whole lines (the kernel above reads each element of A from N2 threads and 172 B of every
+// KiB of a row per wave); four rows in flight per thread.  Each (m, n) sum runs over its slice's rows in ascending
+// order, as above.
+__global__ __launch_bounds__(256) void gemm_atb_smalln_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                              float* __restrict__ part, long long K, int N1, int N2,
+                                                              long long kslice) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= N1) return;
+    const int slice = blockIdx.y;
+    const long long k0 = (long long)slice * kslice;
+    long long k1 = k0 + kslice;
+    if (k1 > K) k1 = K;
+    float s[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) s[n] = 0.f;
+    long long r = k0;
+    for (; r + 4 <= k1; r += 4) {
+        float a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = A[(r + u) * N1 + m];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int n = 0; n < 8; ++n)
+                if (n < N2) s[n] = fmaf(a[u], B[(r + u) * N2 + n], s[n]);
+    }
+    for (; r < k1; ++r) {
+        const float a = A[r * N1 + m];
+#pragma unroll
+        for (int n = 0; n < 8; ++n)
+            if (n < N2) s[n] = fmaf(a, B[r * N2 + n], s[n]);
+    }
+#pragma unroll
+    for (int n = 0; n < 8; ++n)
+        if (n < N2) part[((size_t)slice * N1 + m) * N2 + n] = s[n];
+}
+
 __global__ __launch_bounds__(256) void reduce_slices_kernel(const float* __restrict__ part, int slices, long long count,
                                                             float* __restrict__ out, int accumulate) {
     const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -233,6 +271,32 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A
     float s = 0.f;
     for (long long r = k0; r < k1; ++r) s += A[r * N + n];
     part[(size_t)slice * N + n] = s;
+}
+
+// the same sums (each column over its slice's rows, ascending) with four adjacent columns per thread — 16-B loads —
+// and four rows in flight: N % 4 == 0, 16-byte aligned A
+__global__ __launch_bounds__(256) void colsum4_kernel(const float* __restrict__ A, float* __restrict__ part, long long K,
+                                                      int N, long long kslice) {
+    const int n = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (n >= N) return;
+    const int slice = blockIdx.y;
+    const long long k0 = (long long)slice * kslice;
+    long long k1 = k0 + kslice;
+    if (k1 > K) k1 = K;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    long long r = k0;
+    for (; r + 4 <= k1; r += 4) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(A + (size_t)(r + u) * N + n);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+    for (; r < k1; ++r) {
+        const float4 v = *reinterpret_cast<const float4*>(A + (size_t)r * N + n);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(part + (size_t)slice * N + n) = s;
 }
 
 // out = g * (y > 0) [* scale[row]]
@@ -509,6 +573,7 @@ extern "C" int mdno_gemm_atb_split_f16(const float* a, const float* b, int64_t r
 
 extern "C" size_t mdno_reduce_workspace_bytes(int n1, int n2) {
     if (n2 <= 1) return align_up((size_t)kColSlices * (size_t)n1 * sizeof(float), 256);
+    if (n2 <= 8) return align_up((size_t)kColSlices * (size_t)n1 * (size_t)n2 * sizeof(float), 256);   // gemm_atb_smalln_kernel
     return align_up((size_t)kSlices * (size_t)n1 * (size_t)n2 * sizeof(float), 256);
 }
 
@@ -522,6 +587,15 @@ extern "C" int mdno_gemm_atb(const float* a, const float* b, int64_t rows, int n
     kslice = (kslice + BK - 1) / BK * BK;
     const bool mfma = n1 % 128 == 0 && n2 % 128 == 0 &&
                       ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0;
+    if (!mfma && n2 <= 8) {      // few columns of B: a stream over A, many more slices
+        const long long ks = (rows + kColSlices - 1) / kColSlices;
+        hipLaunchKernelGGL(gemm_atb_smalln_kernel, dim3((n1 + 255) / 256, kColSlices), dim3(256), 0, s, a, b, part,
+                           (long long)rows, n1, n2, ks);
+        const long long cnt = (long long)n1 * n2;
+        hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, (const float*)part,
+                           kColSlices, cnt, c, accumulate);
+        return check_launch("mdno_gemm_atb");
+    }
     if (mfma)
         hipLaunchKernelGGL(gemm_atb_mfma_kernel, dim3(n2 / 128, n1 / 128, kSlices), dim3(256), 0, s, a, b, part,
                            (long long)rows, n1, n2, kslice);
@@ -541,8 +615,12 @@ extern "C" int mdno_colsum(const float* a, int64_t rows, int n, float* out, int 
     hipStream_t s = static_cast<hipStream_t>(stream);
     float* part = static_cast<float*>(workspace);
     const long long kslice = (rows + kColSlices - 1) / kColSlices;
-    hipLaunchKernelGGL(colsum_kernel, dim3((n + 255) / 256, kColSlices), dim3(256), 0, s, a, part, (long long)rows, n,
-                       kslice);
+    if (n % 4 == 0 && (reinterpret_cast<uintptr_t>(a) & 15) == 0)
+        hipLaunchKernelGGL(colsum4_kernel, dim3((n / 4 + 255) / 256, kColSlices), dim3(256), 0, s, a, part, (long long)rows, n,
+                           kslice);
+    else
+        hipLaunchKernelGGL(colsum_kernel, dim3((n + 255) / 256, kColSlices), dim3(256), 0, s, a, part, (long long)rows, n,
+                           kslice);
     hipLaunchKernelGGL(reduce_slices_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const float*)part, kColSlices,
                        (long long)n, out, accumulate);
     return check_launch("mdno_colsum");

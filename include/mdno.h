@@ -42,6 +42,7 @@ extern "C" {
 
 #define MDNO_AGGR_ADD  0
 #define MDNO_AGGR_MEAN 1
+#define MDNO_AGGR_MAX  2   /* mdno_nnconv_fwd only (inference): per-channel max over a node's messages, 0 for no message */
 
 /* How the two wide edge-MLP GEMMs are evaluated (fp32 in, fp32 out either way):
  *   SPLIT_BF16  every fp32 operand is split exactly into 3 bf16 planes and the product accumulated
@@ -161,7 +162,9 @@ int mdno_edge_mlp_fwd(const float* edge_pos, const int32_t* src, const int32_t* 
  * K3-K6  conv application — replaces NNConv_old.forward/message/update (graph_kernel.py:194-209)
  * and torch_geometric's gather + scatter-mean:
  *   y[r] = act( aggr_{p in row r} ( x[src[p]] . W_e[p] )  +  x[r] . root  +  bias )
- *   aggr = sum (MDNO_AGGR_ADD) or sum / max(deg,1) (MDNO_AGGR_MEAN); act = ReLU if relu != 0
+ *   aggr = sum (MDNO_AGGR_ADD), sum / max(deg,1) (MDNO_AGGR_MEAN) or the per-channel maximum over the row's
+ *   messages, 0 for a row without any (MDNO_AGGR_MAX — torch_geometric's "max", NNConv_old docstring
+ *   graph_kernel.py:148-150); act = ReLU if relu != 0
  *   (the ReLU of graph_kernel.py:300/302 fused).  root / bias may be NULL.
  *   x f32 [R,Cin]  W_e f32 [E,Cin,Cout]  y f32 [R,Cout]; y must not alias x.
  * ---------------------------------------------------------------------------------------- */

@@ -12,7 +12,7 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("MDNO_LIB", _HERE / "libmdno.so"))
 
 OK, EINVAL, ELAUNCH, EWORKSPACE, EUNSUPPORTED = 0, -1, -2, -3, -4
-AGGR = {"add": 0, "mean": 1}
+AGGR = {"add": 0, "mean": 1, "max": 2}      # "max": mdno_nnconv_fwd only (inference)
 STATUS_EDGE_OVERFLOW, STATUS_BAD_AMINOACID = 1, 2
 ABI_VERSION = 11
 GEMM_MODES = {"split_bf16": 0, "f32": 1, "split_f16": 2}

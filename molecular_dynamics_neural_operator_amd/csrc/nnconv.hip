@@ -99,9 +99,19 @@ __global__ __launch_bounds__(WAVES * 64) void nnconv64_row_kernel(
 #pragma unroll
     for (int u = 0; u < CPW; ++u) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int p = beg + wave + u * WAVES; p < end; p += CHAINS)
-            edge_accumulate64(acc, x + (size_t)src[p] * 64, w_e + (size_t)p * 4096, g, q);
-        acc = reduce_over_g(acc);
+        if (aggr != MDNO_AGGR_MAX) {
+            for (int p = beg + wave + u * WAVES; p < end; p += CHAINS)
+                edge_accumulate64(acc, x + (size_t)src[p] * 64, w_e + (size_t)p * 4096, g, q);
+            acc = reduce_over_g(acc);
+        } else {      // every message in full, then the running maximum of the chain (-inf: a chain without edges)
+            acc = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+            for (int p = beg + wave + u * WAVES; p < end; p += CHAINS) {
+                float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+                edge_accumulate64(m, x + (size_t)src[p] * 64, w_e + (size_t)p * 4096, g, q);
+                m = reduce_over_g(m);
+                acc = make_float4(fmaxf(acc.x, m.x), fmaxf(acc.y, m.y), fmaxf(acc.z, m.z), fmaxf(acc.w, m.w));
+            }
+        }
         if (lane < 16) *reinterpret_cast<float4*>(&red[wave + u * WAVES][4 * lane]) = acc;
     }
     // the root term x[r].root is one more "edge" with its own accumulator, taken by the wave that
@@ -115,8 +125,14 @@ __global__ __launch_bounds__(WAVES * 64) void nnconv64_row_kernel(
     __syncthreads();
     if (tid < 64) {
         float s = 0.f;
+        if (aggr != MDNO_AGGR_MAX) {
 #pragma unroll
-        for (int c = 0; c < CHAINS; ++c) s += red[c][tid];   // fixed order: bitwise reproducible
+            for (int c = 0; c < CHAINS; ++c) s += red[c][tid];   // fixed order: bitwise reproducible
+        } else if (deg > 0) {
+            s = red[0][tid];
+#pragma unroll
+            for (int c = 1; c < CHAINS; ++c) s = fmaxf(s, red[c][tid]);
+        }
         if (aggr == MDNO_AGGR_MEAN) s = s / (float)(deg > 1 ? deg : 1);
         if (root != nullptr) s += rootred[tid];
         if (bias != nullptr) s += bias[tid];
@@ -160,7 +176,7 @@ __global__ __launch_bounds__(256) void nnconv_generic_kernel(
             const float* w = w_e + (size_t)p * Cin * Cout + o;
             float m = 0.f;
             for (int i = 0; i < Cin; ++i) m = fmaf(xj[i], w[(size_t)i * Cout], m);
-            s += m;
+            s = aggr != MDNO_AGGR_MAX ? s + m : (p == beg ? m : fmaxf(s, m));
         }
         if (aggr == MDNO_AGGR_MEAN) s = s / (float)(deg > 1 ? deg : 1);
         if (root != nullptr) {
@@ -184,8 +200,9 @@ int mdno::nnconv(const float* x, const int* row_ptr, const int* src, int num_row
     MDNO_REQUIRE(x && row_ptr && src && w_e && y, MDNO_EINVAL, "nnconv: null pointer");
     MDNO_REQUIRE(num_rows > 0 && Cin > 0 && Cout > 0, MDNO_EINVAL, "nnconv: rows=%d Cin=%d Cout=%d", num_rows, Cin,
                  Cout);
-    MDNO_REQUIRE(aggr == MDNO_AGGR_ADD || aggr == MDNO_AGGR_MEAN, MDNO_EUNSUPPORTED,
-                 "nnconv: aggr %d not implemented (add, mean)", aggr);
+    MDNO_REQUIRE(aggr == MDNO_AGGR_ADD || aggr == MDNO_AGGR_MEAN || aggr == MDNO_AGGR_MAX, MDNO_EUNSUPPORTED,
+                 "nnconv: aggr %d not implemented (add, mean, max)", aggr);
+    MDNO_REQUIRE(aggr != MDNO_AGGR_MAX || fc == nullptr, MDNO_EUNSUPPORTED, "nnconv: max aggregation inside the model");
     MDNO_REQUIRE(x != y, MDNO_EINVAL, "nnconv: y aliases x");
     const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_e) |
                            reinterpret_cast<uintptr_t>(root)) & 15) == 0;

@@ -92,9 +92,11 @@ class LpLoss(object):
 
 # --------------------------------------------------------------------------- edge-MLP
 class DenseNet(nn.Module):
-    """``DenseNet(layers, nonlinearity, out_nonlinearity=None, normalize=False)``; the HIP path
-    implements the configuration the model uses — three Linear layers with ReLU between them
-    (graph_kernel.py:271) — and raises for anything else."""
+    """``DenseNet(layers, nonlinearity, out_nonlinearity=None, normalize=False)`` (graph_kernel.py:217-242).  The
+    configuration the model uses — three Linear layers with ReLU between them (graph_kernel.py:271) — runs as the
+    fused edge-MLP kernels; any other depth, ``normalize=True`` (BatchNorm1d in eval mode, folded into the Linear in
+    front of it) and a ReLU ``out_nonlinearity`` run layer by layer on the library's Linear kernel.  Other
+    nonlinearities and batch statistics (BatchNorm1d in training mode) are not implemented."""
 
     def __init__(self, layers, nonlinearity, out_nonlinearity=None, normalize=False):
         super().__init__()
@@ -121,8 +123,38 @@ class DenseNet(nn.Module):
         l0, l2, l4 = self.layers[0], self.layers[2], self.layers[4]
         return (l0.weight, l0.bias, l2.weight, l2.bias, l4.weight, l4.bias)
 
+    def _layerwise(self, x):
+        """Any depth / eval-mode BatchNorm / ReLU output: one Linear kernel per layer (graph_kernel.py:239-242)."""
+        mods = list(self.layers)
+        i = 0
+        while i < len(mods):
+            lin = mods[i]
+            if not isinstance(lin, nn.Linear):
+                raise NotImplementedError(f"DenseNet: unexpected layer {type(lin).__name__} at position {i}")
+            w, b = lin.weight, lin.bias
+            i += 1
+            if i < len(mods) and isinstance(mods[i], nn.BatchNorm1d):
+                bn = mods[i]
+                if bn.training or not bn.track_running_stats:
+                    raise NotImplementedError("DenseNet(normalize=True): batch statistics are not implemented; call .eval()")
+                scale = (bn.weight if bn.affine else torch.ones_like(bn.running_var)) / torch.sqrt(bn.running_var + bn.eps)
+                shift = (bn.bias if bn.affine else torch.zeros_like(bn.running_mean)) - bn.running_mean * scale
+                w, b = w * scale[:, None], (b if b is not None else 0.0) * scale + shift
+                i += 1
+            relu = False
+            if i < len(mods) and not isinstance(mods[i], (nn.Linear, nn.BatchNorm1d)):
+                if not isinstance(mods[i], nn.ReLU):
+                    raise NotImplementedError(f"DenseNet: nonlinearity {type(mods[i]).__name__} (the HIP path has ReLU)")
+                relu = True
+                i += 1
+            x = ops.linear(x, w, b, relu=relu)
+        return x
+
     def forward(self, x):
         _no_training(self)
+        if not self._hip_ok:
+            with torch.no_grad():
+                return self._layerwise(ops.f32(x))
         w = self.hip_weights()
         x = ops.f32(x)
         E = x.shape[0]
@@ -164,12 +196,15 @@ class NNConv_old(nn.Module):
         _no_training(self)
         x = x.unsqueeze(-1) if x.dim() == 1 else x
         pseudo = edge_attr.unsqueeze(-1) if edge_attr.dim() == 1 else edge_attr
-        if self.aggr not in ("add", "mean"):
-            raise NotImplementedError(f"aggr={self.aggr!r}: the HIP path implements 'add' and 'mean'")
+        if self.aggr not in ("add", "mean", "max"):
+            raise NotImplementedError(f"aggr={self.aggr!r}: the HIP path implements 'add', 'mean' and 'max'")
         with torch.no_grad():
             graph = ops.coo_to_csr(edge_index, x.shape[0])
-            dims = self.net._dims
-            w_e = ops.edge_mlp(self.net.hip_weights(), dims[0], dims[1], dims[3], graph, edge_attr=pseudo)
+            if getattr(self.net, "_hip_ok", False):
+                dims = self.net._dims
+                w_e = ops.edge_mlp(self.net.hip_weights(), dims[0], dims[1], dims[3], graph, edge_attr=pseudo)
+            else:       # any other edge network: evaluated in COO order, rows then put in the conv's edge order
+                w_e = self.net(pseudo).index_select(0, graph.perm[:pseudo.shape[0]].long()).contiguous()
             return ops.nnconv(x, graph, w_e, self.root, self.bias, self.aggr, relu=False)
 
     def __repr__(self):

@@ -66,6 +66,9 @@ def nnconv_apply(x: Tensor, edge_index: Tensor, w_e: Tensor, root: Optional[Tens
         cnt = torch.zeros(n, dtype=x.dtype)
         cnt.index_add_(0, dst, torch.ones(dst.shape[0], dtype=x.dtype))
         out = out / cnt.clamp(min=1).unsqueeze(-1)
+    elif aggr == "max":      # torch_geometric's scatter max: per channel over a node's messages, 0 for no message
+        out = torch.zeros(n, cout, dtype=x.dtype)
+        out.index_reduce_(0, dst, msg, "amax", include_self=False)
     elif aggr != "add":
         raise ValueError(f"aggr {aggr!r} not restated")
     if root is not None:

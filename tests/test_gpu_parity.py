@@ -377,6 +377,52 @@ def test_nnconv64_vs_oracle(dev, O, aggr, use_root, use_bias, relu):
     assert torch.equal(got, again)
 
 
+@pytest.mark.parametrize("cin,cout", [(64, 64), (5, 7)])
+def test_nnconv_max_aggregation_and_other_edge_networks(dev, O, cin, cout):
+    """The rest of the reference's NNConv_old / DenseNet surface (graph_kernel.py:148-150, 217-242), which the model
+    itself does not use: aggr="max" (per-channel maximum over a node's messages, 0 for a node without any), and an
+    edge network of another depth with BatchNorm1d (eval) and a ReLU on its output."""
+    from molecular_dynamics_neural_operator_amd.graph_kernel import DenseNet, NNConv_old
+    torch.manual_seed(21)
+    n, E = 40, 300
+    ei = torch.stack([torch.randint(0, n, (E,)), torch.randint(0, n - 3, (E,))])      # nodes n-3.. get no message
+    ea = torch.randn(E, 6)
+    x = torch.randn(n, cin)
+    for aggr in ("max", "mean"):
+        net = DenseNet([6, 32, 32, cin * cout], torch.nn.ReLU)
+        conv = NNConv_old(cin, cout, net, aggr=aggr).eval()
+        sd = {k: v.detach().clone() for k, v in conv.state_dict().items()}
+        want = O.nnconv_forward(x, ei, ea, sd, "", aggr=aggr)
+        got = conv.to(dev)(x.to(dev), ei.to(dev), ea.to(dev))
+        close(got, want, name=f"aggr={aggr}")
+        if aggr == "max":      # rows without messages: root term and bias only
+            close(got[n - 3:], x[n - 3:] @ sd["root"] + sd["bias"])
+    # a four-layer edge network with BatchNorm (eval: running statistics) and a ReLU output, inside the conv
+    net = DenseNet([6, 16, 24, 16, cin * cout], torch.nn.ReLU, out_nonlinearity=torch.nn.ReLU, normalize=True)
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.normal_(0.0, 0.5)
+            m.running_var.uniform_(0.5, 2.0)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0.0, 0.2)
+    conv = NNConv_old(cin, cout, net, aggr="add").eval()
+    with torch.no_grad():
+        w_e = ea.double()
+        for layer in copy_double(net).layers:      # the reference's DenseNet.forward: the layers in order
+            w_e = layer(w_e)
+        want = O.nnconv_apply(x.double(), ei, w_e, conv.root.double(), conv.bias.double(), "add")
+    close(net.to(dev)(ea.to(dev)), w_e, name="DenseNet, 4 layers + BatchNorm")
+    close(conv.to(dev)(x.to(dev), ei.to(dev), ea.to(dev)), want, name="conv over it")
+    net.train()
+    with pytest.raises(NotImplementedError):
+        net(ea.to(dev))
+
+
+def copy_double(module):
+    import copy
+    return copy.deepcopy(module).cpu().double().eval()
+
+
 def test_nnconv64_linearity_at_bba_size(dev):
     """Size-independent property at the benchmark shape (N=504, E~60k): without bias/ReLU the
     operator is linear in x, and equals the sum over a split of the edge weights."""
@@ -821,12 +867,12 @@ def test_errors_are_loud(dev):
     model.eval()
     with pytest.raises(MdnoError):                 # CPU sample: no CPU fallback
         model(PairData(t(z["x_aminoacid"]), t(z["x_position"]), None, t(z["edge_attr"]), t(z["edge_index"])))
-    with pytest.raises(NotImplementedError):
-        NNConv_old(8, 8, DenseNet([6, 16, 16, 64], torch.nn.ReLU), aggr="max").eval().to(dev)(
+    with pytest.raises(NotImplementedError):       # an aggregation torch_geometric does not have either
+        NNConv_old(8, 8, DenseNet([6, 16, 16, 64], torch.nn.ReLU), aggr="median").eval().to(dev)(
             torch.zeros(3, 8, device=dev), torch.zeros((2, 1), dtype=torch.long, device=dev),
             torch.zeros(1, 6, device=dev))
-    with pytest.raises(NotImplementedError):
-        DenseNet([6, 16, 64], torch.nn.ReLU).eval().to(dev)(torch.zeros(2, 6, device=dev))
+    with pytest.raises(NotImplementedError):       # a nonlinearity the library has no kernel for
+        DenseNet([6, 16, 64], torch.nn.Tanh).eval().to(dev)(torch.zeros(2, 6, device=dev))
     with pytest.raises(MdnoError):                 # y aliases x
         g = ops.coo_to_csr(torch.zeros((2, 1), dtype=torch.long, device=dev), 2)
         x = torch.zeros(2, 64, device=dev)

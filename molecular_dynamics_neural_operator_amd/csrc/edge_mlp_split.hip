@@ -192,11 +192,13 @@ __global__ __launch_bounds__(256) void split_bias64_kernel(const float* __restri
 // the ~6 TB/s the chip stores at.)  The edge's attributes stay in registers; the block's slice of W0
 // and b0 (3.5 KiB) sits in LDS and is read as broadcasts.
 constexpr int MAX_F = 8;
-constexpr int L0_ROWS = 128, L0_UNITS = 128;
+constexpr int L0_ROWS = 128, L0_UNITS = 128, L0_UNITS_SMALL = 32;
 
 // MODE 1: emit the two fp16 planes (and raise f16_flags[1] on a value out of fp16 range) instead of the
 // three bf16 planes; MODE 0 given f16_flags runs only when a flag is up (fallback); MODE 2: both images
 // (launches of a few rows, whose GEMMs pick their operand image themselves: gemm_split_f16_small_kernel).
+// (MODE 2 takes 32 hidden units per workgroup instead of 128: a launch of a few hundred rows is three row tiles, and
+// with 64 outputs per thread its 24 workgroups computed for 4 us; 96 workgroups of 16 outputs per thread do not)
 template <int FT, int MODE>   // FT = compile-time ker_in (6 for position-derived attributes), 0 = run-time F
 __global__ __launch_bounds__(256) void edge_l0_split_kernel(
     const float* __restrict__ frames, int frame, const int* __restrict__ t_dev, int rows_per_frame,
@@ -205,17 +207,18 @@ __global__ __launch_bounds__(256) void edge_l0_split_kernel(
     const float* __restrict__ w0, const float* __restrict__ b0, unsigned char* __restrict__ hp,
     int* __restrict__ f16_flags, int f16_need, unsigned char* __restrict__ hp_f16) {
     constexpr bool F16 = MODE != 0, BF16 = MODE != 1;
-    __shared__ __attribute__((aligned(16))) float wsh[L0_UNITS * MAX_F];
-    __shared__ __attribute__((aligned(16))) float bsh[L0_UNITS];
+    constexpr int UNITS = MODE == 2 ? L0_UNITS_SMALL : L0_UNITS;
+    __shared__ __attribute__((aligned(16))) float wsh[UNITS * MAX_F];
+    __shared__ __attribute__((aligned(16))) float bsh[UNITS];
     if (MODE == 0 && f16_flags != nullptr && !f16_blocked(f16_flags, f16_need)) return;   // fallback launch, not needed
     unsigned char* const hph = MODE == 2 ? hp_f16 : hp;
     const int Fn = FT ? FT : F;
     const long long E = *num_edges;
     const long long tile0 = (long long)blockIdx.x * L0_ROWS;   // first row of this tile inside the chunk
     if (e_begin + tile0 >= E || tile0 >= e_count) return;
-    const int u0 = blockIdx.y * L0_UNITS, tid = threadIdx.x;
-    for (int i = tid; i < L0_UNITS * Fn; i += 256) wsh[i] = w0[(size_t)u0 * Fn + i];
-    if (tid < L0_UNITS) bsh[tid] = b0[u0 + tid];
+    const int u0 = blockIdx.y * UNITS, tid = threadIdx.x;
+    for (int i = tid; i < UNITS * Fn; i += 256) wsh[i] = w0[(size_t)u0 * Fn + i];
+    if (tid < UNITS) bsh[tid] = b0[u0 + tid];
     const int lane = tid & 63, r = (tid >> 6) * 32 + (lane >> 1), half = lane & 1;
     const long long le = tile0 + r, e = e_begin + le;
     const bool valid = e < E && le < e_count;
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(256) void edge_l0_split_kernel(
     const int nkt = k >> 4;
     bool bad = false, seen = false;
 #pragma unroll 2
-    for (int t = 0; t < L0_UNITS / 16; ++t) {
+    for (int t = 0; t < UNITS / 16; ++t) {
         const int c = t * 16 + half * 8;       // this thread's 8 hidden units, relative to u0
         __bf16 o[3][8];
         _Float16 oh[2][8];
@@ -280,7 +283,7 @@ static int launch_edge_l0_split(const float* pos_mode, int frame, const int* t_d
                                 long long e0, int cnt, int F, int k, const float* w0, const float* b0,
                                 unsigned char* hp, hipStream_t s, bool f16 = false, int* f16_flags = nullptr,
                                 int f16_need = 0, unsigned char* hp_f16 = nullptr) {
-    const dim3 grid((cnt + L0_ROWS - 1) / L0_ROWS, k / L0_UNITS);
+    const dim3 grid((cnt + L0_ROWS - 1) / L0_ROWS, k / (hp_f16 ? L0_UNITS_SMALL : L0_UNITS));
     // hp_f16 given: both images (bf16 planes -> hp, fp16 planes -> hp_f16)
 #define MDNO_L0(FT, MODE)                                                                                             \
     hipLaunchKernelGGL((edge_l0_split_kernel<FT, MODE>), grid, dim3(256), 0, s, pos_mode, frame, t_dev, rows_per_frame, \

@@ -724,61 +724,77 @@ __global__ __launch_bounds__(1024 / MI) void gemm_split_f16_kernel(SplitGemmArgs
     if (OUT == 4 && seen) const_cast<int*>(g.f16_flags)[3] = 1;
 }
 
-// ---- the same product for a FEW rows (a 28-atom chain has 330 edges): 128 x 64 tiles, 8 waves of 32 x 32.
+// ---- the same product for a FEW rows (a 28-atom chain has 330 edges): (32 WM) x 64 tiles, WM x 2 waves of 32 x 32.
 // At E = 330 the kernel above launches 2 x 8 (hidden layer) or 2 x 32 (last layer) workgroups whose K loops
 // take 35-40 us whatever the row count — 24 MFMAs per wave per stage, 32 stages.  Here a wave has 6 MFMAs per
-// stage and the launch has 3 x 16 / 3 x 64 workgroups, so the K loop is as long as the 768 KiB of operand
-// planes take to reach one CU (64 B/clk: ~5 us).  The stages (A: one 128-row tile = 16 KiB, B: half a tile =
-// 4 runs of 2 KiB) sit in a ring of six with five in flight: a CU's share of the L2 bandwidth times the L2
-// latency is ~50 KiB, the ring holds 120.  Per output element the MFMAs are the same instructions in the
+// stage, and what bounds the K loop is how many KiB of operand planes ONE CU has to pull through its L2 -> LDS
+// path (~64 B/clk): (32 WM + 64) x K x 4 B per workgroup.  WM is chosen so that the launch has about as many
+// workgroups as the chip has CUs: the last layer (64 column tiles) takes 128 x 64 tiles (768 KiB per workgroup),
+// the hidden layer (16 column tiles) 32 x 64 (384 KiB).  The stages (A: WM KiB per k-step and plane, B: 2 KiB)
+// sit in a ring of six with five in flight.  Per output element the MFMAs are the same instructions in the
 // same order as in gemm_split_f16_kernel (k-steps ascending; cross terms a_lo b_hi, a_hi b_lo, then
-// a_hi b_hi), so both kernels give the same bits and the choice between them — made from the launch's row
+// a_hi b_hi), so all these kernels give the same bits and the choice between them — made from the launch's row
 // capacity — never shows in a result (an ensemble member's trajectory is the same alone and in a batch).
-constexpr int F16S_TM = 128, F16S_TN = 64, F16S_RING = 6;
-constexpr int F16S_STAGE_BYTES = F16_TILE_BYTES + F16_TILE_BYTES / 2;       // 24 KiB
-constexpr int F16S_LDS_BYTES = F16S_RING * F16S_STAGE_BYTES;               // 144 KiB
+constexpr int F16S_TN = 64, F16S_RING = 6;
+constexpr int f16s_stage_bytes(int wm) { return (4 * wm + 8) * 1024; }      // 24 / 16 / 12 KiB
+constexpr int f16s_lds_bytes(int wm) {
+    return F16S_RING * f16s_stage_bytes(wm) > 2 * wm * 32 * 40 * 4 ? F16S_RING * f16s_stage_bytes(wm) : 2 * wm * 32 * 40 * 4;
+}
 
-template <int OUT>
-__global__ __launch_bounds__(512) void gemm_split_f16_small_kernel(SplitGemmArgs g) {
+template <int OUT, int WM>
+__global__ __launch_bounds__(128 * WM) void gemm_split_f16_small_kernel(SplitGemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int TM = 32 * WM, WAVES = 2 * WM, PPW = 2 + 4 / WM, STAGE = f16s_stage_bytes(WM);
+    constexpr int A_BYTES = 4 * WM * 1024;                // A part of a stage: 4 runs (k-step, plane) of WM KiB
     const bool blocked = g.f16_flags != nullptr && f16_blocked(g.f16_flags, g.f16_need);
     if (blocked && g.Ap_b == nullptr) return;      // (the bf16 launch behind this one redoes the chunk)
     long long valid = g.num_edges ? (long long)(*g.num_edges) - g.row_begin : (long long)g.rows_valid;
     if (valid > g.rows) valid = g.rows;
     if (valid <= 0) return;
-    const int tiles_mv = (int)((valid + F16S_TM - 1) / F16S_TM);
+    const int tiles_mv = (int)((valid + TM - 1) / TM);
     const int nwg = g.tiles_n * tiles_mv;
     const int orig = blockIdx.x;
     if (orig >= nwg) return;
     // XCD x owns a contiguous run of tiles, row tiles fastest: the row tiles of one B panel are neighbours
     const int xcd = orig & 7, q = nwg >> 3, r8 = nwg & 7;
     const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
-    const int bm = (tile % tiles_mv) * F16S_TM, bn = (tile / tiles_mv) * F16S_TN;
+    const int bm = (tile % tiles_mv) * TM, bn = (tile / tiles_mv) * F16S_TN;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;              // 4 x 2 waves of 32 x 32
+    const int wm = wave >> 1, wn = wave & 1;              // WM x 2 waves of 32 x 32
     const int l31 = lane & 31, h = lane >> 5;
     const int nkt = g.K / TK, nst = g.K / 32;
     const size_t tile_stride = (size_t)nkt * 2 << 12;     // bytes of one 128-row tile of an operand image
     const unsigned char* const a_panel = g.Ap + (size_t)(bm >> 7) * tile_stride;
     const unsigned char* const b_panel = g.Bp + (size_t)(bn >> 7) * tile_stride;
     const int panel_bytes = (int)tile_stride;
-    // piece w + 8t of a stage: t = 0, 1 -> KiB w, w + 8 of the A tile's 16 KiB run; t = 2 -> B piece w: run
-    // w >> 1 (k-step, plane) of 4 KiB in HBM, of which this tile's 64 columns are one 2 KiB half
-    const unsigned v_a0 = (unsigned)(wave * 1024 + lane * 16), v_a1 = v_a0 + 8192;
-    const unsigned v_b = (unsigned)((wave >> 1) * 4096 + ((bn >> 6) & 1) * 2048 + (wave & 1) * 1024 + lane * 16);
+    const int a_row0 = (bm & 127) * 32;                   // this tile's rows inside a 4 KiB plane tile
+    const int b_row0 = ((bn >> 6) & 1) * 2048;
+    // piece wave + t * WAVES of a stage lands at that many KiB of the slot.  t = 0, 1: A — run (k-step, plane)
+    // q / WM of 4 KiB in HBM, of which this tile's rows are WM KiB; t >= 2: B — run b >> 1, the tile's 64 columns
+    // are one 2 KiB half of it
+    unsigned voff[PPW];
+#pragma unroll
+    for (int t = 0; t < PPW; ++t) {
+        if (t < 2) {
+            const int qa = wave + t * WAVES;
+            voff[t] = (unsigned)((qa / WM) * 4096 + a_row0 + (qa % WM) * 1024 + lane * 16);
+        } else {
+            const int b = wave + (t - 2) * WAVES;
+            voff[t] = (unsigned)((b >> 1) * 4096 + b_row0 + (b & 1) * 1024 + lane * 16);
+        }
+    }
 #define MDNO_DMA_STAGE(ST, SLOT)                                                                         \
     {                                                                                                    \
         const unsigned ko = (unsigned)(ST) * F16_TILE_BYTES;                                             \
-        lds_u8* ldst = (lds_u8*)(lds + (SLOT) * F16S_STAGE_BYTES + wave * 1024);                          \
-        dma_piece_buffer(a_panel, panel_bytes, ldst, v_a0, ko);                                          \
-        dma_piece_buffer(a_panel, panel_bytes, ldst + 8192, v_a1, ko);                                   \
-        dma_piece_buffer(b_panel, panel_bytes, ldst + 16384, v_b, ko);                                   \
+        lds_u8* ldst = (lds_u8*)(lds + (SLOT) * STAGE + wave * 1024);                                    \
+        _Pragma("unroll") for (int t = 0; t < PPW; ++t)                                                  \
+            dma_piece_buffer(t < 2 ? a_panel : b_panel, panel_bytes, ldst + t * WAVES * 1024, voff[t], ko); \
     }
     const int hsw = (h ^ ((l31 >> 3) & 1)) << 4;
-    const int a_rd = (wm * 32 + l31) * 32 + hsw;                          // + ks * 8192 + p * 4096
-    const int b_rd = F16_TILE_BYTES + (wn * 32 + l31) * 32 + hsw;         // + (ks * 2 + p) * 2048
+    const int a_rd = (wm * 32 + l31) * 32 + hsw;                          // + (ks * 2 + p) * WM KiB
+    const int b_rd = A_BYTES + (wn * 32 + l31) * 32 + hsw;                // + (ks * 2 + p) * 2 KiB
 
     f32x16 acc, accx;
 #pragma unroll
@@ -794,23 +810,24 @@ __global__ __launch_bounds__(512) void gemm_split_f16_small_kernel(SplitGemmArgs
         // activations of an untrained net): one k-step at a time, no ring.
         us = 1.f;
         const size_t tile_stride_b = (size_t)nkt * 3 << 12;
-        const unsigned char* a_src = g.Ap_b + (size_t)(bm >> 7) * tile_stride_b + lane * 16;
-        const unsigned char* b_src = g.Bp_b + (size_t)(bn >> 7) * tile_stride_b + ((bn >> 6) & 1) * 2048 + lane * 16;
-        const int a_rb = (wm * 32 + l31) * 32 + hsw, b_rb = 3 * PLANE_BYTES + (wn * 32 + l31) * 32 + hsw;
+        const unsigned char* a_src = g.Ap_b + (size_t)(bm >> 7) * tile_stride_b + a_row0 + lane * 16;
+        const unsigned char* b_src = g.Bp_b + (size_t)(bn >> 7) * tile_stride_b + b_row0 + lane * 16;
+        const int a_rb = (wm * 32 + l31) * 32 + hsw, b_rb = 3 * WM * 1024 + (wn * 32 + l31) * 32 + hsw;
         for (int kt = 0; kt < nkt; ++kt) {
             __syncthreads();      // the previous k-step's fragment reads are done
-            for (int q = wave; q < 18; q += 8) {      // A: 12 KiB (three planes), B: three 2 KiB halves
-                const unsigned char* src = q < 12 ? a_src + (size_t)kt * 12288 + q * 1024
-                                                  : b_src + (size_t)kt * 12288 + ((q - 12) >> 1) * 4096 + ((q - 12) & 1) * 1024;
-                __builtin_amdgcn_global_load_lds((glb_u8*)src, (lds_u8*)(lds + q * 1024), 16, 0, 0);
+            for (int qq = wave; qq < 3 * WM + 6; qq += WAVES) {      // A: three planes of WM KiB, B: three 2 KiB halves
+                const unsigned char* src = qq < 3 * WM
+                                               ? a_src + (size_t)kt * 12288 + (qq / WM) * 4096 + (qq % WM) * 1024
+                                               : b_src + (size_t)kt * 12288 + ((qq - 3 * WM) >> 1) * 4096 + ((qq - 3 * WM) & 1) * 1024;
+                __builtin_amdgcn_global_load_lds((glb_u8*)src, (lds_u8*)(lds + qq * 1024), 16, 0, 0);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             bf16x8 a[3], b[3];
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
-                a[p] = *reinterpret_cast<const bf16x8*>(lds + p * PLANE_BYTES + a_rb);
-                b[p] = *reinterpret_cast<const bf16x8*>(lds + p * (PLANE_BYTES / 2) + b_rb);
+                a[p] = *reinterpret_cast<const bf16x8*>(lds + p * (WM * 1024) + a_rb);
+                b[p] = *reinterpret_cast<const bf16x8*>(lds + p * 2048 + b_rb);
             }
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
@@ -825,25 +842,25 @@ __global__ __launch_bounds__(512) void gemm_split_f16_small_kernel(SplitGemmArgs
         if (!blocked && t < nst) MDNO_DMA_STAGE(t, t)
     int slot = 0, slot_in = F16S_RING - 1;
     for (int st = 0; st < (blocked ? 0 : nst); ++st) {
-        // stages still in flight behind stage st: min(RING - 2, nst - 1 - st) groups of three pieces
+        // stages still in flight behind stage st: min(RING - 2, nst - 1 - st) groups of PPW pieces
         const int behind = nst - 1 - st;
-        if (behind >= 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if (behind == 3) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-        else if (behind == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else if (behind == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        if (behind >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * PPW) : "memory");
+        else if (behind == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PPW) : "memory");
+        else if (behind == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+        else if (behind == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // everybody's pieces of stage st have landed, and nobody still reads the slot multiplied at st - 1
         // (a wave's fragment reads feed its MFMAs, so they have returned before it gets here)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (st + F16S_RING - 1 < nst) MDNO_DMA_STAGE(st + F16S_RING - 1, slot_in)
-        const unsigned char* sb = lds + slot * F16S_STAGE_BYTES;
+        const unsigned char* sb = lds + slot * STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const f16x8 a0 = *reinterpret_cast<const f16x8*>(sb + ks * 8192 + a_rd);
-            const f16x8 a1 = *reinterpret_cast<const f16x8*>(sb + ks * 8192 + 4096 + a_rd);
-            const f16x8 b0 = *reinterpret_cast<const f16x8*>(sb + ks * 4096 + b_rd);
-            const f16x8 b1 = *reinterpret_cast<const f16x8*>(sb + ks * 4096 + 2048 + b_rd);
+            const f16x8 a0 = *reinterpret_cast<const f16x8*>(sb + (ks * 2) * (WM * 1024) + a_rd);
+            const f16x8 a1 = *reinterpret_cast<const f16x8*>(sb + (ks * 2 + 1) * (WM * 1024) + a_rd);
+            const f16x8 b0 = *reinterpret_cast<const f16x8*>(sb + (ks * 2) * 2048 + b_rd);
+            const f16x8 b1 = *reinterpret_cast<const f16x8*>(sb + (ks * 2 + 1) * 2048 + b_rd);
             accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, accx, 0, 0, 0);
             accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, accx, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc, 0, 0, 0);
@@ -859,48 +876,78 @@ __global__ __launch_bounds__(512) void gemm_split_f16_small_kernel(SplitGemmArgs
         ua[e] = (g.a_unscale && !blocked) ? g.a_unscale[bm + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] : 1.f;
     bool bad = false, seen = false;
     const int n = bn + wn * 32 + l31;
+    if (OUT == 4) {
+        // A lane holds ONE column of 16 rows: stored from the accumulators, the up to five plane images would take 80
+        // two-byte stores per lane.  Instead the wave turns its 32 x 32 tile through a private LDS patch (the ring is
+        // idle once everybody has left the K loop) and each lane converts and stores 8 adjacent columns of a row:
+        // 16 B per plane and store.  Rows of 40 floats: the two half-waves (rows r, r + 4) hit disjoint banks.
+        __syncthreads();
+        float* patch = reinterpret_cast<float*>(lds) + wave * (32 * 40);
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            patch[((e & 3) + 8 * (e >> 2) + 4 * h) * 40 + l31] = fmaxf((acc[e] + accx[e] * F16_LO_UNSCALE) * us * ua[e] + bv, 0.f);
+        // (LDS operations of one wave execute in order: no wait between its writes and its reads)
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const int row = pr * 16 + (lane >> 2), ch = lane & 3;
+            const int m = bm + wm * 32 + row, n0 = bn + wn * 32 + ch * 8;
+            const float4 v0 = *reinterpret_cast<const float4*>(patch + row * 40 + ch * 8);
+            const float4 v1 = *reinterpret_cast<const float4*>(patch + row * 40 + ch * 8 + 4);
+            if (m < valid) {
+                const float rv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                _Float16 oh[2][8];
+                __bf16 ob[3][8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    bad |= !(rv[j] < F16_MAX);
+                    seen |= rv[j] >= F16_ACT_MIN;
+                    split2h(rv[j], oh[0][j], oh[1][j]);
+                    split3(rv[j], ob[0][j], ob[1][j], ob[2][j]);
+                }
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+                    *reinterpret_cast<uint4*>(g.Cp + tiled_off2(m, n0, g.N >> 4, p)) = *reinterpret_cast<const uint4*>(oh[p]);
+                if (g.Cp_b != nullptr) {      // and the bf16 image, for a consumer that finds a flag up
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        *reinterpret_cast<uint4*>(g.Cp_b + tiled_off(m, n0, g.N >> 4, p)) = *reinterpret_cast<const uint4*>(ob[p]);
+                }
+            }
+        }
+        if (bad) atomicOr(const_cast<int*>(g.f16_flags) + 1, 1);
+        if (seen) const_cast<int*>(g.f16_flags)[3] = 1;
+        return;
+    }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int m = bm + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (m < valid) {
             const float v = (acc[e] + accx[e] * F16_LO_UNSCALE) * us * ua[e] + bv;
-            if (OUT == 4) {
-                const float rv = fmaxf(v, 0.f);
-                bad |= !(rv < F16_MAX);
-                seen |= rv >= F16_ACT_MIN;
-                _Float16 ph, pl;
-                split2h(rv, ph, pl);
-                const size_t o = tiled_off2(m, n, g.N >> 4, 0);
-                *reinterpret_cast<_Float16*>(g.Cp + o) = ph;
-                *reinterpret_cast<_Float16*>(g.Cp + o + PLANE_BYTES) = pl;
-                if (g.Cp_b != nullptr) {      // and the bf16 image, for a consumer that finds a flag up
-                    __bf16 qh, qm, ql;
-                    split3(rv, qh, qm, ql);
-                    const size_t ob = tiled_off(m, n, g.N >> 4, 0);
-                    *reinterpret_cast<__bf16*>(g.Cp_b + ob) = qh;
-                    *reinterpret_cast<__bf16*>(g.Cp_b + ob + PLANE_BYTES) = qm;
-                    *reinterpret_cast<__bf16*>(g.Cp_b + ob + 2 * PLANE_BYTES) = ql;
-                }
-            } else {
-                g.C[(size_t)m * g.N + n] = OUT == 3 ? fmaxf(v, 0.f) : v;
-            }
+            g.C[(size_t)m * g.N + n] = OUT == 3 ? fmaxf(v, 0.f) : v;
         }
     }
-    if (OUT == 4 && bad) atomicOr(const_cast<int*>(g.f16_flags) + 1, 1);
-    if (OUT == 4 && seen) const_cast<int*>(g.f16_flags)[3] = 1;
 }
 
 // few rows: the 256-row kernel would leave more than half of the CUs without a tile
 constexpr int F16S_MAX_BIG_TILES = 128;
 
-template <int OUT>
-int launch_split_f16_gemm_small(SplitGemmArgs g, hipStream_t s) {
-    static std::atomic<unsigned long long> lds_raised{0};
-    MDNO_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(&gemm_split_f16_small_kernel<OUT>), F16S_LDS_BYTES, lds_raised));
+template <int OUT, int WM>
+int launch_split_f16_gemm_small_wm(SplitGemmArgs g, hipStream_t s) {
+    static std::atomic<unsigned long long> lds_raised{0};     // one per <OUT, WM> instantiation
+    MDNO_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(&gemm_split_f16_small_kernel<OUT, WM>), f16s_lds_bytes(WM), lds_raised));
     g.tiles_n = g.N / F16S_TN;
-    g.tiles_m = g.rows / F16S_TM;
-    hipLaunchKernelGGL((gemm_split_f16_small_kernel<OUT>), dim3(g.tiles_n * g.tiles_m), dim3(512), F16S_LDS_BYTES, s, g);
+    g.tiles_m = g.rows / (32 * WM);
+    hipLaunchKernelGGL((gemm_split_f16_small_kernel<OUT, WM>), dim3(g.tiles_n * g.tiles_m), dim3(128 * WM), f16s_lds_bytes(WM), s, g);
     return check_launch("split-f16 GEMM (few rows)");
+}
+
+// the tallest tile that still gives the launch (by its row capacity) about one workgroup per CU
+template <int OUT>
+int launch_split_f16_gemm_small(const SplitGemmArgs& g, hipStream_t s) {
+    const long long col_tiles = g.N / F16S_TN;
+    if (col_tiles * (g.rows / 128) >= 256) return launch_split_f16_gemm_small_wm<OUT, 4>(g, s);
+    if (col_tiles * (g.rows / 64) >= 256) return launch_split_f16_gemm_small_wm<OUT, 2>(g, s);
+    return launch_split_f16_gemm_small_wm<OUT, 1>(g, s);
 }
 
 template <int OUT, int MI>

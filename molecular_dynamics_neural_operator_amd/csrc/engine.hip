@@ -188,7 +188,7 @@ int forward_impl(const mdno_kernelnn_params* p, const float* frames, int t0, con
                 const FcTail fc{p->fc2_w, p->fc2_b, p->out_width, out_frames, t_out, t_dev,
                                 tail ? *tail : StepTail{nullptr, nullptr, nullptr, nullptr}};
                 MDNO_TRY(nnconv(cur, row_ptr, src, R, ws.w_e, root, bias, C, C, MDNO_AGGR_MEAN, /*relu=*/1, nxt, s,
-                                last ? &fc : nullptr));
+                                last ? &fc : nullptr, edge_cap));
                 fc_done = last;
                 float* t = cur; cur = nxt; nxt = t;
             }

@@ -172,7 +172,7 @@ struct FcTail {
 };
 int nnconv(const float* x, const int* row_ptr, const int* src, int num_rows, const float* w_e, const float* root,
            const float* bias, int Cin, int Cout, int aggr, int relu, float* y, hipStream_t s,
-           const FcTail* fc = nullptr);
+           const FcTail* fc = nullptr, long long edge_cap = -1);      // edge_cap: bound on the edge count, if known
 
 int node_prologue(const mdno_kernelnn_params* p, const float* frames, int t0, const int* t_dev, int M, int W, int N,
                   const long long* aa, int aa_per_member, float* x0, int* status, hipStream_t s);

@@ -42,14 +42,19 @@ __device__ __forceinline__ void fma4(float4& a, float s, const float4& w) {
     a.w = fmaf(s, w.w, a.w);
 }
 
-// acc += x[16g..16g+15] . Wblk[16g..16g+15][4q..4q+3]
+// acc += x[16g..16g+15] . Wblk[16g..16g+15][4q..4q+3].  STREAM: W is read once per application and is far larger
+// than the caches (nt loads leave them to x); !STREAM: all of W_e fits the L2s (a short chain: 330 edges = 5.4 MB
+// over 8 x 4 MB), the 2 x depth applications of a forward re-read it, and a row's 12 x 16 KiB reach its ONE CU at
+// the L2's 66-73 GB/s per CU instead of the Infinity Cache's 33 (MI355X_MICROARCH.md, gather rates): the
+// application is bound by exactly that
+template <bool STREAM = true>
 __device__ __forceinline__ void edge_accumulate64(float4& acc, const float* __restrict__ xrow,
                                                   const float* __restrict__ wmat, int g, int q) {
     // the 16 KiB of W first: their address does not wait for src[p], which the x row's does
     const float* wp = wmat + (16 * g) * 64 + 4 * q;
     float4 w[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) w[r] = ld4_stream(wp + r * 64);
+    for (int r = 0; r < 16; ++r) w[r] = STREAM ? ld4_stream(wp + r * 64) : ld4(wp + r * 64);
     const float* xp = xrow + 16 * g;
     const float4 x0 = ld4(xp), x1 = ld4(xp + 4), x2 = ld4(xp + 8), x3 = ld4(xp + 12);
     // all twenty loads in flight before the first FMA waits for one (left alone, the scheduler waits for the
@@ -78,7 +83,7 @@ __device__ __forceinline__ float4 reduce_over_g(float4 a) {
 // give the same bits and a row's result does not depend on how many rows it is batched with.
 constexpr int CHAINS = 16;
 
-template <int WAVES>
+template <int WAVES, bool STREAM = true>
 __global__ __launch_bounds__(WAVES * 64) void nnconv64_row_kernel(
     const float* __restrict__ x, const int* __restrict__ row_ptr, const int* __restrict__ src,
     const float* __restrict__ w_e, const float* __restrict__ root, const float* __restrict__ bias,
@@ -101,13 +106,13 @@ __global__ __launch_bounds__(WAVES * 64) void nnconv64_row_kernel(
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (aggr != MDNO_AGGR_MAX) {
             for (int p = beg + wave + u * WAVES; p < end; p += CHAINS)
-                edge_accumulate64(acc, x + (size_t)src[p] * 64, w_e + (size_t)p * 4096, g, q);
+                edge_accumulate64<STREAM>(acc, x + (size_t)src[p] * 64, w_e + (size_t)p * 4096, g, q);
             acc = reduce_over_g(acc);
         } else {      // every message in full, then the running maximum of the chain (-inf: a chain without edges)
             acc = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
             for (int p = beg + wave + u * WAVES; p < end; p += CHAINS) {
                 float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
-                edge_accumulate64(m, x + (size_t)src[p] * 64, w_e + (size_t)p * 4096, g, q);
+                edge_accumulate64<STREAM>(m, x + (size_t)src[p] * 64, w_e + (size_t)p * 4096, g, q);
                 m = reduce_over_g(m);
                 acc = make_float4(fmaxf(acc.x, m.x), fmaxf(acc.y, m.y), fmaxf(acc.z, m.z), fmaxf(acc.w, m.w));
             }
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(WAVES * 64) void nnconv64_row_kernel(
     // got the fewest edges
     const bool root_wave = root != nullptr && wave == (deg % WAVES);
     float4 racc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (root_wave) edge_accumulate64(racc, x + (size_t)row * 64, root, g, q);
+    if (root_wave) edge_accumulate64<false>(racc, x + (size_t)row * 64, root, g, q);      // (every row reads root: cached)
 
     racc = reduce_over_g(racc);
     if (root_wave && lane < 16) *reinterpret_cast<float4*>(&rootred[4 * lane]) = racc;
@@ -196,8 +201,10 @@ __global__ __launch_bounds__(256) void nnconv_generic_kernel(
 
 int mdno::nnconv(const float* x, const int* row_ptr, const int* src, int num_rows, const float* w_e,
                  const float* root, const float* bias, int Cin, int Cout, int aggr, int relu, float* y,
-                 hipStream_t s, const FcTail* fc) {
+                 hipStream_t s, const FcTail* fc, long long edge_cap) {
     MDNO_REQUIRE(x && row_ptr && src && w_e && y, MDNO_EINVAL, "nnconv: null pointer");
+    // all of W_e within the L2s' reach (8 x 4 MiB): the applications of a forward find it there
+    const bool w_e_cacheable = edge_cap > 0 && edge_cap * (long long)Cin * Cout * 4 <= (24ll << 20);
     MDNO_REQUIRE(num_rows > 0 && Cin > 0 && Cout > 0, MDNO_EINVAL, "nnconv: rows=%d Cin=%d Cout=%d", num_rows, Cin,
                  Cout);
     MDNO_REQUIRE(aggr == MDNO_AGGR_ADD || aggr == MDNO_AGGR_MEAN || aggr == MDNO_AGGR_MAX, MDNO_EUNSUPPORTED,
@@ -211,7 +218,7 @@ int mdno::nnconv(const float* x, const int* row_ptr, const int* src, int num_row
                  MDNO_EINVAL, "nnconv: incomplete output-layer tail");
     const FcTail no_tail{};
     if (fc && !(Cin == 64 && Cout == 64 && aligned)) {      // the generic kernel has no tail: the layer gets its own launch
-        MDNO_TRY(nnconv(x, row_ptr, src, num_rows, w_e, root, bias, Cin, Cout, aggr, relu, y, s, nullptr));
+        MDNO_TRY(nnconv(x, row_ptr, src, num_rows, w_e, root, bias, Cin, Cout, aggr, relu, y, s, nullptr, edge_cap));
         return fc_out(y, fc->w, fc->b, num_rows, Cout, fc->out_width, fc->out, fc->t_out, fc->t_dev, s,
                       fc->step.done ? &fc->step : nullptr);
     }
@@ -223,6 +230,9 @@ int mdno::nnconv(const float* x, const int* row_ptr, const int* src, int num_row
         if (num_rows >= 4096)
             hipLaunchKernelGGL(nnconv64_row_kernel<4>, dim3(num_rows), dim3(256), 0, s, x, row_ptr, src, w_e, root,
                                bias, y, num_rows, aggr, relu, fc ? *fc : no_tail);
+        else if (w_e_cacheable)
+            hipLaunchKernelGGL((nnconv64_row_kernel<16, false>), dim3(num_rows), dim3(1024), 0, s, x, row_ptr, src, w_e,
+                               root, bias, y, num_rows, aggr, relu, fc ? *fc : no_tail);
         else
             hipLaunchKernelGGL(nnconv64_row_kernel<16>, dim3(num_rows), dim3(1024), 0, s, x, row_ptr, src, w_e, root,
                                bias, y, num_rows, aggr, relu, fc ? *fc : no_tail);

@@ -186,7 +186,7 @@ int forward_impl(const mdno_kernelnn_params* p, const float* frames, int t0, con
                 // the forward's last application also applies the output layer to its rows (and ends the step)
                 const bool last = block + 1 == blocks && d + 1 == p->depth;
                 const FcTail fc{p->fc2_w, p->fc2_b, p->out_width, out_frames, t_out, t_dev,
-                                tail ? *tail : StepTail{nullptr, nullptr, nullptr, nullptr}};
+                                tail ? *tail : StepTail{nullptr, nullptr, nullptr, nullptr}, tail ? tail->row_done : nullptr};
                 MDNO_TRY(nnconv(cur, row_ptr, src, R, ws.w_e, root, bias, C, C, MDNO_AGGR_MEAN, /*relu=*/1, nxt, s,
                                 last ? &fc : nullptr, edge_cap));
                 fc_done = last;
@@ -200,7 +200,7 @@ int forward_impl(const mdno_kernelnn_params* p, const float* frames, int t0, con
 }
 
 struct RolloutWs {
-    int *row_ptr, *src, *dst, *num_edges, *t_dev;
+    int *row_ptr, *src, *dst, *num_edges, *t_dev, *row_done;
     void* fwd;
     size_t fwd_bytes, total;
 };
@@ -214,6 +214,7 @@ RolloutWs carve_rollout(void* ws, const mdno_kernelnn_params* p, int M, int N, l
     r.dst = cv.take<int>((size_t)edge_cap);
     r.num_edges = cv.take<int>(64);   // counters on their own 256-B line
     r.t_dev = r.num_edges + 1;        // (+2: finished workgroups of the step's last kernel, StepTail::done)
+    r.row_done = cv.take<int>(R <= 256 ? 256 : 0);      // short chains: parts of a row finished (FcTail::row_done)
     r.fwd_bytes = carve_fwd(nullptr, p, M, N, edge_cap, use_factored(p, M, edge_cap, true)).total;
     r.fwd = cv.take<char>(r.fwd_bytes);
     r.total = cv.used();
@@ -267,9 +268,12 @@ extern "C" size_t mdno_rollout_workspace_bytes(const mdno_kernelnn_params* p, in
 
 namespace mdno {
 namespace {
-__global__ void set_step_kernel(int* t_dev, int v) {
-    t_dev[0] = v;
-    t_dev[1] = 0;      // StepTail::done
+__global__ void set_step_kernel(int* t_dev, int v, int* row_done, int n_rows) {
+    if (threadIdx.x == 0) {
+        t_dev[0] = v;
+        t_dev[1] = 0;      // StepTail::done
+    }
+    if ((int)threadIdx.x < n_rows) row_done[threadIdx.x] = 0;
 }
 }  // namespace
 }  // namespace mdno
@@ -321,7 +325,8 @@ static int plan_enqueue_step(mdno_rollout_plan* pl, hipStream_t s) {
     else
         MDNO_TRY(radius_graph(pl->traj, W - 1, pl->r.t_dev, pl->M, pl->N, pl->threshold, pl->r.row_ptr, pl->r.src,
                               pl->r.dst, pl->edge_cap, pl->r.num_edges, pl->status, s, act_flags, n_zero));
-    const StepTail tail{pl->r.t_dev, pl->r.num_edges, pl->edges_per_step, pl->r.t_dev + 1};
+    const StepTail tail{pl->r.t_dev, pl->r.num_edges, pl->edges_per_step, pl->r.t_dev + 1,
+                        (long long)pl->M * pl->N <= 256 ? pl->r.row_done : nullptr};
     return forward_impl(&pl->p, pl->traj, 0, pl->r.t_dev, pl->M, W, pl->N, pl->aa, pl->aa_per_member, pl->r.row_ptr,
                         pl->r.src, pl->r.dst, pl->r.num_edges, pl->edge_cap, pl->max_degree, pl->traj, W - 1, nullptr,
                         nullptr, pl->traj, W, nullptr, pl->fw, pl->status, s,
@@ -407,7 +412,8 @@ extern "C" int mdno_rollout_plan_run(mdno_rollout_plan* pl, int start_step, int 
                  "mdno_rollout_plan_run: start_step=%d steps=%d exceed max_steps=%d", start_step, steps, pl->max_steps);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (steps == 0) return MDNO_OK;
-    hipLaunchKernelGGL(set_step_kernel, dim3(1), dim3(1), 0, s, pl->r.t_dev, start_step);
+    hipLaunchKernelGGL(set_step_kernel, dim3(1), dim3(256), 0, s, pl->r.t_dev, start_step, pl->r.row_done,
+                       (long long)pl->M * pl->N <= 256 ? 256 : 0);
     MDNO_TRY(check_launch("set_step"));
     // the weights may have been updated in place since the last call: refresh their images once
     if (pl->weights_cached) MDNO_TRY(plan_prepare_weights(pl, s));

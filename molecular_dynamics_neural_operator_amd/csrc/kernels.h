@@ -158,6 +158,7 @@ struct StepTail {
     const int* num_edges;
     int* edges_per_step;
     int* done;
+    int* row_done = nullptr;   // [rows] zeroed ints, or NULL (FcTail::row_done)
 };
 // The model's output layer on a conv application's rows (fc_out below, same arithmetic): the last application of a
 // forward writes out[(t_out + *t_dev) * rows + r][0..out_width) = w . y[r] + b next to y itself.
@@ -169,6 +170,7 @@ struct FcTail {
     int t_out;
     const int* t_dev;
     StepTail step;      // step.done == NULL: none
+    int* row_done = nullptr;   // [rows] zeroed ints: lets a row be shared by several workgroups (nnconv64_colsplit_kernel)
 };
 int nnconv(const float* x, const int* row_ptr, const int* src, int num_rows, const float* w_e, const float* root,
            const float* bias, int Cin, int Cout, int aggr, int relu, float* y, hipStream_t s,

@@ -163,6 +163,95 @@ __global__ __launch_bounds__(WAVES * 64) void nnconv64_row_kernel(
     }
 }
 
+// Short chains (all of W_e in the L2s, a few dozen rows): what bounds an application is the 12 x 16 KiB of a row
+// arriving at ONE CU (66-73 GB/s from L2).  So SPLIT workgroups share a row by OUTPUT COLUMNS: each reads its
+// 64 / SPLIT columns of every edge's matrix (whole 128-B or 64-B lines of the 256-B rows), 64 / SPLIT lanes per
+// edge and SPLIT edges per wave, and needs nothing from its partners — an output column's sum is formed exactly
+// as in nnconv64_row_kernel (lane (g, q): input rows 16g.., columns 4q..; the same 16 chains, the same g tree,
+// chains added in order), so the split does not change a bit.  Only the output layer riding on the LAST
+// application needs the whole row: the workgroup that finishes a row last (agent-scope counter) reads it back
+// and applies fc2 with fc_out_kernel's arithmetic.  Workgroups b, b+8, ... (one XCD) hold the parts of one row.
+template <int SPLIT>
+__global__ __launch_bounds__(1024 / SPLIT) void nnconv64_colsplit_kernel(
+    const float* __restrict__ x, const int* __restrict__ row_ptr, const int* __restrict__ src,
+    const float* __restrict__ w_e, const float* __restrict__ root, const float* __restrict__ bias,
+    float* __restrict__ y, int num_rows, int aggr, int relu, FcTail fc) {
+    constexpr int QN = 16 / SPLIT;          // q values (groups of 4 columns) per workgroup
+    constexpr int LPE = 4 * QN;             // lanes per edge: (g, ql)
+    constexpr int COLS = 4 * QN;            // output columns of this workgroup
+    __shared__ float red[CHAINS][COLS];
+    __shared__ float rootred[COLS];
+    const unsigned b = blockIdx.x, xcd = b & 7u, i = b >> 3;
+    const int part = (int)(i % SPLIT), row = (int)(i / SPLIT) * 8 + (int)xcd;
+    if (row >= num_rows) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int sub = lane / LPE, l = lane % LPE;
+    const int g = l / QN, q = part * QN + l % QN;
+    const int chain = wave * SPLIT + sub;   // 0..15
+    const int beg = row_ptr[row], end = row_ptr[row + 1];
+    const int deg = end - beg;
+    auto reduce_g = [](float4 a) {          // the g tree of reduce_over_g: g's low bit first, then its high bit
+#pragma unroll
+        for (int o = QN; o <= 2 * QN; o <<= 1) {
+            a.x += __shfl_xor(a.x, o);
+            a.y += __shfl_xor(a.y, o);
+            a.z += __shfl_xor(a.z, o);
+            a.w += __shfl_xor(a.w, o);
+        }
+        return a;
+    };
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = beg + chain; p < end; p += CHAINS)
+        edge_accumulate64<false>(acc, x + (size_t)src[p] * 64, w_e + (size_t)p * 4096, g, q);
+    acc = reduce_g(acc);
+    if (g == 0) *reinterpret_cast<float4*>(&red[chain][4 * (l % QN)]) = acc;
+    // the root term: the chain that got the fewest edges takes it (as the wave deg % 16 does in the row kernel)
+    const bool root_chain = root != nullptr && chain == (deg % CHAINS);
+    float4 racc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (root_chain) edge_accumulate64<false>(racc, x + (size_t)row * 64, root, g, q);
+    racc = reduce_g(racc);
+    if (root_chain && g == 0) *reinterpret_cast<float4*>(&rootred[4 * (l % QN)]) = racc;
+    __syncthreads();
+    if (tid < 64) {      // wave 0: lanes < COLS own an output column each
+        const int col = part * COLS + tid;
+        if (tid < COLS) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < CHAINS; ++c) s += red[c][tid];   // fixed order: bitwise reproducible
+            if (aggr == MDNO_AGGR_MEAN) s = s / (float)(deg > 1 ? deg : 1);
+            if (root != nullptr) s += rootred[tid];
+            if (bias != nullptr) s += bias[col];
+            if (relu) s = fmaxf(s, 0.f);
+            y[(size_t)row * 64 + col] = s;
+        }
+        if (fc.out != nullptr) {
+            // the row's last part to get here applies the output layer to the whole row (release our columns,
+            // acquire the partners': agent scope — the parts may sit on different CUs of the XCD)
+            int last = 0;
+            if (tid == 0)
+                last = __hip_atomic_fetch_add(fc.row_done + row, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == SPLIT - 1;
+            last = __shfl(last, 0);
+            if (last) {
+                if (tid == 0) fc.row_done[row] = 0;
+                const float s = __builtin_nontemporal_load(y + (size_t)row * 64 + tid);      // (never from a stale L1 line)
+                const int step = fc.t_dev ? *fc.t_dev : 0;
+                float* o_ptr = fc.out + ((size_t)(fc.t_out + step) * num_rows + row) * fc.out_width;
+                for (int o = 0; o < fc.out_width; ++o) {
+                    float v = fmaf(s, fc.w[(size_t)o * 64 + tid], 0.f);
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+                    if (tid == 0) o_ptr[o] = v + (fc.b ? fc.b[o] : 0.f);
+                }
+                if (fc.step.done != nullptr && tid == 0 && atomicAdd(fc.step.done, 1) == num_rows - 1) {
+                    *fc.step.done = 0;
+                    if (fc.step.edges_per_step) fc.step.edges_per_step[step] = *fc.step.num_edges;
+                    *fc.step.t_dev = step + 1;
+                }
+            }
+        }
+    }
+}
+
 // Any (Cin, Cout): one wave per destination row, lane = output column (strided), sequential edges.
 // Used for the small-dimension fixtures; not a performance path.
 __global__ __launch_bounds__(256) void nnconv_generic_kernel(
@@ -230,7 +319,13 @@ int mdno::nnconv(const float* x, const int* row_ptr, const int* src, int num_row
         if (num_rows >= 4096)
             hipLaunchKernelGGL(nnconv64_row_kernel<4>, dim3(num_rows), dim3(256), 0, s, x, row_ptr, src, w_e, root,
                                bias, y, num_rows, aggr, relu, fc ? *fc : no_tail);
-        else if (w_e_cacheable)
+        else if (w_e_cacheable && aggr != MDNO_AGGR_MAX && num_rows <= 256 && (!fc || fc->row_done)) {
+            // a few dozen rows: four workgroups per row, 16 output columns each (N = 28, same box: 0.111 ms/step with
+            // one workgroup per row, 0.102 with two, 0.098 with four)
+            const unsigned rows8 = (unsigned)((num_rows + 7) / 8 * 8);
+            hipLaunchKernelGGL((nnconv64_colsplit_kernel<4>), dim3(rows8 * 4), dim3(256), 0, s, x, row_ptr, src, w_e, root,
+                               bias, y, num_rows, aggr, relu, fc ? *fc : no_tail);
+        } else if (w_e_cacheable)
             hipLaunchKernelGGL((nnconv64_row_kernel<16, false>), dim3(num_rows), dim3(1024), 0, s, x, row_ptr, src, w_e,
                                root, bias, y, num_rows, aggr, relu, fc ? *fc : no_tail);
         else

@@ -556,7 +556,10 @@ constexpr int F16_STAGE_BYTES = 3 * F16_TILE_BYTES;       // A tile 0 | A tile 1
 // 128 B/clk); MI = 4 — 4 waves of 128x64, a third fewer fragment reads per MFMA, but 2 x 128 accumulator
 // registers and hence ONE wave per SIMD — was measured at 452 us against 392: nothing hides the
 // barrier and the fragment-read latency any more.  Only MI = 2 is instantiated.
-template <int OUT, int MI>
+// ROW_SCALE: the rows of A carry their own power-of-two scale as well (g.a_unscale; split_linear_f16) — its own
+// instantiation: the 32 extra registers and multiplies in the epilogue cost the inference kernels 12 % (353 -> 400 us
+// for the hidden GEMM at N = 504) when they sat in the common one
+template <int OUT, int MI, bool ROW_SCALE = false>
 __global__ __launch_bounds__(1024 / MI) void gemm_split_f16_kernel(SplitGemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int TM = F16_TM, WAVES = 16 / MI;
@@ -684,12 +687,14 @@ __global__ __launch_bounds__(1024 / MI) void gemm_split_f16_kernel(SplitGemmArgs
 
     // the rows' own scale factors, all fetched before the first store (a load inside the predicated store blocks
     // would put a full wait in front of every store)
-    float ua[MI][16];
+    float ua[ROW_SCALE ? MI : 1][16];
+    if (ROW_SCALE) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e)
-            ua[i][e] = g.a_unscale ? g.a_unscale[bm + wm * (MI * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] : 1.f;
+            for (int e = 0; e < 16; ++e)
+                ua[ROW_SCALE ? i : 0][e] = g.a_unscale[bm + wm * (MI * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h];
+    }
     bool bad = false, seen = false;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -701,7 +706,9 @@ __global__ __launch_bounds__(1024 / MI) void gemm_split_f16_kernel(SplitGemmArgs
             for (int e = 0; e < 16; ++e) {
                 const int m = bm + wm * (MI * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (m < valid) {
-                    const float v = (acc[i][j][e] + accx[i][j][e] * F16_LO_UNSCALE) * us * ua[i][e] + bv;
+                    float v = (acc[i][j][e] + accx[i][j][e] * F16_LO_UNSCALE) * us;
+                    if (ROW_SCALE) v *= ua[ROW_SCALE ? i : 0][e];
+                    v += bv;
                     if (OUT == 2) {
                         g.C[((size_t)(m >> 7) * (g.N >> 5) + (n >> 5)) * 4096 + (m & 127) * 32 + (n & 31)] = fmaxf(v, 0.f);
                     } else if (OUT == 4) {
@@ -960,6 +967,12 @@ int launch_split_f16_gemm(SplitGemmArgs g, hipStream_t s) {
     if (OUT != 2 && (g.N / TN) * (g.rows / F16_TM) <= F16S_MAX_BIG_TILES) return launch_split_f16_gemm_small<OUT>(g, s);
     g.tiles_n = g.N / TN;
     g.tiles_m = g.rows / F16_TM;
+    if (g.a_unscale != nullptr) {
+        static std::atomic<unsigned long long> lds_raised_rs{0};
+        MDNO_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(&gemm_split_f16_kernel<OUT, MI, true>), lds_bytes, lds_raised_rs));
+        hipLaunchKernelGGL((gemm_split_f16_kernel<OUT, MI, true>), dim3(g.tiles_n * g.tiles_m), dim3(1024 / MI), lds_bytes, s, g);
+        return check_launch("split-f16 GEMM");
+    }
     hipLaunchKernelGGL((gemm_split_f16_kernel<OUT, MI>), dim3(g.tiles_n * g.tiles_m), dim3(1024 / MI), lds_bytes, s, g);
     return check_launch("split-f16 GEMM");
 }

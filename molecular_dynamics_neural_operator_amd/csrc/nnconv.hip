@@ -171,7 +171,7 @@ __global__ __launch_bounds__(WAVES * 64) void nnconv64_row_kernel(
 // chains added in order), so the split does not change a bit.  Only the output layer riding on the LAST
 // application needs the whole row: the workgroup that finishes a row last (agent-scope counter) reads it back
 // and applies fc2 with fc_out_kernel's arithmetic.  Workgroups b, b+8, ... (one XCD) hold the parts of one row.
-template <int SPLIT>
+template <int SPLIT, bool STREAM>
 __global__ __launch_bounds__(1024 / SPLIT) void nnconv64_colsplit_kernel(
     const float* __restrict__ x, const int* __restrict__ row_ptr, const int* __restrict__ src,
     const float* __restrict__ w_e, const float* __restrict__ root, const float* __restrict__ bias,
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(1024 / SPLIT) void nnconv64_colsplit_kernel(
     };
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int p = beg + chain; p < end; p += CHAINS)
-        edge_accumulate64<false>(acc, x + (size_t)src[p] * 64, w_e + (size_t)p * 4096, g, q);
+        edge_accumulate64<STREAM>(acc, x + (size_t)src[p] * 64, w_e + (size_t)p * 4096, g, q);
     acc = reduce_g(acc);
     if (g == 0) *reinterpret_cast<float4*>(&red[chain][4 * (l % QN)]) = acc;
     // the root term: the chain that got the fewest edges takes it (as the wave deg % 16 does in the row kernel)
@@ -319,12 +319,21 @@ int mdno::nnconv(const float* x, const int* row_ptr, const int* src, int num_row
         if (num_rows >= 4096)
             hipLaunchKernelGGL(nnconv64_row_kernel<4>, dim3(num_rows), dim3(256), 0, s, x, row_ptr, src, w_e, root,
                                bias, y, num_rows, aggr, relu, fc ? *fc : no_tail);
-        else if (w_e_cacheable && aggr != MDNO_AGGR_MAX && num_rows <= 256 && (!fc || fc->row_done)) {
-            // a few dozen rows: four workgroups per row, 16 output columns each (N = 28, same box: 0.111 ms/step with
-            // one workgroup per row, 0.102 with two, 0.098 with four)
+        else if (aggr != MDNO_AGGR_MAX && num_rows <= 128 && (!fc || fc->row_done)) {
+            // fewer rows than CUs: four workgroups per row, 16 output columns each — a row's edges reach one CU at
+            // 66-73 GB/s from L2 and 33 GB/s from the Infinity Cache, so rows alone would leave most of the chip's
+            // fetch paths idle (N = 28, same box: 0.111 ms/step with one workgroup per row, 0.102 with two, 0.098
+            // with four)
             const unsigned rows8 = (unsigned)((num_rows + 7) / 8 * 8);
-            hipLaunchKernelGGL((nnconv64_colsplit_kernel<4>), dim3(rows8 * 4), dim3(256), 0, s, x, row_ptr, src, w_e, root,
-                               bias, y, num_rows, aggr, relu, fc ? *fc : no_tail);
+            if (num_rows > 64)      // (as many workgroups as CUs at most; two parts read whole 128-B lines)
+                hipLaunchKernelGGL((nnconv64_colsplit_kernel<2, true>), dim3(rows8 * 2), dim3(512), 0, s, x, row_ptr, src,
+                                   w_e, root, bias, y, num_rows, aggr, relu, fc ? *fc : no_tail);
+            else if (w_e_cacheable)
+                hipLaunchKernelGGL((nnconv64_colsplit_kernel<4, false>), dim3(rows8 * 4), dim3(256), 0, s, x, row_ptr, src,
+                                   w_e, root, bias, y, num_rows, aggr, relu, fc ? *fc : no_tail);
+            else
+                hipLaunchKernelGGL((nnconv64_colsplit_kernel<4, true>), dim3(rows8 * 4), dim3(256), 0, s, x, row_ptr, src,
+                                   w_e, root, bias, y, num_rows, aggr, relu, fc ? *fc : no_tail);
         } else if (w_e_cacheable)
             hipLaunchKernelGGL((nnconv64_row_kernel<16, false>), dim3(num_rows), dim3(1024), 0, s, x, row_ptr, src, w_e,
                                root, bias, y, num_rows, aggr, relu, fc ? *fc : no_tail);

@@ -964,7 +964,9 @@ int launch_split_f16_gemm(SplitGemmArgs g, hipStream_t s) {
     MDNO_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(&gemm_split_f16_kernel<OUT, MI>), lds_bytes, lds_raised));
     MDNO_REQUIRE(g.K % 32 == 0 && g.N % TN == 0 && g.rows % F16_TM == 0, MDNO_EUNSUPPORTED,
                  "split-f16 GEMM: rows=%d N=%d K=%d", g.rows, g.N, g.K);
-    if (OUT != 2 && (g.N / TN) * (g.rows / F16_TM) <= F16S_MAX_BIG_TILES) return launch_split_f16_gemm_small<OUT>(g, s);
+    if constexpr (OUT != 2) {      // (the factored conv's k-tiled H is written by the 256-row kernel only)
+        if ((g.N / TN) * (g.rows / F16_TM) <= F16S_MAX_BIG_TILES) return launch_split_f16_gemm_small<OUT>(g, s);
+    }
     g.tiles_n = g.N / TN;
     g.tiles_m = g.rows / F16_TM;
     if (g.a_unscale != nullptr) {

@@ -273,6 +273,48 @@ def test_propogate_notebook_loop_and_mse(dev, O, tmp_path):
         assert not fc[i].x_position.is_cuda
 
 
+# ------------------------------------------------------------------------------- shape A: short chains
+def test_shape_a_short_chain_paths_do_not_change_a_bit(dev):
+    """N = 28, full model (k = 1024, depth 6): one member runs the short-chain kernels (graph + prologue in one
+    launch, few-row GEMMs with 32- and 128-row tiles, conv split four ways by output columns, fc2 and the step
+    advance inside the last conv application, eight steps per graph launch), three members the two-way split, ten
+    members the kernels of the large shapes.  A member's trajectory must be the same bits in all three, and under
+    graph replay as under plain launches."""
+    from molecular_dynamics_neural_operator_amd import synthetic as syn
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN
+    from molecular_dynamics_neural_operator_amd.rollout import RolloutEngine
+    from molecular_dynamics_neural_operator_amd.weights import near_identity_state_dict
+    N, W, steps = 28, 10, 13
+    model = KernelNN(64, 1024, 6, 6, 7, 3, 20, 4)
+    model.load_state_dict(near_identity_state_dict(64, 1024, seed=0, kernel_gain=0.02, feature_gain=0.1, kernel_to_coords=1.0))
+    model.eval().to(dev)
+    base = syn.jitter_window(syn.chain_frame(N, seed=1), W, seed=1)
+    wins = syn.ensemble_windows(base, 10, sigma=0.1, seed0=100)                                   # [10,W,N,3]
+    tm = torch.from_numpy(np.ascontiguousarray(wins.transpose(1, 0, 2, 3)))                        # [W,10,N,3]
+    aa = torch.from_numpy(syn.amino_acids(N, seed=1))
+    e10 = RolloutEngine(model, 10, N, W, 8.0, max_steps=steps, device=dev)
+    assert e10.conv_mode == "materialized"
+    big = e10.run(tm, aa, steps).clone()
+    assert bool(torch.isfinite(big).all()) and float((big[-1] - big[0]).abs().max()) > 1e-3       # the frames move
+    e3 = RolloutEngine(model, 3, N, W, 8.0, max_steps=steps, device=dev)
+    three = e3.run(tm[:, 4:7].contiguous(), aa, steps).clone()
+    assert torch.equal(three, big[:, 4:7])
+    e1g = RolloutEngine(model, 1, N, W, 8.0, max_steps=steps, device=dev, use_graph=True)
+    e1e = RolloutEngine(model, 1, N, W, 8.0, max_steps=steps, device=dev, use_graph=False)
+    for m in (0, 5, 9):
+        solo = e1g.run(tm[:, m:m + 1].contiguous(), aa, steps).clone()
+        assert torch.equal(solo[:, 0], big[:, m]), m
+        assert torch.equal(e1e.run(tm[:, m:m + 1].contiguous(), aa, steps), solo)
+        assert torch.equal(e1g.edges_per_step, e1e.edges_per_step) and int(e1g.edges_per_step.min()) > 0
+    # stepping in pieces (8-step graph launches and single steps mixed) == one call
+    e1g.reset(tm[:, 9:10].contiguous(), aa)
+    e1g.step(3)
+    e1g.step(9)
+    e1g.step(1)
+    e1g.synchronize()
+    assert torch.equal(e1g.frames()[:, 0], big[:, 9])
+
+
 # ------------------------------------------------------------------------------- cfg3: 8 members x 504
 def test_cfg3_eight_members_n504_full_model(dev):
     """One GPU's share of the 64-member ensemble at 8 GPUs (BASELINE configs[2]): 8 x N=504, full model,

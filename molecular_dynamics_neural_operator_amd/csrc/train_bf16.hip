@@ -354,8 +354,14 @@ template <class WT>
 __device__ __forceinline__ float4 ldw4(const WT* p);
 template <>
 __device__ __forceinline__ float4 ldw4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// (W_e is read once per conv application and is far larger than the caches: streamed past them)
 template <>
-__device__ __forceinline__ float4 ldw4<__bf16>(const __bf16* p) { return ld4_bf16(p); }
+__device__ __forceinline__ float4 ldw4<__bf16>(const __bf16* p) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 u = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p));
+    return make_float4(__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                       __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u));
+}
 
 // (W first: its address does not wait for src[p], which the x row's does; all twenty loads in flight before the
 // first FMA waits — a batch row has ~12 edges, one per wave, so a workgroup's life is its chain of round trips)

@@ -360,13 +360,23 @@ __global__ __launch_bounds__(256) void inv_degree_kernel(const int* __restrict__
 // come from the src-sorted CSR (row_ptr_s, eid_s, dst_s).  Lane (g, q) owns rows 16g..16g+15 x
 // columns 4q..4q+3 of W_e as in the forward kernel; per-lane partial dot products are summed over
 // ALL the row's edges first and reduced across the 16 q-lanes once per row.
+// STREAM: the matrix is an edge's W_e — read once per application, far larger than the caches: non-temporal loads
+template <bool STREAM>
 __device__ __forceinline__ void wg_accumulate(float (&acc)[16], const float* __restrict__ wmat,
                                               const float* __restrict__ gvec, int g, int q) {
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
     const float4 gq = *reinterpret_cast<const float4*>(gvec + 4 * q);
     const float* wp = wmat + (16 * g) * 64 + 4 * q;
     float4 w[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) w[r] = *reinterpret_cast<const float4*>(wp + r * 64);
+    for (int r = 0; r < 16; ++r) {
+        if (STREAM) {
+            const f32x4_t t = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(wp + r * 64));
+            w[r] = make_float4(t.x, t.y, t.z, t.w);
+        } else {
+            w[r] = *reinterpret_cast<const float4*>(wp + r * 64);
+        }
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r)
         acc[r] = fmaf(w[r].x, gq.x, fmaf(w[r].y, gq.y, fmaf(w[r].z, gq.z, fmaf(w[r].w, gq.w, acc[r]))));
@@ -386,8 +396,8 @@ __global__ __launch_bounds__(256) void nnconv_bwd_x_kernel(const float* __restri
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     for (int p = beg + wave; p < end; p += 4)
-        wg_accumulate(acc, w_e + (size_t)eid_s[p] * 4096, gs + (size_t)dst_s[p] * 64, g, q);
-    if (root != nullptr && wave == ((end - beg) & 3)) wg_accumulate(acc, root, gz + (size_t)row * 64, g, q);
+        wg_accumulate<true>(acc, w_e + (size_t)eid_s[p] * 4096, gs + (size_t)dst_s[p] * 64, g, q);
+    if (root != nullptr && wave == ((end - beg) & 3)) wg_accumulate<false>(acc, root, gz + (size_t)row * 64, g, q);
     // reduce over the 16 q-lanes of each group: xor 1,2,4,8
 #pragma unroll
     for (int r = 0; r < 16; ++r) {

@@ -99,44 +99,64 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
         *reinterpret_cast<uint4*>(planes + tiled_off(row, k0, nkt, p)) = *reinterpret_cast<const uint4*>(o[p]);
 }
 
-// One wave per row: the row's largest magnitude, then the power of two that lifts it to [2^13, 2^14)
-// (f16_row_scale; exact), then the two-plane split of the scaled row.  unscale[row] = 1/scale is what the
-// GEMM epilogue multiplies the row's output column by.  Lane = 16-B chunks lane, lane+64, ... (8 k each).
+// Four rows per workgroup, one wave each for the first pass: the row's largest magnitude, then the power of two that
+// lifts it to [2^13, 2^14) (f16_row_scale; exact).  unscale[row] = 1/scale is what the GEMM epilogue multiplies the
+// row's output column (or row) by.  Second pass, all four waves over the four rows together: lane = (k-tile of 16,
+// row, 8-k half), so that a store instruction writes the 4 rows x 32 B of a k-tile that lie next to each other in a
+// plane tile — 128-B runs instead of the 32-B pieces a wave-per-row store scatters 8 KiB apart (the activations of a
+// training batch are 0.2-0.7 GB per split: their stores are what this kernel takes).
 __global__ __launch_bounds__(256) void split_planes_f16_kernel(const float* __restrict__ w, int rows, int K,
                                                                unsigned char* __restrict__ planes,
                                                                float* __restrict__ unscale,
                                                                int* __restrict__ range_flag) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= rows) return;                      // (wave-uniform)
-    const float* wr = w + (size_t)row * K;
+    __shared__ float scale_s[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row0 = blockIdx.x * 4;
     const int chunks = K >> 3;
-    float mx = 0.f;
-    for (int c = lane; c < chunks; c += 64) {
-        const float4 v0 = *reinterpret_cast<const float4*>(wr + 8 * c);
-        const float4 v1 = *reinterpret_cast<const float4*>(wr + 8 * c + 4);
-        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v0.z), fabsf(v0.w))));
-        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v1.x), fabsf(v1.y)), fmaxf(fabsf(v1.z), fabsf(v1.w))));
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    const float sc = f16_row_scale(mx);
-    if (lane == 0) unscale[row] = 1.f / sc;       // (power of two: exact)
-    const int nkt = K >> 4;
-    bool bad = false;
-    for (int c = lane; c < chunks; c += 64) {
-        const float4 v0 = *reinterpret_cast<const float4*>(wr + 8 * c);
-        const float4 v1 = *reinterpret_cast<const float4*>(wr + 8 * c + 4);
-        const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-        _Float16 o[2][8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float xs = x[j] * sc;
-            bad |= !(fabsf(xs) < F16_MAX);        // (inf / NaN only: the row's max sits below 2^14)
-            split2h(xs, o[0][j], o[1][j]);
+    {
+        const int row = row0 + wave;
+        float mx = 0.f;
+        if (row < rows) {
+            const float* wr = w + (size_t)row * K;
+            for (int c = lane; c < chunks; c += 64) {
+                const float4 v0 = *reinterpret_cast<const float4*>(wr + 8 * c);
+                const float4 v1 = *reinterpret_cast<const float4*>(wr + 8 * c + 4);
+                mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v0.z), fabsf(v0.w))));
+                mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v1.x), fabsf(v1.y)), fmaxf(fabsf(v1.z), fabsf(v1.w))));
+            }
         }
 #pragma unroll
-        for (int p = 0; p < 2; ++p)
-            *reinterpret_cast<uint4*>(planes + tiled_off2(row, 8 * c, nkt, p)) = *reinterpret_cast<const uint4*>(o[p]);
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        const float sc = f16_row_scale(mx);
+        if (lane == 0) {
+            scale_s[wave] = sc;
+            if (row < rows) unscale[row] = 1.f / sc;       // (power of two: exact)
+        }
+    }
+    __syncthreads();
+    const int nkt = K >> 4;
+    const int r = (threadIdx.x >> 1) & 3, half = threadIdx.x & 1;      // thread -> (k-tile, row, half)
+    const int row = row0 + r;
+    const float sc = scale_s[r];
+    bool bad = false;
+    if (row < rows) {
+        const float* wr = w + (size_t)row * K;
+        for (int kt = threadIdx.x >> 3; kt < nkt; kt += 32) {
+            const int k0 = kt * 16 + half * 8;
+            const float4 v0 = *reinterpret_cast<const float4*>(wr + k0);
+            const float4 v1 = *reinterpret_cast<const float4*>(wr + k0 + 4);
+            const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            _Float16 o[2][8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xs = x[j] * sc;
+                bad |= !(fabsf(xs) < F16_MAX);        // (inf / NaN only: the row's max sits below 2^14)
+                split2h(xs, o[0][j], o[1][j]);
+            }
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                *reinterpret_cast<uint4*>(planes + tiled_off2(row, k0, nkt, p)) = *reinterpret_cast<const uint4*>(o[p]);
+        }
     }
     if (bad) atomicOr(range_flag, 1);
 }

@@ -32,6 +32,17 @@ def default_edge_cap(members: int, n_atoms: int, threshold: float, density: floa
     return max(members * per_member, members * n_atoms)
 
 
+# conv_mode "auto", decided on the window an engine is reset with: the factored formulation keeps a 256 KiB object
+# per SOURCE NODE and application (Y_j) where the materialised one streams 16 KiB per EDGE, and saves the wide last
+# GEMM of the edge-MLP — it wins from a mean degree of ~40 on (measured on one box: chains of 600-1,300 atoms at
+# 25-30 edges per atom are 3-25 % faster materialised, the 504-atom box at 120 per atom 2.2x faster factored),
+# provided the graph is large enough to fill its launches.  Protein-like chains (10-30 neighbours within 8 A) stay
+# materialised whatever their length; dense boxes go factored.
+AUTO_FACTORED_MIN_DEGREE = 40
+AUTO_FACTORED_MIN_EDGES = 16384        # per member
+AUTO_MATERIALIZED_MAX_WORKSPACE = 64 << 30
+
+
 class RolloutEngine:
     """Owns the trajectory buffer [W+max_steps, M, N, 3], the workspace and the captured step."""
 
@@ -65,6 +76,39 @@ class RolloutEngine:
         self.stream = torch.cuda.Stream(device=dev)
         self.use_graph = bool(use_graph)
         self.steps_done = 0
+        # "auto": what the edge capacity suggests until a window is known; reset() decides on its graph
+        self._auto = (getattr(model, "conv_mode", None) if hasattr(model, "param_pack") else self.pack.conv_mode) == "auto"
+
+    def _pack_for(self, conv_mode: str):
+        if hasattr(self.model, "param_pack"):
+            return self.model.param_pack(self.device, conv_mode=conv_mode)
+        p = self.pack
+        return ops.ParamPack({v: p.tensors[k] for k, v in ops.ParamPack.KEYS.items() if k in p.tensors},
+                             p.struct.depth, self.device, p.gemm_mode, conv_mode)
+
+    def _resolve_auto(self) -> bool:
+        """conv_mode "auto" on the graph of the window's last frame (AUTO_FACTORED_* above).  Returns True if the
+        engine changed formulation (its plan must then be rebuilt)."""
+        R = self.M * self.N
+        probe_cap = max(AUTO_FACTORED_MIN_DEGREE * R, self.M * AUTO_FACTORED_MIN_EDGES) + R
+        g = ops.radius_graph(self.traj[self.W - 1].reshape(R, 3), self.N, self.threshold, edge_cap=probe_cap)
+        e = int(g.num_edges.item())
+        dense = bool(int(g.status.item()) & STATUS_EDGE_OVERFLOW) or (
+            e >= AUTO_FACTORED_MIN_DEGREE * R and e >= self.M * AUTO_FACTORED_MIN_EDGES)
+        want = "factored" if dense else "materialized"
+        if want == self.conv_mode:
+            return False
+        pack = self._pack_for(want)
+        if {v: k for k, v in _lib.CONV_MODES.items()}[
+                int(self.lib.mdno_resolve_conv_mode(pack.ref, self.M, self.edge_cap))] != want:
+            return False                 # (factored is not available for this model's dimensions)
+        need = self.lib.mdno_rollout_workspace_bytes(pack.ref, self.M, self.N, self.edge_cap)
+        if need > self.workspace.numel():
+            if want == "materialized" and need > AUTO_MATERIALIZED_MAX_WORKSPACE:
+                return False             # W_e at this edge capacity does not fit: stay factored
+            self.workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+        self.pack, self.conv_mode = pack, want
+        return True
 
     def _create_plan(self):
         if self.plan:
@@ -98,7 +142,8 @@ class RolloutEngine:
         else:
             self.aa.copy_(aa)
         torch.cuda.current_stream(self.device).synchronize()
-        if new_aa or not self.plan:
+        changed = self._auto and self._resolve_auto()
+        if new_aa or changed or not self.plan:
             self._create_plan()
         self.steps_done = 0
 

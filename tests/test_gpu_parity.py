@@ -831,28 +831,47 @@ def test_factored_conv_large_member_source_major_order(dev):
     close(out["factored"], out["materialized"])
 
 
-def test_conv_mode_auto_resolves_by_edge_capacity(dev):
-    """conv_mode="auto" (the default): materialized for small graphs, factored from edge_cap 24,576 on
-    (include/mdno.h MDNO_CONV_AUTO); both give the same trajectory to fp32 rounding."""
+def test_conv_mode_auto_resolves_on_the_graph_it_is_reset_with(dev):
+    """conv_mode="auto" (the default).  At construction an engine only knows its edge capacity (include/mdno.h
+    MDNO_CONV_AUTO: factored from 24,576 edges of capacity per member on); reset() decides on the window's graph:
+    factored for a dense graph (mean degree >= 40 and >= 16,384 edges per member), materialized otherwise — a
+    protein-like chain stays materialized whatever its length.  Both give the same trajectory to fp32 rounding."""
     from molecular_dynamics_neural_operator_amd import synthetic as syn
     from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN
     from molecular_dynamics_neural_operator_amd.rollout import RolloutEngine
     from molecular_dynamics_neural_operator_amd.weights import near_identity_state_dict
-    N, W, steps = 120, 4, 3
+    W, steps = 4, 3
     model = KernelNN(64, 128, 2, 6, 7, 3, 20, 4)
     model.load_state_dict(near_identity_state_dict(64, 128, seed=6, kernel_gain=1e-2, feature_gain=0.1, kernel_to_coords=1.0))
     model.eval().to(dev)
     assert model.conv_mode == "auto"
-    win = torch.from_numpy(syn.jitter_window(syn.box_frame(N, seed=6), W, seed=6))
-    aa = torch.from_numpy(syn.amino_acids(N, seed=6))
-    small = RolloutEngine(model, 1, N, W, 8.0, max_steps=steps, device=dev)                    # cap = N^2 = 14,400
-    big = RolloutEngine(model, 1, N, W, 8.0, max_steps=steps, device=dev, edge_cap=32768)
-    assert (small.conv_mode, big.conv_mode) == ("materialized", "factored")
-    close(big.run(win, aa, steps), small.run(win, aa, steps))
-    model.conv_mode = "factored"
-    forced = RolloutEngine(model, 1, N, W, 8.0, max_steps=steps, device=dev)
-    assert forced.conv_mode == "factored"
-    assert torch.equal(forced.run(win, aa, steps), big.frames())
+
+    def case(frame, N, want_before, want_after):
+        win = torch.from_numpy(syn.jitter_window(frame, W, seed=6))
+        aa = torch.from_numpy(syn.amino_acids(N, seed=6))
+        model.conv_mode = "auto"
+        eng = RolloutEngine(model, 1, N, W, 8.0, max_steps=steps, device=dev)
+        assert eng.conv_mode == want_before
+        got = eng.run(win, aa, steps).clone()
+        assert eng.conv_mode == want_after, (N, eng.conv_mode, int(eng.edges_per_step[0]))
+        for mode in ("factored", "materialized"):
+            model.conv_mode = mode
+            forced = RolloutEngine(model, 1, N, W, 8.0, max_steps=steps, device=dev)
+            assert forced.conv_mode == mode
+            out = forced.run(win, aa, steps)
+            if mode == want_after:
+                assert torch.equal(out, got)
+            else:
+                close(out, got)
+        model.conv_mode = "auto"
+        return int(eng.edges_per_step[0])
+
+    e = case(syn.box_frame(120, seed=6), 120, "materialized", "materialized")     # dense but small: 14,400 of capacity
+    assert e < 16384
+    e = case(syn.box_frame(220, seed=6), 220, "factored", "factored")             # dense and large enough
+    assert e >= 16384 and e >= 40 * 220
+    e = case(syn.chain_frame(220, seed=6), 220, "factored", "materialized")       # a chain: ~13-20 neighbours per atom
+    assert e < 40 * 220
 
 
 def test_errors_are_loud(dev):

@@ -24,6 +24,7 @@ ap.add_argument("--kernel-width", type=int, default=1024)
 ap.add_argument("--depth", type=int, default=6)
 ap.add_argument("--gemm-mode", default="split_f16")
 ap.add_argument("--conv-mode", default="auto")
+ap.add_argument("--edge-cap", type=int, default=None, help="edge capacity of the engine (default: M * N * N)")
 a = ap.parse_args()
 
 dev = torch.device("cuda:0")
@@ -38,7 +39,7 @@ model.eval().to(dev)
 model.gemm_mode, model.conv_mode = a.gemm_mode, a.conv_mode
 
 warm = 20
-eng = RolloutEngine(model, M, N, W, 8.0, max_steps=warm + 2 * a.steps, device=dev)
+eng = RolloutEngine(model, M, N, W, 8.0, max_steps=warm + 2 * a.steps, device=dev, edge_cap=a.edge_cap)
 eng.reset(torch.from_numpy(wins), aa)
 eng.step(warm)
 eng.synchronize()

@@ -57,6 +57,10 @@ class RolloutEngine:
         self.max_steps = int(max_steps)
         self.edge_cap = int(edge_cap) if edge_cap is not None else self.M * self.N * self.N
         self.edge_cap = max(self.edge_cap, self.M * self.N)
+        # no capacity given and the complete-graph bound is large (N > 256): the capacity is fitted to the graph of
+        # the window the engine is reset with (4x its edges), and the workspace allocated then — W_e at N^2 edges
+        # would be 16 GB at N = 1,000 for a chain that has 30,000
+        self._fit_cap = edge_cap is None and self.M * self.N * self.N > 65536
         self.max_degree = int(max_degree)      # factored conv grid bound; 0 = n_atoms (always safe)
         self.pack = model.param_pack(self.device) if hasattr(model, "param_pack") else model
         if not isinstance(self.pack, ops.ParamPack):
@@ -66,8 +70,10 @@ class RolloutEngine:
         self.conv_mode = {v: k for k, v in _lib.CONV_MODES.items()}[
             int(self.lib.mdno_resolve_conv_mode(self.pack.ref, self.M, self.edge_cap))]
         self.traj = torch.zeros((self.W + self.max_steps, self.M, self.N, 3), dtype=torch.float32, device=dev)
-        nbytes = self.lib.mdno_rollout_workspace_bytes(self.pack.ref, self.M, self.N, self.edge_cap)
-        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self.workspace = None
+        if not self._fit_cap:
+            nbytes = self.lib.mdno_rollout_workspace_bytes(self.pack.ref, self.M, self.N, self.edge_cap)
+            self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         self.edges_per_step = torch.zeros(self.max_steps, dtype=torch.int32, device=dev)
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
         self.aa = None
@@ -86,15 +92,27 @@ class RolloutEngine:
         return ops.ParamPack({v: p.tensors[k] for k, v in ops.ParamPack.KEYS.items() if k in p.tensors},
                              p.struct.depth, self.device, p.gemm_mode, conv_mode)
 
-    def _resolve_auto(self) -> bool:
-        """conv_mode "auto" on the graph of the window's last frame (AUTO_FACTORED_* above).  Returns True if the
-        engine changed formulation (its plan must then be rebuilt)."""
+    def _probe_edges(self) -> Tuple[int, bool]:
+        """Edges of the radius graph of the window's last frame, counted up to the bounds the decisions below look
+        at; (count, True) when there are more."""
         R = self.M * self.N
         probe_cap = max(AUTO_FACTORED_MIN_DEGREE * R, self.M * AUTO_FACTORED_MIN_EDGES) + R
         g = ops.radius_graph(self.traj[self.W - 1].reshape(R, 3), self.N, self.threshold, edge_cap=probe_cap)
-        e = int(g.num_edges.item())
-        dense = bool(int(g.status.item()) & STATUS_EDGE_OVERFLOW) or (
-            e >= AUTO_FACTORED_MIN_DEGREE * R and e >= self.M * AUTO_FACTORED_MIN_EDGES)
+        return int(g.num_edges.item()), bool(int(g.status.item()) & STATUS_EDGE_OVERFLOW)
+
+    def _fit_capacity(self, e: int, over: bool) -> bool:
+        R = self.M * self.N
+        cap = self.M * self.N * self.N if over else min(self.M * self.N * self.N, max(4 * e, e + 16 * R) + R)
+        if cap == self.edge_cap:
+            return False
+        self.edge_cap = cap
+        return True
+
+    def _resolve_auto(self, e: int, over: bool) -> bool:
+        """conv_mode "auto" on the graph of the window's last frame (AUTO_FACTORED_* above).  Returns True if the
+        engine changed formulation (its plan must then be rebuilt)."""
+        R = self.M * self.N
+        dense = over or (e >= AUTO_FACTORED_MIN_DEGREE * R and e >= self.M * AUTO_FACTORED_MIN_EDGES)
         want = "factored" if dense else "materialized"
         if want == self.conv_mode:
             return False
@@ -103,10 +121,8 @@ class RolloutEngine:
                 int(self.lib.mdno_resolve_conv_mode(pack.ref, self.M, self.edge_cap))] != want:
             return False                 # (factored is not available for this model's dimensions)
         need = self.lib.mdno_rollout_workspace_bytes(pack.ref, self.M, self.N, self.edge_cap)
-        if need > self.workspace.numel():
-            if want == "materialized" and need > AUTO_MATERIALIZED_MAX_WORKSPACE:
-                return False             # W_e at this edge capacity does not fit: stay factored
-            self.workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+        if want == "materialized" and need > AUTO_MATERIALIZED_MAX_WORKSPACE:
+            return False                 # W_e at this edge capacity does not fit: stay factored
         self.pack, self.conv_mode = pack, want
         return True
 
@@ -142,7 +158,18 @@ class RolloutEngine:
         else:
             self.aa.copy_(aa)
         torch.cuda.current_stream(self.device).synchronize()
-        changed = self._auto and self._resolve_auto()
+        changed = False
+        if self._auto or self._fit_cap:
+            e, over = self._probe_edges()
+            if self._fit_cap:
+                changed |= self._fit_capacity(e, over)
+            if self._auto:
+                changed |= self._resolve_auto(e, over)
+        need = self.lib.mdno_rollout_workspace_bytes(self.pack.ref, self.M, self.N, self.edge_cap)
+        if self.workspace is None or need > self.workspace.numel() or 2 * need < self.workspace.numel():
+            self.workspace = None        # (release before allocating: the two could be tens of GB each)
+            self.workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+            changed = True
         if new_aa or changed or not self.plan:
             self._create_plan()
         self.steps_done = 0

@@ -872,6 +872,18 @@ def test_conv_mode_auto_resolves_on_the_graph_it_is_reset_with(dev):
     assert e >= 16384 and e >= 40 * 220
     e = case(syn.chain_frame(220, seed=6), 220, "factored", "materialized")       # a chain: ~13-20 neighbours per atom
     assert e < 40 * 220
+    # without an explicit capacity and with N > 256, the capacity is fitted to the reset window's graph (4x its edges)
+    # instead of the complete graph's N^2, and the workspace allocated then
+    N = 300
+    win = torch.from_numpy(syn.jitter_window(syn.chain_frame(N, seed=6), W, seed=6))
+    aa = torch.from_numpy(syn.amino_acids(N, seed=6))
+    fitted = RolloutEngine(model, 1, N, W, 8.0, max_steps=steps, device=dev)
+    assert fitted.workspace is None and fitted.edge_cap == N * N
+    out = fitted.run(win, aa, steps).clone()
+    e = int(fitted.edges_per_step[0])
+    assert fitted.conv_mode == "materialized" and e < fitted.edge_cap <= 4 * e + 17 * N + 1 < N * N
+    full = RolloutEngine(model, 1, N, W, 8.0, max_steps=steps, device=dev, edge_cap=N * N)
+    assert torch.equal(full.run(win, aa, steps), out) and full.edge_cap == N * N
 
 
 def test_errors_are_loud(dev):

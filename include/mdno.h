@@ -72,7 +72,11 @@ extern "C" {
 #define MDNO_CONV_FACTORED     1
 /*   AUTO          FACTORED where it applies and the graph is large enough to pay for its fixed cost
  *                 per application (the Y GEMM and a 16-iteration pipeline per source: edge capacity
- *                 per member >= 24,576), MATERIALIZED otherwise (small graphs: 2x faster at N=28..120). */
+ *                 per member >= 24,576), MATERIALIZED otherwise (small graphs: 2x faster at N=28..120).
+ *                 The library sees a CAPACITY only: a caller that knows its graphs should pass FACTORED for
+ *                 dense ones (mean degree >= ~40 and >= ~16k edges per member) and MATERIALIZED otherwise —
+ *                 protein-like chains of any length; the Python RolloutEngine does so from the window it is
+ *                 reset with. */
 #define MDNO_CONV_AUTO         2
 
 /* status word bits written by device code (read back by the caller after synchronising) */

@@ -23,3 +23,14 @@ for steps in (100, 1000):
     out = recursive_propagation(model, ds, 'cuda', steps, [0], 8.0)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(f"recursive_propagation {steps} steps: {dt*1e3:.1f} ms = {steps/dt:.0f} it/s; last E = {out[-1].edge_index.shape[1]}")
+
+# KernelNN.forward(data) with the sample's own edge list, called in a loop as the notebook does
+s = ds[0].to('cuda')
+with torch.no_grad():
+    for _ in range(20):
+        model(s)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(300):
+        out = model(s)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+print(f"model(data), N={N}: {dt/300*1e3:.3f} ms per call = {300/dt:.0f} calls/s")

@@ -15,7 +15,7 @@ Two things are patched at run time, nothing in the reference is edited:
 The reference itself never travels: only the data written here is committed.
 
 Usage:  python oracle/gen_golden.py [--out tests/golden] [--skip-large] [--only NAME[,NAME]]
-        (sections: base, live504, checkpoint, train; every section seeds itself, so any subset
+        (sections: base, live28, live504, checkpoint, train; every section seeds itself, so any subset
         reproduces the same files)
 """
 from __future__ import annotations
@@ -128,6 +128,65 @@ def gen_live504(gk, ds, out: Path):
           f"latent zeros {zf:.2f}, |latent| max {np.abs(tf_lat0).max():.2f}")
 
 
+def gen_live28(gk, ds, out: Path):
+    """The reference's own BBA shape (N=28 C-alpha chain, nb:1034; the size of its one published number,
+    nb:370) at the CLI-default model size (width 64 / k=1024 / depth 6, graph_kernel.py:528-537) with the
+    live near-identity weight set of `gen_live504`: 20 teacher-forced forwards on the reference's own
+    ContactMapDataset samples (latent of the first) and 20 free-running steps through the reference's
+    recursive_propagation (graph_kernel.py:396-413), with the edge count and the smallest distance-to-cutoff
+    gap of every produced frame.  ~40 reference forwards of 66 ms."""
+    from molecular_dynamics_neural_operator_amd import synthetic as syn
+    from molecular_dynamics_neural_operator_amd.weights import near_identity_state_dict
+    THR, N, W, NTF, NFREE = 8.0, 28, 10, 20, 20
+    T = W + NTF + 1
+    base = syn.chain_frame(N, seed=0)
+    traj = syn.ou_trajectory(base, T, sigma=0.15, theta=0.2, seed=6)          # [T,N,3]
+    aa = torch.from_numpy(syn.amino_acids(N, seed=0))
+    gk.args = Namespace(window_size=W, num_residues=N, batch_size=1)
+    cms = np.empty(T, dtype=object)
+    for t in range(T):
+        cms[t] = _flat_contact_map(gk.construct_pairdata(traj[t:t + 1], aa, threshold=THR))
+    gains = dict(seed=0, kernel_gain=0.02, feature_gain=0.1, kernel_to_coords=1.0)
+    sd = near_identity_state_dict(64, 1024, **gains)
+    model = gk.KernelNN(64, 1024, 6, 6, 7, 3, 20, 4)
+    print("live28 load:", model.load_state_dict(sd))
+    model.eval()
+    names, sums, asums = _checksums(model.state_dict())
+    with tempfile.TemporaryDirectory() as td:
+        h5 = Path(td) / "synthetic28.h5"
+        with open(h5, "wb") as fh:
+            np.savez(fh, contact_map=cms, point_cloud=np.transpose(traj, (0, 2, 1)).copy(),
+                     rmsd=np.zeros(T, np.float32), amino_acids=aa.numpy())
+        dset = ds.ContactMapDataset(str(h5), window_size=W, horizon=1, node_feature_dset_path=str(h5))
+        tf_out, tf_lat0 = [], None
+        with torch.no_grad():
+            for i in range(NTF):
+                o, lat = model(dset[i], return_latent=True)
+                tf_out.append(o.numpy())
+                if i == 0:
+                    tf_lat0 = lat.numpy()
+        holder = Namespace(module=model, eval=lambda: None)
+        fc = gk.recursive_propagation(holder, dset, "cpu", num_steps=NFREE, starting_points=[0], threshold=THR)
+    free = np.stack([f.x_position[-1].numpy() for f in fc])
+    free_E = np.array([f.edge_index.shape[1] for f in fc])
+    free_gap = np.array([syn.min_threshold_gap(f.x_position[-1].numpy(), THR) for f in fc])
+    free_cm = np.array([_cm_checksum(_flat_contact_map(f)) for f in fc])
+    np.savez_compressed(
+        out / "kernelnn_live28.npz",
+        ctor=np.array([64, 1024, 6, 6, 7, 3, 20, 4]), threshold=THR, window=W,
+        weight_gains=np.array([gains["seed"], gains["kernel_gain"], gains["feature_gain"], gains["kernel_to_coords"]]),
+        param_names=names, param_sum=sums, param_abs_sum=asums,
+        frames=traj, amino_acids=aa.numpy(),
+        contact_map_len=np.array([c.size for c in cms]), contact_map_checksum=np.array([_cm_checksum(c) for c in cms]),
+        teacher_forced_out=np.stack(tf_out), teacher_forced_latent0=tf_lat0,
+        free_frames=free, free_num_edges=free_E, free_min_gap=free_gap, free_edge_checksum=free_cm,
+    )
+    zf = float((tf_lat0 == 0).mean())
+    step = float(np.linalg.norm(free[1:] - free[:-1], axis=-1).mean())
+    print(f"kernelnn_live28: ok; E0 {cms[0].size // 2}, free-run E {free_E}, min gap {free_gap.min():.2e}, "
+          f"latent zeros {zf:.2f}, |latent| max {np.abs(tf_lat0).max():.2f}, mean |step| {step:.3f} A")
+
+
 def gen_checkpoint(gk, out: Path):
     """A `best.pt`-shaped checkpoint (graph_kernel.py:630-639) written from the reference's own
     KernelNN wrapped as `main` wraps it (DataParallel -> `module.` key prefix, :528), stored as
@@ -232,7 +291,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", type=Path, default=REPO / "tests" / "golden")
     ap.add_argument("--skip-large", action="store_true", help="skip the N=504 full-size forwards (minutes of CPU)")
-    ap.add_argument("--only", default="", help="comma-separated sections: base, live504, checkpoint, train (default: all)")
+    ap.add_argument("--only", default="", help="comma-separated sections: base, live28, live504, checkpoint, train (default: all)")
     a = ap.parse_args()
     a.out.mkdir(parents=True, exist_ok=True)
     torch.set_num_threads(8)
@@ -244,6 +303,8 @@ def main():
         gen_checkpoint(gk, a.out)
     if not only or "train" in only:
         gen_train_step(gk, ds, a.out)
+    if not only or "live28" in only:
+        gen_live28(gk, ds, a.out)
     if (not only and not a.skip_large) or "live504" in only:
         gen_live504(gk, ds, a.out)
     if only and "base" not in only:

@@ -108,8 +108,8 @@ def test_live504_teacher_forced_reference_golden(dev, live504, gemm_mode):
 
 
 @pytest.mark.parametrize("conv_mode,gemm_mode", [("factored", "split_bf16"), ("materialized", "split_bf16"),
-                                                 ("factored", "split_f16"), ("factored", "f32"),
-                                                 ("materialized", "f32")])
+                                                 ("factored", "split_f16"), ("materialized", "split_f16"),
+                                                 ("factored", "f32"), ("materialized", "f32")])
 def test_live504_free_run_reference_golden(dev, live504, conv_mode, gemm_mode):
     """5 free-running steps through recursive_propagation (on-device loop) against the reference's own
     loop (graph_kernel.py:396-413).  A pair whose distance sits within 2e-4 A of the cutoff in the
@@ -237,6 +237,119 @@ def test_split_f16_hidden_gemm_accuracy_and_range_fallback(dev, live504):
     a, b, c = forward("split_f16", s), forward("split_bf16", s), forward("f32", s)
     assert bool(torch.isfinite(a).all()) and not torch.equal(a, b)
     assert rel(a, c) < 3 * max(rel(b, c), 1e-6) and rel(a, c) < 1e-5, (rel(a, c), rel(b, c))
+
+
+# ------------------------------------------------------------------------------- shape A, live fixture (N = 28)
+@pytest.fixture(scope="module")
+def live28(tmp_path_factory):
+    """The reference's own KernelNN at ITS OWN BBA size (N=28, nb:1034) and the CLI model size (width 64, k=1024,
+    depth 6) with live weights: 20 teacher-forced forwards + 20 free-running steps of the reference's
+    recursive_propagation (oracle/gen_golden.py gen_live28).  No produced frame has a pair within 1e-3 A of the
+    cutoff, so graphs must agree exactly."""
+    from molecular_dynamics_neural_operator_amd import synthetic as syn
+    from molecular_dynamics_neural_operator_amd.dataset import ContactMapDataset, write_trajectory_npz
+    from molecular_dynamics_neural_operator_amd.weights import near_identity_state_dict
+    z = load_golden("kernelnn_live28.npz")
+    thr, W = float(z["threshold"]), int(z["window"])
+    frames = z["frames"]
+    cms = [syn.contact_map(f, thr) for f in frames]
+    assert [c.size for c in cms] == list(z["contact_map_len"])
+    assert [cm_checksum(c) for c in cms] == list(z["contact_map_checksum"])      # the reference's own contact maps
+    path = tmp_path_factory.mktemp("live28") / "traj.npz"
+    write_trajectory_npz(path, frames, cms, z["amino_acids"])
+    dset = ContactMapDataset(str(path), window_size=W, horizon=1)
+    seed, kg, fg, kc = z["weight_gains"]
+    sd = near_identity_state_dict(64, 1024, seed=int(seed), kernel_gain=float(kg), feature_gain=float(fg),
+                                  kernel_to_coords=float(kc))
+    for n, s_, a_ in zip([str(x) for x in z["param_names"]], z["param_sum"], z["param_abs_sum"]):
+        assert float(sd[n].double().sum()) == pytest.approx(float(s_), rel=1e-12, abs=1e-12), n
+        assert float(sd[n].double().abs().sum()) == pytest.approx(float(a_), rel=1e-12), n
+    assert float(z["free_min_gap"].min()) > 1e-4
+    return z, dset, sd
+
+
+def _live28_model(z, sd, dev, gemm_mode):
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN
+    model = KernelNN(*[int(v) for v in z["ctor"]])
+    model.load_state_dict(sd)
+    model.eval().to(dev)
+    model.gemm_mode = gemm_mode
+    return model
+
+
+@pytest.mark.parametrize("gemm_mode", ["split_f16", "split_bf16", "f32"])
+def test_live28_teacher_forced_reference_golden(dev, live28, gemm_mode):
+    """model(sample) on the reference's 20 dataset samples (the sample's own edge list: the graph of the window's
+    FIRST frame, dataset.py:189-201) against the reference's forwards; latent of the first to rel-L2 <= 1e-5."""
+    z, dset, sd = live28
+    model = _live28_model(z, sd, dev, gemm_mode)
+    lat0 = z["teacher_forced_latent0"]
+    assert 0.3 < float((lat0 == 0).mean()) < 0.7 and float(np.abs(lat0).max()) < 50      # live, bounded
+    for i in range(z["teacher_forced_out"].shape[0]):
+        s = dset[i].to(dev)
+        with torch.no_grad():
+            out, lat = model(s, return_latent=True)
+        close(out, z["teacher_forced_out"][i], name=f"live28 tf{i} {gemm_mode}")
+        if i == 0:
+            close(lat, lat0, name=f"live28 latent0 {gemm_mode}")
+
+
+@pytest.mark.parametrize("members", [1, 3, 10])
+@pytest.mark.parametrize("gemm_mode", ["split_f16", "split_bf16", "f32"])
+def test_live28_free_run_short_chain_kernels_reference_golden(dev, live28, members, gemm_mode):
+    """The short-chain kernels of DESIGN 4.8 held to the REFERENCE first-hand, at full model size.  The reference's
+    free run (graph_kernel.py:396-413) from its second iteration on IS the engine's loop (graph of the newest frame):
+    the engine starts from the window the reference's second iteration sees — frames 1..W-1 of the data + the
+    reference's own first produced frame — and must reproduce its remaining 19 frames and their edge counts.
+    1 member: `step_head_small_kernel`, `gemm_split_f16_small_kernel`, `nnconv64_colsplit_kernel<4>`, `FcTail`,
+    eight steps per graph launch; 3 members: `colsplit<2>`; 10 members: the row kernels of the large shapes (the
+    golden window is ONE member of the batch, the others are perturbed copies)."""
+    from molecular_dynamics_neural_operator_amd import synthetic as syn
+    from molecular_dynamics_neural_operator_amd.rollout import RolloutEngine
+    z, dset, sd = live28
+    model = _live28_model(z, sd, dev, gemm_mode)
+    thr, W = float(z["threshold"]), int(z["window"])
+    want, want_E = z["free_frames"], z["free_num_edges"]
+    N = want.shape[1]
+    steps = want.shape[0] - 1
+    win = np.concatenate([z["frames"][1:W], want[:1]], axis=0).astype(np.float32)            # [W,N,3]
+    slot = {1: 0, 3: 1, 10: 6}[members]
+    wins = syn.ensemble_windows(win, members, sigma=0.1, seed0=300)                            # [M,W,N,3]
+    wins[slot] = win
+    tm = torch.from_numpy(np.ascontiguousarray(wins.transpose(1, 0, 2, 3)))                    # [W,M,N,3]
+    aa = torch.from_numpy(z["amino_acids"])
+    for use_graph in (True, False):
+        eng = RolloutEngine(model, members, N, W, thr, max_steps=steps, device=dev, use_graph=use_graph)
+        got = eng.run(tm, aa, steps).cpu().numpy()[:, slot]
+        assert eng.conv_mode == "materialized"
+        for s in range(steps):
+            close(got[s], want[s + 1], name=f"live28 free step {s + 1} M={members} {gemm_mode} graph={use_graph}")
+        if members == 1:
+            assert eng.edges_per_step.cpu().tolist() == [int(e) for e in want_E[:steps]]
+        eng.close()
+
+
+@pytest.mark.parametrize("gemm_mode", ["split_f16", "split_bf16", "f32"])
+def test_live28_recursive_propagation_api_reference_golden(dev, live28, gemm_mode):
+    """The reference's own call, `recursive_propagation(model, dataset, device, 20, [0])`, at its own BBA size:
+    all 20 frames, every returned PairData's edge list (bit-exact: checksum of the reference's) and window."""
+    from molecular_dynamics_neural_operator_amd.graph_kernel import recursive_propagation
+    z, dset, sd = live28
+    model = _live28_model(z, sd, dev, gemm_mode)
+    want = z["free_frames"]
+    fc = recursive_propagation(model, dset, dev, num_steps=want.shape[0], starting_points=[0],
+                               threshold=float(z["threshold"]))
+    assert len(fc) == want.shape[0]
+    W = int(z["window"])
+    for s, f in enumerate(fc):
+        assert not f.x_position.is_cuda and tuple(f.x_position.shape) == (W, want.shape[1], 3)
+        close(f.x_position[-1], want[s], name=f"live28 API step {s} {gemm_mode}")
+        if s > 0:
+            assert torch.equal(f.x_position[:-1], fc[s - 1].x_position[1:])                    # the window slides
+        assert f.edge_index.shape[1] == int(z["free_num_edges"][s])
+        flat = np.concatenate([f.edge_index[0].numpy(), f.edge_index[1].numpy()])
+        assert cm_checksum(flat) == z["free_edge_checksum"][s], s
+        assert torch.equal(f.edge_attr, torch.cat([f.x_position[-1][f.edge_index[0]], f.x_position[-1][f.edge_index[1]]], 1))
 
 
 # ------------------------------------------------------------------------------- propogate (nb:336-358)

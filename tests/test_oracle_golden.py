@@ -133,6 +133,52 @@ def test_live504_teacher_forced_and_first_free_step():
     assert nxt["edge_index"].shape[1] == int(z["free_num_edges"][0])
 
 
+def _cm_checksum(cm):
+    c = np.asarray(cm, dtype=np.uint64)
+    w = (np.arange(c.size, dtype=np.uint64) * np.uint64(2654435761) + np.uint64(1)) | np.uint64(1)
+    with np.errstate(over="ignore"):
+        return np.uint64((c * w).sum())
+
+
+def test_live28_teacher_forced_and_free_run():
+    """The reference's own BBA size (N=28, nb:1034) at the CLI model size (width 64, k=1024, depth 6) with live
+    weights (kernelnn_live28.npz): the oracle against ALL 20 teacher-forced forwards of the reference on its
+    ContactMapDataset samples and ALL 20 free-running steps of its recursive_propagation — frames, edge counts and
+    the edge lists themselves (checksums) per step."""
+    from molecular_dynamics_neural_operator_amd import synthetic as syn
+    from molecular_dynamics_neural_operator_amd.weights import near_identity_state_dict
+    z = load_golden("kernelnn_live28.npz")
+    thr, W = float(z["threshold"]), int(z["window"])
+    frames = z["frames"]
+    seed, kg, fg, kc = z["weight_gains"]
+    sd = near_identity_state_dict(64, 1024, seed=int(seed), kernel_gain=float(kg), feature_gain=float(fg),
+                                  kernel_to_coords=float(kc))
+    for n, s_, a_ in zip([str(x) for x in z["param_names"]], z["param_sum"], z["param_abs_sum"]):
+        assert float(sd[n].double().sum()) == pytest.approx(float(s_), rel=1e-12, abs=1e-12), n
+    cms = [syn.contact_map(f, thr) for f in frames]
+    assert [c.size for c in cms] == list(z["contact_map_len"])
+    assert [_cm_checksum(c) for c in cms] == list(z["contact_map_checksum"])
+    pc = np.transpose(frames, (0, 2, 1))
+    depth = int(z["ctor"][2])
+    lat0 = z["teacher_forced_latent0"]
+    assert 0.3 < float((lat0 == 0).mean()) < 0.7 and float(np.abs(lat0).max()) < 50          # live, bounded
+    for i in range(z["teacher_forced_out"].shape[0]):
+        s = O.dataset_sample(pc, cms, z["amino_acids"], i, W, 1)
+        out, lat = O.kernelnn_forward(sd, s["x_position"], s["x_aminoacid"], s["edge_index"], s["edge_attr"], depth,
+                                      return_latent=True, hoist=True)
+        torch.testing.assert_close(out, t(z["teacher_forced_out"][i]), rtol=1e-5, atol=1e-5)
+        if i == 0:
+            torch.testing.assert_close(lat, t(lat0), rtol=1e-5, atol=1e-5)
+    assert float(z["free_min_gap"].min()) > 1e-4       # no pair near the cutoff: the edge lists must be equal
+    fc = O.recursive_propagation(sd, depth, O.dataset_sample(pc, cms, z["amino_acids"], 0, W, 1),
+                                 z["free_frames"].shape[0], thr, hoist=True)
+    for k, f in enumerate(fc):
+        torch.testing.assert_close(f["x_position"][-1], t(z["free_frames"][k]), rtol=1e-4, atol=1e-4)
+        assert f["edge_index"].shape[1] == int(z["free_num_edges"][k])
+        flat = np.concatenate([f["edge_index"][0].numpy(), f["edge_index"][1].numpy()])
+        assert _cm_checksum(flat) == z["free_edge_checksum"][k], k
+
+
 def test_checkpoint_fixture_forward():
     """best.pt-shaped fixture written by the reference's DataParallel-wrapped KernelNN
     (graph_kernel.py:528, :630-639): the oracle strips `module.` and reproduces the forward."""

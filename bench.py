@@ -479,6 +479,45 @@ def leg_cfg5_shape_c(dev, atoms=50000, cutoff=10.0, steps=2):
     return out
 
 
+def leg_cfg2_1000_steps(dev, a, steps=1000):
+    """BASELINE configs[1] as worded — "BBA 1000-step autoregressive rollout, fp32, 1xMI355X": the headline's
+    workload (same start window, weights, capacity and launch mode) run for 1,000 steps in one call, after a
+    10-step warm-up; the window slides through the trajectory buffer the whole time."""
+    from molecular_dynamics_neural_operator_amd import synthetic as syn
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN
+    from molecular_dynamics_neural_operator_amd.rollout import RolloutEngine, default_edge_cap
+    from molecular_dynamics_neural_operator_amd.weights import near_identity_state_dict
+    N, W, warm = a.atoms, a.window, 10
+    model = KernelNN(a.width, a.kernel_width, a.depth, 6, 7, 3, 20, 4)
+    model.load_state_dict(near_identity_state_dict(a.width, a.kernel_width, seed=0, kernel_gain=1e-3, feature_gain=0.1))
+    model.eval().to(dev)
+    model.gemm_mode, model.conv_mode = a.gemm_mode, a.conv_mode
+    win = torch.from_numpy(syn.jitter_window(syn.box_frame(N, seed=1), W, seed=1))
+    aa = torch.from_numpy(syn.amino_acids(N, seed=1))
+    eng = RolloutEngine(model, 1, N, W, a.threshold, max_steps=warm + steps, edge_cap=default_edge_cap(1, N, a.threshold),
+                        device=dev, use_graph=not a.no_graph)
+    eng.reset(win, aa)
+    eng.step(warm)
+    eng.synchronize()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.step(steps)
+    eng.stream.synchronize()
+    dt = time.perf_counter() - t0
+    eng.synchronize()                      # raises on overflow / bad input
+    fr = eng.frames()
+    e = eng.edges_per_step[warm:warm + steps]
+    out = {"steps": steps, "warmup": warm, "atoms": N, "frames_per_s": steps / dt, "ms_per_step": dt / steps * 1e3,
+           "seconds": dt, "finite": bool(torch.isfinite(fr).all()), "conv_mode": eng.conv_mode,
+           "edges_first_last": [int(e[0].item()), int(e[-1].item())], "edges_min_max": [int(e.min().item()), int(e.max().item())],
+           "max_displacement_from_start_A": float((fr[-1, 0] - fr[0, 0]).abs().max().item()),
+           "launch": "plain" if a.no_graph else "hipGraph replay"}
+    eng.close()
+    if not out["finite"]:
+        raise RuntimeError("cfg2 1000-step rollout produced a non-finite frame")
+    return out
+
+
 def leg_shape_a(dev, a):
     """SURVEY.md §8 shape A — the reference's actual BBA (N=28 C-alpha, bba_analysis.ipynb:1034): the in-tree model
     with 1 and with 64 members, and the notebook-era model (window 1, conv1 only, kernel_width 512) whose rollout
@@ -824,7 +863,8 @@ def worker(a):
             eng.close()
             eng = None
         torch.cuda.empty_cache()
-        for name, fn in (("shape_A", lambda: leg_shape_a(dev, a)), ("cfg4_training", lambda: leg_cfg4_training(dev)),
+        for name, fn in (("cfg2_1000_steps", lambda: leg_cfg2_1000_steps(dev, a)),
+                         ("shape_A", lambda: leg_shape_a(dev, a)), ("cfg4_training", lambda: leg_cfg4_training(dev)),
                          ("cfg5_shape_c", lambda: leg_cfg5_shape_c(dev))):
             t0 = time.perf_counter()
             note(f"{name} leg")
@@ -870,6 +910,7 @@ def worker(a):
             "baseline_1gpu_same_workload": ({"workload": "BASELINE configs[2]: 64-member ensemble on one GPU",
                                              "value": ensemble_leg["frames_per_s"], "unit": "frames/s"}
                                             if ensemble_leg else None),
+            "cfg2_1000_steps": config_legs.get("cfg2_1000_steps"),
             "cfg4_training": config_legs.get("cfg4_training"), "cfg5_shape_c": config_legs.get("cfg5_shape_c"),
             "shape_A": config_legs.get("shape_A"),
             "cpu_baseline": cpu, "kernels": kernels, "multi_gpu_timing": mg_timing,

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDNO_ABI_VERSION 11
+#define MDNO_ABI_VERSION 12
 
 #define MDNO_OK            0
 #define MDNO_EINVAL       -1   /* bad argument (null pointer, non-positive size, unsupported dim) */
@@ -210,6 +210,15 @@ size_t mdno_kernelnn_workspace_bytes(const mdno_kernelnn_params* p, int M, int N
  * parameters, M members and this total edge capacity runs on a position-derived radius graph
  * (resolves AUTO; the rule is on edge_cap / M, so it does not depend on the batch a member is in). */
 int mdno_resolve_conv_mode(const mdno_kernelnn_params* p, int M, int64_t edge_cap);
+/* The formulation AUTO should run for a radius graph the caller has COUNTED: M members of N atoms with num_edges
+ * directed edges in total (self-loops included).  FACTORED for dense graphs — mean degree >= 40 AND >= 16,384 edges
+ * per member (measured break-even, DESIGN.md table of deviations) — where the model's dimensions allow it;
+ * MATERIALIZED otherwise (protein-like chains of any length: 10-30 neighbours within 8 A).  Pure host function, no
+ * launch; p->conv_mode is ignored.  A caller with AUTO in its params and a known graph sets p->conv_mode to the
+ * result before mdno_rollout_plan_create / mdno_kernelnn_fwd (the Python RolloutEngine does, on the window it is
+ * reset with); mdno_resolve_conv_mode remains the capacity-only rule the library applies by itself.
+ * Replaces nothing in the reference (graph_kernel.py:194-209 has one formulation). */
+int mdno_conv_mode_for_graph(const mdno_kernelnn_params* p, int M, int N, int64_t num_edges);
 int mdno_kernelnn_fwd(const mdno_kernelnn_params* p, const float* frames, int M, int W, int N,
                       const int64_t* x_aminoacid, int aa_per_member,
                       const int32_t* row_ptr, const int32_t* src, const int32_t* dst,
@@ -342,7 +351,8 @@ int mdno_nnconv_bwd_we(const float* x, const float* gs, const int32_t* src, cons
  *                           into the GEMM's epilogue; n % 256 == 0, k % 32 == 0, k >= 64
  *                           (mdno_linear_bf16_masked_supported); workspace mdno_linear_bf16_workspace_bytes(n, k)
  *   mdno_gemm_atb_bf16      c [n1,n2] fp32 = a^T . b over rows, a bf16 [rows,n1], b bf16 [rows,n2], n1, n2 % 128 == 0;
- *                           fixed row slices added in order; workspace mdno_gemm_atb_bf16_workspace_bytes
+ *                           fixed row slices added in order; workspace mdno_gemm_atb_bf16_workspace_bytes (covers any
+ *                           rows < 2^31 * 32 / (2 * max(n1,n2)) — 8.4M at n = 4096; beyond: MDNO_EWORKSPACE)
  *   mdno_nnconv_bf16w_fwd   mdno_nnconv_fwd at 64x64 with w_e bf16 [E,4096]
  *   mdno_nnconv_bwd_x_bf16w mdno_nnconv_bwd_x with w_e bf16
  *   mdno_nnconv_bwd_we_bf16 d_we bf16 [E,4096] = sum_l x_l[src p] (x) gs_l[dst p] (rounded once, at the end)

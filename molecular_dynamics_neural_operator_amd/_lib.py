@@ -14,7 +14,7 @@ LIB_PATH = Path(os.environ.get("MDNO_LIB", _HERE / "libmdno.so"))
 OK, EINVAL, ELAUNCH, EWORKSPACE, EUNSUPPORTED = 0, -1, -2, -3, -4
 AGGR = {"add": 0, "mean": 1, "max": 2}      # "max": mdno_nnconv_fwd only (inference)
 STATUS_EDGE_OVERFLOW, STATUS_BAD_AMINOACID = 1, 2
-ABI_VERSION = 11
+ABI_VERSION = 12
 GEMM_MODES = {"split_bf16": 0, "f32": 1, "split_f16": 2}
 CONV_MODES = {"materialized": 0, "factored": 1, "auto": 2}
 STATUS_ASYMMETRIC_GRAPH = 4
@@ -62,6 +62,7 @@ SIGNATURES = {
     "mdno_fc_out_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
     "mdno_kernelnn_workspace_bytes": (_SZ, [C.POINTER(KernelNNParams), _I, _I, _L]),
     "mdno_resolve_conv_mode": (_I, [C.POINTER(KernelNNParams), _I, _L]),
+    "mdno_conv_mode_for_graph": (_I, [C.POINTER(KernelNNParams), _I, _I, _L]),
     "mdno_kernelnn_fwd": (_I, [C.POINTER(KernelNNParams), _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _L, _I,
                                _P, _P, _P, _P, _P, _P, _SZ, _P, _P]),
     "mdno_rollout_workspace_bytes": (_SZ, [C.POINTER(KernelNNParams), _I, _I, _L]),

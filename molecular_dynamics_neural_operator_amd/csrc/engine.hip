@@ -88,6 +88,11 @@ struct FwdWs {
 // looks at the capacity PER MEMBER, so a member takes the same path — and gives the same bits —
 // alone, in a batch of 8 or in a shard of 64.
 constexpr long long kAutoFactoredMinEdgeCapPerMember = 24576;
+// the rule on a COUNTED graph (mdno_conv_mode_for_graph): the factored form keeps a 256 KiB object per source node and
+// application where the materialised one streams 16 KiB per edge — it pays from ~40 neighbours per atom on, once the
+// graph fills its launches
+constexpr long long kAutoFactoredMinDegree = 40;
+constexpr long long kAutoFactoredMinEdgesPerMember = 16384;
 
 bool use_factored(const mdno_kernelnn_params* p, int M, long long edge_cap, bool position_graph) {
     if (p->conv_mode == MDNO_CONV_MATERIALIZED || !factored_supported(p->width, p->ker_width)) return false;
@@ -240,6 +245,13 @@ extern "C" size_t mdno_kernelnn_workspace_bytes(const mdno_kernelnn_params* p, i
 
 extern "C" int mdno_resolve_conv_mode(const mdno_kernelnn_params* p, int M, int64_t edge_cap) {
     return p && use_factored(p, M, (long long)edge_cap, true) ? MDNO_CONV_FACTORED : MDNO_CONV_MATERIALIZED;
+}
+
+extern "C" int mdno_conv_mode_for_graph(const mdno_kernelnn_params* p, int M, int N, int64_t num_edges) {
+    if (!p || M <= 0 || N <= 0 || !factored_supported(p->width, p->ker_width)) return MDNO_CONV_MATERIALIZED;
+    const long long rows = (long long)M * N;
+    const bool dense = num_edges >= kAutoFactoredMinDegree * rows && num_edges >= (long long)M * kAutoFactoredMinEdgesPerMember;
+    return dense ? MDNO_CONV_FACTORED : MDNO_CONV_MATERIALIZED;
 }
 
 extern "C" int mdno_kernelnn_fwd(const mdno_kernelnn_params* p, const float* frames, int M, int W, int N,
@@ -395,8 +407,12 @@ extern "C" int mdno_rollout_plan_create(mdno_rollout_plan** plan, const mdno_ker
     if (use_graph && s != nullptr) {
         int rc = capture_steps(pl, s, 1, &pl->graph, &pl->exec);
         // a short chain's step is a few dozen launches of a few microseconds: several steps per graph launch
-        if (rc == MDNO_OK && max_steps >= kStepsPerGraph && step_head_small_supported(M, N))
-            rc = capture_steps(pl, s, kStepsPerGraph, &pl->graph_n, &pl->exec_n);
+        if (rc == MDNO_OK && max_steps >= kStepsPerGraph && step_head_small_supported(M, N) &&
+            capture_steps(pl, s, kStepsPerGraph, &pl->graph_n, &pl->exec_n) != MDNO_OK) {
+            // the many-steps graph is an optimisation: without it the single-step graph above replays every step
+            pl->graph_n = nullptr;
+            pl->exec_n = nullptr;
+        }
         if (rc != MDNO_OK) {
             mdno_rollout_plan_destroy(pl);
             return rc;

@@ -638,7 +638,14 @@ extern "C" int mdno_gemm_atb_bf16(const void* a, const void* b, int64_t rows, in
     MDNO_REQUIRE(workspace_bytes >= mdno_gemm_atb_bf16_workspace_bytes(n1, n2), MDNO_EWORKSPACE,
                  "mdno_gemm_atb_bf16: workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (gemm_tn_pp_supported(rows, n1, n2)) return gemm_tn_pp(a, b, (long long)rows, n1, n2, c, workspace, s);
+    if (gemm_tn_pp_supported(rows, n1, n2)) {
+        // the slab count grows past 32 once a slice's operand panel would reach 2 GiB (rows >= ~8.4M at n = 4096);
+        // the row-independent workspace query does not cover that: refuse rather than write past the buffer
+        MDNO_REQUIRE(workspace_bytes >= gemm_tn_pp_workspace_bytes((long long)rows, n1, n2), MDNO_EWORKSPACE,
+                     "mdno_gemm_atb_bf16: %lld rows need more slabs than mdno_gemm_atb_bf16_workspace_bytes provides",
+                     (long long)rows);
+        return gemm_tn_pp(a, b, (long long)rows, n1, n2, c, workspace, s);
+    }
     const long long slice_rows = ((rows + kTnSlices - 1) / kTnSlices + 31) / 32 * 32;
     hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(n2 / 128, n1 / 128, kTnSlices), dim3(256), 0, s,
                        static_cast<const __bf16*>(a), static_cast<const __bf16*>(b), static_cast<float*>(workspace),

@@ -14,8 +14,8 @@ kernels of libmdno.so (include/mdno.h) on an MI355X.  There is no CPU fallback: 
 Differences from the reference, all explicit:
   * ``KernelNN.forward`` reads the window length and atom count from ``data.x_position``'s shape
     ([W,N,3]) instead of a module-global ``args`` (graph_kernel.py:279) and never calls ``.cuda()``.
-  * one sample per ``forward`` (B=1 semantics); several independent samples go
-    through ``rollout.RolloutEngine`` / ``ops.kernelnn_forward`` as a block-diagonal batch.
+  * B=1 semantics per sample: a list of samples or a collated batch runs as independent
+    block-diagonal members of one forward (``validate``, graph_kernel.py:476-493 -> ``training.validate_epoch``).
   * ``KernelNN.forward`` in training mode with autograd enabled runs the differentiable path of
     ``training.py`` (HIP forward + backward of the kernel-integral block, fp32); stand-alone
     ``NNConv_old`` / ``DenseNet`` forwards are inference-only and raise in that situation.
@@ -269,33 +269,58 @@ class KernelNN(nn.Module):
                      (device.index is None or p.device.index == device.index) for p in params)
         key = (str(device), self.gemm_mode, conv_mode) + tuple(
             (p.data_ptr(), 0 if viewed else p._version) for p in params)
+        # an UNTIED conv2.net: the pack decides by VALUE whether the two edge-MLPs are one (and then evaluates one);
+        # that decision must not outlive an in-place change of either, so their versions stay in the key
+        conv2 = getattr(self, "conv2", None)
+        if conv2 is not None and conv2.net is not self.conv1.net:
+            key += tuple(p._version for net in (self.conv1.net, conv2.net) for p in net.parameters())
         if self._pack is None or self._pack_key != key:
             self._pack = ops.ParamPack(self.state_dict(), self.depth, device, self.gemm_mode, conv_mode)
             self._pack_key = key
         return self._pack
 
-    def forward(self, data: PairData, return_latent: bool = False, single_example: bool = False):
+    def forward(self, data, return_latent: bool = False, single_example: bool = False, _status=None):
+        """``data``: one ``PairData`` sample, a list of samples (what the reference's DataListLoader yields and
+        ``validate`` / ``train`` pass to ``model(batch)``, graph_kernel.py:454, :485) or an already collated batch
+        (``training.collate`` / ``DeviceTrajectory.batch``: time-major x_position [W,B*N,3], ``num_graphs`` = B).
+        Training mode with autograd on: the differentiable path.  Otherwise inference under no_grad: the B samples
+        run as B block-diagonal members of ONE forward (B=1 semantics per sample, nothing kept for a backward);
+        every sample's rows are bit-identical to ``model(sample)`` on it alone."""
         if self.training and torch.is_grad_enabled():
             # differentiable path (training.py): HIP forward + backward of the kernel-integral block
             from .training import train_forward
             if return_latent:
                 raise NotImplementedError("return_latent is an inference-time option")
             return train_forward(self, data)
+        batched = not isinstance(data, PairData)
+        if batched:
+            from .training import collate
+            dev = next(self.parameters()).device
+            if dev.type != "cuda":
+                raise MdnoError("KernelNN.forward needs the model on the GPU (model.to('cuda')); no CPU fallback")
+            if len(data) == 0:
+                raise MdnoError("KernelNN.forward: empty batch")
+            data = collate([s if s.x_position.is_cuda else PairData(**{k: getattr(s, k) for k in PairData._FIELDS}).to(dev)
+                            for s in data])
         x_position = data.x_position
         if x_position.dim() == 2:  # notebook-era single-frame sample [N,3]
             x_position = x_position.unsqueeze(0)
         if not x_position.is_cuda:
             raise MdnoError("KernelNN.forward needs the sample on the GPU (data.to('cuda')); no CPU fallback")
-        n_nodes = data.x_aminoacid.shape[0]
-        if x_position.shape[1] != n_nodes:
+        n_rows = data.x_aminoacid.shape[0]
+        B = int(getattr(data, "num_graphs", 1))
+        if x_position.shape[1] != n_rows or B < 1 or n_rows % B:
             raise MdnoError(
-                f"x_position {tuple(x_position.shape)} vs {n_nodes} nodes: batched samples go through "
-                "rollout.RolloutEngine / ops.kernelnn_forward (one PairData per forward here)")
+                f"x_position {tuple(x_position.shape)} vs {n_rows} nodes in {B} graph(s): a batch is a list of PairData "
+                "or a collated one (training.collate / DeviceTrajectory.batch: x_position [W,B*N,3], num_graphs = B)")
+        W = x_position.shape[0]
         with torch.no_grad():
             pack = self.param_pack(x_position.device, conv_mode="materialized")
-            graph = ops.coo_to_csr(data.edge_index, n_nodes)
-            out, latent = ops.kernelnn_forward(pack, x_position.unsqueeze(1), data.x_aminoacid, graph,
-                                               edge_attr=data.edge_attr, return_latent=return_latent)
+            graph = ops.coo_to_csr(data.edge_index.to(x_position.device), n_rows, validate=_status is None, status=_status)
+            out, latent = ops.kernelnn_forward(pack, ops.f32(x_position).reshape(W, B, n_rows // B, 3),
+                                               data.x_aminoacid.to(x_position.device), graph,
+                                               edge_attr=data.edge_attr.to(x_position.device), return_latent=return_latent,
+                                               check_status=_status is None)
         return [out, latent] if return_latent else out
 
 
@@ -323,14 +348,7 @@ class KernelNNNotebook(KernelNN):
         self._pack = None
         self._pack_key = None
         self.gemm_mode = "split_f16"
-        # how conv applications run inside the on-device rollout / position-graph forward
-        # (include/mdno.h MDNO_CONV_*): "factored" = the reference's sums reassociated per node, W_e
-        # never formed (csrc/factored.hip; needs width 64 and a radius graph built by the library,
-        # otherwise the library itself runs materialized); "materialized" = the reference's W_e
-        # formulation; "auto" (default) = factored once the graph is large enough to pay for its fixed
-        # cost per application (edge capacity >= 24,576), materialized below.  forward(data) with an
-        # explicit edge_index/edge_attr always runs materialized.
-        self.conv_mode = "auto"
+        self.conv_mode = "auto"         # as KernelNN.conv_mode
 
 
 # --------------------------------------------------------------------------- graph construction

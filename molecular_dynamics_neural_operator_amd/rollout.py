@@ -32,13 +32,11 @@ def default_edge_cap(members: int, n_atoms: int, threshold: float, density: floa
     return max(members * per_member, members * n_atoms)
 
 
-# conv_mode "auto", decided on the window an engine is reset with: the factored formulation keeps a 256 KiB object
-# per SOURCE NODE and application (Y_j) where the materialised one streams 16 KiB per EDGE, and saves the wide last
-# GEMM of the edge-MLP — it wins from a mean degree of ~40 on (measured on one box: chains of 600-1,300 atoms at
-# 25-30 edges per atom are 3-25 % faster materialised, the 504-atom box at 120 per atom 2.2x faster factored),
-# provided the graph is large enough to fill its launches.  Protein-like chains (10-30 neighbours within 8 A) stay
-# materialised whatever their length; dense boxes go factored.
-AUTO_FACTORED_MIN_DEGREE = 40
+# conv_mode "auto", decided on the window an engine is reset with (include/mdno.h mdno_conv_mode_for_graph: factored
+# from a mean degree of 40 and 16,384 edges per member on — measured on one box: chains of 600-1,300 atoms at 25-30
+# edges per atom are 3-25 % faster materialised, the 504-atom box at 120 per atom 2.2x faster factored).  Protein-like
+# chains (10-30 neighbours within 8 A) stay materialised whatever their length; dense boxes go factored.
+AUTO_FACTORED_MIN_DEGREE = 40          # (probe bounds only: the rule itself lives in the library)
 AUTO_FACTORED_MIN_EDGES = 16384        # per member
 AUTO_MATERIALIZED_MAX_WORKSPACE = 64 << 30
 
@@ -82,6 +80,7 @@ class RolloutEngine:
         self.stream = torch.cuda.Stream(device=dev)
         self.use_graph = bool(use_graph)
         self.steps_done = 0
+        self._sample_first_step = False
         # "auto": what the edge capacity suggests until a window is known; reset() decides on its graph
         self._auto = (getattr(model, "conv_mode", None) if hasattr(model, "param_pack") else self.pack.conv_mode) == "auto"
 
@@ -111,9 +110,10 @@ class RolloutEngine:
     def _resolve_auto(self, e: int, over: bool) -> bool:
         """conv_mode "auto" on the graph of the window's last frame (AUTO_FACTORED_* above).  Returns True if the
         engine changed formulation (its plan must then be rebuilt)."""
-        R = self.M * self.N
-        dense = over or (e >= AUTO_FACTORED_MIN_DEGREE * R and e >= self.M * AUTO_FACTORED_MIN_EDGES)
-        want = "factored" if dense else "materialized"
+        if over:
+            e = max(e, self.M * max(AUTO_FACTORED_MIN_DEGREE * self.N, AUTO_FACTORED_MIN_EDGES))
+        want = {v: k for k, v in _lib.CONV_MODES.items()}[
+            int(self.lib.mdno_conv_mode_for_graph(self.pack.ref, self.M, self.N, int(e)))]
         if want == self.conv_mode:
             return False
         pack = self._pack_for(want)
@@ -173,6 +173,7 @@ class RolloutEngine:
         if new_aa or changed or not self.plan:
             self._create_plan()
         self.steps_done = 0
+        self._sample_first_step = False
 
     def first_step_from_sample(self, edge_index: torch.Tensor, edge_attr: torch.Tensor) -> None:
         """Produce frame W from the start sample's OWN graph and edge attributes, as the reference's
@@ -193,6 +194,7 @@ class RolloutEngine:
         self.edges_per_step[0] = int(edge_index.shape[1])
         torch.cuda.current_stream(self.device).synchronize()
         self.steps_done = 1
+        self._sample_first_step = True
 
     def step(self, steps: int) -> None:
         """Enqueue `steps` more frames on the engine's stream (asynchronous)."""
@@ -224,9 +226,37 @@ class RolloutEngine:
         self.stream.synchronize()
         check(self.lib.mdno_rollout_plan_timer_detach(self.plan), "timer_detach")
 
+    def _grow_and_rerun(self, st: int) -> int:
+        """The radius graph of some step outgrew a capacity that was FITTED to the start window (no `edge_cap` given,
+        N > 256): the reference keeps building the denser graph (graph_kernel.py:363-368), so the engine does too —
+        capacity x4 (at most the complete graph), new workspace and plan, and the steps from the first truncated one
+        on are run again (frames before it are untouched: their graphs fitted).  Returns the new status word."""
+        target = self.steps_done
+        eps = self.edges_per_step[:target].cpu()
+        hit = (eps >= self.edge_cap).nonzero()
+        first = int(hit[0]) if hit.numel() else 0
+        if self._sample_first_step:
+            first = max(first, 1)                # step 0 ran on the sample's own edge list (cannot overflow)
+        old = self.edge_cap
+        self.edge_cap = min(self.M * self.N * self.N, 4 * old)
+        if self._auto:
+            self._resolve_auto(old, False)       # the graph now has at least `old` edges
+        need = self.lib.mdno_rollout_workspace_bytes(self.pack.ref, self.M, self.N, self.edge_cap)
+        self.workspace = None
+        self.workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+        self.status.zero_()
+        torch.cuda.current_stream(self.device).synchronize()
+        self._create_plan()
+        self.steps_done = first
+        self.step(target - first)
+        self.stream.synchronize()
+        return (st & ~STATUS_EDGE_OVERFLOW) | int(self.status.item())
+
     def synchronize(self) -> None:
         self.stream.synchronize()
         st = int(self.status.item())
+        while (st & STATUS_EDGE_OVERFLOW) and self._fit_cap and self.edge_cap < self.M * self.N * self.N:
+            st = self._grow_and_rerun(st)
         if st & STATUS_EDGE_OVERFLOW:
             raise MdnoError(f"radius graph exceeded edge_cap={self.edge_cap}; construct the engine with a larger cap")
         if st & STATUS_DEGREE_OVERFLOW:

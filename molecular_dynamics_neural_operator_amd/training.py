@@ -215,6 +215,25 @@ class DeviceTrajectory:
         self.cols = torch.from_numpy(np.concatenate([c[1] for c in cms]).astype(np.int32)).to(self.device)
         self.x_aminoacid = dataset.x_aminoacid.to(self.device)
         self._aa_tiled = {}
+        # the per-batch index table travels through a ring of PINNED host buffers: the upload is asynchronous, and a
+        # slot is only rewritten once the copy that read it has passed (its event) — a pageable source would have to
+        # be staged synchronously by the runtime to be safe
+        self._meta_ring, self._meta_slot = [], 0
+
+    _META_SLOTS = 4
+
+    def _meta_buffer(self, words: int):
+        if len(self._meta_ring) < self._META_SLOTS:
+            self._meta_ring.append([torch.empty(max(words, 1024), dtype=torch.int64).pin_memory(), None])
+            slot = self._meta_ring[-1]
+        else:
+            slot = self._meta_ring[self._meta_slot]
+            self._meta_slot = (self._meta_slot + 1) % self._META_SLOTS
+            if slot[1] is not None:
+                slot[1].synchronize()
+            if slot[0].numel() < words:
+                slot[0] = torch.empty(words, dtype=torch.int64).pin_memory()
+        return slot
 
     def __len__(self) -> int:
         return self.length
@@ -225,13 +244,16 @@ class DeviceTrajectory:
             raise IndexError(f"sample indices must lie in [0, {self.length})")
         B = int(idx.size)
         cnt = self.counts[idx]
-        meta = np.empty(3 * B + 1, dtype=np.int64)
+        slot = self._meta_buffer(3 * B + 1)
+        meta = slot[0][:3 * B + 1].numpy()
         meta[:B] = idx
         meta[B:2 * B] = self.offsets[idx]
         meta[2 * B] = 0
         np.cumsum(cnt, out=meta[2 * B + 1:])
         E = int(meta[3 * B])
-        meta_d = torch.from_numpy(meta).to(self.device, non_blocking=True)
+        meta_d = slot[0][:3 * B + 1].to(self.device, non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record(torch.cuda.current_stream(self.device))
         xp, y, ei, ea = ops.collate_samples(self.pos, self.rows, self.cols, meta_d, B, self.N, self.W, self.horizon, E,
                                             int(cnt.max()))
         if B not in self._aa_tiled:
@@ -329,6 +351,44 @@ def train_epoch(model, batches, optimizer, loss_fn, batch_size: Optional[int] = 
         losses.append(l2.detach())
         mses.append(F.mse_loss(out.detach(), y))
     check_train_status(model)
+    n = len(losses)
+    if n == 0:
+        return 0.0, 0.0
+    tot = float(torch.stack(losses).double().cpu().sum())
+    tot_mse = float(torch.stack(mses).double().cpu().sum())
+    return tot / n, tot_mse / n
+
+
+def validate_epoch(model, batches, loss_fn, batch_size: Optional[int] = None):
+    """One validation pass — `validate()` of the reference (graph_kernel.py:476-493): `model.eval()`, no autograd,
+    `out = model(batch)` on every batch (lists of PairData or collated batches), returns (avg relative-L2 loss,
+    avg MSE).  The forward is the inference path (B block-diagonal members of one `mdno_kernelnn_fwd`; nothing is
+    kept for a backward, so a pass needs less memory than a training step); losses stay on the device until the
+    pass is over and index errors are raised once, like `train_epoch`."""
+    was_training = model.training
+    model.eval()
+    dev = next(model.parameters()).device
+    if dev.type != "cuda":
+        raise MdnoError("validation needs the model on the GPU (model.to('cuda')); no CPU fallback")
+    status = getattr(model, "_train_status", None)
+    if status is None or status.device != dev:
+        status = model._train_status = torch.zeros(1, dtype=torch.int32, device=dev)
+    losses, mses = [], []
+    try:
+        with torch.no_grad():
+            for batch in batches:
+                if isinstance(batch, PairData):
+                    B = batch_size or getattr(batch, "num_graphs", 1)
+                    y = batch.y.to(dev)
+                else:
+                    B = len(batch)
+                    y = torch.cat([s.y for s in batch]).to(dev)
+                out = model(batch, _status=status)
+                losses.append(loss_fn(out.view(B, -1), y.view(B, -1)))
+                mses.append(F.mse_loss(out, y))
+        check_train_status(model)
+    finally:
+        model.train(was_training)
     n = len(losses)
     if n == 0:
         return 0.0, 0.0

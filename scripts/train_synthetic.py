@@ -23,7 +23,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from molecular_dynamics_neural_operator_amd import synthetic as syn  # noqa: E402
 from molecular_dynamics_neural_operator_amd.dataset import ContactMapDataset, write_trajectory_npz  # noqa: E402
 from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN, LpLoss  # noqa: E402
-from molecular_dynamics_neural_operator_amd.training import DeviceTrajectory, collate, train_epoch, train_forward  # noqa: E402
+from molecular_dynamics_neural_operator_amd.training import DeviceTrajectory, collate, train_epoch, validate_epoch  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, default=2000)
@@ -98,14 +98,8 @@ loss_fn = LpLoss(size_average=False)
 
 
 def validate():
-    model.train()   # differentiable path == same numbers; no dropout/batchnorm in the model
-    tot = 0.0
-    with torch.enable_grad():
-        for vb in vbatches:
-            out = train_forward(model, vb)
-            y = vb.y if traj_dev is not None else torch.cat([s.y for s in vb]).to(dev)
-            tot += float(loss_fn(out.view(B, -1), y.view(B, -1)).item())
-    return tot / max(len(vbatches), 1)
+    """The reference's validate() (graph_kernel.py:476-493): eval mode, no autograd, model(batch) per batch."""
+    return validate_epoch(model, vbatches, loss_fn)[0]
 
 
 summary = {"frames": a.frames, "batch_size": B, "train_batches": len(batches), "edges_per_batch":

@@ -239,6 +239,133 @@ def test_split_f16_hidden_gemm_accuracy_and_range_fallback(dev, live504):
     assert rel(a, c) < 3 * max(rel(b, c), 1e-6) and rel(a, c) < 1e-5, (rel(a, c), rel(b, c))
 
 
+# ------------------------------------------------------------------------------- cfg2 at its stated length
+def test_cfg2_1000_step_rollout_n504(dev, live504):
+    """BASELINE configs[1] as worded: a 1000-step free-running rollout at N=504, full model, one GPU.
+    (a) the benchmark's stationary weights: 1000 steps in one call — finite, every `edges_per_step` written, the
+    neighbour density stays put — equal BITWISE to the same rollout stepped in uneven pieces (single steps, short
+    and long graph-replay runs mixed), and its first 40 frames bitwise to 40 single plain launches;
+    (b) the live weights of the `kernelnn_live504` golden through the reference's call sites (first step on the
+    sample's own graph, then the on-device loop): the first 5 of 1000 frames are the frames `recursive_propagation`
+    returns — which are held to the REFERENCE's free run — and the run stays finite while the cloud contracts from
+    60k edges to the complete graph (E = N^2), i.e. the edge count sweeps its whole range inside one captured step."""
+    from molecular_dynamics_neural_operator_amd import synthetic as syn
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN, recursive_propagation
+    from molecular_dynamics_neural_operator_amd.rollout import RolloutEngine, default_edge_cap
+    from molecular_dynamics_neural_operator_amd.weights import near_identity_state_dict
+    N, W, steps = 504, 10, 1000
+    model = KernelNN(64, 1024, 6, 6, 7, 3, 20, 4)
+    model.load_state_dict(near_identity_state_dict(64, 1024, seed=0, kernel_gain=1e-3, feature_gain=0.1))
+    model.eval().to(dev)
+    win = torch.from_numpy(syn.jitter_window(syn.box_frame(N, seed=1), W, seed=1))
+    aa = torch.from_numpy(syn.amino_acids(N, seed=1))
+    cap = default_edge_cap(1, N, 8.0)
+    eng = RolloutEngine(model, 1, N, W, 8.0, max_steps=steps, edge_cap=cap, device=dev)
+    one = eng.run(win, aa, steps).clone()
+    e_one = eng.edges_per_step.clone()
+    assert eng.conv_mode == "factored" and one.shape == (steps, 1, N, 3) and bool(torch.isfinite(one).all())
+    e = e_one.cpu().numpy()
+    assert e.min() > 0.97 * e[0] and e.max() < 1.03 * e[0] and 55000 < e[0] < 66000, (e[0], e.min(), e.max())
+    assert float((one[-1] - one[0]).abs().max()) > 1e-2                                   # the frames do move
+    eng.reset(win, aa)
+    done = 0
+    for piece in (1, 7, 1, 64, 3, 500, 8, 1, steps):
+        n = min(piece, steps - done)
+        if n:
+            eng.step(n)
+            done += n
+    eng.synchronize()
+    assert torch.equal(eng.frames(), one) and torch.equal(eng.edges_per_step, e_one)
+    eng.close()
+    plain = RolloutEngine(model, 1, N, W, 8.0, max_steps=40, edge_cap=cap, device=dev, use_graph=False)
+    plain.reset(win, aa)
+    for _ in range(40):
+        plain.step(1)
+    plain.synchronize()
+    assert torch.equal(plain.frames(), one[:40]) and torch.equal(plain.edges_per_step, e_one[:40])
+    plain.close()
+
+    # (b) live weights, the reference's call sites
+    z, dset, sd = live504
+    live = KernelNN(*[int(v) for v in z["ctor"]])
+    live.load_state_dict(sd)
+    live.eval().to(dev)
+    live.conv_mode = "factored"
+    thr = float(z["threshold"])
+    fc = recursive_propagation(live, dset, dev, num_steps=5, starting_points=[0], threshold=thr)
+    api = torch.stack([f.x_position[-1] for f in fc])                                      # [5,N,3], golden-checked
+    close(api[0], z["free_frames"][0], name="cfg2 live first frame vs the reference")
+    s0 = dset[0]
+    eng = RolloutEngine(live, 1, N, W, thr, max_steps=steps, edge_cap=N * N, device=dev)
+    eng.reset(s0.x_position.unsqueeze(1), s0.x_aminoacid)
+    eng.first_step_from_sample(s0.edge_index, s0.edge_attr)
+    for piece in (2, 9, 88, steps):
+        n = min(piece, steps - eng.steps_done)
+        if n:
+            eng.step(n)
+    eng.synchronize()
+    fr = eng.frames()
+    assert fr.shape[0] == steps and bool(torch.isfinite(fr).all())
+    assert torch.equal(fr[:5, 0].cpu(), api)
+    e = eng.edges_per_step.cpu().numpy()
+    assert e[0] == s0.edge_index.shape[1] and [int(v) for v in e[1:5]] == [f.edge_index.shape[1] for f in fc[:4]]
+    assert (e > 0).all() and e[49] > 1.5 * e[0] and e[-1] == N * N, (e[:6], e[49], e[-1])
+    eng.close()
+
+
+# ------------------------------------------------------------------------------- a fitted capacity that is outgrown
+def test_recursive_propagation_outgrows_fitted_capacity(dev, O):
+    """A chain of N > 256 atoms gets an edge capacity fitted to its start window (4x its edges, not N^2).  An untrained
+    model pulls the atoms together — the graph becomes complete within a step or two — and the reference simply
+    builds the denser graph (graph_kernel.py:363-368).  So must `recursive_propagation` (which has no edge_cap
+    argument): capacity grown, steps from the first truncated one re-run, results as the oracle's host loop."""
+    from molecular_dynamics_neural_operator_amd import synthetic as syn
+    from molecular_dynamics_neural_operator_amd.dataset import PairData
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN, recursive_propagation
+    from molecular_dynamics_neural_operator_amd.rollout import RolloutEngine
+    from molecular_dynamics_neural_operator_amd._lib import MdnoError
+    N, W, steps, thr = 260, 4, 4, 8.0
+    torch.manual_seed(5)
+    model = KernelNN(64, 128, 2, 6, 7, 3, 20, 4)
+    with torch.no_grad():
+        for p_ in model.conv1.net.layers[4].parameters():
+            p_.mul_(0.2)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.eval().to(dev)
+    win = syn.jitter_window(syn.chain_frame(N, seed=7), W, seed=7)
+    aa = torch.from_numpy(syn.amino_acids(N, seed=7))
+    s0 = O.construct_pairdata(win[:1], aa, thr)                       # a dataset sample: graph of the FIRST frame
+    sample = PairData(x_aminoacid=aa, x_position=torch.from_numpy(win), y=None,
+                      edge_attr=s0["edge_attr"], edge_index=s0["edge_index"])
+    start = dict(x_position=torch.from_numpy(win), x_aminoacid=aa, edge_index=s0["edge_index"], edge_attr=s0["edge_attr"])
+    ref = O.recursive_propagation(sd, 2, start, steps, thr, hoist=True)
+    e_ref = [f["edge_index"].shape[1] for f in ref]
+    e0 = s0["edge_index"].shape[1]
+    assert e_ref[-1] > 6 * e0, (e0, e_ref)                            # the cloud does collapse: far beyond 4x
+    fc = recursive_propagation(model, [sample], dev, num_steps=steps, starting_points=[0], threshold=thr)
+    for k in range(steps):
+        close(fc[k].x_position[-1], ref[k]["x_position"][-1], name=f"outgrown capacity, step {k}")
+        assert fc[k].edge_index.shape[1] == e_ref[k]
+    # the engine itself: same frames, capacity grown, edge counts of the re-run steps recorded
+    eng = RolloutEngine(model, 1, N, W, thr, max_steps=steps, device=dev)
+    eng.reset(torch.from_numpy(win), aa)
+    cap0 = eng.edge_cap
+    assert cap0 < N * N // 2
+    eng.first_step_from_sample(sample.edge_index, sample.edge_attr)
+    eng.step(steps - 1)
+    eng.synchronize()
+    assert eng.edge_cap > cap0 and eng.edges_per_step.cpu().tolist() == [e0] + e_ref[:-1]
+    assert torch.equal(eng.frames()[:, 0].cpu(), torch.stack([f.x_position[-1] for f in fc]))
+    eng.close()
+    # a capacity the CALLER chose is a contract: overflow raises
+    eng = RolloutEngine(model, 1, N, W, thr, max_steps=steps, edge_cap=cap0, device=dev)
+    eng.reset(torch.from_numpy(win), aa)
+    eng.step(steps)
+    with pytest.raises(MdnoError):
+        eng.synchronize()
+    eng.close()
+
+
 # ------------------------------------------------------------------------------- shape A, live fixture (N = 28)
 @pytest.fixture(scope="module")
 def live28(tmp_path_factory):

@@ -478,6 +478,99 @@ def test_device_trajectory_batches_equal_host_collation(dev, tmp_path):
         assert torch.equal(res[0][1][n], res[1][1][n]), n
 
 
+@pytest.mark.parametrize("gemm_mode", ["split_f16", "split_bf16", "f32"])
+def test_validate_epoch_eval_mode_batched_forward(dev, O, tmp_path, gemm_mode):
+    """The reference's validate() (graph_kernel.py:476-493): model.eval(), torch.no_grad(), out = model(batch) on a
+    list of samples.  In eval mode a list / a device-collated batch runs as B block-diagonal members of one inference
+    forward: every sample's rows are BITWISE `model(sample)` on it alone, equal to the training-mode forward to
+    fp32 rounding, the losses are the oracle's validation losses, nothing is kept for a backward (peak memory of a
+    validation pass below that of a training step), and an index error is raised once per pass."""
+    from molecular_dynamics_neural_operator_amd.dataset import ContactMapDataset, PairData
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN, LpLoss
+    from molecular_dynamics_neural_operator_amd.training import DeviceTrajectory, train_forward, validate_epoch
+    z = load_golden("rollout_20.npz")
+    path = tmp_path / "traj.npz"
+    write_golden_trajectory(path, z)
+    dset = ContactMapDataset(str(path), window_size=int(z["window"]), horizon=1)
+    traj = DeviceTrajectory(dset, dev)
+    torch.manual_seed(11)
+    model = KernelNN(64, 128, 2, 6, 7, 3, 20, 4)
+    with torch.no_grad():
+        for p_ in model.conv1.net.layers[4].parameters():
+            p_.mul_(0.2)
+    model.to(dev)
+    model.gemm_mode = gemm_mode
+    model.eval()
+    idx = [0, 7, 19, 7, 12]
+    N = dset[0].x_aminoacid.shape[0]
+    with torch.no_grad():
+        singles = [model(dset[i].to(dev)) for i in idx]
+        out_list = model([dset[i] for i in idx])                        # CPU samples, as a DataListLoader yields them
+        out_dev = model(traj.batch(idx))
+        out_lat, lat = model([dset[i].to(dev) for i in idx], return_latent=True)
+    assert out_list.shape == (len(idx) * N, 3) and lat.shape == (len(idx) * N, 64)
+    assert torch.equal(out_list, torch.cat(singles)) and torch.equal(out_dev, out_list) and torch.equal(out_lat, out_list)
+    assert not dset[0].x_position.is_cuda and not out_list.requires_grad
+    # eval mode under enable_grad still takes the inference path (no autograd state)
+    with torch.enable_grad():
+        assert not model([dset[0], dset[1]]).requires_grad
+    # == the training-mode forward on the same batch, to fp32 rounding (different kernels: fp32 Linear ops there)
+    model.train()
+    with torch.enable_grad():
+        tr = train_forward(model, traj.batch(idx))
+    assert rel_err(out_list, tr) < 2e-6
+    # validate_epoch: the reference's averages (loss per batch via LpLoss(size_average=False), MSE per batch)
+    loss_fn = LpLoss(size_average=False)
+    vb = [[3, 4], [10, 2], [19, 0]]
+    model.eval()
+    got_loss, got_mse = validate_epoch(model, ([dset[i] for i in b] for b in vb), loss_fn)
+    got_loss_d, got_mse_d = validate_epoch(model, (traj.batch(b) for b in vb), loss_fn)
+    assert (got_loss, got_mse) == (got_loss_d, got_mse_d) and not model.training
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    want_loss = want_mse = 0.0
+    for b in vb:
+        outs, ys = [], []
+        for i in b:
+            s = dset[i]
+            outs.append(O.kernelnn_forward(sd, s.x_position, s.x_aminoacid, s.edge_index, s.edge_attr, model.depth, hoist=True))
+            ys.append(s.y)
+        o, y = torch.cat(outs), torch.cat(ys)
+        want_loss += float(O.lp_loss_rel(o.view(2, -1), y.view(2, -1), size_average=False))
+        want_mse += float(F.mse_loss(o, y))
+    assert got_loss == pytest.approx(want_loss / 3, rel=1e-5) and got_mse == pytest.approx(want_mse / 3, rel=1e-5)
+    model.train()
+    validate_epoch(model, [[dset[0]]], loss_fn)
+    assert model.training                                               # the mode it was called in is restored
+    # memory: a validation pass on a batch of 16 stays below a training step on the same batch
+    big = list(range(16))
+    opt = torch.optim.Adam(model.parameters(), lr=1e-5)
+    from molecular_dynamics_neural_operator_amd.training import train_epoch
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    validate_epoch(model, [traj.batch(big)], loss_fn)
+    torch.cuda.synchronize()
+    peak_val = torch.cuda.max_memory_allocated() - base
+    torch.cuda.reset_peak_memory_stats()
+    train_epoch(model, [traj.batch(big)], opt, loss_fn)
+    torch.cuda.synchronize()
+    peak_train = torch.cuda.max_memory_allocated() - base
+    print(f"peak memory above the resident set: validation {peak_val / 2**20:.1f} MiB, training {peak_train / 2**20:.1f} MiB")
+    assert peak_val < peak_train
+    # an amino-acid id outside the table: raised once, at the end of the pass; cleared afterwards
+    bad = dset[0]
+    bad.x_aminoacid = bad.x_aminoacid.clone()
+    bad.x_aminoacid[3] = 20
+    with pytest.raises(IndexError):
+        validate_epoch(model, [[dset[1], bad]], loss_fn)
+    validate_epoch(model, [[dset[1], dset[2]]], loss_fn)
+    with pytest.raises(IndexError):
+        model.eval()
+        with torch.no_grad():
+            model([dset[1], bad])                                       # a direct call checks at once
+
+
+
 def test_training_index_errors_are_deferred_not_lost(dev, tmp_path):
     """The training forward does not wait for the device; an amino-acid id outside the embedding table (the
     reference: IndexError from nn.Embedding inside that forward) is raised by check_train_status / at the end

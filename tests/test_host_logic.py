@@ -95,6 +95,11 @@ def test_no_gpu_means_loud_failure_not_cpu_fallback():
                   torch.from_numpy(z["edge_attr"]), torch.from_numpy(z["edge_index"]))
     with pytest.raises(MdnoError):
         m(pd)
+    with pytest.raises(MdnoError):          # a list of samples (validate(): model(batch)) on a CPU model: no fallback either
+        m([pd, pd])
+    from molecular_dynamics_neural_operator_amd.training import validate_epoch
+    with pytest.raises(MdnoError):
+        validate_epoch(m, [[pd, pd]], LpLoss(size_average=False))
     with pytest.raises(MdnoError):
         construct_pairdata(z["x_position"], None)
     with pytest.raises(MdnoError):

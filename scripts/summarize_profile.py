@@ -102,6 +102,42 @@ for M in (1, 8):
                         "launches_per_application": launches_per_app, "source": f"profiles/{tag}_m{M}_pmc.json"})
 
 
+# shape C (N = 50,000): per-source GEMM per conv application (one launch per 512 sources) and the materialised conv
+# kernel on the 2.0M-edge slice (scripts/run_shape_c.py), same counters and corrections
+pmc_c = {}
+for counter, sub in (("FETCH_SIZE", "pmc_fetch_shape_c"), ("WRITE_SIZE", "pmc_write_shape_c")):
+    files = glob.glob(str(src / sub / "*" / "*_counter_collection.csv"))
+    if not files:
+        continue
+    agg = defaultdict(list)
+    for r in csv.DictReader(open(newest(files))):
+        if r["Counter_Name"] == counter:
+            agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        pmc_c.setdefault(k, {})[counter + "_KB_avg"] = sum(v) / len(v)
+        pmc_c[k][counter + "_launches"] = len(v)
+if pmc_c:
+    for k, d in pmc_c.items():
+        f, w = d.get("FETCH_SIZE_KB_avg"), d.get("WRITE_SIZE_KB_avg")
+        if f is not None and w is not None:
+            d["hbm_bytes_per_launch_corrected"] = 2.0 * f * 1024 + w * 1024
+    (out / f"{tag}_shapeC_pmc.json").write_text(json.dumps(pmc_c, indent=1, sort_keys=True))
+    print("wrote", out / f"{tag}_shapeC_pmc.json")
+    atoms_c = 50000
+    name = next((n for n in pmc_c if n.startswith("gemm_per_source_split_kernel") and "hbm_bytes_per_launch_corrected" in pmc_c[n]), None)
+    if name:
+        lpa = -(-atoms_c // 512)
+        traffic.append({"kernel": "gemm_per_source_split_kernel", "atoms": atoms_c, "members": 1, "conv_mode": "factored",
+                        "gemm_mode": "split_f16", "hbm_bytes_per_launch": pmc_c[name]["hbm_bytes_per_launch_corrected"] * lpa,
+                        "launches_per_application": lpa, "source": f"profiles/{tag}_shapeC_pmc.json"})
+    name = next((n for n in pmc_c if n.startswith("nnconv64_row_kernel") and "hbm_bytes_per_launch_corrected" in pmc_c[n]), None)
+    if name:
+        traffic.append({"kernel": "nnconv64_row_kernel", "atoms": atoms_c, "members": 1, "conv_mode": "materialized",
+                        "gemm_mode": "slice", "hbm_bytes_per_launch": pmc_c[name]["hbm_bytes_per_launch_corrected"],
+                        "launches_per_application": 1, "source": f"profiles/{tag}_shapeC_pmc.json",
+                        "note": "first rows of the 50k-atom graph holding 2.0M edges (scripts/run_shape_c.py, bench.py cfg5 leg)"})
+
+
 def mfma_summary(sub, dest, what, keep):
     """GRBM_GUI_ACTIVE / SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES per launch -> kernel cycles and matrix-pipe occupancy"""
     files = glob.glob(str(src / sub / "*" / "*_counter_collection.csv"))

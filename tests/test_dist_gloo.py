@@ -1,5 +1,6 @@
-"""N>1 path on CPU: world_size-2 gloo processes shard an ensemble by member and collect the
-trajectories with the one all-gather the design uses (rollout.gather_trajectories)."""
+"""N>1 path on CPU: gloo processes (world 2, and world 8 = the node the scaling series runs on) shard an ensemble
+by member and collect the trajectories with the one all-gather the design uses (rollout.gather_trajectories);
+even (64 members over 8 ranks: BASELINE configs[2]) and uneven (61 over 8, 5 over 2) member counts."""
 import os
 import socket
 
@@ -38,16 +39,16 @@ def _worker(rank, world, port, total, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("total", [8, 5])
-def test_member_sharding_and_allgather_world2(total):
+@pytest.mark.parametrize("world,total", [(2, 8), (2, 5), (8, 64), (8, 61), (8, 5)])
+def test_member_sharding_and_allgather(world, total):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in procs)
+    res = sorted(q.get(timeout=300) for _ in procs)
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
-    assert res == [(0, True), (1, True)]
+    assert res == [(r, True) for r in range(world)]

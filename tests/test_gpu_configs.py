@@ -855,6 +855,35 @@ def test_bench_launches_its_own_ranks(dev):
     assert line["config"]["total_members"] == 4 and line["config"]["members_this_rank"] == 2
 
 
+def test_bench_multi_rank_line_schema(dev):
+    """The N > 1 bench line as the driver's scaling series reads it, rehearsed with FOUR ranks on whatever GPUs the
+    box has (a one-GPU box: the ranks share the card, gloo; the box allows six GPU processes at once, this test
+    holds one, so four ranks is what fits — the 8-rank rendezvous itself is rehearsed on CPU in test_dist_gloo.py):
+    default strong scaling over the ensemble, an uneven shard (7 members over 4 ranks), `multi_gpu_timing` per
+    rank, rank 0's `roofline`, and NONE of the single-GPU legs (they belong to the N = 1 line)."""
+    line = _run_bench(["--gpus", "4", "--steps", "2", "--warmup", "1", "--total-members", "7", "--atoms", "28", "--chain",
+                       "--kernel-width", "128", "--depth", "2"])
+    assert line["n_gpus"] == 4 and line["scaling"] == "strong" and line["value"] > 0 and line["higher_is_better"]
+    assert line["metric"] == "rolled-out MD frames/sec" and line["unit"] == "frames/s" and line["dtype"] == "f32"
+    assert line["steps"] == 2 and line["warmup"] == 1 and line["vs_baseline"] is None
+    cfg = line["config"]
+    assert cfg["total_members"] == 7 and cfg["members_this_rank"] == 2 and cfg["members_per_gpu_max"] == 2
+    assert "ensemble-sharded x4" in cfg["parallelism"] and ("gloo" in cfg["parallelism"] or "nccl" in cfg["parallelism"])
+    mg = line["multi_gpu_timing"]
+    assert len(mg["per_rank_steps_ms"]) == 4 and len(mg["per_rank_gather_ms"]) == 4 and all(v > 0 for v in mg["per_rank_steps_ms"])
+    assert mg["gathered_bytes_per_rank"] == 2 * 2 * 28 * 3 * 4
+    # value = all members' frames / the slowest rank's wall time (within the all-gather's overhead of it)
+    assert line["value"] <= 7 * 2 / (max(mg["per_rank_steps_ms"]) * 1e-3) * 1.001
+    assert line["roofline"] is not None and line["roofline"]["bound"] in ("hbm", "mfma") and line["roofline"]["frac"] > 0
+    for leg in ("ensemble64_single_gpu", "baseline_1gpu_same_workload", "cfg2_1000_steps", "cfg4_training", "cfg5_shape_c",
+                "shape_A", "cpu_baseline", "other_conv_mode"):
+        assert line[leg] is None, leg
+    # default member count for N > 1 is BASELINE configs[2]'s 64 (checked without running it: the parser's rule)
+    import bench
+    a = bench.parse(["--gpus", "8"])
+    assert a.total_members is None and bench.ENSEMBLE_MEMBERS == 64
+
+
 NCCL_CHILD = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, os.environ["MDNO_REPO"])

@@ -384,6 +384,37 @@ int mdno_colsum_bf16(const void* a, int64_t rows, int n, float* out, void* works
                      void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Training: the 2*depth conv applications of a step as ONE call each way (graph_kernel.py:299-302 and what autograd
+ * does for them in train(), :445-474) — the same kernels in the same order as 2*depth mdno_nnconv_*_fwd calls and
+ * 2*depth (mdno_relu_bwd2, mdno_nnconv_bwd_x*) pairs, with every ReLU backward below the top one done by the
+ * input-gradient kernel above it (same arithmetic; 2*depth - 1 launches fewer).  Width 64, mean aggregation.
+ *   x_layers f32 [2*depth+1, R, 64]: [0] = the block's input; forward writes [a] = relu(conv(x[a-1])), conv1's
+ *            root/bias for a <= depth, conv2's above.  w_e f32 / bf16 [E,4096] in destination-sorted edge order.
+ *   backward: g_out [R,64] = dLoss/dx[2*depth]; inv_deg [R] (mdno_inv_degree); edges grouped by source as for
+ *            mdno_nnconv_bwd_x.  Writes gz, gs f32 [2*depth, R, 64] (gz[a-1] = g_a * (x[a] > 0), gs = gz * inv_deg:
+ *            the operands of mdno_nnconv_bwd_root / mdno_nnconv_bwd_we*) and g_in [R,64] = dLoss/dx[0].
+ *   mdno_colsum_atb_bf16  colsum [n] = column sums of a bf16 [rows,n] and atb [n,kb] = a^T . b for b fp32 [rows,kb]
+ *            (kb = 6 or 8) in one pass: bias and weight gradient of the edge-MLP's first layer (b = edge_attr);
+ *            n % 8 == 0; workspace mdno_colsum_atb_bf16_workspace_bytes(n, kb).
+ * ---------------------------------------------------------------------------------------- */
+int mdno_nnconv_chain_fwd(float* x_layers, const int32_t* row_ptr, const int32_t* src, int num_rows, const float* w_e,
+                          const float* root1, const float* bias1, const float* root2, const float* bias2, int depth,
+                          void* stream);
+int mdno_nnconv_chain_bwd(const float* g_out, const float* x_layers, const float* inv_deg, const int32_t* row_ptr_s,
+                          const int32_t* eid_s, const int32_t* dst_s, int num_rows, const float* w_e, const float* root1,
+                          const float* root2, int depth, float* gz, float* gs, float* g_in, void* stream);
+int mdno_nnconv_chain_bf16w_fwd(float* x_layers, const int32_t* row_ptr, const int32_t* src, int num_rows,
+                                const void* w_e, const float* root1, const float* bias1, const float* root2,
+                                const float* bias2, int depth, void* stream);
+int mdno_nnconv_chain_bf16w_bwd(const float* g_out, const float* x_layers, const float* inv_deg,
+                                const int32_t* row_ptr_s, const int32_t* eid_s, const int32_t* dst_s, int num_rows,
+                                const void* w_e, const float* root1, const float* root2, int depth, float* gz, float* gs,
+                                float* g_in, void* stream);
+size_t mdno_colsum_atb_bf16_workspace_bytes(int n, int kb);
+int mdno_colsum_atb_bf16(const void* a, const float* b, int64_t rows, int n, int kb, float* colsum, float* atb,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Training: batch assembly on the device (csrc/collate.hip) — replaces, for a trajectory resident in HBM,
  * ContactMapDataset.__getitem__ per sample (dataset.py:180-227, incl. the per-edge attribute loop :194-201)
  * and torch_geometric's DataListLoader / Batch.from_data_list collation (graph_kernel.py:513-519, :454;

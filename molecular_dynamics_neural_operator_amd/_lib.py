@@ -107,6 +107,12 @@ SIGNATURES = {
     "mdno_relu_bwd_bf16": (_I, [_P, _P, _L, _I, _I, _P, _P]),
     "mdno_colsum_bf16_workspace_bytes": (_SZ, [_I]),
     "mdno_colsum_bf16": (_I, [_P, _L, _I, _P, _P, _SZ, _P]),
+    "mdno_nnconv_chain_fwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P]),
+    "mdno_nnconv_chain_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P]),
+    "mdno_nnconv_chain_bf16w_fwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P]),
+    "mdno_nnconv_chain_bf16w_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P]),
+    "mdno_colsum_atb_bf16_workspace_bytes": (_SZ, [_I, _I]),
+    "mdno_colsum_atb_bf16": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _SZ, _P]),
     "mdno_node_prologue_bwd_workspace_bytes": (_SZ, [C.POINTER(KernelNNParams), _I]),
     "mdno_node_prologue_bwd": (_I, [C.POINTER(KernelNNParams), _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _SZ,
                                     _P]),

@@ -12,7 +12,7 @@ mkdir -p "$here/build"
 for f in "${srcs[@]}"; do
   o="$here/build/${f%.hip}.o"
   objs+=("$o")
-  if [[ ! -f "$o" || "$here/$f" -nt "$o" || "$here/common.h" -nt "$o" || "$here/kernels.h" -nt "$o" || "$here/split_layout.h" -nt "$o" || "$here/graph_small.h" -nt "$o" || "$here/mfma_f32.h" -nt "$o" || "$here/../../include/mdno.h" -nt "$o" ]]; then
+  if [[ ! -f "$o" || "$here/$f" -nt "$o" || "$here/common.h" -nt "$o" || "$here/kernels.h" -nt "$o" || "$here/split_layout.h" -nt "$o" || "$here/graph_small.h" -nt "$o" || "$here/mfma_f32.h" -nt "$o" || "$here/reduce.h" -nt "$o" || "$here/../../include/mdno.h" -nt "$o" ]]; then
     "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function \
       -c "$here/$f" -o "$o" "$@" &
     pids+=($!)

@@ -359,7 +359,15 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
     const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= count) return;
     float4 s = *reinterpret_cast<const float4*>(slab + i);
-    for (int z = 1; z < slices; ++z) {
+    int z = 1;
+    for (; z + 4 <= slices; z += 4) {        // four slabs in flight, added in slab order
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(slab + (size_t)(z + u) * count + i);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+    for (; z < slices; ++z) {
         const float4 v = *reinterpret_cast<const float4*>(slab + (size_t)z * count + i);
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }

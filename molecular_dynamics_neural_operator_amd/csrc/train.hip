@@ -13,6 +13,7 @@
 // (no float atomics), so gradients are bitwise reproducible.
 #include "kernels.h"
 #include "mfma_f32.h"
+#include "reduce.h"
 
 namespace mdno {
 namespace {
@@ -250,15 +251,6 @@ __global__ __launch_bounds__(256) void gemm_atb_smalln_kernel(const float* __res
         if (n < N2) part[((size_t)slice * N1 + m) * N2 + n] = s[n];
 }
 
-__global__ __launch_bounds__(256) void reduce_slices_kernel(const float* __restrict__ part, int slices, long long count,
-                                                            float* __restrict__ out, int accumulate) {
-    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (id >= count) return;
-    float s = accumulate ? out[id] : 0.f;
-    for (int k = 0; k < slices; ++k) s += part[(size_t)k * count + id];
-    out[id] = s;
-}
-
 // column sums of A [K,N] in fixed order: part[slice][N] then reduce_slices
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A, float* __restrict__ part, long long K,
                                                      int N, long long kslice) {
@@ -382,11 +374,16 @@ __device__ __forceinline__ void wg_accumulate(float (&acc)[16], const float* __r
         acc[r] = fmaf(w[r].x, gq.x, fmaf(w[r].y, gq.y, fmaf(w[r].z, gq.z, fmaf(w[r].w, gq.w, acc[r]))));
 }
 
+// y_below != NULL: gz_below / gs_below of the application below are written instead of g_prev (mdno_relu_bwd2 fused)
 __global__ __launch_bounds__(256) void nnconv_bwd_x_kernel(const float* __restrict__ gz, const float* __restrict__ gs,
                                                            const int* __restrict__ row_ptr_s,
                                                            const int* __restrict__ eid_s, const int* __restrict__ dst_s,
                                                            const float* __restrict__ w_e, const float* __restrict__ root,
-                                                           float* __restrict__ g_prev, int num_rows) {
+                                                           float* __restrict__ g_prev, int num_rows,
+                                                           const float* __restrict__ y_below = nullptr,
+                                                           const float* __restrict__ inv_deg = nullptr,
+                                                           float* __restrict__ gz_below = nullptr,
+                                                           float* __restrict__ gs_below = nullptr) {
     __shared__ float red[4][64];
     const int row = blockIdx.x;
     if (row >= num_rows) return;
@@ -413,7 +410,17 @@ __global__ __launch_bounds__(256) void nnconv_bwd_x_kernel(const float* __restri
         for (int r = 0; r < 16; ++r) red[wave][16 * g + r] = acc[r];
     }
     __syncthreads();
-    if (tid < 64) g_prev[(size_t)row * 64 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    if (tid < 64) {
+        const float v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        const size_t at = (size_t)row * 64 + tid;
+        if (y_below != nullptr) {
+            const bool on = y_below[at] > 0.f;
+            gz_below[at] = on ? v : 0.f;
+            gs_below[at] = on ? v * inv_deg[row] : 0.f;
+        } else {
+            g_prev[at] = v;
+        }
+    }
 }
 
 // ---------------------------------------------------------------- conv backward: d root, d bias
@@ -602,8 +609,7 @@ extern "C" int mdno_gemm_atb(const float* a, const float* b, int64_t rows, int n
         hipLaunchKernelGGL(gemm_atb_smalln_kernel, dim3((n1 + 255) / 256, kColSlices), dim3(256), 0, s, a, b, part,
                            (long long)rows, n1, n2, ks);
         const long long cnt = (long long)n1 * n2;
-        hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, (const float*)part,
-                           kColSlices, cnt, c, accumulate);
+        launch_reduce_slices((const float*)part, kColSlices, cnt, c, accumulate, s);
         return check_launch("mdno_gemm_atb");
     }
     if (mfma)
@@ -613,8 +619,7 @@ extern "C" int mdno_gemm_atb(const float* a, const float* b, int64_t rows, int n
         hipLaunchKernelGGL(gemm_atb_generic_kernel, dim3((n1 * n2 + 255) / 256, kSlices), dim3(256), 0, s, a, b, part,
                            (long long)rows, n1, n2, kslice);
     const long long count = (long long)n1 * n2;
-    hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, (const float*)part,
-                       kSlices, count, c, accumulate);
+    launch_reduce_slices((const float*)part, kSlices, count, c, accumulate, s);
     return check_launch("mdno_gemm_atb");
 }
 
@@ -631,8 +636,7 @@ extern "C" int mdno_colsum(const float* a, int64_t rows, int n, float* out, int 
     else
         hipLaunchKernelGGL(colsum_kernel, dim3((n + 255) / 256, kColSlices), dim3(256), 0, s, a, part, (long long)rows, n,
                            kslice);
-    hipLaunchKernelGGL(reduce_slices_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const float*)part, kColSlices,
-                       (long long)n, out, accumulate);
+    launch_reduce_slices((const float*)part, kColSlices, (long long)n, out, accumulate, s);
     return check_launch("mdno_colsum");
 }
 
@@ -704,11 +708,9 @@ extern "C" int mdno_nnconv_bwd_root(const float* x, const float* gz, int64_t row
     hipLaunchKernelGGL(nnconv_bwd_root_kernel, dim3(blocks), dim3(256), 0, s, x, gz, (long long)rows, slice_rows,
                        part_root, part_bias);
     if (d_root)
-        hipLaunchKernelGGL(reduce_slices_kernel, dim3(16), dim3(256), 0, s, (const float*)part_root, blocks, 4096ll,
-                           d_root, accumulate);
+        launch_reduce_slices((const float*)part_root, blocks, 4096ll, d_root, accumulate, s);
     if (d_bias)
-        hipLaunchKernelGGL(reduce_slices_kernel, dim3(1), dim3(256), 0, s, (const float*)part_bias, blocks, 64ll, d_bias,
-                           accumulate);
+        launch_reduce_slices((const float*)part_bias, blocks, 64ll, d_bias, accumulate, s);
     return check_launch("mdno_nnconv_bwd_root");
 }
 
@@ -721,4 +723,41 @@ extern "C" int mdno_nnconv_bwd_we(const float* x, const float* gs, const int32_t
                        static_cast<hipStream_t>(stream), x, gs, src, dst, (long long)E, layers, (long long)layer_stride,
                        d_we, accumulate);
     return check_launch("mdno_nnconv_bwd_we");
+}
+
+// ---------------------------------------------------------------- the conv applications of a training step as ONE call
+extern "C" int mdno_nnconv_chain_fwd(float* x_layers, const int32_t* row_ptr, const int32_t* src, int num_rows,
+                                     const float* w_e, const float* root1, const float* bias1, const float* root2,
+                                     const float* bias2, int depth, void* stream) {
+    MDNO_REQUIRE(x_layers && row_ptr && src && w_e && num_rows > 0 && depth > 0, MDNO_EINVAL,
+                 "mdno_nnconv_chain_fwd: bad arguments");
+    const size_t stride = (size_t)num_rows * 64;
+    for (int a = 1; a <= 2 * depth; ++a)
+        MDNO_TRY(mdno_nnconv_fwd(x_layers + (a - 1) * stride, row_ptr, src, num_rows, w_e, a <= depth ? root1 : root2,
+                                 a <= depth ? bias1 : bias2, 64, 64, MDNO_AGGR_MEAN, 1, x_layers + a * stride, stream));
+    return MDNO_OK;
+}
+
+extern "C" int mdno_nnconv_chain_bwd(const float* g_out, const float* x_layers, const float* inv_deg,
+                                     const int32_t* row_ptr_s, const int32_t* eid_s, const int32_t* dst_s, int num_rows,
+                                     const float* w_e, const float* root1, const float* root2, int depth, float* gz,
+                                     float* gs, float* g_in, void* stream) {
+    MDNO_REQUIRE(g_out && x_layers && inv_deg && row_ptr_s && eid_s && dst_s && w_e && gz && gs && g_in && num_rows > 0 &&
+                     depth > 0, MDNO_EINVAL, "mdno_nnconv_chain_bwd: bad arguments");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int L = 2 * depth;
+    const size_t stride = (size_t)num_rows * 64;
+    MDNO_TRY(mdno_relu_bwd2(g_out, x_layers + L * stride, inv_deg, num_rows, 64, gz + (L - 1) * stride, gs + (L - 1) * stride,
+                            stream));
+    for (int a = L; a >= 1; --a) {
+        const float* root = a <= depth ? root1 : root2;
+        if (a > 1)
+            hipLaunchKernelGGL(nnconv_bwd_x_kernel, dim3(num_rows), dim3(256), 0, s, gz + (a - 1) * stride, gs + (a - 1) * stride,
+                               row_ptr_s, eid_s, dst_s, w_e, root, (float*)nullptr, num_rows, x_layers + (a - 1) * stride,
+                               inv_deg, gz + (a - 2) * stride, gs + (a - 2) * stride);
+        else
+            hipLaunchKernelGGL(nnconv_bwd_x_kernel, dim3(num_rows), dim3(256), 0, s, gz, gs, row_ptr_s, eid_s, dst_s, w_e, root,
+                               g_in, num_rows, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+    }
+    return check_launch("mdno_nnconv_chain_bwd");
 }

@@ -15,6 +15,7 @@
 //   relu_bwd_bf16, colsum_bf16   the elementwise / reduction ops on bf16 operands
 // Reductions keep fixed-order partial sums (no float atomics): gradients are bitwise reproducible.
 #include "kernels.h"
+#include "reduce.h"
 
 namespace mdno {
 namespace {
@@ -328,15 +329,6 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const __bf16* __restr
     }
 }
 
-__global__ __launch_bounds__(256) void reduce_slices_bf16path_kernel(const float* __restrict__ part, int slices,
-                                                                     long long count, float* __restrict__ out) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= count) return;
-    float s = 0.f;
-    for (int k = 0; k < slices; ++k) s += part[(size_t)k * count + i];     // fixed order
-    out[i] = s;
-}
-
 // ---------------------------------------------------------------- conv forward, bf16 W_e
 // nnconv64_row_kernel (nnconv.hip) with 8-B loads of four bf16: same lane map (lane (g,q) owns input rows
 // 16g..16g+15 x output columns 4q..4q+3), same 16 summation chains, fp32 accumulation.
@@ -438,13 +430,20 @@ __device__ __forceinline__ void wg_acc(float (&acc)[16], const WT* __restrict__ 
         acc[r] = fmaf(w[r].x, gq.x, fmaf(w[r].y, gq.y, fmaf(w[r].z, gq.z, fmaf(w[r].w, gq.w, acc[r]))));
 }
 
+// y_below != NULL: the gradient leaves through the ReLU of the application below (whose output is y_below) —
+// gz_below = g_prev * (y_below > 0), gs_below = gz_below * inv_deg[row] are written instead of g_prev: what
+// mdno_relu_bwd2 would make of g_prev in a launch of its own, same arithmetic
 __global__ __launch_bounds__(256) void nnconv_bwd_x_bf16w_kernel(const float* __restrict__ gz, const float* __restrict__ gs,
                                                                  const int* __restrict__ row_ptr_s,
                                                                  const int* __restrict__ eid_s,
                                                                  const int* __restrict__ dst_s,
                                                                  const __bf16* __restrict__ w_e,
                                                                  const float* __restrict__ root,
-                                                                 float* __restrict__ g_prev, int num_rows) {
+                                                                 float* __restrict__ g_prev, int num_rows,
+                                                                 const float* __restrict__ y_below = nullptr,
+                                                                 const float* __restrict__ inv_deg = nullptr,
+                                                                 float* __restrict__ gz_below = nullptr,
+                                                                 float* __restrict__ gs_below = nullptr) {
     __shared__ float red[4][64];
     const int row = blockIdx.x;
     if (row >= num_rows) return;
@@ -467,7 +466,92 @@ __global__ __launch_bounds__(256) void nnconv_bwd_x_bf16w_kernel(const float* __
         for (int r = 0; r < 16; ++r) red[wave][16 * g + r] = acc[r];
     }
     __syncthreads();
-    if (tid < 64) g_prev[(size_t)row * 64 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    if (tid < 64) {
+        const float v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        const size_t at = (size_t)row * 64 + tid;
+        if (y_below != nullptr) {
+            const bool on = y_below[at] > 0.f;
+            gz_below[at] = on ? v : 0.f;
+            gs_below[at] = on ? v * inv_deg[row] : 0.f;
+        } else {
+            g_prev[at] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- column sums + A^T.B for a few fp32 columns
+// colsum[n] = sum_r a[r][n] and atb[n][j] = sum_r a[r][n] * b[r][j] (j < KB <= 8) in ONE pass over a bf16 [rows,n]:
+// the bias and weight gradient of the edge-MLP's FIRST layer (b = the fp32 edge attributes, 6 columns), which were a
+// column-sum pass plus a 128-column zero-padded bf16 A^T.B over the same 89 MB.  Same slicing as colsum_bf16_kernel.
+template <int KB>
+__global__ __launch_bounds__(256) void colsum_atb_bf16_kernel(const __bf16* __restrict__ a, const float* __restrict__ b,
+                                                              float* __restrict__ part, long long rows, int n,
+                                                              long long slice_rows) {
+    __shared__ float red[4][64][8];
+    const int cg = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int col = blockIdx.x * 512 + cg * 8;
+    const long long r0 = (long long)blockIdx.y * slice_rows;
+    long long r1 = r0 + slice_rows;
+    if (r1 > rows) r1 = rows;
+    float s[KB + 1][8];
+#pragma unroll
+    for (int m = 0; m <= KB; ++m)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[m][j] = 0.f;
+    if (col < n) {
+        auto add = [&](const uint4& u, const float (&bv)[KB]) {
+            const unsigned w[4] = {u.x, u.y, u.z, u.w};
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[2 * j] = __builtin_bit_cast(float, w[j] << 16);
+                v[2 * j + 1] = __builtin_bit_cast(float, w[j] & 0xffff0000u);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                s[0][j] += v[j];
+#pragma unroll
+                for (int m = 0; m < KB; ++m) s[m + 1][j] = fmaf(v[j], bv[m], s[m + 1][j]);
+            }
+        };
+        for (long long r = r0 + rl; r < r1; r += 8) {       // two of this wave's rows in flight
+            const bool two = r + 4 < r1;
+            const uint4 u0 = *reinterpret_cast<const uint4*>(a + (size_t)r * n + col);
+            const uint4 u1 = two ? *reinterpret_cast<const uint4*>(a + (size_t)(r + 4) * n + col) : make_uint4(0, 0, 0, 0);
+            float b0[KB], b1[KB];
+#pragma unroll
+            for (int m = 0; m < KB; ++m) {
+                b0[m] = b[(size_t)r * KB + m];
+                b1[m] = two ? b[(size_t)(r + 4) * KB + m] : 0.f;
+            }
+            add(u0, b0);
+            if (two) add(u1, b1);
+        }
+    }
+    // four row phases combined in phase order, one quantity at a time (8 KiB of LDS)
+    for (int m = 0; m <= KB; ++m) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[rl][cg][j] = s[m][j];
+        __syncthreads();
+        if (rl == 0 && col < n) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                part[((size_t)blockIdx.y * (KB + 1) + m) * n + col + j] =
+                    (red[0][cg][j] + red[1][cg][j]) + (red[2][cg][j] + red[3][cg][j]);
+        }
+    }
+}
+
+// out[n][KB] <- reduced [KB][n] (columns of atb), colsum <- row 0
+template <int KB>
+__global__ __launch_bounds__(256) void colsum_atb_finish_kernel(const float* __restrict__ red, int n, float* __restrict__ colsum,
+                                                                float* __restrict__ atb) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n) return;
+    colsum[c] = red[c];
+#pragma unroll
+    for (int m = 0; m < KB; ++m) atb[(size_t)c * KB + m] = red[(size_t)(m + 1) * n + c];
 }
 
 // ---------------------------------------------------------------- d W_e as bf16
@@ -532,16 +616,25 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const __bf16* __restri
     float s[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) s[j] = 0.f;
-    if (col < n)
-        for (long long r = r0 + rl; r < r1; r += 4) {
-            const uint4 u = *reinterpret_cast<const uint4*>(a + (size_t)r * n + col);
+    if (col < n) {
+        auto add = [&](const uint4& u) {
             const unsigned w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 s[2 * j] += __builtin_bit_cast(float, w[j] << 16);
                 s[2 * j + 1] += __builtin_bit_cast(float, w[j] & 0xffff0000u);
             }
+        };
+        long long r = r0 + rl;
+        for (; r + 12 < r1; r += 16) {       // four of this thread's rows in flight (same rows, same order)
+            uint4 u[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) u[v] = *reinterpret_cast<const uint4*>(a + (size_t)(r + 4 * v) * n + col);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) add(u[v]);
         }
+        for (; r < r1; r += 4) add(*reinterpret_cast<const uint4*>(a + (size_t)r * n + col));
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) red[rl][cg][j] = s[j];
     __syncthreads();
@@ -651,8 +744,7 @@ extern "C" int mdno_gemm_atb_bf16(const void* a, const void* b, int64_t rows, in
                        static_cast<const __bf16*>(a), static_cast<const __bf16*>(b), static_cast<float*>(workspace),
                        (long long)rows, n1, n2, slice_rows);
     const long long count = (long long)n1 * n2;
-    hipLaunchKernelGGL(reduce_slices_bf16path_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s,
-                       static_cast<const float*>(workspace), kTnSlices, count, c);
+    launch_reduce_slices(static_cast<const float*>(workspace), kTnSlices, count, c, 0, s);
     return check_launch("gemm_tn_bf16_kernel");
 }
 
@@ -719,7 +811,76 @@ extern "C" int mdno_colsum_bf16(const void* a, int64_t rows, int n, float* out, 
     MDNO_REQUIRE(n % 8 == 0 && (reinterpret_cast<uintptr_t>(a) & 15) == 0, MDNO_EUNSUPPORTED, "mdno_colsum_bf16: n=%d (x8)", n);
     hipLaunchKernelGGL(colsum_bf16_kernel, dim3((n + 511) / 512, kColSlicesB), dim3(256), 0, s, static_cast<const __bf16*>(a),
                        static_cast<float*>(workspace), (long long)rows, n, slice_rows);
-    hipLaunchKernelGGL(reduce_slices_bf16path_kernel, dim3((n + 255) / 256), dim3(256), 0, s,
-                       static_cast<const float*>(workspace), kColSlicesB, (long long)n, out);
+    launch_reduce_slices(static_cast<const float*>(workspace), kColSlicesB, (long long)n, out, 0, s);
     return check_launch("colsum_bf16_kernel");
+}
+
+// ---------------------------------------------------------------- the conv applications of a training step as ONE call
+extern "C" int mdno_nnconv_chain_bf16w_fwd(float* x_layers, const int32_t* row_ptr, const int32_t* src, int num_rows,
+                                           const void* w_e, const float* root1, const float* bias1, const float* root2,
+                                           const float* bias2, int depth, void* stream) {
+    MDNO_REQUIRE(x_layers && row_ptr && src && w_e && num_rows > 0 && depth > 0, MDNO_EINVAL,
+                 "mdno_nnconv_chain_bf16w_fwd: bad arguments");
+    const size_t stride = (size_t)num_rows * 64;
+    for (int a = 1; a <= 2 * depth; ++a)
+        MDNO_TRY(mdno_nnconv_bf16w_fwd(x_layers + (a - 1) * stride, row_ptr, src, num_rows, w_e, a <= depth ? root1 : root2,
+                                       a <= depth ? bias1 : bias2, MDNO_AGGR_MEAN, 1, x_layers + a * stride, stream));
+    return MDNO_OK;
+}
+
+extern "C" int mdno_nnconv_chain_bf16w_bwd(const float* g_out, const float* x_layers, const float* inv_deg,
+                                           const int32_t* row_ptr_s, const int32_t* eid_s, const int32_t* dst_s,
+                                           int num_rows, const void* w_e, const float* root1, const float* root2, int depth,
+                                           float* gz, float* gs, float* g_in, void* stream) {
+    MDNO_REQUIRE(g_out && x_layers && inv_deg && row_ptr_s && eid_s && dst_s && w_e && gz && gs && g_in && num_rows > 0 &&
+                     depth > 0, MDNO_EINVAL, "mdno_nnconv_chain_bf16w_bwd: bad arguments");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int L = 2 * depth;
+    const size_t stride = (size_t)num_rows * 64;
+    // the gradient enters through the ReLU of application L; every later ReLU is the epilogue of the kernel above it
+    MDNO_TRY(mdno_relu_bwd2(g_out, x_layers + L * stride, inv_deg, num_rows, 64, gz + (L - 1) * stride, gs + (L - 1) * stride,
+                            stream));
+    for (int a = L; a >= 1; --a) {
+        const float* root = a <= depth ? root1 : root2;
+        if (a > 1)
+            hipLaunchKernelGGL(nnconv_bwd_x_bf16w_kernel, dim3(num_rows), dim3(256), 0, s, gz + (a - 1) * stride,
+                               gs + (a - 1) * stride, row_ptr_s, eid_s, dst_s, static_cast<const __bf16*>(w_e), root,
+                               (float*)nullptr, num_rows, x_layers + (a - 1) * stride, inv_deg, gz + (a - 2) * stride,
+                               gs + (a - 2) * stride);
+        else
+            hipLaunchKernelGGL(nnconv_bwd_x_bf16w_kernel, dim3(num_rows), dim3(256), 0, s, gz, gs, row_ptr_s, eid_s, dst_s,
+                               static_cast<const __bf16*>(w_e), root, g_in, num_rows, (const float*)nullptr,
+                               (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+    }
+    return check_launch("mdno_nnconv_chain_bf16w_bwd");
+}
+
+extern "C" size_t mdno_colsum_atb_bf16_workspace_bytes(int n, int kb) {
+    return align_up((size_t)(kColSlicesB + 1) * (size_t)(kb + 1) * n * sizeof(float), 256);
+}
+
+extern "C" int mdno_colsum_atb_bf16(const void* a, const float* b, int64_t rows, int n, int kb, float* colsum, float* atb,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+    MDNO_REQUIRE(a && b && colsum && atb && workspace && rows > 0 && n > 0, MDNO_EINVAL, "mdno_colsum_atb_bf16: bad arguments");
+    MDNO_REQUIRE(n % 8 == 0 && (kb == 6 || kb == 8) && (reinterpret_cast<uintptr_t>(a) & 15) == 0, MDNO_EUNSUPPORTED,
+                 "mdno_colsum_atb_bf16: n=%d (x8), kb=%d (6 or 8)", n, kb);
+    MDNO_REQUIRE(workspace_bytes >= mdno_colsum_atb_bf16_workspace_bytes(n, kb), MDNO_EWORKSPACE,
+                 "mdno_colsum_atb_bf16: workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long long slice_rows = (rows + kColSlicesB - 1) / kColSlicesB;
+    float* part = static_cast<float*>(workspace);
+    float* red = part + (size_t)kColSlicesB * (kb + 1) * n;
+    const dim3 grid((n + 511) / 512, kColSlicesB);
+    if (kb == 6)
+        hipLaunchKernelGGL(colsum_atb_bf16_kernel<6>, grid, dim3(256), 0, s, static_cast<const __bf16*>(a), b, part,
+                           (long long)rows, n, slice_rows);
+    else
+        hipLaunchKernelGGL(colsum_atb_bf16_kernel<8>, grid, dim3(256), 0, s, static_cast<const __bf16*>(a), b, part,
+                           (long long)rows, n, slice_rows);
+    launch_reduce_slices(part, kColSlicesB, (long long)(kb + 1) * n, red, 0, s);
+    if (kb == 6)
+        hipLaunchKernelGGL(colsum_atb_finish_kernel<6>, dim3((n + 255) / 256), dim3(256), 0, s, (const float*)red, n, colsum, atb);
+    else
+        hipLaunchKernelGGL(colsum_atb_finish_kernel<8>, dim3((n + 255) / 256), dim3(256), 0, s, (const float*)red, n, colsum, atb);
+    return check_launch("mdno_colsum_atb_bf16");
 }

@@ -6,16 +6,18 @@
 //
 // One thread per atom walks its own LSTM backward through time: the forward is replayed once keeping
 // (h_t, c_t) of every window step in registers (6 floats x W <= 16), each backward step rebuilds its gates
-// from x_t and h_{t-1}.  Parameter gradients are summed over atoms in a FIXED order — butterfly inside a
-// wave, waves in order through LDS, workgroups in order by a second kernel — so they are bitwise
-// reproducible (no float atomics); the embedding gradient, a scatter by residue type, is gathered per
-// table entry in atom order.
+// from x_t and h_{t-1}.  A workgroup is ONE wave = 64 atoms (round 4; it was 256 atoms = 14 workgroups for a
+// cfg4 batch, each thread walking row-strided global loads one round trip at a time: 154 us): the wave's
+// 64 x 64 tile of g0 * (x0 > 0) is brought to LDS by whole-row loads and every later loop reads LDS.
+// Parameter gradients are summed over atoms in a FIXED order — butterfly inside the wave, workgroups in
+// order by a second kernel — so they are bitwise reproducible (no float atomics); the embedding gradient, a
+// scatter by residue type, is gathered per table entry in atom order.
 #include "kernels.h"
 
 namespace mdno {
 namespace {
 
-constexpr int H = 3, MAX_W = 16, MAX_EMB = 16, ROWS = 256;   // atoms per workgroup
+constexpr int H = 3, MAX_W = 16, MAX_EMB = 16, ROWS = 64;   // atoms (rows) per workgroup
 constexpr int N_LSTM = 4 * H * H * 2 + 4 * H + H * H + H;     // w_ih 36 | w_hh 36 | bias 12 (b_ih and b_hh share it) | fc_w 9 | fc_b 3 = 96
 
 __device__ __forceinline__ float sigm(float v) { return 1.0f / (1.0f + expf(-v)); }
@@ -43,13 +45,17 @@ struct PrologueBwdArgs {
     int stride;
 };
 
+template <int EMB>      // compile-time bound on emb_dim (a multiple of 4)
 __global__ __launch_bounds__(ROWS) void node_prologue_bwd_kernel(PrologueBwdArgs a) {
+    __shared__ float gz_s[ROWS][65];                   // g0 * (x0 > 0): this wave's atoms x 64 output columns of a pass
+    __shared__ float w_s[64][EMB + H + 1];             // the pass's 64 rows of fc1_w, zero-padded
+    __shared__ float red_s[ROWS][N_LSTM + 1];          // per-atom LSTM parameter gradients, summed by column
     __shared__ float feat_s[ROWS][MAX_EMB + H];        // the fc1 input of every atom of this workgroup
     __shared__ float dfeat_s[ROWS][MAX_EMB];           // its gradient wrt the embedding part
     __shared__ int aa_s[ROWS];
-    __shared__ float red[4];
-    const int tid = threadIdx.x;
-    const int r = blockIdx.x * ROWS + tid;
+    const int tid = threadIdx.x;                       // = lane: the workgroup is one wave
+    const int rbase = blockIdx.x * ROWS;
+    const int r = rbase + tid;
     const bool live = r < a.R;
     const int in_w = a.emb_dim + H;
     const bool lstm = a.w_ih != nullptr;
@@ -126,36 +132,123 @@ __global__ __launch_bounds__(ROWS) void node_prologue_bwd_kernel(PrologueBwdArgs
 #pragma unroll
         for (int k = 0; k < H; ++k) feat[MAX_EMB + k] = p[k];
     }
-    // ---- d feat = fc1_w^T . (g0 * (x0 > 0))
-    float dfeat[MAX_EMB + H];
 #pragma unroll
-    for (int i = 0; i < MAX_EMB + H; ++i) dfeat[i] = 0.f;
-    if (live) {
-        const float* gr = a.g0 + (size_t)r * a.width;
-        const float* xr = a.x0 + (size_t)r * a.width;
-        for (int o = 0; o < a.width; ++o) {
-            const float gz = xr[o] > 0.f ? gr[o] : 0.f;
-            const float* w = a.fc1_w + (size_t)o * in_w;
-            for (int e = 0; e < a.emb_dim; ++e) dfeat[e] = fmaf(gz, w[e], dfeat[e]);
+    for (int i = 0; i < MAX_EMB + H; ++i) feat_s[tid][i] = live ? feat[i] : 0.f;
+    aa_s[tid] = live ? (int)id : -1;
+
+    // ---- fc1 backward, 64 output columns per pass: gz tile -> LDS (whole 256-B row segments, every load of the pass
+    //      in flight at once), then d feat = fc1_w^T . gz (thread = atom) and d fc1_w, d fc1_b (thread = output
+    //      column, atoms in order).  EMB (template) bounds emb_dim at compile time: the inner loops are straight code.
+    float dfeat[EMB + H];
 #pragma unroll
-            for (int k = 0; k < H; ++k) dfeat[MAX_EMB + k] = fmaf(gz, w[a.emb_dim + k], dfeat[MAX_EMB + k]);
+    for (int i = 0; i < EMB + H; ++i) dfeat[i] = 0.f;
+    const int n_emb = a.num_emb * a.emb_dim;
+    float* Pw = P + N_LSTM + n_emb;
+    float* Pb = Pw + (size_t)a.width * in_w;
+    for (int o0 = 0; o0 < a.width; o0 += 64) {
+        const int o = o0 + tid;
+        const int ncol = a.width - o0 < 64 ? a.width - o0 : 64;
+        __syncthreads();
+        // this pass's rows of fc1_w, zero-padded to EMB + H columns (broadcast reads below)
+        {
+            float wrow[EMB + H];
+#pragma unroll
+            for (int i = 0; i < EMB + H; ++i) wrow[i] = 0.f;
+            if (o < a.width) {
+#pragma unroll
+                for (int e = 0; e < EMB; ++e)
+                    if (e < a.emb_dim) wrow[e] = a.fc1_w[(size_t)o * in_w + e];
+#pragma unroll
+                for (int k = 0; k < H; ++k) wrow[EMB + k] = a.fc1_w[(size_t)o * in_w + a.emb_dim + k];
+            }
+#pragma unroll
+            for (int i = 0; i < EMB + H; ++i) w_s[tid][i] = wrow[i];
+        }
+        if ((a.width & 3) == 0 && ncol == 64) {
+            // lane (row group rg = lane >> 4, column quad c4 = lane & 15) x 16 rows: 32 float4 loads in flight
+            const int rg = tid >> 4, c4 = tid & 15;
+            float4 xv[16], gv[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int rr = rbase + rg + 4 * j;
+                const size_t at = (size_t)(rr < a.R ? rr : a.R - 1) * a.width + o0 + 4 * c4;
+                xv[j] = *reinterpret_cast<const float4*>(a.x0 + at);
+                gv[j] = *reinterpret_cast<const float4*>(a.g0 + at);
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const bool in = rbase + rg + 4 * j < a.R;
+                float* d = &gz_s[rg + 4 * j][4 * c4];
+                d[0] = in && xv[j].x > 0.f ? gv[j].x : 0.f;
+                d[1] = in && xv[j].y > 0.f ? gv[j].y : 0.f;
+                d[2] = in && xv[j].z > 0.f ? gv[j].z : 0.f;
+                d[3] = in && xv[j].w > 0.f ? gv[j].w : 0.f;
+            }
+        } else {
+#pragma unroll 8
+            for (int q = 0; q < ROWS; ++q) {
+                const int rr = rbase + q;
+                float v = 0.f;
+                if (rr < a.R && o < a.width) {
+                    const size_t at = (size_t)rr * a.width + o;
+                    v = a.x0[at] > 0.f ? a.g0[at] : 0.f;
+                }
+                gz_s[q][tid] = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int oo = 0; oo < ncol; ++oo) {
+            const float gz = gz_s[tid][oo];
+#pragma unroll
+            for (int i = 0; i < EMB + H; ++i) dfeat[i] = fmaf(gz, w_s[oo][i], dfeat[i]);
+        }
+        float acc[EMB + H + 1];
+#pragma unroll
+        for (int i = 0; i <= EMB + H; ++i) acc[i] = 0.f;
+#pragma unroll 4
+        for (int q = 0; q < ROWS; ++q) {
+            const float gz = gz_s[q][tid];
+#pragma unroll
+            for (int i = 0; i < EMB; ++i) acc[i] = fmaf(gz, feat_s[q][i], acc[i]);
+#pragma unroll
+            for (int k = 0; k < H; ++k) acc[EMB + k] = fmaf(gz, feat_s[q][MAX_EMB + k], acc[EMB + k]);
+            acc[EMB + H] += gz;
+        }
+        if (o < a.width) {
+#pragma unroll
+            for (int i = 0; i < EMB; ++i)
+                if (i < a.emb_dim) Pw[(size_t)o * in_w + i] = acc[i];
+#pragma unroll
+            for (int k = 0; k < H; ++k) Pw[(size_t)o * in_w + a.emb_dim + k] = acc[EMB + k];
+            Pb[o] = acc[EMB + H];
         }
     }
 #pragma unroll
-    for (int i = 0; i < MAX_EMB + H; ++i) feat_s[tid][i] = live ? feat[i] : 0.f;
-#pragma unroll
-    for (int e = 0; e < MAX_EMB; ++e) dfeat_s[tid][e] = live ? dfeat[e] : 0.f;
-    aa_s[tid] = live ? (int)id : -1;
+    for (int e = 0; e < MAX_EMB; ++e) dfeat_s[tid][e] = (live && e < EMB) ? dfeat[e < EMB ? e : 0] : 0.f;
+    __syncthreads();
+    // embedding: entry (row, col) adds the atoms of its residue type in atom order
+    for (int j = tid; j < n_emb; j += ROWS) {
+        const int row = j / a.emb_dim, col = j - row * a.emb_dim;
+        float s = 0.f;
+#pragma unroll 8
+        for (int q = 0; q < ROWS; ++q) {
+            const float v = dfeat_s[q][col];
+            s += aa_s[q] == row ? v : 0.f;
+        }
+        P[N_LSTM + j] = s;
+    }
 
     // ---- LSTM + lstm_fc backward for this atom; per-thread parameter gradients
+    if (!lstm) return;
     float glstm[N_LSTM];
 #pragma unroll
     for (int i = 0; i < N_LSTM; ++i) glstm[i] = 0.f;
-    if (lstm && live) {
+    if (live) {
         float dh[H] = {0.f, 0.f, 0.f}, dc[H] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < H; ++k) {        // feat[4+k] = fc_b[k] + sum_j fc_w[k][j] h_W[j]
-            const float d = dfeat[MAX_EMB + k];
+            const float d = dfeat[EMB + k];
             glstm[93 + k] = d;
 #pragma unroll
             for (int j = 0; j < H; ++j) {
@@ -197,56 +290,17 @@ __global__ __launch_bounds__(ROWS) void node_prologue_bwd_kernel(PrologueBwdArgs
             }
         }
     }
-    // ---- reduce over the workgroup, fixed order
-    if (lstm) {
+    // ---- sum over the wave's atoms in atom order: lane i adds column i (and i + 64) of the per-atom gradients
 #pragma unroll
-        for (int i = 0; i < N_LSTM; ++i) {
-            const float s = block_sum(glstm[i], red);
-            if (tid == 0) P[i] = s;
-        }
-    }
+    for (int i = 0; i < N_LSTM; ++i) red_s[tid][i] = glstm[i];
     __syncthreads();
-    // embedding: entry (row, col) adds the atoms of its residue type in atom order
-    const int n_emb = a.num_emb * a.emb_dim;
-    for (int j = tid; j < n_emb; j += ROWS) {
-        const int row = j / a.emb_dim, col = j - row * a.emb_dim;
-        float s = 0.f;
-        for (int q = 0; q < ROWS; ++q)
-            if (aa_s[q] == row) s += dfeat_s[q][col];
-        P[N_LSTM + j] = s;
-    }
-    // fc1: thread (o, quarter) sums gz[r][o] * feat[r][:] over its 64 atoms; quarters added in order
-    float* Pw = P + N_LSTM + n_emb;
-    float* Pb = Pw + (size_t)a.width * in_w;
-    for (int o0 = 0; o0 < a.width; o0 += 64) {
-        const int o = o0 + (tid & 63), part = tid >> 6;
-        float acc[MAX_EMB + H + 1];
-#pragma unroll
-        for (int i = 0; i <= MAX_EMB + H; ++i) acc[i] = 0.f;
-        if (o < a.width) {
-            for (int q = part * 64; q < part * 64 + 64; ++q) {
-                const int rr = blockIdx.x * ROWS + q;
-                if (rr >= a.R) break;
-                const float gz = a.x0[(size_t)rr * a.width + o] > 0.f ? a.g0[(size_t)rr * a.width + o] : 0.f;
-#pragma unroll
-                for (int i = 0; i < MAX_EMB + H; ++i) acc[i] = fmaf(gz, feat_s[q][i], acc[i]);
-                acc[MAX_EMB + H] += gz;
-            }
-        }
-        // 4-way combine through LDS, one value per (quarter, o), quarters in order
-        __shared__ float comb[4][64];
-        for (int i = 0; i <= MAX_EMB + H; ++i) {
-            const bool used = i < a.emb_dim || (i >= MAX_EMB && i < MAX_EMB + H) || i == MAX_EMB + H;
-            if (!used) continue;                       // uniform
-            __syncthreads();
-            comb[part][tid & 63] = acc[i];
-            __syncthreads();
-            if (part == 0 && o < a.width) {
-                const float s = (comb[0][tid] + comb[1][tid]) + (comb[2][tid] + comb[3][tid]);
-                if (i == MAX_EMB + H) Pb[o] = s;
-                else Pw[(size_t)o * in_w + (i < MAX_EMB ? i : a.emb_dim + (i - MAX_EMB))] = s;
-            }
-        }
+    {
+        float s0 = 0.f, s1 = 0.f;
+        const int c1 = tid < N_LSTM - 64 ? 64 + tid : 64;
+#pragma unroll 8
+        for (int q = 0; q < ROWS; ++q) { s0 += red_s[q][tid]; s1 += red_s[q][c1]; }
+        P[tid] = s0;
+        if (tid < N_LSTM - 64) P[64 + tid] = s1;
     }
 }
 
@@ -256,7 +310,8 @@ __global__ __launch_bounds__(256) void reduce_blocks_kernel(const float* __restr
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= count) return;
     float s = 0.f;
-    for (int b = 0; b < blocks; ++b) s += part[(size_t)b * stride + j];
+#pragma unroll 8
+    for (int b = 0; b < blocks; ++b) s += part[(size_t)b * stride + j];     // (independent loads, added in order)
     out[j] = s;
 }
 
@@ -265,46 +320,48 @@ __global__ __launch_bounds__(256) void reduce_blocks_kernel(const float* __restr
 __global__ __launch_bounds__(256) void fc_out_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ g, int R, int width, int ow,
                                                          float* __restrict__ dx, float* __restrict__ part, int stride) {
+    // a workgroup owns ROWS = 64 rows; thread (quarter = its wave, column c) owns 16 of them: 16 independent row loads
+    // in flight instead of a 64-deep chain of round trips (round 3: 256 rows per workgroup, 14 workgroups, 60 us)
+    constexpr int QR = ROWS / 4;
     __shared__ float comb[4][64];
     const int tid = threadIdx.x, c0 = tid & 63, part_id = tid >> 6;
-    const int rbase = blockIdx.x * ROWS;
+    const int rbase = blockIdx.x * ROWS, r0 = rbase + part_id * QR;
     float* P = part + (size_t)blockIdx.x * stride;
-    // dx: thread (row quarter, column) walks its 64 rows
     for (int cb = 0; cb < width; cb += 64) {
         const int c = cb + c0;
-        for (int q = part_id * 64; q < part_id * 64 + 64; ++q) {
-            const int r = rbase + q;
-            if (r >= R || c >= width) break;
+        const bool col = c < width;
+        float xv[QR];
+#pragma unroll
+        for (int q = 0; q < QR; ++q) xv[q] = (col && r0 + q < R) ? x[(size_t)(r0 + q) * width + c] : 0.f;
+        float dxv[QR];
+#pragma unroll
+        for (int q = 0; q < QR; ++q) dxv[q] = 0.f;
+        for (int o = 0; o < ow; ++o) {
+            const float wv = col ? w[(size_t)o * width + c] : 0.f;
             float s = 0.f;
-            for (int o = 0; o < ow; ++o) s = fmaf(g[(size_t)r * ow + o], w[(size_t)o * width + c], s);
-            dx[(size_t)r * width + c] = s;
-        }
-    }
-    // dW[o][c], db[o]: quarters of the workgroup's rows, combined in order
-    for (int o = 0; o < ow; ++o) {
-        for (int cb = 0; cb < width; cb += 64) {
-            const int c = cb + c0;
-            float s = 0.f;
-            if (c < width)
-                for (int q = part_id * 64; q < part_id * 64 + 64; ++q) {
-                    const int r = rbase + q;
-                    if (r >= R) break;
-                    s = fmaf(g[(size_t)r * ow + o], x[(size_t)r * width + c], s);
-                }
+#pragma unroll
+            for (int q = 0; q < QR; ++q) {
+                const float gv = r0 + q < R ? g[(size_t)(r0 + q) * ow + o] : 0.f;      // (uniform in the wave)
+                dxv[q] = fmaf(gv, wv, dxv[q]);
+                s = fmaf(gv, xv[q], s);
+            }
             __syncthreads();
             comb[part_id][c0] = s;
             __syncthreads();
-            if (part_id == 0 && c < width) P[o * width + c] = (comb[0][c0] + comb[1][c0]) + (comb[2][c0] + comb[3][c0]);
+            if (part_id == 0 && col) P[o * width + c] = (comb[0][c0] + comb[1][c0]) + (comb[2][c0] + comb[3][c0]);
         }
-        float sb = 0.f;
-        const int r = rbase + tid;
-        if (r < R) sb = g[(size_t)r * ow + o];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) sb += __shfl_xor(sb, off);
-        __syncthreads();
-        if (c0 == 0) comb[0][part_id] = sb;
-        __syncthreads();
-        if (tid == 0) P[ow * width + o] = (comb[0][0] + comb[0][1]) + (comb[0][2] + comb[0][3]);
+        for (int q = 0; q < QR; ++q)
+            if (col && r0 + q < R) dx[(size_t)(r0 + q) * width + c] = dxv[q];
+    }
+    // db[o]: the workgroup's rows, butterfly in wave 0
+    if (part_id == 0) {
+        for (int o = 0; o < ow; ++o) {
+            float sb = rbase + c0 < R ? g[(size_t)(rbase + c0) * ow + o] : 0.f;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) sb += __shfl_xor(sb, off);
+            if (c0 == 0) P[ow * width + o] = sb;
+        }
     }
 }
 
@@ -351,7 +408,9 @@ extern "C" int mdno_node_prologue_bwd(const mdno_kernelnn_params* p, const float
     PrologueBwdArgs a{frames, R, N, W, (const long long*)x_aminoacid, aa_per_member, p->lstm_w_ih, p->lstm_w_hh,
                       p->lstm_b_ih, p->lstm_b_hh, p->lstm_fc_w, p->lstm_fc_b, p->emb_w, p->fc1_w, p->fc1_b,
                       p->num_embeddings, p->embedding_dim, p->width, x0, g0, part, tot};
-    hipLaunchKernelGGL(node_prologue_bwd_kernel, dim3(blocks), dim3(ROWS), 0, s, a);
+    if (p->embedding_dim <= 4) hipLaunchKernelGGL(node_prologue_bwd_kernel<4>, dim3(blocks), dim3(ROWS), 0, s, a);
+    else if (p->embedding_dim <= 8) hipLaunchKernelGGL(node_prologue_bwd_kernel<8>, dim3(blocks), dim3(ROWS), 0, s, a);
+    else hipLaunchKernelGGL(node_prologue_bwd_kernel<MAX_EMB>, dim3(blocks), dim3(ROWS), 0, s, a);
     auto reduce = [&](int off, int count, float* out) {
         hipLaunchKernelGGL(reduce_blocks_kernel, dim3((count + 255) / 256), dim3(256), 0, s, (const float*)part + off,
                            blocks, tot, count, out);
@@ -378,7 +437,7 @@ extern "C" int mdno_fc_out_bwd(const float* x, const float* w, const float* g, i
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int blocks = (rows + ROWS - 1) / ROWS, stride = out_width * width + out_width;
     float* part = static_cast<float*>(workspace);
-    hipLaunchKernelGGL(fc_out_bwd_kernel, dim3(blocks), dim3(ROWS), 0, s, x, w, g, rows, width, out_width, dx, part, stride);
+    hipLaunchKernelGGL(fc_out_bwd_kernel, dim3(blocks), dim3(256), 0, s, x, w, g, rows, width, out_width, dx, part, stride);
     hipLaunchKernelGGL(reduce_blocks_kernel, dim3((out_width * width + 255) / 256), dim3(256), 0, s, (const float*)part,
                        blocks, stride, out_width * width, d_w);
     hipLaunchKernelGGL(reduce_blocks_kernel, dim3((out_width + 255) / 256), dim3(256), 0, s,

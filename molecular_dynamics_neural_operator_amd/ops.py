@@ -540,6 +540,57 @@ def colsum_bf16(a: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def nnconv_chain_fwd(x_layers: torch.Tensor, graph: CSRGraph, w_e: torch.Tensor, root1, bias1, root2, bias2,
+                     depth: int) -> None:
+    """x_layers f32 [2*depth+1, R, 64]: [0] given, [a] = relu(conv(x[a-1])) written in place — the 2*depth conv
+    applications of the block in one call (w_e fp32 or bf16 [E,4096])."""
+    lib = _lib.load()
+    R = x_layers.shape[1]
+    args = (ptr(x_layers), ptr(graph.row_ptr), ptr(graph.src), R, ptr(w_e), ptr(f32(root1)), ptr(f32(bias1)),
+            ptr(f32(root2)), ptr(f32(bias2)), int(depth), stream_ptr(x_layers.device))
+    if w_e.dtype == torch.bfloat16:
+        check(lib.mdno_nnconv_chain_bf16w_fwd(*args), "mdno_nnconv_chain_bf16w_fwd")
+    else:
+        check(lib.mdno_nnconv_chain_fwd(*args), "mdno_nnconv_chain_fwd")
+
+
+def nnconv_chain_bwd(g_out: torch.Tensor, x_layers: torch.Tensor, inv_deg: torch.Tensor, by_src: CSRGraph,
+                     w_e: torch.Tensor, root1, root2, depth: int):
+    """Backward through the 2*depth applications -> (gz [L,R,64], gs [L,R,64], g_in [R,64])."""
+    lib = _lib.load()
+    L, R = 2 * depth, x_layers.shape[1]
+    dev = x_layers.device
+    gz = torch.empty((L, R, 64), dtype=torch.float32, device=dev)
+    gs = torch.empty((L, R, 64), dtype=torch.float32, device=dev)
+    g_in = torch.empty((R, 64), dtype=torch.float32, device=dev)
+    args = (ptr(f32(g_out)), ptr(x_layers), ptr(inv_deg), ptr(by_src.row_ptr), ptr(by_src.perm), ptr(by_src.src), R,
+            ptr(w_e), ptr(f32(root1)), ptr(f32(root2)), int(depth), ptr(gz), ptr(gs), ptr(g_in), stream_ptr(dev))
+    if w_e.dtype == torch.bfloat16:
+        check(lib.mdno_nnconv_chain_bf16w_bwd(*args), "mdno_nnconv_chain_bf16w_bwd")
+    else:
+        check(lib.mdno_nnconv_chain_bwd(*args), "mdno_nnconv_chain_bwd")
+    return gz, gs, g_in
+
+
+def colsum_atb_bf16(a: torch.Tensor, b: torch.Tensor):
+    """(column sums of a bf16 [rows,n], a^T . b for b fp32 [rows,6 or 8]) in one pass over a -> ([n], [n,kb]);
+    other shapes: the two separate ops."""
+    lib = _lib.load()
+    a, b = _bf16(a), f32(b)
+    rows, n = a.shape
+    kb = b.shape[1]
+    if kb not in (6, 8) or n % 8:
+        pad = torch.zeros((rows, 128), dtype=torch.float32, device=a.device)
+        pad[:, :kb].copy_(b)
+        return colsum_bf16(a), gemm_atb_bf16(a, cast_bf16(pad))[:, :kb].contiguous()
+    colsum = torch.empty(n, dtype=torch.float32, device=a.device)
+    atb = torch.empty((n, kb), dtype=torch.float32, device=a.device)
+    ws = _ws(lib.mdno_colsum_atb_bf16_workspace_bytes(n, kb), a.device)
+    check(lib.mdno_colsum_atb_bf16(ptr(a), ptr(b), rows, n, kb, ptr(colsum), ptr(atb), ptr(ws), ws.numel(),
+                                   stream_ptr(a.device)), "mdno_colsum_atb_bf16")
+    return colsum, atb
+
+
 # ------------------------------------------------------------------------------------------------
 # Per-atom ends (node prologue, fc2) forward + backward for training (include/mdno.h, csrc/train_nodes.hip)
 def fc_out(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:

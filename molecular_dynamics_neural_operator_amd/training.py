@@ -52,9 +52,7 @@ class KernelIntegralBlock(torch.autograd.Function):
         L = 2 * depth
         X = torch.empty((L + 1, R, 64), dtype=torch.float32, device=x0.device)
         X[0].copy_(x0)
-        for a in range(1, L + 1):
-            root, bias = (root1, bias1) if a <= depth else (root2, bias2)
-            ops.nnconv(X[a - 1], graph, w_e, root, bias, "mean", relu=True, out=X[a])
+        ops.nnconv_chain_fwd(X, graph, w_e, root1, bias1, root2, bias2, depth)        # the 2*depth applications, one call
         ctx.graph, ctx.depth, ctx.gemm_mode = graph, depth, gemm_mode
         ctx.save_for_backward(ea, h1, h2, w_e, X, w0, w1, w2, root1, root2)
         return X[L].clone()
@@ -68,9 +66,7 @@ class KernelIntegralBlock(torch.autograd.Function):
         L = 2 * depth
         X = torch.empty((L + 1, R, 64), dtype=torch.float32, device=x0.device)
         X[0].copy_(x0)
-        for a in range(1, L + 1):
-            root, bias = (root1, bias1) if a <= depth else (root2, bias2)
-            ops.nnconv_bf16w(X[a - 1], graph, w_e, root, bias, "mean", relu=True, out=X[a])
+        ops.nnconv_chain_fwd(X, graph, w_e, root1, bias1, root2, bias2, depth)
         ctx.graph, ctx.depth, ctx.gemm_mode = graph, depth, "bf16"
         ctx.save_for_backward(ea, h1, h2, w_e, X, w0, w1, w2, root1, root2)
         return X[L].clone()
@@ -82,12 +78,7 @@ class KernelIntegralBlock(torch.autograd.Function):
         L, R = 2 * depth, X.shape[1]
         by_src = getattr(graph, "by_src", None) or ops.source_sorted(graph, R)
         inv = ops.inv_degree(graph, "mean")
-        GZ = torch.empty((L, R, 64), dtype=torch.float32, device=X.device)
-        GS = torch.empty((L, R, 64), dtype=torch.float32, device=X.device)
-        g = ops.f32(g_out)
-        for a in range(L, 0, -1):
-            ops.relu_bwd2(g, X[a], inv, GZ[a - 1], GS[a - 1])
-            g = ops.nnconv_bwd_x_bf16w(GZ[a - 1], GS[a - 1], by_src, w_e, root1 if a <= depth else root2)
+        GZ, GS, g = ops.nnconv_chain_bwd(g_out, X, inv, by_src, w_e, root1, root2, depth)
         d_root1, d_bias1 = ops.nnconv_bwd_root(X[0:depth].reshape(-1, 64), GZ[0:depth].reshape(-1, 64))
         d_root2, d_bias2 = ops.nnconv_bwd_root(X[depth:L].reshape(-1, 64), GZ[depth:L].reshape(-1, 64))
         d_we = ops.nnconv_bwd_we_bf16(X[0:L], GS, graph)                 # bf16 [E, 4096]
@@ -99,12 +90,8 @@ class KernelIntegralBlock(torch.autograd.Function):
         d_b1 = ops.colsum_bf16(gz2)
         d_w1 = ops.gemm_atb_bf16(gz2, h1)
         gz1 = ops.linear_bf16_relu_bwd(gz2, ops.transpose(w1), h1)
-        d_b0 = ops.colsum_bf16(gz1)
-        # d_w0 = gz1^T . ea with ea [E, 6]: the six attribute columns ride in a zero-padded 128-column bf16
-        # operand of the same A^T.B kernel (the generic fp32 kernel took as long as the big products)
-        ea_pad = torch.zeros((ea.shape[0], 128), dtype=torch.float32, device=ea.device)
-        ea_pad[:, :ea.shape[1]].copy_(ea)
-        d_w0 = ops.gemm_atb_bf16(gz1, ops.cast_bf16(ea_pad))[:, :ea.shape[1]].contiguous()
+        # first layer: bias and weight gradient in ONE pass over gz1 (d_w0 = gz1^T . ea with the fp32 attributes)
+        d_b0, d_w0 = ops.colsum_atb_bf16(gz1, ea)
         return (g, None, None, None, None, d_w0, d_b0, d_w1, d_b1, d_w2, d_b2, d_root1, d_bias1, d_root2, d_bias2)
 
     @staticmethod
@@ -116,12 +103,7 @@ class KernelIntegralBlock(torch.autograd.Function):
         L, R = 2 * depth, X.shape[1]
         by_src = getattr(graph, "by_src", None) or ops.source_sorted(graph, R)
         inv = ops.inv_degree(graph, "mean")
-        GZ = torch.empty((L, R, 64), dtype=torch.float32, device=X.device)
-        GS = torch.empty((L, R, 64), dtype=torch.float32, device=X.device)
-        g = ops.f32(g_out)
-        for a in range(L, 0, -1):
-            ops.relu_bwd2(g, X[a], inv, GZ[a - 1], GS[a - 1])
-            g = ops.nnconv_bwd_x(GZ[a - 1], GS[a - 1], by_src, w_e, root1 if a <= depth else root2)
+        GZ, GS, g = ops.nnconv_chain_bwd(g_out, X, inv, by_src, w_e, root1, root2, depth)
         d_root1, d_bias1 = ops.nnconv_bwd_root(X[0:depth].reshape(-1, 64), GZ[0:depth].reshape(-1, 64))
         d_root2, d_bias2 = ops.nnconv_bwd_root(X[depth:L].reshape(-1, 64), GZ[depth:L].reshape(-1, 64))
         d_we = ops.nnconv_bwd_we(X[0:L], GS, graph)

@@ -11,7 +11,7 @@ left between the two is fp32-vs-fp64 accumulation only:
   backward  dW_e = bf16(sum over the 2*depth applications of x_src (x) gs_dst)
             gz2  = bf16(mask(h2) * (dW_e.bf16(W2)))          db2 = colsum(dW_e), dW2 = dW_e^T.h2
             gz1  = bf16(mask(h1) * (gz2.bf16(W1)))           db1 = colsum(gz2),  dW1 = gz2^T.h1
-            db0 = colsum(gz1),  dW0 = gz1^T.bf16(ea)         (ea is cast to bf16 for this product only)
+            db0 = colsum(gz1),  dW0 = gz1^T.ea               (one pass over gz1, fp32 attributes)
 
 Everything else (per-atom prologue, conv applications on the rounded W_e, fc2, loss) is fp32 on the device and
 fp64 here.  Rounding is round-to-nearest-even (torch's .to(bfloat16) == v_cvt_pk_bf16_f32)."""
@@ -48,7 +48,7 @@ class _RoundBackward(torch.autograd.Function):
 
 
 class _Layer0(torch.autograd.Function):
-    """ea.W0^T + b0 with dW0 = g^T.bf16(ea) (training.py: the zero-padded bf16 copy of ea)."""
+    """ea.W0^T + b0 with dW0 = g^T.ea (training.py: mdno_colsum_atb_bf16, fp32 attributes)."""
 
     @staticmethod
     def forward(ctx, ea, w0, b0):
@@ -58,7 +58,7 @@ class _Layer0(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (ea,) = ctx.saved_tensors
-        return None, g.t() @ _r(ea), g.sum(0)
+        return None, g.t() @ ea, g.sum(0)
 
 
 def edge_mlp_bf16(edge_attr, p, prefix="conv1.net."):

@@ -92,6 +92,60 @@ def test_nnconv_backward_ops_vs_autograd(dev, O):
     assert rel_err(d_we, want) < 1e-5
 
 
+@pytest.mark.parametrize("bf16", [False, True])
+def test_conv_chain_entries_equal_the_single_ops(dev, bf16):
+    """mdno_nnconv_chain_*: the 2*depth applications of a step in one call each way.  Forward == 2*depth single conv
+    calls, bitwise; backward (every ReLU backward below the top one fused into the input-gradient kernel above it)
+    == 2*depth (relu_bwd2, nnconv_bwd_x) pairs, bitwise — on an irregular batch graph (hub, isolated node)."""
+    from molecular_dynamics_neural_operator_amd import ops
+    gen = torch.Generator().manual_seed(11)
+    R, E, depth = 300, 4000, 3
+    L = 2 * depth
+    ei = torch.randint(0, R, (2, E), generator=gen)
+    ei[1, :300] = 17
+    ei[1, ei[1] == 40] = 41
+    g = ops.coo_to_csr(ei.to(dev), R)
+    by_src = ops.source_sorted(g, R)
+    w_e = (torch.randn(E, 4096, generator=gen) * 0.05).to(dev)
+    if bf16:
+        w_e = w_e.to(torch.bfloat16)
+    r1, r2 = [(torch.randn(64, 64, generator=gen) * 0.2).to(dev) for _ in range(2)]
+    b1, b2 = [torch.randn(64, generator=gen).to(dev) for _ in range(2)]
+    conv = ops.nnconv_bf16w if bf16 else ops.nnconv
+    bwd_x = ops.nnconv_bwd_x_bf16w if bf16 else ops.nnconv_bwd_x
+    X = torch.zeros((L + 1, R, 64), device=dev)
+    X[0] = torch.randn(R, 64, generator=gen).to(dev)
+    want = X.clone()
+    for a in range(1, L + 1):
+        conv(want[a - 1], g, w_e, r1 if a <= depth else r2, b1 if a <= depth else b2, "mean", relu=True, out=want[a])
+    ops.nnconv_chain_fwd(X, g, w_e, r1, b1, r2, b2, depth)
+    assert torch.equal(X, want) and float(X[L].abs().max()) > 0
+    inv = ops.inv_degree(g, "mean")
+    g_out = torch.randn(R, 64, generator=gen).to(dev)
+    GZ, GS = torch.empty((L, R, 64), device=dev), torch.empty((L, R, 64), device=dev)
+    gg = g_out
+    for a in range(L, 0, -1):
+        ops.relu_bwd2(gg, X[a], inv, GZ[a - 1], GS[a - 1])
+        gg = bwd_x(GZ[a - 1], GS[a - 1], by_src, w_e, r1 if a <= depth else r2)
+    gz, gs, g_in = ops.nnconv_chain_bwd(g_out, X, inv, by_src, w_e, r1, r2, depth)
+    assert torch.equal(gz, GZ) and torch.equal(gs, GS) and torch.equal(g_in, gg)
+
+
+def test_colsum_atb_bf16_one_pass(dev):
+    """colsum(a) and a^T . b (b = 6 fp32 attribute columns) in one pass over a bf16 [rows, n]: against fp64 of the
+    stored values, reproducible, and the odd shapes fall back to the two separate ops."""
+    from molecular_dynamics_neural_operator_amd import ops
+    gen = torch.Generator().manual_seed(2)
+    for rows, n, kb in ((43712, 1024, 6), (1000, 512, 8), (77, 128, 6), (500, 256, 5)):
+        a = (torch.randn(rows, n, generator=gen) * (torch.rand(rows, 1, generator=gen) > 0.5)).to(torch.bfloat16).to(dev)
+        b = (torch.randn(rows, kb, generator=gen) * 10).to(dev)
+        cs, atb = ops.colsum_atb_bf16(a, b)
+        a64 = a.double().cpu()
+        assert rel_err(cs, a64.sum(0)) < 2e-6 and rel_err(atb, a64.t() @ b.double().cpu()) < (2e-6 if kb != 5 else 1e-2)
+        cs2, atb2 = ops.colsum_atb_bf16(a, b)
+        assert torch.equal(cs, cs2) and torch.equal(atb, atb2)
+
+
 def _as_dicts(samples):
     return [dict(x_position=s.x_position.cpu(), x_aminoacid=s.x_aminoacid.cpu(), y=s.y.cpu(),
                  edge_index=s.edge_index.cpu(), edge_attr=s.edge_attr.cpu()) for s in samples]

@@ -800,16 +800,23 @@ def worker(a):
                 "note": f"executed 16-bit MFMA flops ({products:.0f} plane products per fp32 product) vs the dense "
                         "bf16/fp16 peak"}
 
-    def per_source_roofline(ks, e):   # factored path: M_j = H_j . Y_j^T, all launches of one conv application
+    def per_source_roofline(ks, e):   # factored path, its dominant kernel over all launches of one conv application
         launches_per_app = max(1, round(ks["nnconv"]["launches"] / (a.steps * 2 * a.depth)))
         avg_s = ks["nnconv"]["avg_ms"] * 1e-3 * launches_per_app      # one application over all R rows
-        alg = e * KW * 4 + R * C * KW * 4 + 2 * e * C * 4 + (R + 1) * 4        # H once + Y once + 2 k-slice partials out
-        flops = 2.0 * e * KW * C                                                # fp32-equivalent
         split = a.gemm_mode != "f32"
+        flops = 2.0 * e * KW * C                                                # fp32-equivalent
+        if split:
+            # destination-side form (csrc/moment.hip K1): S_t = sum_{e->t} x_src (x) h_e — H read once, S written once,
+            # the source index per edge, row_ptr (the neighbours' 384-B feature planes are gathered from L2)
+            name = "moment_kernel"
+            alg = e * KW * 4 + R * C * KW * 4 + e * 4 + (R + 1) * 4
+        else:
+            # source-side form (csrc/factored.hip): M_j = H_j . Y_j^T — H once + Y once + 2 k-slice partials out
+            name = "gemm_per_source_kernel"
+            alg = e * KW * 4 + R * C * KW * 4 + 2 * e * C * 4 + (R + 1) * 4
         # matrix-pipe work as executed: 6 bf16 plane products per fp32 product, or the fp32 MFMA itself
         mfma_exec, mfma_peak = (6.0 * flops, MFMA_BF16_PEAK_TFLOPS) if split else (flops, MFMA_F32_PEAK_TFLOPS)
         t_hbm, t_mfma = alg / (HBM_PEAK_GBS * 1e9), mfma_exec / (mfma_peak * 1e12)
-        name = "gemm_per_source_split_kernel" if split else "gemm_per_source_kernel"
         r = {"kernel": name, "conv_mode": "factored", "avg_launch_ms": avg_s * 1e3, "launches_per_application": launches_per_app,
              "algorithmic_bytes_per_launch": alg, "flops_per_launch": flops,
              "traffic": profiled_traffic(name, N, M, "factored", a.gemm_mode),

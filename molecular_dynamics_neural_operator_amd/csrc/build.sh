@@ -5,7 +5,7 @@ set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 out="$here/../libmdno.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-srcs=(engine.hip graph.hip edge_mlp.hip edge_mlp_split.hip factored.hip nnconv.hip node_ops.hip train.hip train_bf16.hip train_nodes.hip collate.hip gemm_bf16.hip)
+srcs=(engine.hip graph.hip edge_mlp.hip edge_mlp_split.hip factored.hip moment.hip nnconv.hip node_ops.hip train.hip train_bf16.hip train_nodes.hip collate.hip gemm_bf16.hip)
 objs=()
 pids=()
 mkdir -p "$here/build"

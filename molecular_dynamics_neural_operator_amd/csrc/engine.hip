@@ -79,7 +79,16 @@ struct FwdWs {
     void *mlp, *fact;
     size_t mlp_bytes, total;
     bool factored;
+    bool moment;      // factored, destination-side form (moment.hip): the split GEMM modes
 };
+
+// The factored conv's two forms: destination-side (moment.hip) for the split GEMM modes, source-side (factored.hip,
+// exact fp32 MFMA kernels) for gemm_mode F32.  MDNO_FACTORED_SOURCE_SIDE=1 (development A/B) forces the latter's
+// split kernels.
+bool use_moment(const mdno_kernelnn_params* p) {
+    static const bool force_old = getenv("MDNO_FACTORED_SOURCE_SIDE") != nullptr;
+    return !force_old && p->gemm_mode != MDNO_GEMM_F32 && moment_supported(p->width, p->ker_width);
+}
 
 // The factored conv applies to graphs the library builds itself (symmetric radius graphs) at width 64.
 // AUTO adds a size rule: below ~8-10k edges the factored form's fixed cost per application (Y GEMM
@@ -111,7 +120,9 @@ FwdWs carve_fwd(void* ws, const mdno_kernelnn_params* p, int M, int N, long long
         // no W_e at all: the last hidden activation H [edge_cap, k] plus the per-node Y and per-edge M
         // k-tiled [e/128][k/32][128][32]: whole 128-row tiles, so the row count is rounded up
         f.h2 = cv.take<float>((size_t)((edge_cap + 127) / 128 * 128) * p->ker_width);
-        f.fact = cv.take<char>(factored_workspace_bytes((int)R, p->ker_width, edge_cap));
+        f.moment = use_moment(p);
+        f.fact = cv.take<char>(f.moment ? moment_workspace_bytes((int)R, p->ker_width)
+                                        : factored_workspace_bytes((int)R, p->ker_width, edge_cap));
         f.mlp_bytes = mdno_edge_mlp_workspace_bytes(p->ker_width, p->ker_width, edge_cap, p->gemm_mode);
     } else {
         f.mlp_bytes = mdno_edge_mlp_workspace_bytes(p->ker_width, p->width * p->width, edge_cap, p->gemm_mode);
@@ -143,6 +154,37 @@ int forward_impl(const mdno_kernelnn_params* p, const float* frames, int t0, con
         // (the CSR arrays' names refer to the materialised reading; here their roles are swapped)
         MDNO_REQUIRE(edge_frames && !edge_attr && dst, MDNO_EINVAL,
                      "factored conv needs a position-derived radius graph (edge_pos, dst)");
+        if (ws.moment) {
+            // destination-side form: row r = DESTINATION r with in-edges src[p] -> r, attributes [pos[src], pos[dst]]
+            // as the reference has them (graph_kernel.py:372-379); no symmetry needed
+            const MomentWs mw = moment_carve(ws.fact, R, p->ker_width);
+            if (!prep_only) MDNO_TRY(moment_prepare_graph(row_ptr, R, mw, s));
+            int app = 0;
+            for (int block = 0; block < blocks; ++block) {
+                const bool own = block == 1 && separate_conv2_kernel(p);
+                if (block == 0 || own) {
+                    EdgeMlpWeights w = own ? EdgeMlpWeights{p->k2_w0, p->k2_b0, p->k2_w1, p->k2_b1, p->k2_w2, p->k2_b2}
+                                           : EdgeMlpWeights{p->k_w0, p->k_b0, p->k_w1, p->k_b1, p->k_w2, p->k_b2};
+                    MDNO_TRY(edge_mlp_hidden(edge_frames, edge_frame, t_dev, R, src, dst, nullptr, nullptr, num_edges, edge_cap,
+                                             p->ker_in, p->ker_width, p->gemm_mode, w, ws.h2, ws.mlp, ws.mlp_bytes, s,
+                                             block == 0 ? phase : (phase & ~WP_FLAGS_ZEROED)));
+                    if ((phase & WP_PHASE_MASK) != WP_RUN_ONLY) MDNO_TRY(moment_prepare_weights(w.w2, w.b2, p->ker_width, mw, s));
+                }
+                if (prep_only) return MDNO_OK;
+                const float* b3 = own ? p->k2_b2 : p->k_b2;
+                const float* root = block == 0 ? p->conv1_root : p->conv2_root;
+                const float* bias = block == 0 ? p->conv1_bias : p->conv2_bias;
+                for (int d = 0; d < p->depth; ++d, ++app) {
+                    const bool last = block + 1 == blocks && d + 1 == p->depth;
+                    MDNO_TRY(moment_conv(cur, ws.h2, row_ptr, src, R, p->ker_width, b3, root, bias, MDNO_AGGR_MEAN, /*relu=*/1,
+                                         nxt, mw, s, app, /*x_prepared=*/app > 0, /*emit_next=*/!last));
+                    float* t = cur; cur = nxt; nxt = t;
+                }
+            }
+            if (latent) MDNO_HIP(hipMemcpyAsync(latent, cur, sizeof(float) * (size_t)R * C, hipMemcpyDeviceToDevice, s));
+            MDNO_TRY(fc_out(cur, p->fc2_w, p->fc2_b, R, C, p->out_width, out_frames, t_out, t_dev, s, tail));
+            return MDNO_OK;
+        }
         const FactoredWs fw = factored_carve(ws.fact, R, p->ker_width, edge_cap);
         const int cgm = conv_gemm_mode(p->gemm_mode);
         if (!prep_only) MDNO_TRY(factored_prepare_graph(row_ptr, src, dst, R, N, cgm, edge_cap, fw, status, s));

@@ -762,6 +762,13 @@ static int tail_slices(int gemm_mode, int rows_per_member) {
     return gemm_mode == MDNO_GEMM_SPLIT_BF16 && (long long)rows_per_member * KS <= 2048 ? KS_TAIL : KS;
 }
 
+int degree_order_chunks(const int* row_ptr, int num_rows, int chunk_rows, int* order, hipStream_t s) {
+    MDNO_REQUIRE(chunk_rows == kYChunkRows, MDNO_EINVAL, "degree_order_chunks: chunk of %d rows (only %d)", chunk_rows, kYChunkRows);
+    hipLaunchKernelGGL(source_order_kernel<kYChunkRows>, dim3((num_rows + kYChunkRows - 1) / kYChunkRows), dim3(kYChunkRows), 0, s,
+                       row_ptr, num_rows, order);
+    return check_launch("source_order_kernel");
+}
+
 int factored_prepare_graph(const int* row_ptr, const int* col, const int* rowid, int num_rows, int rows_per_member,
                            int gemm_mode, long long edge_cap, const FactoredWs& f, int* status, hipStream_t s) {
     MDNO_REQUIRE(edge_cap <= REV_MASK, MDNO_EUNSUPPORTED, "factored conv: edge_cap %lld exceeds %d", edge_cap, REV_MASK);

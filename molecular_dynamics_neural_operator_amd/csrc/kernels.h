@@ -137,6 +137,27 @@ constexpr int kMaxF16Applications = 62;
 // x_prepared: the bf16 image of x and q = x.B3 are already in f.xp / f.q (left there by the previous
 // application, which was given this application's b3 as next_b3); next_b3 NULL: nothing follows.
 
+// Factored conv, destination-side form (moment.hip: S_t = sum_{e->t} x_src (x) h_e, then y_t = W3 : S_t) — what the
+// split GEMM modes run; factored.hip's source-side kernels remain for gemm_mode F32.
+struct MomentWs {
+    float *w3r, *s, *part;
+    void* xq[2];              // bf16 planes [node][3][64] of the node features, ping-pong over the applications
+    int* order;               // destinations of each S chunk by decreasing degree
+    long long part_stride;
+};
+bool moment_supported(int width, int ker_width);
+size_t moment_workspace_bytes(int num_rows, int ker_width);
+MomentWs moment_carve(void* ws, int num_rows, int ker_width);
+int moment_prepare_weights(const float* w3, const float* b3, int ker_width, const MomentWs& f, hipStream_t s);
+int moment_prepare_graph(const int* row_ptr, int num_rows, const MomentWs& f, hipStream_t s);
+// parity: index of this application inside the forward (selects the xq buffer read; the other one is written when
+// emit_next).  x_prepared: xq[parity & 1] already holds the planes of x (left by the previous application).
+int moment_conv(const float* x, const float* h2, const int* row_ptr, const int* src, int num_rows, int ker_width,
+                const float* b3, const float* root, const float* bias, int aggr, int relu, float* y, const MomentWs& f,
+                hipStream_t s, int parity, bool x_prepared, bool emit_next);
+// order[chunk*chunk_rows + rank] = index inside the chunk of the row with that rank (degree descending; factored.hip)
+int degree_order_chunks(const int* row_ptr, int num_rows, int chunk_rows, int* order, hipStream_t s);
+
 // bf16 training GEMMs (gemm_bf16.hip): 256 x 256 tiles, 8 waves, two wave groups one phase apart over an
 // LDS-DMA ring of 32-k stages.
 //   gemm_nt_pp         C = act(A . W^T + b), A bf16 [rows,K], W bf16 [N,K], C bf16 or fp32 (N % 256 == 0, K % 32 == 0, K >= 64)

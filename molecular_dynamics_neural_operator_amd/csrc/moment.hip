@@ -1,0 +1,536 @@
+// Factored conv, destination-side form ("edge moment"): the same function as
+//     y_t = act( mean_{e -> t} x_src(e) . reshape(W3 h_e + b3, [Cin,Cout]) + x_t . root + bias )     (graph_kernel.py:194-209)
+// with the sum over a destination's in-edges taken BEFORE the contraction with W3:
+//     S_t[i][c] = sum_{e -> t} x_src(e)[i] * h_e[c]                  (K1)  one GEMM per destination over its own edges,
+//                                                                          contraction over the EDGES: [64 x deg] . [deg x k]
+//     z_t[o]    = sum_{i,c} S_t[i][c] * W3[i*64 + o][c]              (K2)  one tall GEMM [R, 64 k] x [64 k, 64], K-sliced
+//     y_t       = act( (z_t + s0_t . B3) / max(deg_t, 1) + x_t . root + bias ),  s0_t = sum_{e -> t} x_src(e)   (K3)
+// Against the source-side form of factored.hip (Y_j = x_j . W3T per source, M_j = H_j . Y_j^T per source, gather of
+// the 256-B messages per destination) this needs no reverse-edge index and no symmetric graph, has no 128-row tiles
+// of a node's edges (a destination's edges are the contraction length: any degree, H read exactly once — the
+// source-side form re-read Y_j once per 128 edges of a source: 1.33x the algorithmic bytes at degree 362), writes
+// no per-edge partial messages (62 MB per application at N = 504) and ends in a per-node epilogue instead of a
+// gather: HBM bytes per application  E k 4 (H) + 2 R 64 k 4 (S out, S in) + 64 k 64 4 (W3)  — 529 MB at N = 504,
+// E = 60.6k, k = 1024 against 692 MB measured for the three source-side kernels.
+//
+// All three products run on the bf16 matrix pipe at fp32 accuracy: every fp32 operand is split exactly into three
+// bf16 planes (x = hi + mid + lo) and the six leading plane products are accumulated in fp32 (edge_mlp_split.hip).
+//   K1  moment_kernel     workgroup = (destination t, 256 of the k hidden units); stage = 16 edges: H rows (fp32,
+//                         k-tiled image written by the hidden GEMM, streamed once, non-temporal) and the bf16 planes
+//                         of the neighbours' features (gathered from L2) go to LDS edge-major, i.e. with the
+//                         contraction index SLOWEST, and the MFMA fragments come out of gfx950's transposing read
+//                         ds_read_b64_tr_b16; register prefetch of the next stage under the MFMAs.
+//   K2  project_kernel    workgroup = (128 destinations, 1/128 of the 64 k contraction): S and W3 tiles fp32 -> planes
+//                         on the fly (the loop of factored.hip's per-source kernel); partial sums per K slice.
+//   K3  finish_kernel     per destination: K slices added in slice order, s0 gathered in edge order, B3 / root / bias /
+//                         mean / ReLU, and the bf16 planes of y_t the next application's K1 gathers.
+// Fixed summation orders everywhere: a destination's result depends on its own edges only (bitwise the same alone or
+// in any batch), no float atomics.
+#include "kernels.h"
+#include "split_layout.h"
+
+namespace mdno {
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// (a, b) -> packed bf16 pair (one v_cvt_pk_bf16_f32) and the pair's values back in fp32
+__device__ __forceinline__ unsigned pack_bf16(float a, float b, float& fa, float& fb) {
+    const f32x2 v = {a, b};
+    const bf16x2 p = __builtin_convertvector(v, bf16x2);
+    const unsigned u = __builtin_bit_cast(unsigned, p);
+    fa = __builtin_bit_cast(float, u << 16);
+    fb = __builtin_bit_cast(float, u & 0xffff0000u);
+    return u;
+}
+
+// four fp32 -> 3 x four bf16 (hi, mid, lo), 8 bytes per plane at dst + p * plane_bytes
+__device__ __forceinline__ void split_store4(const float4 v, unsigned char* dst, int plane_bytes) {
+    float h0, h1, h2, h3, m0, m1, m2, m3, t0, t1;
+    uint2 hi, mid, lo;
+    hi.x = pack_bf16(v.x, v.y, h0, h1);
+    hi.y = pack_bf16(v.z, v.w, h2, h3);
+    const float r0 = v.x - h0, r1 = v.y - h1, r2 = v.z - h2, r3 = v.w - h3;
+    mid.x = pack_bf16(r0, r1, m0, m1);
+    mid.y = pack_bf16(r2, r3, m2, m3);
+    lo.x = pack_bf16(r0 - m0, r1 - m1, t0, t1);
+    lo.y = pack_bf16(r2 - m2, r3 - m3, t0, t1);
+    *reinterpret_cast<uint2*>(dst) = hi;
+    *reinterpret_cast<uint2*>(dst + plane_bytes) = mid;
+    *reinterpret_cast<uint2*>(dst + 2 * plane_bytes) = lo;
+}
+
+// the six leading plane products of (a0 + a1 + a2)(b0 + b1 + b2), smallest first
+#define MDNO_MMA6(A, B, ACC)                                                        \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], B[1], ACC, 0, 0, 0);        \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2], B[0], ACC, 0, 0, 0);        \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[2], ACC, 0, 0, 0);        \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], B[0], ACC, 0, 0, 0);        \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[1], ACC, 0, 0, 0);        \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[0], ACC, 0, 0, 0);
+
+// ---------------------------------------------------------------- node features -> bf16 planes [node][3][64]
+// (the operand K1 gathers per edge: 384 B per node; written by K3 for every later application)
+constexpr int XQ_ROW = 3 * 64;      // bf16 elements per node
+
+__global__ __launch_bounds__(256) void split_nodes_kernel(const float* __restrict__ x, int rows, __bf16* __restrict__ xq,
+                                                          __bf16* __restrict__ xq_other) {
+    const int id = blockIdx.x * 256 + threadIdx.x;      // (row, group of 4 channels)
+    if (id < XQ_ROW / 2) {                              // the all-zero row behind the nodes, in both buffers (once per forward)
+        reinterpret_cast<unsigned*>(xq + (size_t)rows * XQ_ROW)[id] = 0u;
+        reinterpret_cast<unsigned*>(xq_other + (size_t)rows * XQ_ROW)[id] = 0u;
+    }
+    if (id >= rows * 16) return;
+    const int row = id >> 4, c4 = (id & 15) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(x + (size_t)row * 64 + c4);
+    split_store4(v, reinterpret_cast<unsigned char*>(xq + (size_t)row * XQ_ROW + c4), 64 * 2);
+}
+
+// ---------------------------------------------------------------- W3 [64*64, k] -> W3R tiled [64k/32][64 o][32]
+// W3R[kappa][o] = W3[(i*64 + o)*k + c] with kappa = i*k + c (and B3[i][o] at kappa = 64 k + i): the B operand of K2,
+// one 8 KiB run per 32 kappa
+__global__ __launch_bounds__(256) void w3_moment_kernel(const float* __restrict__ w3, const float* __restrict__ b3, int k,
+                                                        float* __restrict__ w3r) {
+    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;      // over (kappa tile, o, kappa & 31)
+    const long long total = (long long)(64 * k + 64) * 64;
+    if (id >= total) return;
+    const int kl = (int)(id & 31), o = (int)((id >> 5) & 63);
+    const long long kappa = (id >> 11) * 32 + kl;
+    if (kappa >= (long long)64 * k) {      // the s0 rows: B3[i][o] = b3[i*64 + o]
+        w3r[id] = b3[(kappa - (long long)64 * k) * 64 + o];
+        return;
+    }
+    const int i = (int)(kappa / k), c = (int)(kappa - (long long)i * k);
+    w3r[id] = w3[((size_t)i * 64 + o) * k + c];
+}
+
+// ---------------------------------------------------------------- K1: S_t = X_N(t)^T . H_t
+// k-tiles (32 kappa) of a destination's row of the S image: 64 k / 32 for S_t itself + 2 for s0_t (kappa = 64 k + i)
+__host__ __device__ constexpr size_t moment_nkt(int K) { return (size_t)64 * K / 32 + 2; }
+constexpr int MO_EDGES = 16;                 // edges per stage = one MFMA k-step
+constexpr int MO_CQ = 256;                   // hidden units per workgroup
+constexpr int MO_HROW = MO_CQ * 2 + 64;      // LDS bytes per edge row of an H plane (64 B of padding: the four rows of a
+                                             // transposing read's block fall into four different 64-B bank quarters)
+constexpr int MO_XROW = 64 * 2 + 64;         // the same for the 64 feature columns
+constexpr int MO_HPLANE = MO_EDGES * MO_HROW, MO_XPLANE = MO_EDGES * MO_XROW;
+constexpr int MO_LDS = 3 * MO_HPLANE + 3 * MO_XPLANE;      // 36,864 B
+
+// Grid: (destination within the chunk, visited by decreasing degree) x (k / 256).  S chunk layout: the fp32 k-tiled
+// image K2 streams, [node/128][64k/32][128][32] with kappa = i*k + c.
+__global__ __launch_bounds__(256, 3) void moment_kernel(const float* __restrict__ Hm, const __bf16* __restrict__ xq,
+                                                        const int* __restrict__ row_ptr, const int* __restrict__ src,
+                                                        const int* __restrict__ order, float* __restrict__ S, int K,
+                                                        int row0, const float* __restrict__ x) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[MO_LDS];
+    const int tl = order[row0 + blockIdx.x];       // index inside this launch's chunk of destinations
+    const int t = row0 + tl;
+    const int cq = blockIdx.y;
+    const int beg = row_ptr[t], end = row_ptr[t + 1];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nkt = K >> 5;
+    if (cq == K / MO_CQ) {
+        // one more workgroup per destination: s0_t[i] = sum_{e -> t} x_src(e)[i] (the b3 term's operand: the last MLP
+        // layer's bias seen through the summed neighbours), stored as kappa = 64 K + i of the same image, so that K2
+        // multiplies it with B3 like any other slice.  16 chains x 16 lanes (4 features each), four edges in flight
+        // per chain, chains added in order: a fixed order.
+        __shared__ float4 sred[16][16];
+        const int es = tid >> 4, q = tid & 15;
+        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int p = beg + es; p < end; p += 64) {
+            int sj[4];
+            bool on[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                on[u] = p + 16 * u < end;
+                sj[u] = on[u] ? src[p + 16 * u] : 0;
+            }
+            float4 g[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                g[u] = on[u] ? *reinterpret_cast<const float4*>(x + (size_t)sj[u] * 64 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s0.x += g[u].x; s0.y += g[u].y; s0.z += g[u].z; s0.w += g[u].w; }
+        }
+        sred[es][q] = s0;
+        __syncthreads();
+        if (es == 0) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) { const float4 v = sred[c][q]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+            const int i = 4 * q;       // features 4q..4q+3: k-tile 64K/32 + (i >> 5), columns i & 31 ..
+            float* d = S + ((size_t)(tl >> 7) * moment_nkt(K) + (size_t)64 * K / 32 + (i >> 5)) * 4096 + (tl & 127) * 32 + (i & 31);
+            *reinterpret_cast<float4*>(d) = a;
+        }
+        return;
+    }
+    // ---- staging roles
+    // H: thread (edge er = tid >> 4, column group cc = tid & 15) loads four float4: hidden units cq*256 + u*64 + cc*4 ..
+    const int er = tid >> 4, cc = tid & 15;
+    // X: threads 0..191: edge xe = tid / 12, 32 B (two 16-B pieces 2*xs, 2*xs + 1 of the 24 of a node's planes)
+    const int xe = tid / 12, xs = tid - xe * 12;
+    const bool xrole = tid < 192;
+    auto h_ptr = [&](int e, int u) {      // element (edge e, hidden unit cq*256 + u*64 + cc*4) of the k-tiled H
+        const int c = cq * MO_CQ + u * 64 + cc * 4;
+        return Hm + ((size_t)(e >> 7) * nkt + (c >> 5)) * 4096 + (e & 127) * 32 + (c & 31);
+    };
+    float4 rh[4];
+    uint4 rx[2];
+    int sidx = 0;      // source node of this thread's X edge in the stage being loaded
+#define MO_NT(DST, P)                                                                               \
+    {                                                                                               \
+        const f32x4 t_ = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(P));             \
+        DST = make_float4(t_.x, t_.y, t_.z, t_.w);                                                  \
+    }
+    auto load_stage = [&](int e0) {       // edges e0 .. e0+15 of this row -> registers (zeros past the end)
+        const int e = e0 + er;
+        if (e < end) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) MO_NT(rh[u], h_ptr(e, u))
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) rh[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        rx[0] = rx[1] = make_uint4(0u, 0u, 0u, 0u);
+        if (xrole && e0 + xe < end) {
+            const uint4* p = reinterpret_cast<const uint4*>(xq + (size_t)sidx * XQ_ROW) + 2 * xs;
+            rx[0] = p[0];
+            rx[1] = p[1];
+        }
+    };
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            split_store4(rh[u], lds + er * MO_HROW + (u * 64 + cc * 4) * 2, MO_HPLANE);
+        if (xrole) {
+            // pieces 2*xs, 2*xs+1 of [plane][64]: plane = piece >> 3, 16-B chunk = piece & 7
+            const int p0 = 2 * xs, p1 = 2 * xs + 1;
+            *reinterpret_cast<uint4*>(lds + 3 * MO_HPLANE + (p0 >> 3) * MO_XPLANE + xe * MO_XROW + (p0 & 7) * 16) = rx[0];
+            *reinterpret_cast<uint4*>(lds + 3 * MO_HPLANE + (p1 >> 3) * MO_XPLANE + xe * MO_XROW + (p1 & 7) * 16) = rx[1];
+        }
+    };
+    // ---- fragment addresses (ds_read_b64_tr_b16): 16-lane group gq, lane = 4*qq + pp inside it reads row 8*(gq>>1) + qq
+    // (+4 for the second half), 8 B at column 16*(gq&1) + 4*pp of the block; lane i of the group receives column i
+    const int gq = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+    const int frow = 8 * (gq >> 1) + qq, fcol = 16 * (gq & 1) + 4 * pp;
+    const unsigned char* hb = lds + frow * MO_HROW + (wave * 64 + fcol) * 2;                  // + cb*64 B, + plane
+    const unsigned char* xb = lds + 3 * MO_HPLANE + frow * MO_XROW + fcol * 2;               // + ih*64 B, + plane
+    auto tr_frag = [&](const unsigned char* p_, int row_bytes) {
+        typedef short s16x4 __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p_));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p_ + 4 * row_bytes));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    f32x16 acc[2][2];      // [feature half ih][hidden block cb of this wave's 64]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int stages = (end - beg + MO_EDGES - 1) / MO_EDGES;
+    if (stages > 0) {
+        if (xrole && beg + xe < end) sidx = src[beg + xe];
+        load_stage(beg);
+        if (xrole && beg + MO_EDGES + xe < end) sidx = src[beg + MO_EDGES + xe];
+        store_stage();
+        __syncthreads();
+        for (int st = 0; st < stages; ++st) {
+            const int e_next = beg + (st + 1) * MO_EDGES;
+            if (st + 1 < stages) {
+                load_stage(e_next);
+                if (xrole && e_next + MO_EDGES + xe < end) sidx = src[e_next + MO_EDGES + xe];
+            }
+            __builtin_amdgcn_sched_barrier(0);      // keep the prefetch above the MFMAs
+            {
+                bf16x8 a[2][3], b[3];
+#pragma unroll
+                for (int ih = 0; ih < 2; ++ih)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) a[ih][p] = tr_frag(xb + p * MO_XPLANE + ih * 64, MO_XROW);
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) b[p] = tr_frag(hb + p * MO_HPLANE + cb * 64, MO_HROW);
+                    MDNO_MMA6(a[0], b, acc[0][cb])
+                    MDNO_MMA6(a[1], b, acc[1][cb])
+                }
+            }
+            if (st + 1 < stages) {
+                __syncthreads();
+                store_stage();
+                __syncthreads();
+            }
+        }
+    }
+#undef MO_NT
+    // ---- S_t[i][c] -> the k-tiled image: kappa = i*K + c, tile (t >> 7, kappa >> 5), row t & 127, column kappa & 31
+    // (a lane holds one hidden unit c = column l31 of the block, 16 feature rows: 128-B runs per half wave)
+    const int l31 = lane & 31, h = lane >> 5;
+    float* Sb = S + (size_t)(tl >> 7) * moment_nkt(K) * 4096 + (tl & 127) * 32 + l31;
+#pragma unroll
+    for (int ih = 0; ih < 2; ++ih)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const int c0 = cq * MO_CQ + wave * 64 + cb * 32;      // multiple of 32
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int i = ih * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const size_t kt = ((size_t)i * K + c0) >> 5;
+                Sb[kt * 4096] = acc[ih][cb][e];
+            }
+        }
+}
+
+// ---------------------------------------------------------------- K2: z = S . W3R, K-sliced
+// Workgroup (row tile rt of 128 destinations, slice): partial[slice][row][64] = S[rt][kappa in slice] . W3R[kappa][:].
+// The loop of factored.hip's gemm_per_source_split_kernel (fp32 K-tiles of both operands -> three bf16 planes on the
+// fly, XOR-swizzled 64-B LDS rows, six plane products), with the row tile's S in the role of H_j and W3R in the role
+// of Y_j.  PJ_SLICES is a constant and a slice's k-tiles a function of k alone: the association of a destination's
+// sum does not depend on the launch.  The last slice also takes the two s0 k-tiles (x B3).  (64-row workgroups —
+// twice as many, each staging the same W3R tiles for half the rows — took 43 us against 34.)
+constexpr int PJ_SLICES = 128;
+constexpr int PJ_A_PLANE = 128 * 64, PJ_B_PLANE = 64 * 64, PJ_B_BASE = 3 * PJ_A_PLANE;
+
+__global__ __launch_bounds__(256, 4) void project_kernel(const float* __restrict__ S, const float* __restrict__ w3r,
+                                                         float* __restrict__ part, int K, int cnt, int row0,
+                                                         long long part_stride) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * PJ_A_PLANE + 3 * PJ_B_PLANE];
+    // The row tiles of one K slice stream the same W3R tiles: they sit on ONE XCD (workgroup ids b, b+8, .. share an
+    // XCD) next to each other, so that the slice's 8 KiB tiles come through that XCD's L2 once instead of once per row
+    // tile through the fabric (67 -> 17 MB per application at four row tiles).
+    const int ntile = gridDim.x / PJ_SLICES;
+    const int xcd = blockIdx.x & 7, rr = blockIdx.x >> 3;
+    const int rt = rr % ntile, slice = (rr / ntile) * 8 + xcd;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int srow = tid >> 3, scol = (tid & 7) * 4;
+    const int nkt = (int)moment_nkt(K), per = (nkt - 2) / PJ_SLICES;
+    const int kt0 = slice * per, nk = per + (slice == PJ_SLICES - 1 ? 2 : 0);
+    const int rows_here = cnt - rt * 128 < 128 ? cnt - rt * 128 : 128;
+    const int live = (rows_here + 31) >> 5;       // 32-row groups holding at least one destination
+    const float* A0 = S + ((size_t)rt * nkt + kt0) * 4096 + srow * 32 + scol;
+    const float* Bg = w3r + (size_t)kt0 * 2048 + srow * 32 + scol;
+    float4 ra0, ra1 = make_float4(0.f, 0.f, 0.f, 0.f), ra2 = ra1, ra3 = ra1, rb0, rb1;
+#define PJ_LOAD(KT)                                                                                  \
+    ra0 = *reinterpret_cast<const float4*>(A0 + (size_t)(KT) * 4096);                                \
+    if (live > 1) ra1 = *reinterpret_cast<const float4*>(A0 + (size_t)(KT) * 4096 + 32 * 32);        \
+    if (live > 2) ra2 = *reinterpret_cast<const float4*>(A0 + (size_t)(KT) * 4096 + 64 * 32);        \
+    if (live > 3) ra3 = *reinterpret_cast<const float4*>(A0 + (size_t)(KT) * 4096 + 96 * 32);        \
+    rb0 = *reinterpret_cast<const float4*>(Bg + (size_t)(KT) * 2048);                                \
+    rb1 = *reinterpret_cast<const float4*>(Bg + (size_t)(KT) * 2048 + 1024);
+    auto st_off = [&](int row) { return row * 64 + ((((tid & 7) >> 1) ^ ((row >> 2) & 3)) << 4) + (tid & 1) * 8; };
+    unsigned char* a_st0 = lds + st_off(srow);
+    unsigned char* a_st1 = lds + st_off(srow + 32);
+    unsigned char* a_st2 = lds + st_off(srow + 64);
+    unsigned char* a_st3 = lds + st_off(srow + 96);
+    unsigned char* b_st0 = lds + PJ_B_BASE + st_off(srow);
+    unsigned char* b_st1 = lds + PJ_B_BASE + st_off(srow + 32);
+#define PJ_STORE()                                                \
+    split_store4(ra0, a_st0, PJ_A_PLANE);                         \
+    if (live > 1) split_store4(ra1, a_st1, PJ_A_PLANE);           \
+    if (live > 2) split_store4(ra2, a_st2, PJ_A_PLANE);           \
+    if (live > 3) split_store4(ra3, a_st3, PJ_A_PLANE);           \
+    split_store4(rb0, b_st0, PJ_B_PLANE);                         \
+    split_store4(rb1, b_st1, PJ_B_PLANE);
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+    const int arow = wave * 32 + l31, brow0 = l31, brow1 = 32 + l31;
+    const int a_sw = (arow >> 2) & 3, b_sw0 = (brow0 >> 2) & 3, b_sw1 = (brow1 >> 2) & 3;
+    const unsigned char* a_rd = lds + arow * 64;
+    const unsigned char* b_rd0 = lds + PJ_B_BASE + brow0 * 64;
+    const unsigned char* b_rd1 = lds + PJ_B_BASE + brow1 * 64;
+#define PJ_MMA_TILE()                                                                                    \
+    _Pragma("unroll") for (int st = 0; st < 2; ++st) {                                                   \
+        bf16x8 a[3], b0[3], b1[3];                                                                       \
+        _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                  \
+            a[p] = *reinterpret_cast<const bf16x8*>(a_rd + p * PJ_A_PLANE + (((2 * st + h) ^ a_sw) << 4));   \
+            b0[p] = *reinterpret_cast<const bf16x8*>(b_rd0 + p * PJ_B_PLANE + (((2 * st + h) ^ b_sw0) << 4)); \
+            b1[p] = *reinterpret_cast<const bf16x8*>(b_rd1 + p * PJ_B_PLANE + (((2 * st + h) ^ b_sw1) << 4)); \
+        }                                                                                                \
+        MDNO_MMA6(a, b0, acc0) MDNO_MMA6(a, b1, acc1)                                                    \
+    }
+    PJ_LOAD(0)
+    PJ_STORE()
+    __syncthreads();
+    const bool rows_live = wave < live;
+    for (int kt = 0; kt < nk - 1; ++kt) {
+        PJ_LOAD(kt + 1)
+        __builtin_amdgcn_sched_barrier(0);
+        if (rows_live) { PJ_MMA_TILE() }
+        __syncthreads();
+        PJ_STORE()
+        __syncthreads();
+    }
+    if (rows_live) { PJ_MMA_TILE() }
+#undef PJ_LOAD
+#undef PJ_STORE
+#undef PJ_MMA_TILE
+    float* Po = part + (size_t)slice * part_stride;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int m = rt * 128 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (m < cnt) {
+            Po[(size_t)(row0 + m) * 64 + l31] = acc0[e];
+            Po[(size_t)(row0 + m) * 64 + 32 + l31] = acc1[e];
+        }
+    }
+}
+
+// ---------------------------------------------------------------- K3: slices + root + bias + mean + act
+// One workgroup (32 chains x 16 lanes) per destination: chain es adds K slices es, es+32, .. in that order, the 32
+// chains are added in chain order through LDS; the root product is split over the chains the same way.  Every load
+// depends on the destination's index only (one round trip).  Also emits the bf16 planes of y_t for the next
+// application's K1.
+constexpr int FN_CHAINS = 32;
+
+__global__ __launch_bounds__(FN_CHAINS * 16) void finish_kernel(const float* __restrict__ part, long long part_stride,
+                                                                const int* __restrict__ row_ptr, const float* __restrict__ x,
+                                                                const float* __restrict__ root, const float* __restrict__ bias,
+                                                                float* __restrict__ y, int row0, int aggr, int relu,
+                                                                __bf16* __restrict__ next_xq) {
+    constexpr int CPT = 64 / FN_CHAINS;
+    __shared__ float4 red[FN_CHAINS][16];
+    __shared__ float4 red2[FN_CHAINS][16];
+    const int tid = threadIdx.x, es = tid >> 4, q = tid & 15;
+    const int t = row0 + blockIdx.x;
+    const int deg = row_ptr[t + 1] - row_ptr[t];
+    float4 rootv[CPT], biasv = make_float4(0.f, 0.f, 0.f, 0.f);
+    float xin[CPT];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        rootv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        xin[i] = 0.f;
+        if (root != nullptr) {
+            xin[i] = x[(size_t)t * 64 + CPT * es + i];
+            rootv[i] = *reinterpret_cast<const float4*>(root + (CPT * es + i) * 64 + 4 * q);
+        }
+    }
+    if (bias != nullptr && es == 0) biasv = *reinterpret_cast<const float4*>(bias + 4 * q);
+    float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    {
+        float4 v[PJ_SLICES / FN_CHAINS];
+#pragma unroll
+        for (int u = 0; u < PJ_SLICES / FN_CHAINS; ++u)
+            v[u] = *reinterpret_cast<const float4*>(part + (size_t)(es + u * FN_CHAINS) * part_stride + (size_t)t * 64 + 4 * q);
+#pragma unroll
+        for (int u = 0; u < PJ_SLICES / FN_CHAINS; ++u) { z.x += v[u].x; z.y += v[u].y; z.z += v[u].z; z.w += v[u].w; }
+    }
+    float4 racc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        racc.x = fmaf(xin[i], rootv[i].x, racc.x); racc.y = fmaf(xin[i], rootv[i].y, racc.y);
+        racc.z = fmaf(xin[i], rootv[i].z, racc.z); racc.w = fmaf(xin[i], rootv[i].w, racc.w);
+    }
+    red[es][q] = z;
+    red2[es][q] = racc;
+    __syncthreads();
+    if (es == 0) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f), rs = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int c = 0; c < FN_CHAINS; ++c) {
+            const float4 a = red[c][q], b = red2[c][q];
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+            rs.x += b.x; rs.y += b.y; rs.z += b.z; rs.w += b.w;
+        }
+        if (aggr == MDNO_AGGR_MEAN) {
+            const float inv = (float)(deg > 1 ? deg : 1);
+            s.x /= inv; s.y /= inv; s.z /= inv; s.w /= inv;
+        }
+        if (root != nullptr) { s.x += rs.x; s.y += rs.y; s.z += rs.z; s.w += rs.w; }
+        if (bias != nullptr) { s.x += biasv.x; s.y += biasv.y; s.z += biasv.z; s.w += biasv.w; }
+        if (relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
+        *reinterpret_cast<float4*>(y + (size_t)t * 64 + 4 * q) = s;
+        if (next_xq != nullptr) split_store4(s, reinterpret_cast<unsigned char*>(next_xq + (size_t)t * XQ_ROW + 4 * q), 64 * 2);
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------- host side
+constexpr int kMomentChunkRows = 512;      // destinations per S chunk: 512 x 64 k x 4 B = 128 MiB at k = 1024, written by K1
+                                           // and read back by K2 while still in the 256 MiB Infinity Cache
+static int moment_chunk_rows(int num_rows) {
+    const int padded = (num_rows + 127) / 128 * 128;
+    return padded < kMomentChunkRows ? padded : kMomentChunkRows;
+}
+
+bool moment_supported(int width, int ker_width) { return width == 64 && ker_width % MO_CQ == 0 && (64 * ker_width / 32) % PJ_SLICES == 0; }
+static size_t s_chunk_floats(int num_rows, int ker_width) { return (size_t)(moment_chunk_rows(num_rows) / 128) * moment_nkt(ker_width) * 4096; }
+
+size_t moment_workspace_bytes(int num_rows, int ker_width) {
+    Carver cv(nullptr);
+    cv.take<float>((size_t)(64 * ker_width + 64) * 64);                            // W3R (+ the B3 rows)
+    cv.take<float>(s_chunk_floats(num_rows, ker_width));                           // S (+ s0), one chunk of destinations
+    cv.take<float>((size_t)PJ_SLICES * num_rows * 64);                             // K-slice partials of z
+    cv.take<__bf16>((size_t)(num_rows + 1) * XQ_ROW);                              // bf16 planes of the node features (+ a zero row), ping
+    cv.take<__bf16>((size_t)(num_rows + 1) * XQ_ROW);                              // ... pong
+    cv.take<int>((size_t)num_rows);                                                // destinations of each chunk by decreasing degree
+    return cv.used();
+}
+
+MomentWs moment_carve(void* ws, int num_rows, int ker_width) {
+    MomentWs f{};
+    Carver cv(ws);
+    f.w3r = cv.take<float>((size_t)(64 * ker_width + 64) * 64);
+    f.s = cv.take<float>(s_chunk_floats(num_rows, ker_width));
+    f.part = cv.take<float>((size_t)PJ_SLICES * num_rows * 64);
+    f.part_stride = (long long)num_rows * 64;
+    f.xq[0] = cv.take<__bf16>((size_t)(num_rows + 1) * XQ_ROW);
+    f.xq[1] = cv.take<__bf16>((size_t)(num_rows + 1) * XQ_ROW);
+    f.order = cv.take<int>((size_t)num_rows);
+    return f;
+}
+
+int moment_prepare_weights(const float* w3, const float* b3, int ker_width, const MomentWs& f, hipStream_t s) {
+    const long long total = (long long)(64 * ker_width + 64) * 64;
+    hipLaunchKernelGGL(w3_moment_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w3, b3, ker_width, f.w3r);
+    return check_launch("w3_moment_kernel");
+}
+
+int moment_prepare_graph(const int* row_ptr, int num_rows, const MomentWs& f, hipStream_t s) {
+    TimedSection ts(KID_GRAPH, s);
+    return degree_order_chunks(row_ptr, num_rows, kMomentChunkRows, f.order, s);
+}
+
+int moment_conv(const float* x, const float* h2, const int* row_ptr, const int* src, int num_rows, int ker_width,
+                const float* b3, const float* root, const float* bias, int aggr, int relu, float* y, const MomentWs& f,
+                hipStream_t s, int parity, bool x_prepared, bool emit_next) {
+    MDNO_REQUIRE(moment_supported(64, ker_width), MDNO_EUNSUPPORTED, "moment conv: ker_width=%d (x256)", ker_width);
+    __bf16* xq_in = static_cast<__bf16*>(f.xq[parity & 1]);
+    __bf16* xq_out = emit_next ? static_cast<__bf16*>(f.xq[(parity & 1) ^ 1]) : nullptr;
+    if (!x_prepared) {
+        TimedSection ts(KID_FACT_Y, s);
+        hipLaunchKernelGGL(split_nodes_kernel, dim3((num_rows * 16 + 255) / 256), dim3(256), 0, s, x, num_rows, xq_in,
+                           static_cast<__bf16*>(f.xq[(parity & 1) ^ 1]));
+    }
+    for (int r0 = 0; r0 < num_rows; r0 += kMomentChunkRows) {
+        const int cnt = num_rows - r0 < kMomentChunkRows ? num_rows - r0 : kMomentChunkRows;
+        {   // K1: the chunk's destinations x the k/256 column blocks
+            TimedSection ts(KID_NNCONV, s);
+            hipLaunchKernelGGL(moment_kernel, dim3(cnt, ker_width / MO_CQ + 1), dim3(256), 0, s, h2, (const __bf16*)xq_in, row_ptr,
+                               src, (const int*)f.order, f.s, ker_width, r0, x);
+        }
+        {   // K2: row tiles x K slices
+            TimedSection ts(KID_FACT_Y, s);
+            hipLaunchKernelGGL(project_kernel, dim3(((cnt + 127) / 128) * PJ_SLICES), dim3(256), 0, s, (const float*)f.s,
+                               (const float*)f.w3r, f.part, ker_width, cnt, r0, f.part_stride);
+        }
+        {   // K3
+            TimedSection ts(KID_NNCONV_COMBINE, s);
+            hipLaunchKernelGGL(finish_kernel, dim3(cnt), dim3(FN_CHAINS * 16), 0, s, (const float*)f.part, f.part_stride,
+                               row_ptr, x, root, bias, y, r0, aggr, relu, xq_out);
+        }
+    }
+    return check_launch("moment_conv");
+}
+
+}  // namespace mdno

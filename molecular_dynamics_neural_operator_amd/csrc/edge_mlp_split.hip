@@ -23,7 +23,7 @@
 //   layer 1      H1 x W1 -> relu -> split  ---------> H2 tiled planes        (epilogue emits planes)
 //   layer 2      H2 x W2 + b  -> fp32 W_e[E, Cin*Cout]  (row-major, what the conv streams)
 // so no fp32 activation is ever stored (materialized conv).  The factored conv stops after layer 1,
-// whose epilogue then writes H as k-tiled fp32 (OUT 2), and reuses the same GEMM for Y = X . W3T
+// whose epilogue then writes H as k-tiled fp32 (OUT 2: what csrc/moment.hip and csrc/factored.hip stream)
 // (split_gemm_rows); the training ops use it through split_linear (OUT 0 / 3).
 //
 // GEMM kernel: 256x128 block tile, k-step 16 per stage, 8 waves (4x2), wave tile 64x64 = 2x2
@@ -159,48 +159,6 @@ __global__ __launch_bounds__(256) void split_planes_f16_kernel(const float* __re
         }
     }
     if (bad) atomicOr(range_flag, 1);
-}
-
-// ---------------------------------------------------------------- x [rows,64] -> planes, + q = x . B
-// Block = 4 rows x 64 threads; thread (row, o) accumulates q[row][o] = sum_i x[row][i] * b[i*64 + o]
-// (i ascending, fmaf), threads o < 8 also split the row's 8-float chunk o.
-__global__ __launch_bounds__(256) void split_bias64_kernel(const float* __restrict__ x, const float* __restrict__ b,
-                                                           int rows, unsigned char* __restrict__ planes,
-                                                           float* __restrict__ q, unsigned char* __restrict__ planes_h,
-                                                           int* __restrict__ range_flag) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), o = threadIdx.x & 63;
-    if (row >= rows) return;
-    const float* xr = x + (size_t)row * 64;
-    float acc = 0.f;
-#pragma unroll 16
-    for (int i = 0; i < 64; ++i) acc = fmaf(xr[i], b[i * 64 + o], acc);
-    q[(size_t)row * 64 + o] = acc;
-    if (o < 8) {
-        const float4 v0 = *reinterpret_cast<const float4*>(xr + 8 * o);
-        const float4 v1 = *reinterpret_cast<const float4*>(xr + 8 * o + 4);
-        const float xv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-        __bf16 pl[3][8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) split3(xv[j], pl[0][j], pl[1][j], pl[2][j]);
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-            *reinterpret_cast<uint4*>(planes + tiled_off(row, 8 * o, 4, p)) = *reinterpret_cast<const uint4*>(pl[p]);
-        if (planes_h != nullptr) {
-            _Float16 ph[2][8];
-            bool bad = false, seen = false;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                bad |= !(fabsf(xv[j]) < F16_MAX);
-                seen |= fabsf(xv[j]) >= F16_ACT_MIN;
-                split2h(xv[j], ph[0][j], ph[1][j]);
-            }
-            if (bad) atomicOr(range_flag, 1);
-            if (seen) range_flag[F16_SEEN_OFF] = 1;      // (same value from every thread that stores it: no atomic)
-#pragma unroll
-            for (int p = 0; p < 2; ++p)
-                *reinterpret_cast<uint4*>(planes_h + tiled_off2(row, 8 * o, 4, p)) = *reinterpret_cast<const uint4*>(ph[p]);
-        }
-    }
 }
 
 // ---------------------------------------------------------------- layer 0 (+ attr gather) -> planes
@@ -481,7 +439,7 @@ __global__ __launch_bounds__(TM * 2, 2) void gemm_split_bf16_kernel(SplitGemmArg
                 const int m = bm + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (m < valid) {
                     const float v = acc[i][j][e] + bv;
-                    if (OUT == 2) {   // k-tiled fp32 image [m/128][n/32][128][32] (csrc/factored.hip step (2))
+                    if (OUT == 2) {   // k-tiled fp32 image [m/128][n/32][128][32] (csrc/moment.hip K1, csrc/factored.hip step (2))
                         g.C[((size_t)(m >> 7) * (g.N >> 5) + (n >> 5)) * 4096 + (m & 127) * 32 + (n & 31)] = fmaxf(v, 0.f);
                     } else if (OUT == 1) {
                         __bf16 ph, pm, pl;
@@ -999,127 +957,6 @@ int launch_split_f16_gemm(SplitGemmArgs g, hipStream_t s) {
     return check_launch("split-f16 GEMM");
 }
 
-// ---------------------------------------------------------------- K = 64 GEMM on two fp16 planes
-// C [rows, N] = A . Bt^T for the factored conv's Y = X . W3T (factored.hip step (1)): 4.2 GFLOP for a
-// 132 MB result — a store with a little arithmetic in front.  K is four k-steps, so a 128 x 128 tile's
-// whole operand set is 32 KiB of A planes + 32 KiB of B planes, each ONE contiguous run of the tiled
-// images.  A workgroup owns one 128-column panel of B for the whole launch (a launch is at most a Y
-// chunk of rows: a handful of row tiles): B comes in once, and the row tiles are walked with the NEXT
-// tile's A burst issued ahead of the current tile's 64 stores per lane, then waited for with a COUNTED
-// wait (vmcnt counts loads and stores in issue order on gfx9: `vmcnt(56)` = the 8 DMA pieces and the
-// oldest 8 stores are done), so the operand latency sits under the store stream instead of in front of
-// it.  64 KiB of LDS: two workgroups per CU.  (One tile per workgroup with everything reloaded: 31 us per
-// launch at N=504; the 256-row bf16 kernel with its four-stage pipeline: 37 us.)
-// Out of fp16 range (flag_w: a weight, flag_x: a node feature of this application — exploding
-// activations of an untrained net get there) the SAME launch multiplies the bf16 plane images instead,
-// in two halves of K through the same LDS: no second launch, bit-identical to gemm_split_bf16_kernel.
-constexpr int K64_LDS_BYTES = 2 * 4 * 2 * PLANE_BYTES;     // A | B, 4 k-steps x 2 planes x 4 KiB each
-
-// (two waves per SIMD = the two workgroups per CU the LDS allows: without the bound the two code paths
-// together take 260 registers and leave one)
-__global__ __launch_bounds__(256, 2) void gemm_k64_f16_kernel(const unsigned char* __restrict__ Ah,
-                                                           const unsigned char* __restrict__ Bh,
-                                                           const unsigned char* __restrict__ Ab,
-                                                           const unsigned char* __restrict__ Bb,
-                                                           const int* __restrict__ flag_w,
-                                                           const int* __restrict__ flag_x,
-                                                           const float* __restrict__ b_unscale,
-                                                           float* __restrict__ C, int rows_valid, int N, int tiles_m) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int tn = blockIdx.x, bn = tn * TN;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
-    // fp16 planes only for node features that are in range AND hold a value >= F16_ACT_MIN (split_layout.h)
-    const bool blocked = (__builtin_nontemporal_load(flag_w) | __builtin_nontemporal_load(flag_x)) != 0 ||
-                         __builtin_nontemporal_load(flag_x + F16_SEEN_OFF) == 0;
-    f32x16 acc[2][2], accx[2][2];
-    float us0 = 1.f, us1 = 1.f;      // per-column undo of the W3T rows' power-of-two scale (fp16 path only)
-    const int hsw = (h ^ ((l31 >> 3) & 1)) << 4;
-    const int a_rd = (wm * 64 + l31) * 32 + hsw, b_rd = 32768 + (wn * 64 + l31) * 32 + hsw;
-    // (fallback: accx stays zero and the sum below is acc itself, bit for bit)
-#define MDNO_K64_STORE_IF(TM_, COND)                                                                    \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                      \
-        const int n = bn + wn * 64 + j * 32 + l31;                                                       \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                    \
-            _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                             \
-                const int m = (TM_) * 128 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;           \
-                if (COND) C[(size_t)m * N + n] = (acc[i][j][e] + accx[i][j][e] * F16_LO_UNSCALE) * (j ? us1 : us0); \
-            }                                                                                            \
-    }
-    // (a full tile stores without the 64 per-row tests; only a launch's last tile can be ragged)
-#define MDNO_K64_STORE(TM_)                                                                              \
-    if (((TM_) + 1) * 128 <= rows_valid) { MDNO_K64_STORE_IF(TM_, true) } else { MDNO_K64_STORE_IF(TM_, m < rows_valid) }
-#define MDNO_K64_ZERO()                                                                                  \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                        \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                    \
-            _Pragma("unroll") for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.f; accx[i][j][e] = 0.f; }
-    if (!blocked) {
-        const unsigned char* a_src = Ah + lane * 16;                            // 32 KiB per 128-row tile
-        const unsigned char* b_src = Bh + ((size_t)tn << 15) + lane * 16;
-        us0 = b_unscale[bn + wn * 64 + l31];
-        us1 = b_unscale[bn + wn * 64 + 32 + l31];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {       // wave w moves KiB w, w+4, ... of B and of the first A tile
-            const int piece = wave + 4 * t;
-            __builtin_amdgcn_global_load_lds((glb_u8*)(b_src + piece * 1024), (lds_u8*)(lds + 32768 + piece * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_u8*)(a_src + piece * 1024), (lds_u8*)(lds + piece * 1024), 16, 0, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(us0), "+v"(us1) : : "memory");   // (pinned here: see the bias note above)
-        for (int tm = 0; tm < tiles_m; ++tm) {
-            // everybody's pieces of this tile's A (and of B) have landed.  Bare barrier instructions:
-            // __syncthreads() carries a fence the compiler lowers to vmcnt(0), i.e. a wait for the stores
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            MDNO_K64_ZERO()
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) mma_f16_kstep<2>(acc, accx, lds + ks * 2 * PLANE_BYTES, a_rd, b_rd);
-            // every wave's fragment reads of A have returned (they fed its MFMAs): A may be overwritten
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            const bool more = tm + 1 < tiles_m;
-            if (more) {
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const int piece = wave + 4 * t;
-                    __builtin_amdgcn_global_load_lds((glb_u8*)(a_src + ((size_t)(tm + 1) << 15) + piece * 1024),
-                                                     (lds_u8*)(lds + piece * 1024), 16, 0, 0);
-                }
-                asm volatile("" ::: "memory");
-            }
-            MDNO_K64_STORE(tm)
-            // a tile that is followed by another one is a full tile: exactly 64 stores per lane were issued
-            // behind the 8 DMA pieces
-            if (more) asm volatile("s_waitcnt vmcnt(56)" ::: "memory");
-        }
-    } else {
-        // bf16 planes: 12 KiB per k-step per 128-row tile; two k-steps (24 KiB of A, 24 KiB of B) at a time
-        for (int tm = 0; tm < tiles_m; ++tm) {
-            const unsigned char* a_src = Ab + (size_t)tm * 4 * 3 * PLANE_BYTES + lane * 16;
-            const unsigned char* b_src = Bb + (size_t)tn * 4 * 3 * PLANE_BYTES + lane * 16;
-            MDNO_K64_ZERO()
-            for (int half = 0; half < 2; ++half) {
-                if (half || tm) __syncthreads();      // everyone is done reading what is about to be overwritten
-#pragma unroll
-                for (int t = 0; t < 6; ++t) {
-                    const int piece = wave + 4 * t;       // 24 pieces of A, 24 of B
-                    __builtin_amdgcn_global_load_lds((glb_u8*)(a_src + (half * 24 + piece) * 1024), (lds_u8*)(lds + piece * 1024), 16, 0, 0);
-                    __builtin_amdgcn_global_load_lds((glb_u8*)(b_src + (half * 24 + piece) * 1024), (lds_u8*)(lds + 32768 + piece * 1024), 16, 0, 0);
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) mma_split_stage(acc, lds + ks * 3 * PLANE_BYTES, a_rd, b_rd);
-            }
-            MDNO_K64_STORE(tm)
-        }
-    }
-#undef MDNO_K64_STORE
-#undef MDNO_K64_STORE_IF
-#undef MDNO_K64_ZERO
-}
-
 template <int TM, int OUT>
 int launch_split_gemm_tm(SplitGemmArgs g, hipStream_t s) {
     constexpr int lds_bytes = 2 * stage_bytes(TM);
@@ -1155,7 +992,7 @@ int fill_ints(int* p, int n, int value, hipStream_t s) {
     return check_launch("fill_ints_kernel");
 }
 
-// ---------------------------------------------------------------- generic pieces (factored.hip step (1))
+// ---------------------------------------------------------------- generic pieces
 size_t split_planes_bytes(long long rows, int K) {
     return (size_t)3 * ((rows + 255) / 256 * 256) * K * sizeof(__bf16);   // whole 256-row GEMM tiles
 }
@@ -1168,15 +1005,6 @@ int split_planes(const float* a, int rows, int K, void* planes, hipStream_t s) {
     return check_launch("split_planes_kernel");
 }
 
-int split_planes_bias64(const float* x, int rows, const float* b, float* q, void* planes, hipStream_t s, void* planes_h,
-                        int* range_flag) {
-    MDNO_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && b && q && (!planes_h || range_flag), MDNO_EINVAL,
-                 "split_planes_bias64: bad arguments");
-    hipLaunchKernelGGL(split_bias64_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, b, rows,
-                       static_cast<unsigned char*>(planes), q, static_cast<unsigned char*>(planes_h), range_flag);
-    return check_launch("split_bias64_kernel");
-}
-
 size_t split_planes_f16_bytes(long long rows, int K) {
     return (size_t)2 * ((rows + 255) / 256 * 256) * K * sizeof(_Float16);
 }
@@ -1187,31 +1015,6 @@ int split_planes_f16(const float* a, int rows, int K, void* planes, float* unsca
     hipLaunchKernelGGL(split_planes_f16_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, a, rows, K,
                        static_cast<unsigned char*>(planes), unscale, range_flag);
     return check_launch("split_planes_f16_kernel");
-}
-
-int split_gemm_rows_k64_f16(const void* a_planes, const void* b_planes, const void* a_bf16, const void* b_bf16,
-                            const int* flag_w, const int* flag_x, const float* b_unscale, int rows, int N, float* C,
-                            hipStream_t s) {
-    MDNO_REQUIRE(N % TN == 0 && rows > 0 && a_bf16 && b_bf16 && flag_w && flag_x && b_unscale, MDNO_EUNSUPPORTED,
-                 "split_gemm_rows_k64_f16: rows=%d N=%d", rows, N);
-    static std::atomic<unsigned long long> lds_raised{0};
-    MDNO_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(&gemm_k64_f16_kernel), K64_LDS_BYTES, lds_raised));
-    const int tiles_m = (rows + 127) / 128, tiles_n = N / TN;
-    hipLaunchKernelGGL(gemm_k64_f16_kernel, dim3(tiles_n), dim3(256), K64_LDS_BYTES, s,
-                       static_cast<const unsigned char*>(a_planes), static_cast<const unsigned char*>(b_planes),
-                       static_cast<const unsigned char*>(a_bf16), static_cast<const unsigned char*>(b_bf16), flag_w, flag_x,
-                       b_unscale, C, rows, N, tiles_m);
-    return check_launch("gemm_k64_f16_kernel");
-}
-
-// C[rows, N] (fp32 row-major) = A . Bt^T from tiled planes of A [rows, K] and Bt [N, K]
-int split_gemm_rows(const void* a_planes, const void* b_planes, int rows, int N, int K, float* C, hipStream_t s) {
-    MDNO_REQUIRE(K % 32 == 0 && N % TN == 0 && rows > 0, MDNO_EUNSUPPORTED, "split_gemm_rows: rows=%d N=%d K=%d", rows, N, K);
-    SplitGemmArgs g{static_cast<const unsigned char*>(a_planes), static_cast<const unsigned char*>(b_planes), nullptr, C,
-                    nullptr, nullptr, 0, (rows + 255) / 256 * 256, N, K, 0, 0, rows, 1};
-    // m-fastest tile order: the tiles of one B panel run back to back on one XCD.  256-row tiles also
-    // here: 128-row ones measured 57 vs 49 us at R=504, N=65536
-    return (N >= 2048 && rows > 128) ? launch_split_gemm_tm<256, 0>(g, s) : launch_split_gemm_tm<128, 0>(g, s);
 }
 
 // act(A . W^T + b) for the training ops: A [rows,K] and W [N,K] are split here, every call

@@ -83,11 +83,10 @@ struct FwdWs {
 };
 
 // The factored conv's two forms: destination-side (moment.hip) for the split GEMM modes, source-side (factored.hip,
-// exact fp32 MFMA kernels) for gemm_mode F32.  MDNO_FACTORED_SOURCE_SIDE=1 (development A/B) forces the latter's
-// split kernels.
-bool use_moment(const mdno_kernelnn_params* p) {
-    static const bool force_old = getenv("MDNO_FACTORED_SOURCE_SIDE") != nullptr;
-    return !force_old && p->gemm_mode != MDNO_GEMM_F32 && moment_supported(p->width, p->ker_width);
+// exact fp32 MFMA kernels) for gemm_mode F32.
+bool use_moment(const mdno_kernelnn_params* p) { return p->gemm_mode != MDNO_GEMM_F32; }
+bool factored_available(const mdno_kernelnn_params* p) {
+    return use_moment(p) ? moment_supported(p->width, p->ker_width) : factored_supported(p->width, p->ker_width);
 }
 
 // The factored conv applies to graphs the library builds itself (symmetric radius graphs) at width 64.
@@ -104,7 +103,7 @@ constexpr long long kAutoFactoredMinDegree = 40;
 constexpr long long kAutoFactoredMinEdgesPerMember = 16384;
 
 bool use_factored(const mdno_kernelnn_params* p, int M, long long edge_cap, bool position_graph) {
-    if (p->conv_mode == MDNO_CONV_MATERIALIZED || !factored_supported(p->width, p->ker_width)) return false;
+    if (p->conv_mode == MDNO_CONV_MATERIALIZED || !factored_available(p)) return false;
     if (p->conv_mode == MDNO_CONV_FACTORED) return true;   // (forward_impl insists on a position graph)
     return position_graph && edge_cap / (M > 0 ? M : 1) >= kAutoFactoredMinEdgeCapPerMember;
 }
@@ -185,9 +184,11 @@ int forward_impl(const mdno_kernelnn_params* p, const float* frames, int t0, con
             MDNO_TRY(fc_out(cur, p->fc2_w, p->fc2_b, R, C, p->out_width, out_frames, t_out, t_dev, s, tail));
             return MDNO_OK;
         }
+        // gemm_mode F32: source-side form on the exact fp32 MFMA.  Symmetric radius graph, attributes from positions:
+        // row r = SOURCE r -> destinations src[p] (the CSR arrays' names refer to the materialised reading; here their
+        // roles are swapped)
         const FactoredWs fw = factored_carve(ws.fact, R, p->ker_width, edge_cap);
-        const int cgm = conv_gemm_mode(p->gemm_mode);
-        if (!prep_only) MDNO_TRY(factored_prepare_graph(row_ptr, src, dst, R, N, cgm, edge_cap, fw, status, s));
+        if (!prep_only) MDNO_TRY(factored_prepare_graph(row_ptr, src, dst, R, edge_cap, fw, status, s));
         for (int block = 0; block < blocks; ++block) {
             const bool own = block == 1 && separate_conv2_kernel(p);
             if (block == 0 || own) {
@@ -197,22 +198,15 @@ int forward_impl(const mdno_kernelnn_params* p, const float* frames, int t0, con
                 MDNO_TRY(edge_mlp_hidden(edge_frames, edge_frame, t_dev, R, /*src=*/dst, /*dst=*/src, nullptr, nullptr,
                                          num_edges, edge_cap, p->ker_in, p->ker_width, p->gemm_mode, w, ws.h2, ws.mlp,
                                          ws.mlp_bytes, s, block == 0 ? phase : (phase & ~WP_FLAGS_ZEROED)));
-                if ((phase & WP_PHASE_MASK) != WP_RUN_ONLY) MDNO_TRY(factored_prepare_weights(w.w2, p->ker_width, cgm, fw, s));
+                if ((phase & WP_PHASE_MASK) != WP_RUN_ONLY) MDNO_TRY(factored_prepare_weights(w.w2, p->ker_width, fw, s));
             }
             if (prep_only) return MDNO_OK;
-            const float* b3 = (block == 1 && separate_conv2_kernel(p)) ? p->k2_b2 : p->k_b2;
+            const float* b3 = own ? p->k2_b2 : p->k_b2;
             const float* root = block == 0 ? p->conv1_root : p->conv2_root;
             const float* bias = block == 0 ? p->conv1_bias : p->conv2_bias;
             for (int d = 0; d < p->depth; ++d) {
-                // each application leaves the next one's operands (bf16 image of its output, q) behind
-                const bool first = block == 0 && d == 0;
-                const float* next_b3 = d + 1 < p->depth ? b3
-                                       : block + 1 < blocks ? (separate_conv2_kernel(p) ? p->k2_b2 : p->k_b2)
-                                                            : nullptr;
-                MDNO_TRY(factored_conv(cur, ws.h2, row_ptr, R, N, max_degree > 0 ? max_degree : N, p->ker_width,
-                                       cgm, b3, root, bias, MDNO_AGGR_MEAN, /*relu=*/1, nxt, fw, status, s,
-                                       /*x_prepared=*/!first, next_b3,
-                                       p->gemm_mode == MDNO_GEMM_SPLIT_F16 ? block * p->depth + d : -1));
+                MDNO_TRY(factored_conv(cur, ws.h2, row_ptr, R, max_degree > 0 ? max_degree : N, p->ker_width, b3, root, bias,
+                                       MDNO_AGGR_MEAN, /*relu=*/1, nxt, fw, status, s));
                 float* t = cur; cur = nxt; nxt = t;
             }
         }
@@ -290,7 +284,7 @@ extern "C" int mdno_resolve_conv_mode(const mdno_kernelnn_params* p, int M, int6
 }
 
 extern "C" int mdno_conv_mode_for_graph(const mdno_kernelnn_params* p, int M, int N, int64_t num_edges) {
-    if (!p || M <= 0 || N <= 0 || !factored_supported(p->width, p->ker_width)) return MDNO_CONV_MATERIALIZED;
+    if (!p || M <= 0 || N <= 0 || !factored_available(p)) return MDNO_CONV_MATERIALIZED;
     const long long rows = (long long)M * N;
     const bool dense = num_edges >= kAutoFactoredMinDegree * rows && num_edges >= (long long)M * kAutoFactoredMinEdgesPerMember;
     return dense ? MDNO_CONV_FACTORED : MDNO_CONV_MATERIALIZED;

@@ -70,20 +70,13 @@ int edge_mlp_split_hidden(const float* frames, int frame, const int* t_dev, int 
                           const int* dst, const float* edge_attr, const int* perm, const int* num_edges,
                           long long edge_cap, long long chunk, int ker_in, int ker_width, const EdgeMlpWeights& w,
                           float* h_out, void* workspace, hipStream_t s, int phase = WP_BOTH, bool f16 = false);
-// gemm_mode as the factored conv's own kernels see it: SPLIT_F16 changes the edge-MLP GEMMs and Y = X.W3T
-// (range-checked operands); the per-source GEMM of that mode runs the SPLIT_BF16 kernel
-inline int conv_gemm_mode(int gemm_mode) { return gemm_mode == MDNO_GEMM_SPLIT_F16 ? MDNO_GEMM_SPLIT_BF16 : gemm_mode; }
 
 // Pieces of the split-bf16 GEMM usable on their own (edge_mlp_split.hip): fp32 [rows,K] -> tiled bf16
 // planes (buffer of split_planes_bytes), and C[rows,N] = A . Bt^T (fp32 row-major) from two such images.
 size_t split_planes_bytes(long long rows, int K);
 int split_planes(const float* a, int rows, int K, void* planes, hipStream_t s);
-// K = 64 only: the same split of x [rows,64], fused with q[r][o] = sum_i x[r][i] * b[i*64 + o] (fp32 [rows,64])
-int split_planes_bias64(const float* x, int rows, const float* b, float* q, void* planes, hipStream_t s,
-                        void* planes_f16 = nullptr, int* range_flag = nullptr);   // planes_f16: also the two-plane
-                                                       // fp16 image of x; *range_flag raised when |x| >= 65504
 int fill_ints(int* p, int n, int value, hipStream_t s);     // n <= 256, by a kernel
-// two-plane fp16 images (SPLIT_F16) and the K = 64 GEMM on them (the factored conv's Y = X . W3T)
+// two-plane fp16 images (SPLIT_F16)
 size_t split_planes_f16_bytes(long long rows, int K);
 // C [n1,n2] (+)= A^T . B for fp32 operands on two fp16 planes each, columns scaled by powers of two (gemm_bf16.hip)
 bool gemm_atb_f16_supported(long long rows, int n1, int n2);
@@ -97,45 +90,27 @@ int split_linear_f16(const float* a, const float* w, const float* bias, long lon
                      void* workspace, hipStream_t s);
 // (each row scaled by a power of two into fp16's upper binades; unscale[row] = the factor that undoes it)
 int split_planes_f16(const float* a, int rows, int K, void* planes, float* unscale, int* range_flag, hipStream_t s);
-// (bf16 images of the same operands + the two range flags: the kernel multiplies those when a flag is up)
-int split_gemm_rows_k64_f16(const void* a_planes, const void* b_planes, const void* a_bf16, const void* b_bf16,
-                            const int* flag_w, const int* flag_x, const float* b_unscale, int rows, int N, float* C,
-                            hipStream_t s);
-int split_gemm_rows(const void* a_planes, const void* b_planes, int rows, int N, int K, float* C, hipStream_t s);
 // C = act(A . W^T + b) with both operands split on the way in (training ops)
 size_t split_linear_workspace_bytes(long long rows, int N, int K);
 bool split_linear_supported(long long rows, int N, int K);
 int split_linear(const float* a, const float* w, const float* bias, long long rows, int N, int K, int relu, float* c,
                  void* workspace, hipStream_t s);
 
-// Factored conv (factored.hip): see the file header.
+// Factored conv, source-side form on the exact fp32 MFMA (factored.hip: what gemm_mode F32 runs): see the file header.
 struct FactoredWs {
     float *w3t, *y, *m, *q;
-    void *w3tp, *xp;          // split-bf16 images of W3T and of the current node features
-    void *w3th, *xh;          // the same as two fp16 planes (SPLIT_F16)
-    float* w3tus;             // per-row unscale factors of the fp16 image of W3T
-    int* f16_flags;           // [0]: W3T not finite; [1 + a]: the node features entering application a are out of
-                              // fp16 range; [64 + 1 + a]: they hold a value >= F16_ACT_MIN (split_layout.h)
     int* rev;
-    int* order;               // sources of each Y chunk by decreasing degree (factored_prepare_graph)
     long long part_stride;
 };
 bool factored_supported(int width, int ker_width);
 size_t factored_workspace_bytes(int num_rows, int ker_width, long long edge_cap);
 FactoredWs factored_carve(void* ws, int num_rows, int ker_width, long long edge_cap);
-int factored_prepare_weights(const float* w3, int ker_width, int gemm_mode, const FactoredWs& f, hipStream_t s);
-int factored_prepare_graph(const int* row_ptr, const int* col, const int* rowid, int num_rows, int rows_per_member,
-                           int gemm_mode, long long edge_cap, const FactoredWs& f, int* status, hipStream_t s);
-int factored_conv(const float* x, const float* h2, const int* row_ptr, int num_rows, int rows_per_member,
-                  int max_degree, int ker_width,
-                  int gemm_mode, const float* b3, const float* root, const float* bias, int aggr, int relu, float* y,
-                  const FactoredWs& f, int* status, hipStream_t s, bool x_prepared, const float* next_b3,
-                  int application = -1);
-// application >= 0 (SPLIT_F16): index of this conv application inside the forward; step (1) then runs on
-// the fp16 planes, guarded by f16_flags[0] and f16_flags[1 + application].  -1: bf16 planes.
-constexpr int kMaxF16Applications = 62;
-// x_prepared: the bf16 image of x and q = x.B3 are already in f.xp / f.q (left there by the previous
-// application, which was given this application's b3 as next_b3); next_b3 NULL: nothing follows.
+int factored_prepare_weights(const float* w3, int ker_width, const FactoredWs& f, hipStream_t s);
+int factored_prepare_graph(const int* row_ptr, const int* col, const int* rowid, int num_rows, long long edge_cap,
+                           const FactoredWs& f, int* status, hipStream_t s);
+int factored_conv(const float* x, const float* h2, const int* row_ptr, int num_rows, int max_degree, int ker_width,
+                  const float* b3, const float* root, const float* bias, int aggr, int relu, float* y,
+                  const FactoredWs& f, int* status, hipStream_t s);
 
 // Factored conv, destination-side form (moment.hip: S_t = sum_{e->t} x_src (x) h_e, then y_t = W3 : S_t) — what the
 // split GEMM modes run; factored.hip's source-side kernels remain for gemm_mode F32.
@@ -155,8 +130,6 @@ int moment_prepare_graph(const int* row_ptr, int num_rows, const MomentWs& f, hi
 int moment_conv(const float* x, const float* h2, const int* row_ptr, const int* src, int num_rows, int ker_width,
                 const float* b3, const float* root, const float* bias, int aggr, int relu, float* y, const MomentWs& f,
                 hipStream_t s, int parity, bool x_prepared, bool emit_next);
-// order[chunk*chunk_rows + rank] = index inside the chunk of the row with that rank (degree descending; factored.hip)
-int degree_order_chunks(const int* row_ptr, int num_rows, int chunk_rows, int* order, hipStream_t s);
 
 // bf16 training GEMMs (gemm_bf16.hip): 256 x 256 tiles, 8 waves, two wave groups one phase apart over an
 // LDS-DMA ring of 32-k stages.

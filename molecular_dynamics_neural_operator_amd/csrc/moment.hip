@@ -108,6 +108,31 @@ __global__ __launch_bounds__(256) void w3_moment_kernel(const float* __restrict_
     w3r[id] = w3[((size_t)i * 64 + o) * k + c];
 }
 
+// ---------------------------------------------------------------- destinations by decreasing degree
+// One workgroup per S chunk of CH destinations: order[chunk*CH + rank] = index inside the chunk of the destination
+// with that rank (degree descending, ties by index).  Once per graph: all workgroups of a K1 launch are resident
+// together, and a CU then gets one destination from every quarter of the sorted list instead of four of any size.
+template <int CH>
+__global__ __launch_bounds__(CH) void degree_order_kernel(const int* __restrict__ row_ptr, int num_rows,
+                                                          int* __restrict__ order) {
+    __shared__ __attribute__((aligned(16))) int key[CH];      // degree * CH + (CH - 1 - index): all distinct
+    const int base = blockIdx.x * CH, t = threadIdx.x;
+    const int cnt = num_rows - base < CH ? num_rows - base : CH;
+    int dg = t < cnt ? row_ptr[base + t + 1] - row_ptr[base + t] : 0;
+    dg = dg < (1 << 20) ? dg : (1 << 20);      // (the key must fit an int; beyond that the order does not matter)
+    const int mine = t < cnt ? dg * CH + (CH - 1 - t) : -1;
+    key[t] = mine;
+    __syncthreads();
+    if (t >= cnt) return;
+    int rank = 0;
+#pragma unroll 4
+    for (int u = 0; u < CH; u += 4) {
+        const int4 k4 = *reinterpret_cast<const int4*>(&key[u]);
+        rank += (k4.x > mine) + (k4.y > mine) + (k4.z > mine) + (k4.w > mine);
+    }
+    order[base + rank] = t;
+}
+
 // ---------------------------------------------------------------- K1: S_t = X_N(t)^T . H_t
 // k-tiles (32 kappa) of a destination's row of the S image: 64 k / 32 for S_t itself + 2 for s0_t (kappa = 64 k + i)
 __host__ __device__ constexpr size_t moment_nkt(int K) { return (size_t)64 * K / 32 + 2; }
@@ -124,16 +149,22 @@ constexpr int MO_LDS = 3 * MO_HPLANE + 3 * MO_XPLANE;      // 36,864 B
 __global__ __launch_bounds__(256, 3) void moment_kernel(const float* __restrict__ Hm, const __bf16* __restrict__ xq,
                                                         const int* __restrict__ row_ptr, const int* __restrict__ src,
                                                         const int* __restrict__ order, float* __restrict__ S, int K,
-                                                        int row0, const float* __restrict__ x) {
+                                                        int row0, int cnt, const float* __restrict__ x) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[MO_LDS];
-    const int tl = order[row0 + blockIdx.x];       // index inside this launch's chunk of destinations
+    // workgroup ids b, b+8, b+16, .. share an XCD: a destination's k/256 column blocks (and its s0 workgroup) run there
+    // back to back, so that the neighbours' feature planes they all gather come through that L2 once (at N = 50,000 the
+    // planes are 19 MB — far beyond an XCD's 4 MiB — and each block fetched them again through the fabric)
+    const int nq = (K + MO_CQ - 1) / MO_CQ + 1;
+    const int xcd = blockIdx.x & 7, rr = blockIdx.x >> 3;
+    const int cq = rr % nq, ti = (rr / nq) * 8 + xcd;      // ti: rank of the destination (decreasing degree) in the chunk
+    if (ti >= cnt) return;
+    const int tl = order[row0 + ti];               // index inside this launch's chunk of destinations
     const int t = row0 + tl;
-    const int cq = blockIdx.y;
     const int beg = row_ptr[t], end = row_ptr[t + 1];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nkt = K >> 5;
-    if (cq == K / MO_CQ) {
+    if (cq == nq - 1) {
         // one more workgroup per destination: s0_t[i] = sum_{e -> t} x_src(e)[i] (the b3 term's operand: the last MLP
         // layer's bias seen through the summed neighbours), stored as kappa = 64 K + i of the same image, so that K2
         // multiplies it with B3 like any other slice.  16 chains x 16 lanes (4 features each), four edges in flight
@@ -188,12 +219,10 @@ __global__ __launch_bounds__(256, 3) void moment_kernel(const float* __restrict_
     }
     auto load_stage = [&](int e0) {       // edges e0 .. e0+15 of this row -> registers (zeros past the end)
         const int e = e0 + er;
-        if (e < end) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) MO_NT(rh[u], h_ptr(e, u))
-        } else {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) rh[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int u = 0; u < 4; ++u) {      // (u: the 64 hidden units of wave u; none past k — k % 64 == 0)
+            rh[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < end && cq * MO_CQ + u * 64 < K) MO_NT(rh[u], h_ptr(e, u))
         }
         rx[0] = rx[1] = make_uint4(0u, 0u, 0u, 0u);
         if (xrole && e0 + xe < end) {
@@ -235,6 +264,7 @@ __global__ __launch_bounds__(256, 3) void moment_kernel(const float* __restrict_
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int stages = (end - beg + MO_EDGES - 1) / MO_EDGES;
+    const bool wave_live = cq * MO_CQ + wave * 64 < K;      // this wave's 64 hidden units exist
     if (stages > 0) {
         if (xrole && beg + xe < end) sidx = src[beg + xe];
         load_stage(beg);
@@ -248,7 +278,7 @@ __global__ __launch_bounds__(256, 3) void moment_kernel(const float* __restrict_
                 if (xrole && e_next + MO_EDGES + xe < end) sidx = src[e_next + MO_EDGES + xe];
             }
             __builtin_amdgcn_sched_barrier(0);      // keep the prefetch above the MFMAs
-            {
+            if (wave_live) {
                 bf16x8 a[2][3], b[3];
 #pragma unroll
                 for (int ih = 0; ih < 2; ++ih)
@@ -272,6 +302,7 @@ __global__ __launch_bounds__(256, 3) void moment_kernel(const float* __restrict_
 #undef MO_NT
     // ---- S_t[i][c] -> the k-tiled image: kappa = i*K + c, tile (t >> 7, kappa >> 5), row t & 127, column kappa & 31
     // (a lane holds one hidden unit c = column l31 of the block, 16 feature rows: 128-B runs per half wave)
+    if (!wave_live) return;
     const int l31 = lane & 31, h = lane >> 5;
     float* Sb = S + (size_t)(tl >> 7) * moment_nkt(K) * 4096 + (tl & 127) * 32 + l31;
 #pragma unroll
@@ -289,57 +320,71 @@ __global__ __launch_bounds__(256, 3) void moment_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------- K2: z = S . W3R, K-sliced
-// Workgroup (row tile rt of 128 destinations, slice): partial[slice][row][64] = S[rt][kappa in slice] . W3R[kappa][:].
+// Workgroup (256 destinations = two row tiles of the S image, slice): partial[slice][row][64] = S[rows][kappa in slice] . W3R[kappa][:].
 // The loop of factored.hip's gemm_per_source_split_kernel (fp32 K-tiles of both operands -> three bf16 planes on the
 // fly, XOR-swizzled 64-B LDS rows, six plane products), with the row tile's S in the role of H_j and W3R in the role
 // of Y_j.  PJ_SLICES is a constant and a slice's k-tiles a function of k alone: the association of a destination's
-// sum does not depend on the launch.  The last slice also takes the two s0 k-tiles (x B3).  (64-row workgroups —
-// twice as many, each staging the same W3R tiles for half the rows — took 43 us against 34.)
+// sum does not depend on the launch.  The last slice also takes the two s0 k-tiles (x B3).
 constexpr int PJ_SLICES = 128;
-constexpr int PJ_A_PLANE = 128 * 64, PJ_B_PLANE = 64 * 64, PJ_B_BASE = 3 * PJ_A_PLANE;
+// 256 destinations per workgroup: two 128-row tiles of the S image against ONE W3R tile —
+                                   // a CU streams at ~23.5 GB/s whatever the source, and with 128 rows a third of what
+                                   // went through it was W3R (L2 hits): 34 us; (64 rows: 43 us)
+constexpr int PJ_B_PLANE = 64 * 64;
 
-__global__ __launch_bounds__(256, 4) void project_kernel(const float* __restrict__ S, const float* __restrict__ w3r,
+template <int PJ_ROWS>
+__global__ __launch_bounds__(PJ_ROWS * 2, 512 / PJ_ROWS * 2) void project_kernel(const float* __restrict__ S, const float* __restrict__ w3r,
                                                          float* __restrict__ part, int K, int cnt, int row0,
                                                          long long part_stride) {
+    constexpr int PJ_A_PLANE = PJ_ROWS * 64, PJ_B_BASE = 3 * PJ_A_PLANE, NT = PJ_ROWS / 128;
+    constexpr int RQ = PJ_ROWS / 4;       // staging: thread (srow < RQ, 4 columns) takes A rows srow + RQ j and B rows srow (+ RQ)
     __shared__ __attribute__((aligned(16))) unsigned char lds[3 * PJ_A_PLANE + 3 * PJ_B_PLANE];
-    // The row tiles of one K slice stream the same W3R tiles: they sit on ONE XCD (workgroup ids b, b+8, .. share an
-    // XCD) next to each other, so that the slice's 8 KiB tiles come through that XCD's L2 once instead of once per row
-    // tile through the fabric (67 -> 17 MB per application at four row tiles).
-    const int ntile = gridDim.x / PJ_SLICES;
+    // The row groups of one K slice stream the same W3R tiles: they sit on ONE XCD (workgroup ids b, b+8, .. share an
+    // XCD) next to each other, so that a slice's 8 KiB tiles come through that XCD's L2 once.
+    const int ngrp = gridDim.x / PJ_SLICES;
     const int xcd = blockIdx.x & 7, rr = blockIdx.x >> 3;
-    const int rt = rr % ntile, slice = (rr / ntile) * 8 + xcd;
+    const int rg = rr % ngrp, slice = (rr / ngrp) * 8 + xcd;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // rows 32*wave .. +31 of the workgroup's
     const int l31 = lane & 31, h = lane >> 5;
     const int srow = tid >> 3, scol = (tid & 7) * 4;
     const int nkt = (int)moment_nkt(K), per = (nkt - 2) / PJ_SLICES;
     const int kt0 = slice * per, nk = per + (slice == PJ_SLICES - 1 ? 2 : 0);
-    const int rows_here = cnt - rt * 128 < 128 ? cnt - rt * 128 : 128;
+    const int first = rg * PJ_ROWS;
+    const int rows_here = cnt - first < PJ_ROWS ? cnt - first : PJ_ROWS;
     const int live = (rows_here + 31) >> 5;       // 32-row groups holding at least one destination
-    const float* A0 = S + ((size_t)rt * nkt + kt0) * 4096 + srow * 32 + scol;
+    // row r of the workgroup = row r & 127 of tile NT rg + (r >> 7)
+    auto a_ptr = [&](int r) {
+        return S + ((size_t)(NT * rg + (r >> 7)) * nkt + kt0) * 4096 + (r & 127) * 32 + scol;
+    };
+    const float* A0 = a_ptr(srow);
+    const float* A1 = a_ptr(srow + RQ);
+    const float* A2 = a_ptr(srow + 2 * RQ);
+    const float* A3 = a_ptr(srow + 3 * RQ);
     const float* Bg = w3r + (size_t)kt0 * 2048 + srow * 32 + scol;
-    float4 ra0, ra1 = make_float4(0.f, 0.f, 0.f, 0.f), ra2 = ra1, ra3 = ra1, rb0, rb1;
-#define PJ_LOAD(KT)                                                                                  \
-    ra0 = *reinterpret_cast<const float4*>(A0 + (size_t)(KT) * 4096);                                \
-    if (live > 1) ra1 = *reinterpret_cast<const float4*>(A0 + (size_t)(KT) * 4096 + 32 * 32);        \
-    if (live > 2) ra2 = *reinterpret_cast<const float4*>(A0 + (size_t)(KT) * 4096 + 64 * 32);        \
-    if (live > 3) ra3 = *reinterpret_cast<const float4*>(A0 + (size_t)(KT) * 4096 + 96 * 32);        \
-    rb0 = *reinterpret_cast<const float4*>(Bg + (size_t)(KT) * 2048);                                \
-    rb1 = *reinterpret_cast<const float4*>(Bg + (size_t)(KT) * 2048 + 1024);
+    const bool g0 = (srow >> 5) < live, g1 = ((srow + RQ) >> 5) < live, g2 = ((srow + 2 * RQ) >> 5) < live,
+               g3 = ((srow + 3 * RQ) >> 5) < live;
+    float4 ra0 = make_float4(0.f, 0.f, 0.f, 0.f), ra1 = ra0, ra2 = ra0, ra3 = ra0, rb0, rb1 = ra0;
+#define PJ_LOAD(KT)                                                                  \
+    if (g0) ra0 = *reinterpret_cast<const float4*>(A0 + (size_t)(KT) * 4096);        \
+    if (g1) ra1 = *reinterpret_cast<const float4*>(A1 + (size_t)(KT) * 4096);        \
+    if (g2) ra2 = *reinterpret_cast<const float4*>(A2 + (size_t)(KT) * 4096);        \
+    if (g3) ra3 = *reinterpret_cast<const float4*>(A3 + (size_t)(KT) * 4096);        \
+    rb0 = *reinterpret_cast<const float4*>(Bg + (size_t)(KT) * 2048);                \
+    if (RQ < 64) rb1 = *reinterpret_cast<const float4*>(Bg + (size_t)(KT) * 2048 + RQ * 32);
     auto st_off = [&](int row) { return row * 64 + ((((tid & 7) >> 1) ^ ((row >> 2) & 3)) << 4) + (tid & 1) * 8; };
     unsigned char* a_st0 = lds + st_off(srow);
-    unsigned char* a_st1 = lds + st_off(srow + 32);
-    unsigned char* a_st2 = lds + st_off(srow + 64);
-    unsigned char* a_st3 = lds + st_off(srow + 96);
+    unsigned char* a_st1 = lds + st_off(srow + RQ);
+    unsigned char* a_st2 = lds + st_off(srow + 2 * RQ);
+    unsigned char* a_st3 = lds + st_off(srow + 3 * RQ);
     unsigned char* b_st0 = lds + PJ_B_BASE + st_off(srow);
-    unsigned char* b_st1 = lds + PJ_B_BASE + st_off(srow + 32);
-#define PJ_STORE()                                                \
-    split_store4(ra0, a_st0, PJ_A_PLANE);                         \
-    if (live > 1) split_store4(ra1, a_st1, PJ_A_PLANE);           \
-    if (live > 2) split_store4(ra2, a_st2, PJ_A_PLANE);           \
-    if (live > 3) split_store4(ra3, a_st3, PJ_A_PLANE);           \
-    split_store4(rb0, b_st0, PJ_B_PLANE);                         \
-    split_store4(rb1, b_st1, PJ_B_PLANE);
+    unsigned char* b_st1 = lds + PJ_B_BASE + st_off(srow + RQ);
+#define PJ_STORE()                                         \
+    if (g0) split_store4(ra0, a_st0, PJ_A_PLANE);          \
+    if (g1) split_store4(ra1, a_st1, PJ_A_PLANE);          \
+    if (g2) split_store4(ra2, a_st2, PJ_A_PLANE);          \
+    if (g3) split_store4(ra3, a_st3, PJ_A_PLANE);          \
+    split_store4(rb0, b_st0, PJ_B_PLANE);                  \
+    if (RQ < 64) split_store4(rb1, b_st1, PJ_B_PLANE);
     f32x16 acc0, acc1;
 #pragma unroll
     for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
@@ -377,7 +422,7 @@ __global__ __launch_bounds__(256, 4) void project_kernel(const float* __restrict
     float* Po = part + (size_t)slice * part_stride;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-        const int m = rt * 128 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int m = first + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (m < cnt) {
             Po[(size_t)(row0 + m) * 64 + l31] = acc0[e];
             Po[(size_t)(row0 + m) * 64 + 32 + l31] = acc1[e];
@@ -463,7 +508,7 @@ static int moment_chunk_rows(int num_rows) {
     return padded < kMomentChunkRows ? padded : kMomentChunkRows;
 }
 
-bool moment_supported(int width, int ker_width) { return width == 64 && ker_width % MO_CQ == 0 && (64 * ker_width / 32) % PJ_SLICES == 0; }
+bool moment_supported(int width, int ker_width) { return width == 64 && ker_width >= 64 && ker_width % 64 == 0; }      // (64 k / 32 = 2 k k-tiles: a multiple of the 128 slices)
 static size_t s_chunk_floats(int num_rows, int ker_width) { return (size_t)(moment_chunk_rows(num_rows) / 128) * moment_nkt(ker_width) * 4096; }
 
 size_t moment_workspace_bytes(int num_rows, int ker_width) {
@@ -498,13 +543,15 @@ int moment_prepare_weights(const float* w3, const float* b3, int ker_width, cons
 
 int moment_prepare_graph(const int* row_ptr, int num_rows, const MomentWs& f, hipStream_t s) {
     TimedSection ts(KID_GRAPH, s);
-    return degree_order_chunks(row_ptr, num_rows, kMomentChunkRows, f.order, s);
+    hipLaunchKernelGGL(degree_order_kernel<kMomentChunkRows>, dim3((num_rows + kMomentChunkRows - 1) / kMomentChunkRows),
+                       dim3(kMomentChunkRows), 0, s, row_ptr, num_rows, f.order);
+    return check_launch("degree_order_kernel");
 }
 
 int moment_conv(const float* x, const float* h2, const int* row_ptr, const int* src, int num_rows, int ker_width,
                 const float* b3, const float* root, const float* bias, int aggr, int relu, float* y, const MomentWs& f,
                 hipStream_t s, int parity, bool x_prepared, bool emit_next) {
-    MDNO_REQUIRE(moment_supported(64, ker_width), MDNO_EUNSUPPORTED, "moment conv: ker_width=%d (x256)", ker_width);
+    MDNO_REQUIRE(moment_supported(64, ker_width), MDNO_EUNSUPPORTED, "moment conv: ker_width=%d (x64)", ker_width);
     __bf16* xq_in = static_cast<__bf16*>(f.xq[parity & 1]);
     __bf16* xq_out = emit_next ? static_cast<__bf16*>(f.xq[(parity & 1) ^ 1]) : nullptr;
     if (!x_prepared) {
@@ -516,12 +563,13 @@ int moment_conv(const float* x, const float* h2, const int* row_ptr, const int* 
         const int cnt = num_rows - r0 < kMomentChunkRows ? num_rows - r0 : kMomentChunkRows;
         {   // K1: the chunk's destinations x the k/256 column blocks
             TimedSection ts(KID_NNCONV, s);
-            hipLaunchKernelGGL(moment_kernel, dim3(cnt, ker_width / MO_CQ + 1), dim3(256), 0, s, h2, (const __bf16*)xq_in, row_ptr,
-                               src, (const int*)f.order, f.s, ker_width, r0, x);
+            const int nq = (ker_width + MO_CQ - 1) / MO_CQ + 1;
+            hipLaunchKernelGGL(moment_kernel, dim3((unsigned)(((cnt + 7) / 8) * 8 * nq)), dim3(256), 0, s, h2, (const __bf16*)xq_in,
+                               row_ptr, src, (const int*)f.order, f.s, ker_width, r0, cnt, x);
         }
-        {   // K2: row tiles x K slices
+        {   // K2: groups of row tiles x K slices
             TimedSection ts(KID_FACT_Y, s);
-            hipLaunchKernelGGL(project_kernel, dim3(((cnt + 127) / 128) * PJ_SLICES), dim3(256), 0, s, (const float*)f.s,
+            hipLaunchKernelGGL(project_kernel<256>, dim3(((cnt + 255) / 256) * PJ_SLICES), dim3(512), 0, s, (const float*)f.s,
                                (const float*)f.w3r, f.part, ker_width, cnt, r0, f.part_stride);
         }
         {   // K3

@@ -509,14 +509,14 @@ def leg_cfg5_shape_c(dev, atoms=50000, cutoff=10.0, steps=2, slice_edges=2_000_0
     e_mean = float(eng.edges_per_step[1:1 + steps].double().mean().item())
     ks = {k: {"ms_per_step": ms / steps, "launches": int(n)} for k, (ms, n) in tm.items() if n}
     app_s = ks["nnconv"]["ms_per_step"] * 1e-3 / 12            # all launches of one conv application
-    alg = e_mean * KW * 4 + N * C * KW * 4 + 2 * e_mean * C * 4 + (N + 1) * 4
+    alg = e_mean * KW * 4 + N * C * KW * 4 + e_mean * 4 + (N + 1) * 4          # K1 of csrc/moment.hip: H in, S out, src, row_ptr
     out = {"atoms": N, "cutoff_A": cutoff, "edges": E, "mean_degree": E / N, "max_degree": deg_max, "steps": steps,
            "ms_per_step": dt / steps * 1e3, "frames_per_s": steps / dt, "workspace_GiB": ws_gib, "conv_mode": eng.conv_mode,
            "kernels_ms_per_step": {k: round(v["ms_per_step"], 3) for k, v in ks.items()},
-           "roofline": {"bound": "hbm", "kernel": "gemm_per_source_split_kernel", "achieved": alg / app_s / 1e9,
+           "roofline": {"bound": "hbm", "kernel": "moment_kernel", "achieved": alg / app_s / 1e9,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / app_s / 1e9 / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_application": alg, "ms_per_application": app_s * 1e3,
-                        "traffic": profiled_traffic("gemm_per_source_split_kernel", N, 1, "factored", "split_f16")},
+                        "traffic": profiled_traffic("moment_kernel", N, 1, "factored", "split_f16")},
            "conv_materialized_slice": conv_slice,
            "launch": "plain launches (event timer attached)"}
     eng.close()

@@ -20,7 +20,7 @@ from collections import defaultdict
 from pathlib import Path
 
 src = Path(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof")
-tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r04"
 out = Path("profiles")
 out.mkdir(exist_ok=True)
 
@@ -88,21 +88,21 @@ for M in (1, 8):
         continue
     c = cfg["config"]
     # both conv formulations run in a bench (timed path + comparison leg at M <= 8)
-    for kernel, conv_mode in (("gemm_per_source_split_kernel", "factored"), ("nnconv64_row_kernel", "materialized")):
+    for kernel, conv_mode in (("moment_kernel", "factored"), ("nnconv64_row_kernel", "materialized")):
         name = next((n for n in pmc if n.startswith(kernel) and "hbm_bytes_per_launch_corrected" in pmc[n]), None)
         if name is None:
             continue
         per_launch = pmc[name]["hbm_bytes_per_launch_corrected"]
         # the factored conv runs chunk by chunk over the sources: report per conv application
         launches_per_app = 1
-        if kernel == "gemm_per_source_split_kernel":
+        if kernel == "moment_kernel":
             launches_per_app = -(-c["members_this_rank"] * c["atoms"] // 512)
         traffic.append({"kernel": kernel, "atoms": c["atoms"], "members": c["members_this_rank"], "conv_mode": conv_mode,
                         "gemm_mode": c["edge_mlp_gemm"], "hbm_bytes_per_launch": per_launch * launches_per_app,
                         "launches_per_application": launches_per_app, "source": f"profiles/{tag}_m{M}_pmc.json"})
 
 
-# shape C (N = 50,000): per-source GEMM per conv application (one launch per 512 sources) and the materialised conv
+# shape C (N = 50,000): the factored conv's K1 (csrc/moment.hip) per conv application (one launch per 512 destinations) and the materialised conv
 # kernel on the 2.0M-edge slice (scripts/run_shape_c.py), same counters and corrections
 pmc_c = {}
 for counter, sub in (("FETCH_SIZE", "pmc_fetch_shape_c"), ("WRITE_SIZE", "pmc_write_shape_c")):
@@ -124,10 +124,10 @@ if pmc_c:
     (out / f"{tag}_shapeC_pmc.json").write_text(json.dumps(pmc_c, indent=1, sort_keys=True))
     print("wrote", out / f"{tag}_shapeC_pmc.json")
     atoms_c = 50000
-    name = next((n for n in pmc_c if n.startswith("gemm_per_source_split_kernel") and "hbm_bytes_per_launch_corrected" in pmc_c[n]), None)
+    name = next((n for n in pmc_c if n.startswith("moment_kernel") and "hbm_bytes_per_launch_corrected" in pmc_c[n]), None)
     if name:
         lpa = -(-atoms_c // 512)
-        traffic.append({"kernel": "gemm_per_source_split_kernel", "atoms": atoms_c, "members": 1, "conv_mode": "factored",
+        traffic.append({"kernel": "moment_kernel", "atoms": atoms_c, "members": 1, "conv_mode": "factored",
                         "gemm_mode": "split_f16", "hbm_bytes_per_launch": pmc_c[name]["hbm_bytes_per_launch_corrected"] * lpa,
                         "launches_per_application": lpa, "source": f"profiles/{tag}_shapeC_pmc.json"})
     name = next((n for n in pmc_c if n.startswith("nnconv64_row_kernel") and "hbm_bytes_per_launch_corrected" in pmc_c[n]), None)
@@ -165,7 +165,7 @@ def mfma_summary(sub, dest, what, keep):
 
 mfma_summary("pmc_mfma_m1", out / f"{tag}_m1_pmc_mfma.json",
              "python3 bench.py --skip-cpu-baseline --skip-ensemble-leg --single-mode --steps 3 --warmup 1 --no-graph "
-             "(1 member, N=504, split_f16)", ("gemm_split_f16_kernel", "gemm_per_source_split_kernel", "gemm_k64_f16_kernel"))
+             "(1 member, N=504, split_f16)", ("gemm_split_f16_kernel", "moment_kernel", "project_kernel"))
 mfma_summary("pmc_mfma_train", out / f"{tag}_train_pmc_mfma.json",
              "python3 scripts/train_synthetic.py --frames 600 (cfg4 batch: 43.7k edges, k=1024, bf16)", ("gemm_pp_kernel",))
 kernel_stats("train_trace", out / f"{tag}_train_kernel_stats.csv")

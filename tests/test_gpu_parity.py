@@ -679,16 +679,25 @@ def test_factored_conv_matches_materialized_and_reference(dev):
         res[mode] = (eng.run(tm, aa, steps).clone(), eng.edges_per_step.clone())
     assert torch.equal(res["materialized"][1], res["factored"][1])
     close(res["factored"][0], res["materialized"][0])
-    # a max_degree bound that is too small is flagged, not silently truncated
-    # (the bound is honoured in 128-edge tiles: 200 atoms in a 12.6 A box have ~150 neighbours each)
+    # max_degree: the destination-side form (split GEMM modes, csrc/moment.hip) has no degree tiles — a node's edges are
+    # the contraction length — so the bound is irrelevant there; the source-side fp32 form (gemm_mode "f32") honours it
+    # in 128-edge tiles and flags a bound that is too small instead of truncating (200 atoms in a 12.6 A box have
+    # ~150 neighbours each)
     small.conv_mode = "factored"
     from molecular_dynamics_neural_operator_amd import MdnoError
     big = syn.jitter_window(syn.box_frame(200, seed=8), W, seed=8)
+    aa_big = torch.from_numpy(syn.amino_acids(200, seed=8))
+    eng = RolloutEngine(small, 1, 200, W, 8.0, max_steps=2, device=dev, max_degree=64)
+    tight = eng.run(torch.from_numpy(big), aa_big, 2).clone()
+    eng = RolloutEngine(small, 1, 200, W, 8.0, max_steps=2, device=dev, max_degree=200)
+    assert torch.equal(eng.run(torch.from_numpy(big), aa_big, 2), tight)
+    small.gemm_mode = "f32"
     eng = RolloutEngine(small, 1, 200, W, 8.0, max_steps=2, device=dev, max_degree=64)
     with pytest.raises(MdnoError, match="max_degree"):
-        eng.run(torch.from_numpy(big), torch.from_numpy(syn.amino_acids(200, seed=8)), 2)
+        eng.run(torch.from_numpy(big), aa_big, 2)
     eng = RolloutEngine(small, 1, 200, W, 8.0, max_steps=2, device=dev, max_degree=200)
-    eng.run(torch.from_numpy(big), torch.from_numpy(syn.amino_acids(200, seed=8)), 2)
+    close(eng.run(torch.from_numpy(big), aa_big, 2), tight)
+    small.gemm_mode = "split_f16"
     # explicit edge_attr + factored pack is refused, not silently rerouted
     with pytest.raises(MdnoError):
         ops.kernelnn_forward(model.param_pack(dev, conv_mode="factored"), frames.unsqueeze(1), t(z["x_aminoacid"]), g,

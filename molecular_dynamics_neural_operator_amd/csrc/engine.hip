@@ -158,7 +158,6 @@ int forward_impl(const mdno_kernelnn_params* p, const float* frames, int t0, con
             // as the reference has them (graph_kernel.py:372-379); no symmetry needed
             const MomentWs mw = moment_carve(ws.fact, R, p->ker_width);
             if (!prep_only) MDNO_TRY(moment_prepare_graph(row_ptr, R, mw, s));
-            int app = 0;
             for (int block = 0; block < blocks; ++block) {
                 const bool own = block == 1 && separate_conv2_kernel(p);
                 if (block == 0 || own) {
@@ -170,13 +169,11 @@ int forward_impl(const mdno_kernelnn_params* p, const float* frames, int t0, con
                     if ((phase & WP_PHASE_MASK) != WP_RUN_ONLY) MDNO_TRY(moment_prepare_weights(w.w2, w.b2, p->ker_width, mw, s));
                 }
                 if (prep_only) return MDNO_OK;
-                const float* b3 = own ? p->k2_b2 : p->k_b2;
                 const float* root = block == 0 ? p->conv1_root : p->conv2_root;
                 const float* bias = block == 0 ? p->conv1_bias : p->conv2_bias;
-                for (int d = 0; d < p->depth; ++d, ++app) {
-                    const bool last = block + 1 == blocks && d + 1 == p->depth;
-                    MDNO_TRY(moment_conv(cur, ws.h2, row_ptr, src, R, p->ker_width, b3, root, bias, MDNO_AGGR_MEAN, /*relu=*/1,
-                                         nxt, mw, s, app, /*x_prepared=*/app > 0, /*emit_next=*/!last));
+                for (int d = 0; d < p->depth; ++d) {
+                    MDNO_TRY(moment_conv(cur, ws.h2, row_ptr, src, R, p->ker_width, root, bias, MDNO_AGGR_MEAN, /*relu=*/1, nxt,
+                                         mw, s));
                     float* t = cur; cur = nxt; nxt = t;
                 }
             }

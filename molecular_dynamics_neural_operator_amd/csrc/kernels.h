@@ -116,7 +116,6 @@ int factored_conv(const float* x, const float* h2, const int* row_ptr, int num_r
 // split GEMM modes run; factored.hip's source-side kernels remain for gemm_mode F32.
 struct MomentWs {
     float *w3r, *s, *part;
-    void* xq[2];              // bf16 planes [node][3][64] of the node features, ping-pong over the applications
     int* order;               // destinations of each S chunk by decreasing degree
     long long part_stride;
 };
@@ -125,11 +124,9 @@ size_t moment_workspace_bytes(int num_rows, int ker_width);
 MomentWs moment_carve(void* ws, int num_rows, int ker_width);
 int moment_prepare_weights(const float* w3, const float* b3, int ker_width, const MomentWs& f, hipStream_t s);
 int moment_prepare_graph(const int* row_ptr, int num_rows, const MomentWs& f, hipStream_t s);
-// parity: index of this application inside the forward (selects the xq buffer read; the other one is written when
-// emit_next).  x_prepared: xq[parity & 1] already holds the planes of x (left by the previous application).
+// (the last MLP layer's bias b3 is part of W3R: moment_prepare_weights)
 int moment_conv(const float* x, const float* h2, const int* row_ptr, const int* src, int num_rows, int ker_width,
-                const float* b3, const float* root, const float* bias, int aggr, int relu, float* y, const MomentWs& f,
-                hipStream_t s, int parity, bool x_prepared, bool emit_next);
+                const float* root, const float* bias, int aggr, int relu, float* y, const MomentWs& f, hipStream_t s);
 
 // bf16 training GEMMs (gemm_bf16.hip): 256 x 256 tiles, 8 waves, two wave groups one phase apart over an
 // LDS-DMA ring of 32-k stages.

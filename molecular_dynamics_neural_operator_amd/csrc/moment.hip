@@ -3,8 +3,9 @@
 // with the sum over a destination's in-edges taken BEFORE the contraction with W3:
 //     S_t[i][c] = sum_{e -> t} x_src(e)[i] * h_e[c]                  (K1)  one GEMM per destination over its own edges,
 //                                                                          contraction over the EDGES: [64 x deg] . [deg x k]
-//     z_t[o]    = sum_{i,c} S_t[i][c] * W3[i*64 + o][c]              (K2)  one tall GEMM [R, 64 k] x [64 k, 64], K-sliced
-//     y_t       = act( (z_t + s0_t . B3) / max(deg_t, 1) + x_t . root + bias ),  s0_t = sum_{e -> t} x_src(e)   (K3)
+//     z_t[o]    = sum_{i,c} S_t[i][c] * W3[i*64 + o][c] + sum_i s0_t[i] * B3[i][o]      (K2)  one tall GEMM
+//                 [R, 64 k + 64] x [64 k + 64, 64], K-sliced;  s0_t = sum_{e -> t} x_src(e), B3 = reshape(b3, [64, 64])
+//     y_t       = act( z_t / max(deg_t, 1) + x_t . root + bias )                                   (K3)
 // Against the source-side form of factored.hip (Y_j = x_j . W3T per source, M_j = H_j . Y_j^T per source, gather of
 // the 256-B messages per destination) this needs no reverse-edge index and no symmetric graph, has no 128-row tiles
 // of a node's edges (a destination's edges are the contraction length: any degree, H read exactly once — the
@@ -16,14 +17,14 @@
 // All three products run on the bf16 matrix pipe at fp32 accuracy: every fp32 operand is split exactly into three
 // bf16 planes (x = hi + mid + lo) and the six leading plane products are accumulated in fp32 (edge_mlp_split.hip).
 //   K1  moment_kernel     workgroup = (destination t, 256 of the k hidden units); stage = 16 edges: H rows (fp32,
-//                         k-tiled image written by the hidden GEMM, streamed once, non-temporal) and the bf16 planes
-//                         of the neighbours' features (gathered from L2) go to LDS edge-major, i.e. with the
-//                         contraction index SLOWEST, and the MFMA fragments come out of gfx950's transposing read
-//                         ds_read_b64_tr_b16; register prefetch of the next stage under the MFMAs.
+//                         k-tiled image written by the hidden GEMM, streamed once, non-temporal) and the neighbours'
+//                         fp32 feature rows (gathered from L2) are split into planes on the way to LDS, edge-major,
+//                         i.e. with the contraction index SLOWEST, and the MFMA fragments come out of gfx950's
+//                         transposing read ds_read_b64_tr_b16; register prefetch of the next stage under the MFMAs.
+//                         One more workgroup per destination sums the neighbours' features (s0, the b3 term).
 //   K2  project_kernel    workgroup = (128 destinations, 1/128 of the 64 k contraction): S and W3 tiles fp32 -> planes
 //                         on the fly (the loop of factored.hip's per-source kernel); partial sums per K slice.
-//   K3  finish_kernel     per destination: K slices added in slice order, s0 gathered in edge order, B3 / root / bias /
-//                         mean / ReLU, and the bf16 planes of y_t the next application's K1 gathers.
+//   K3  finish_kernel     per destination: K slices added in slice order, root / bias / mean / ReLU.
 // Fixed summation orders everywhere: a destination's result depends on its own edges only (bitwise the same alone or
 // in any batch), no float atomics.
 #include "kernels.h"
@@ -72,23 +73,6 @@ __device__ __forceinline__ void split_store4(const float4 v, unsigned char* dst,
     ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], B[0], ACC, 0, 0, 0);        \
     ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[1], ACC, 0, 0, 0);        \
     ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[0], ACC, 0, 0, 0);
-
-// ---------------------------------------------------------------- node features -> bf16 planes [node][3][64]
-// (the operand K1 gathers per edge: 384 B per node; written by K3 for every later application)
-constexpr int XQ_ROW = 3 * 64;      // bf16 elements per node
-
-__global__ __launch_bounds__(256) void split_nodes_kernel(const float* __restrict__ x, int rows, __bf16* __restrict__ xq,
-                                                          __bf16* __restrict__ xq_other) {
-    const int id = blockIdx.x * 256 + threadIdx.x;      // (row, group of 4 channels)
-    if (id < XQ_ROW / 2) {                              // the all-zero row behind the nodes, in both buffers (once per forward)
-        reinterpret_cast<unsigned*>(xq + (size_t)rows * XQ_ROW)[id] = 0u;
-        reinterpret_cast<unsigned*>(xq_other + (size_t)rows * XQ_ROW)[id] = 0u;
-    }
-    if (id >= rows * 16) return;
-    const int row = id >> 4, c4 = (id & 15) * 4;
-    const float4 v = *reinterpret_cast<const float4*>(x + (size_t)row * 64 + c4);
-    split_store4(v, reinterpret_cast<unsigned char*>(xq + (size_t)row * XQ_ROW + c4), 64 * 2);
-}
 
 // ---------------------------------------------------------------- W3 [64*64, k] -> W3R tiled [64k/32][64 o][32]
 // W3R[kappa][o] = W3[(i*64 + o)*k + c] with kappa = i*k + c (and B3[i][o] at kappa = 64 k + i): the B operand of K2,
@@ -146,14 +130,14 @@ constexpr int MO_LDS = 3 * MO_HPLANE + 3 * MO_XPLANE;      // 36,864 B
 
 // Grid: (destination within the chunk, visited by decreasing degree) x (k / 256).  S chunk layout: the fp32 k-tiled
 // image K2 streams, [node/128][64k/32][128][32] with kappa = i*k + c.
-__global__ __launch_bounds__(256, 3) void moment_kernel(const float* __restrict__ Hm, const __bf16* __restrict__ xq,
+__global__ __launch_bounds__(256, 3) void moment_kernel(const float* __restrict__ Hm,
                                                         const int* __restrict__ row_ptr, const int* __restrict__ src,
                                                         const int* __restrict__ order, float* __restrict__ S, int K,
                                                         int row0, int cnt, const float* __restrict__ x) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[MO_LDS];
     // workgroup ids b, b+8, b+16, .. share an XCD: a destination's k/256 column blocks (and its s0 workgroup) run there
-    // back to back, so that the neighbours' feature planes they all gather come through that L2 once (at N = 50,000 the
-    // planes are 19 MB — far beyond an XCD's 4 MiB — and each block fetched them again through the fabric)
+    // back to back, so that the neighbours' feature rows they all gather come through that L2 once (at N = 50,000 the
+    // features are 12.8 MB — beyond an XCD's 4 MiB — and each block fetched them again through the fabric)
     const int nq = (K + MO_CQ - 1) / MO_CQ + 1;
     const int xcd = blockIdx.x & 7, rr = blockIdx.x >> 3;
     const int cq = rr % nq, ti = (rr / nq) * 8 + xcd;      // ti: rank of the destination (decreasing degree) in the chunk
@@ -202,15 +186,14 @@ __global__ __launch_bounds__(256, 3) void moment_kernel(const float* __restrict_
     // ---- staging roles
     // H: thread (edge er = tid >> 4, column group cc = tid & 15) loads four float4: hidden units cq*256 + u*64 + cc*4 ..
     const int er = tid >> 4, cc = tid & 15;
-    // X: threads 0..191: edge xe = tid / 12, 32 B (two 16-B pieces 2*xs, 2*xs + 1 of the 24 of a node's planes)
-    const int xe = tid / 12, xs = tid - xe * 12;
-    const bool xrole = tid < 192;
+    // X: thread (edge xe = tid >> 4, xs = tid & 15): four fp32 features 4*xs .. of the edge's source row (from L2: the
+    // features of a member are 129 KB), split into the three planes on the way to LDS like H
+    const int xe = tid >> 4, xs = tid & 15;
     auto h_ptr = [&](int e, int u) {      // element (edge e, hidden unit cq*256 + u*64 + cc*4) of the k-tiled H
         const int c = cq * MO_CQ + u * 64 + cc * 4;
         return Hm + ((size_t)(e >> 7) * nkt + (c >> 5)) * 4096 + (e & 127) * 32 + (c & 31);
     };
-    float4 rh[4];
-    uint4 rx[2];
+    float4 rh[4], rx;
     int sidx = 0;      // source node of this thread's X edge in the stage being loaded
 #define MO_NT(DST, P)                                                                               \
     {                                                                                               \
@@ -224,23 +207,14 @@ __global__ __launch_bounds__(256, 3) void moment_kernel(const float* __restrict_
             rh[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (e < end && cq * MO_CQ + u * 64 < K) MO_NT(rh[u], h_ptr(e, u))
         }
-        rx[0] = rx[1] = make_uint4(0u, 0u, 0u, 0u);
-        if (xrole && e0 + xe < end) {
-            const uint4* p = reinterpret_cast<const uint4*>(xq + (size_t)sidx * XQ_ROW) + 2 * xs;
-            rx[0] = p[0];
-            rx[1] = p[1];
-        }
+        rx = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e0 + xe < end) rx = *reinterpret_cast<const float4*>(x + (size_t)sidx * 64 + 4 * xs);
     };
     auto store_stage = [&]() {
 #pragma unroll
         for (int u = 0; u < 4; ++u)
             split_store4(rh[u], lds + er * MO_HROW + (u * 64 + cc * 4) * 2, MO_HPLANE);
-        if (xrole) {
-            // pieces 2*xs, 2*xs+1 of [plane][64]: plane = piece >> 3, 16-B chunk = piece & 7
-            const int p0 = 2 * xs, p1 = 2 * xs + 1;
-            *reinterpret_cast<uint4*>(lds + 3 * MO_HPLANE + (p0 >> 3) * MO_XPLANE + xe * MO_XROW + (p0 & 7) * 16) = rx[0];
-            *reinterpret_cast<uint4*>(lds + 3 * MO_HPLANE + (p1 >> 3) * MO_XPLANE + xe * MO_XROW + (p1 & 7) * 16) = rx[1];
-        }
+        split_store4(rx, lds + 3 * MO_HPLANE + xe * MO_XROW + xs * 8, MO_XPLANE);
     };
     // ---- fragment addresses (ds_read_b64_tr_b16): 16-lane group gq, lane = 4*qq + pp inside it reads row 8*(gq>>1) + qq
     // (+4 for the second half), 8 B at column 16*(gq&1) + 4*pp of the block; lane i of the group receives column i
@@ -266,16 +240,16 @@ __global__ __launch_bounds__(256, 3) void moment_kernel(const float* __restrict_
     const int stages = (end - beg + MO_EDGES - 1) / MO_EDGES;
     const bool wave_live = cq * MO_CQ + wave * 64 < K;      // this wave's 64 hidden units exist
     if (stages > 0) {
-        if (xrole && beg + xe < end) sidx = src[beg + xe];
+        if (beg + xe < end) sidx = src[beg + xe];
         load_stage(beg);
-        if (xrole && beg + MO_EDGES + xe < end) sidx = src[beg + MO_EDGES + xe];
+        if (beg + MO_EDGES + xe < end) sidx = src[beg + MO_EDGES + xe];
         store_stage();
         __syncthreads();
         for (int st = 0; st < stages; ++st) {
             const int e_next = beg + (st + 1) * MO_EDGES;
             if (st + 1 < stages) {
                 load_stage(e_next);
-                if (xrole && e_next + MO_EDGES + xe < end) sidx = src[e_next + MO_EDGES + xe];
+                if (e_next + MO_EDGES + xe < end) sidx = src[e_next + MO_EDGES + xe];
             }
             __builtin_amdgcn_sched_barrier(0);      // keep the prefetch above the MFMAs
             if (wave_live) {
@@ -433,15 +407,13 @@ __global__ __launch_bounds__(PJ_ROWS * 2, 512 / PJ_ROWS * 2) void project_kernel
 // ---------------------------------------------------------------- K3: slices + root + bias + mean + act
 // One workgroup (32 chains x 16 lanes) per destination: chain es adds K slices es, es+32, .. in that order, the 32
 // chains are added in chain order through LDS; the root product is split over the chains the same way.  Every load
-// depends on the destination's index only (one round trip).  Also emits the bf16 planes of y_t for the next
-// application's K1.
+// depends on the destination's index only (one round trip).
 constexpr int FN_CHAINS = 32;
 
 __global__ __launch_bounds__(FN_CHAINS * 16) void finish_kernel(const float* __restrict__ part, long long part_stride,
                                                                 const int* __restrict__ row_ptr, const float* __restrict__ x,
                                                                 const float* __restrict__ root, const float* __restrict__ bias,
-                                                                float* __restrict__ y, int row0, int aggr, int relu,
-                                                                __bf16* __restrict__ next_xq) {
+                                                                float* __restrict__ y, int row0, int aggr, int relu) {
     constexpr int CPT = 64 / FN_CHAINS;
     __shared__ float4 red[FN_CHAINS][16];
     __shared__ float4 red2[FN_CHAINS][16];
@@ -494,7 +466,6 @@ __global__ __launch_bounds__(FN_CHAINS * 16) void finish_kernel(const float* __r
         if (bias != nullptr) { s.x += biasv.x; s.y += biasv.y; s.z += biasv.z; s.w += biasv.w; }
         if (relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
         *reinterpret_cast<float4*>(y + (size_t)t * 64 + 4 * q) = s;
-        if (next_xq != nullptr) split_store4(s, reinterpret_cast<unsigned char*>(next_xq + (size_t)t * XQ_ROW + 4 * q), 64 * 2);
     }
 }
 
@@ -516,8 +487,6 @@ size_t moment_workspace_bytes(int num_rows, int ker_width) {
     cv.take<float>((size_t)(64 * ker_width + 64) * 64);                            // W3R (+ the B3 rows)
     cv.take<float>(s_chunk_floats(num_rows, ker_width));                           // S (+ s0), one chunk of destinations
     cv.take<float>((size_t)PJ_SLICES * num_rows * 64);                             // K-slice partials of z
-    cv.take<__bf16>((size_t)(num_rows + 1) * XQ_ROW);                              // bf16 planes of the node features (+ a zero row), ping
-    cv.take<__bf16>((size_t)(num_rows + 1) * XQ_ROW);                              // ... pong
     cv.take<int>((size_t)num_rows);                                                // destinations of each chunk by decreasing degree
     return cv.used();
 }
@@ -529,8 +498,6 @@ MomentWs moment_carve(void* ws, int num_rows, int ker_width) {
     f.s = cv.take<float>(s_chunk_floats(num_rows, ker_width));
     f.part = cv.take<float>((size_t)PJ_SLICES * num_rows * 64);
     f.part_stride = (long long)num_rows * 64;
-    f.xq[0] = cv.take<__bf16>((size_t)(num_rows + 1) * XQ_ROW);
-    f.xq[1] = cv.take<__bf16>((size_t)(num_rows + 1) * XQ_ROW);
     f.order = cv.take<int>((size_t)num_rows);
     return f;
 }
@@ -549,23 +516,15 @@ int moment_prepare_graph(const int* row_ptr, int num_rows, const MomentWs& f, hi
 }
 
 int moment_conv(const float* x, const float* h2, const int* row_ptr, const int* src, int num_rows, int ker_width,
-                const float* b3, const float* root, const float* bias, int aggr, int relu, float* y, const MomentWs& f,
-                hipStream_t s, int parity, bool x_prepared, bool emit_next) {
+                const float* root, const float* bias, int aggr, int relu, float* y, const MomentWs& f, hipStream_t s) {
     MDNO_REQUIRE(moment_supported(64, ker_width), MDNO_EUNSUPPORTED, "moment conv: ker_width=%d (x64)", ker_width);
-    __bf16* xq_in = static_cast<__bf16*>(f.xq[parity & 1]);
-    __bf16* xq_out = emit_next ? static_cast<__bf16*>(f.xq[(parity & 1) ^ 1]) : nullptr;
-    if (!x_prepared) {
-        TimedSection ts(KID_FACT_Y, s);
-        hipLaunchKernelGGL(split_nodes_kernel, dim3((num_rows * 16 + 255) / 256), dim3(256), 0, s, x, num_rows, xq_in,
-                           static_cast<__bf16*>(f.xq[(parity & 1) ^ 1]));
-    }
     for (int r0 = 0; r0 < num_rows; r0 += kMomentChunkRows) {
         const int cnt = num_rows - r0 < kMomentChunkRows ? num_rows - r0 : kMomentChunkRows;
         {   // K1: the chunk's destinations x the k/256 column blocks
             TimedSection ts(KID_NNCONV, s);
             const int nq = (ker_width + MO_CQ - 1) / MO_CQ + 1;
-            hipLaunchKernelGGL(moment_kernel, dim3((unsigned)(((cnt + 7) / 8) * 8 * nq)), dim3(256), 0, s, h2, (const __bf16*)xq_in,
-                               row_ptr, src, (const int*)f.order, f.s, ker_width, r0, cnt, x);
+            hipLaunchKernelGGL(moment_kernel, dim3((unsigned)(((cnt + 7) / 8) * 8 * nq)), dim3(256), 0, s, h2, row_ptr, src,
+                               (const int*)f.order, f.s, ker_width, r0, cnt, x);
         }
         {   // K2: groups of row tiles x K slices
             TimedSection ts(KID_FACT_Y, s);
@@ -575,7 +534,7 @@ int moment_conv(const float* x, const float* h2, const int* row_ptr, const int* 
         {   // K3
             TimedSection ts(KID_NNCONV_COMBINE, s);
             hipLaunchKernelGGL(finish_kernel, dim3(cnt), dim3(FN_CHAINS * 16), 0, s, (const float*)f.part, f.part_stride,
-                               row_ptr, x, root, bias, y, r0, aggr, relu, xq_out);
+                               row_ptr, x, root, bias, y, r0, aggr, relu);
         }
     }
     return check_launch("moment_conv");

@@ -104,7 +104,7 @@ constexpr long long kAutoFactoredMinEdgesPerMember = 16384;
 
 bool use_factored(const mdno_kernelnn_params* p, int M, long long edge_cap, bool position_graph) {
     if (p->conv_mode == MDNO_CONV_MATERIALIZED || !factored_available(p)) return false;
-    if (p->conv_mode == MDNO_CONV_FACTORED) return true;   // (forward_impl insists on a position graph)
+    if (p->conv_mode == MDNO_CONV_FACTORED) return true;   // (gemm_mode F32: forward_impl insists on a position graph)
     return position_graph && edge_cap / (M > 0 ? M : 1) >= kAutoFactoredMinEdgeCapPerMember;
 }
 
@@ -149,13 +149,12 @@ int forward_impl(const mdno_kernelnn_params* p, const float* frames, int t0, con
     bool fc_done = false;      // the output layer went out with the last conv application
     const int blocks = p->conv2_root ? 2 : 1;   // notebook-era model: conv1 only (lstm_* NULL as well)
     if (ws.factored) {
-        // symmetric radius graph, attributes from positions: row r = SOURCE r -> destinations src[p]
-        // (the CSR arrays' names refer to the materialised reading; here their roles are swapped)
-        MDNO_REQUIRE(edge_frames && !edge_attr && dst, MDNO_EINVAL,
-                     "factored conv needs a position-derived radius graph (edge_pos, dst)");
         if (ws.moment) {
             // destination-side form: row r = DESTINATION r with in-edges src[p] -> r, attributes [pos[src], pos[dst]]
-            // as the reference has them (graph_kernel.py:372-379); no symmetry needed
+            // as the reference has them (graph_kernel.py:372-379) or the caller's own edge_attr (+ perm): ANY graph in
+            // destination-sorted CSR, no symmetry needed
+            MDNO_REQUIRE((edge_frames && dst) || edge_attr, MDNO_EINVAL,
+                         "factored conv needs edge attributes: positions (edge_pos, dst) or edge_attr");
             const MomentWs mw = moment_carve(ws.fact, R, p->ker_width);
             if (!prep_only) MDNO_TRY(moment_prepare_graph(row_ptr, R, mw, s));
             for (int block = 0; block < blocks; ++block) {
@@ -163,7 +162,7 @@ int forward_impl(const mdno_kernelnn_params* p, const float* frames, int t0, con
                 if (block == 0 || own) {
                     EdgeMlpWeights w = own ? EdgeMlpWeights{p->k2_w0, p->k2_b0, p->k2_w1, p->k2_b1, p->k2_w2, p->k2_b2}
                                            : EdgeMlpWeights{p->k_w0, p->k_b0, p->k_w1, p->k_b1, p->k_w2, p->k_b2};
-                    MDNO_TRY(edge_mlp_hidden(edge_frames, edge_frame, t_dev, R, src, dst, nullptr, nullptr, num_edges, edge_cap,
+                    MDNO_TRY(edge_mlp_hidden(edge_frames, edge_frame, t_dev, R, src, dst, edge_attr, perm, num_edges, edge_cap,
                                              p->ker_in, p->ker_width, p->gemm_mode, w, ws.h2, ws.mlp, ws.mlp_bytes, s,
                                              block == 0 ? phase : (phase & ~WP_FLAGS_ZEROED)));
                     if ((phase & WP_PHASE_MASK) != WP_RUN_ONLY) MDNO_TRY(moment_prepare_weights(w.w2, w.b2, p->ker_width, mw, s));
@@ -181,6 +180,8 @@ int forward_impl(const mdno_kernelnn_params* p, const float* frames, int t0, con
             MDNO_TRY(fc_out(cur, p->fc2_w, p->fc2_b, R, C, p->out_width, out_frames, t_out, t_dev, s, tail));
             return MDNO_OK;
         }
+        MDNO_REQUIRE(edge_frames && !edge_attr && dst, MDNO_EINVAL,
+                     "factored conv with gemm_mode F32 needs a position-derived (symmetric) radius graph (edge_pos, dst)");
         // gemm_mode F32: source-side form on the exact fp32 MFMA.  Symmetric radius graph, attributes from positions:
         // row r = SOURCE r -> destinations src[p] (the CSR arrays' names refer to the materialised reading; here their
         // roles are swapped)

@@ -479,7 +479,9 @@ static int moment_chunk_rows(int num_rows) {
     return padded < kMomentChunkRows ? padded : kMomentChunkRows;
 }
 
-bool moment_supported(int width, int ker_width) { return width == 64 && ker_width >= 64 && ker_width % 64 == 0; }      // (64 k / 32 = 2 k k-tiles: a multiple of the 128 slices)
+// k % 128: what the hidden GEMM that writes H tiles by (K1 and K2 themselves only need k % 64: 64 k / 32 = 2 k k-tiles,
+// a multiple of the 128 slices)
+bool moment_supported(int width, int ker_width) { return width == 64 && ker_width >= 128 && ker_width % 128 == 0; }
 static size_t s_chunk_floats(int num_rows, int ker_width) { return (size_t)(moment_chunk_rows(num_rows) / 128) * moment_nkt(ker_width) * 4096; }
 
 size_t moment_workspace_bytes(int num_rows, int ker_width) {
@@ -517,7 +519,7 @@ int moment_prepare_graph(const int* row_ptr, int num_rows, const MomentWs& f, hi
 
 int moment_conv(const float* x, const float* h2, const int* row_ptr, const int* src, int num_rows, int ker_width,
                 const float* root, const float* bias, int aggr, int relu, float* y, const MomentWs& f, hipStream_t s) {
-    MDNO_REQUIRE(moment_supported(64, ker_width), MDNO_EUNSUPPORTED, "moment conv: ker_width=%d (x64)", ker_width);
+    MDNO_REQUIRE(moment_supported(64, ker_width), MDNO_EUNSUPPORTED, "moment conv: ker_width=%d (x128)", ker_width);
     for (int r0 = 0; r0 < num_rows; r0 += kMomentChunkRows) {
         const int cnt = num_rows - r0 < kMomentChunkRows ? num_rows - r0 : kMomentChunkRows;
         {   // K1: the chunk's destinations x the k/256 column blocks

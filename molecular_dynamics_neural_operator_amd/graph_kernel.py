@@ -248,7 +248,7 @@ class KernelNN(nn.Module):
         # otherwise the library itself runs materialized); "materialized" = the reference's W_e
         # formulation; "auto" (default) = factored once the graph is large enough to pay for its fixed
         # cost per application (edge capacity >= 24,576), materialized below.  forward(data) with an
-        # explicit edge_index/edge_attr always runs materialized.
+        # explicit edge_index/edge_attr follows the same rule on its counted graph (split GEMM modes).
         self.conv_mode = "auto"
 
     def __getstate__(self):
@@ -278,6 +278,22 @@ class KernelNN(nn.Module):
             self._pack = ops.ParamPack(self.state_dict(), self.depth, device, self.gemm_mode, conv_mode)
             self._pack_key = key
         return self._pack
+
+    def _conv_mode_for_edges(self, device, members: int, n_atoms: int, n_edges: int) -> str:
+        """Formulation for a forward on an explicit edge list.  "auto": the library's rule on the counted graph
+        (mdno_conv_mode_for_graph: factored for dense graphs — mean degree >= 40 and >= 16,384 edges per member —,
+        materialized for protein-like chains).  The factored form of the split GEMM modes (csrc/moment.hip) takes any
+        edge list; gemm_mode "f32" has the source-side form only, which needs a library-built symmetric graph, so an
+        explicit edge list runs materialized there."""
+        if self.conv_mode == "materialized" or self.gemm_mode == "f32":
+            return "materialized"
+        from . import _lib
+        pack = self.param_pack(device, conv_mode="factored")
+        mode = int(_lib.load().mdno_conv_mode_for_graph(pack.ref, int(members), int(n_atoms), int(n_edges)))
+        if self.conv_mode == "factored":      # asked for: taken wherever the model's dimensions allow it
+            return "factored" if int(_lib.load().mdno_resolve_conv_mode(pack.ref, int(members), 1 << 40)) == _lib.CONV_MODES["factored"] \
+                else "materialized"
+        return {v: k for k, v in _lib.CONV_MODES.items()}[mode]
 
     def forward(self, data, return_latent: bool = False, single_example: bool = False, _status=None):
         """``data``: one ``PairData`` sample, a list of samples (what the reference's DataListLoader yields and
@@ -315,7 +331,8 @@ class KernelNN(nn.Module):
                 "or a collated one (training.collate / DeviceTrajectory.batch: x_position [W,B*N,3], num_graphs = B)")
         W = x_position.shape[0]
         with torch.no_grad():
-            pack = self.param_pack(x_position.device, conv_mode="materialized")
+            pack = self.param_pack(x_position.device, conv_mode=self._conv_mode_for_edges(
+                x_position.device, B, n_rows // B, int(data.edge_index.shape[1])))
             graph = ops.coo_to_csr(data.edge_index.to(x_position.device), n_rows, validate=_status is None, status=_status)
             out, latent = ops.kernelnn_forward(pack, ops.f32(x_position).reshape(W, B, n_rows // B, 3),
                                                data.x_aminoacid.to(x_position.device), graph,

@@ -253,9 +253,12 @@ def kernelnn_forward(pack: ParamPack, frames: torch.Tensor, x_aminoacid: torch.T
     status = graph.status
     ea = f32(edge_attr) if edge_attr is not None else None
     ep = f32(edge_pos).reshape(-1, 3) if edge_pos is not None else None
-    if pack.conv_mode == "factored" and (ea is not None or ep is None):
-        raise MdnoError("conv_mode='factored' needs a radius graph with position-derived attributes "
-                        "(edge_pos); explicit edge_attr runs with conv_mode='materialized'")
+    if pack.conv_mode == "factored" and pack.gemm_mode == "f32" and (ea is not None or ep is None):
+        raise MdnoError("conv_mode='factored' with gemm_mode='f32' (the source-side form) needs a symmetric radius graph "
+                        "with position-derived attributes (edge_pos); explicit edge_attr runs it with a split gemm_mode "
+                        "or conv_mode='materialized'")
+    if ea is None and ep is None:
+        raise MdnoError("kernelnn_forward needs edge_pos (a library-built radius graph) or edge_attr")
     check(lib.mdno_kernelnn_fwd(pack.ref, ptr(frames), M, W, N, ptr(aa), aa_pm, ptr(graph.row_ptr), ptr(graph.src),
                                 ptr(graph.dst), ptr(graph.num_edges), graph.edge_cap, int(graph.max_degree), ptr(ep),
                                 ptr(ea),

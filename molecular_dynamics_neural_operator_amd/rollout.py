@@ -183,9 +183,10 @@ class RolloutEngine:
         if self.M != 1 or self.steps_done != 0:
             raise MdnoError("first_step_from_sample: needs M == 1 and a freshly reset engine")
         graph = ops.coo_to_csr(edge_index.to(self.device), self.N)
-        # an explicit edge list always runs the materialised formulation
+        # an explicit edge list: the engine's formulation where it takes one (the destination-side factored form of the
+        # split GEMM modes does; gemm_mode "f32" has the source-side form only: materialised there)
         pack = self.pack
-        if pack.conv_mode != "materialized":
+        if pack.conv_mode != "materialized" and pack.gemm_mode == "f32":
             pack = ops.ParamPack({v: pack.tensors[k] for k, v in ops.ParamPack.KEYS.items() if k in pack.tensors},
                                  pack.struct.depth, self.device, pack.gemm_mode, "materialized")
         out, _ = ops.kernelnn_forward(pack, self.traj[:self.W], self.aa, graph,

@@ -698,10 +698,57 @@ def test_factored_conv_matches_materialized_and_reference(dev):
     eng = RolloutEngine(small, 1, 200, W, 8.0, max_steps=2, device=dev, max_degree=200)
     close(eng.run(torch.from_numpy(big), aa_big, 2), tight)
     small.gemm_mode = "split_f16"
-    # explicit edge_attr + factored pack is refused, not silently rerouted
+    # explicit edge_attr + factored pack: the destination-side form (split GEMM modes) takes it — tested in
+    # test_factored_conv_on_an_arbitrary_edge_list —, the source-side fp32 form refuses it instead of rerouting
+    model.gemm_mode = "f32"
     with pytest.raises(MdnoError):
         ops.kernelnn_forward(model.param_pack(dev, conv_mode="factored"), frames.unsqueeze(1), t(z["x_aminoacid"]), g,
                              edge_attr=torch.zeros(g.edge_count(), 6, device=dev))
+
+
+@pytest.mark.parametrize("gemm_mode", ["split_f16", "split_bf16"])
+def test_factored_conv_on_an_arbitrary_edge_list(dev, O, gemm_mode):
+    """The destination-side factored form (csrc/moment.hip) needs no symmetric graph and no position-derived
+    attributes: a forward on a random DIRECTED edge list with duplicates, a hub, nodes without in-edges and arbitrary
+    edge attributes, two members, against the oracle's per-edge formulation and against the materialised path."""
+    from molecular_dynamics_neural_operator_amd import ops
+    from molecular_dynamics_neural_operator_amd.dataset import PairData
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN
+    from molecular_dynamics_neural_operator_amd.weights import near_identity_state_dict
+    gen = torch.Generator().manual_seed(21)
+    N, W, E = 150, 10, 9000
+    sd = near_identity_state_dict(64, 384, seed=4, kernel_gain=3e-2, feature_gain=0.3, kernel_to_coords=1.0)
+    model = KernelNN(64, 384, 2, 6, 7, 3, 20, 4)          # k = 384: not a multiple of K1's 256-column blocks
+    model.load_state_dict(sd)
+    model.eval().to(dev)
+    model.gemm_mode = gemm_mode
+    samples = []
+    for m in range(2):
+        ei = torch.randint(0, N, (2, E), generator=gen)
+        ei[1, :700] = 5 + m                                  # a hub
+        ei[1, ei[1] == 40] = 41                              # node 40: no in-edge
+        ei[:, 800:900] = ei[:, 700:800]                      # duplicate edges
+        xp = torch.randn(W, N, 3, generator=gen) * 4
+        ea = torch.randn(E, 6, generator=gen) * 3
+        samples.append(PairData(x_aminoacid=torch.randint(0, 20, (N,), generator=gen), x_position=xp, y=torch.zeros(N, 3),
+                                edge_attr=ea, edge_index=ei))
+    res = {}
+    for conv_mode in ("materialized", "factored"):
+        model.conv_mode = conv_mode
+        assert model._conv_mode_for_edges(dev, 2, N, 2 * E) == conv_mode
+        with torch.no_grad():
+            res[conv_mode] = model(samples)                  # the two samples as one block-diagonal batch
+            one = model(samples[1].to(dev))
+        assert torch.equal(res[conv_mode][N:], one)          # a member does not depend on the batch it is in
+    close(res["factored"], res["materialized"], name=f"factored vs materialized, arbitrary graph {gemm_mode}")
+    want = torch.cat([O.kernelnn_forward(sd, s_.x_position.cpu(), s_.x_aminoacid.cpu(), s_.edge_index.cpu(), s_.edge_attr.cpu(), 2,
+                                         hoist=True) for s_ in samples])
+    close(res["factored"], want, name=f"factored vs oracle, arbitrary graph {gemm_mode}")
+    # gemm_mode "f32" has the source-side form only: an explicit edge list runs materialised there
+    model.gemm_mode, model.conv_mode = "f32", "factored"
+    assert model._conv_mode_for_edges(dev, 2, N, 2 * E) == "materialized"
+    with torch.no_grad():
+        close(model(samples), want, name="f32, arbitrary graph")
 
 
 def test_edge_cases_single_atom_window1_zero_steps_and_c_rollout(dev, O):

@@ -393,23 +393,30 @@ def leg_cfg4_training(dev, frames=10000, batch=128, kernel_width=1024, depth=6, 
             w2b = ops.cast_bf16(w2)
             fl = 2.0 * E0 * kernel_width * 4096
 
-            def gemm_entry(what, fn, fn_random):
-                ms, msr = _event_ms(fn, 10), _event_ms(fn_random, 10)
-                return {"bound": "mfma", "kernel": what, "ms": ms, "achieved": fl / ms / 1e9, "peak": MFMA_BF16_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": fl / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS,
+            # these entry points take the fp32 MASTER weight and cast it per call (a 4.2M-element kernel in front of the
+            # GEMM): timed alone and taken off, so that "ms" is the GEMM kernel (+ its slab reduction for A^T.B)
+            ms_cast = _event_ms(lambda: ops.cast_bf16(w2), 20)
+            w2t = ops.transpose(w2)
+
+            def gemm_entry(what, fn, fn_random, cast):
+                ms_all, msr_all = _event_ms(fn, 10), _event_ms(fn_random, 10)
+                ms, msr = ms_all - cast, msr_all - cast
+                return {"bound": "mfma", "kernel": what, "ms": ms, "ms_incl_weight_cast": ms_all, "achieved": fl / ms / 1e9,
+                        "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS,
                         "operands": "h2 = this batch's hidden activations (post-ReLU), dW_e dense random",
                         "all_random_operands": {"ms": msr, "achieved": fl / msr / 1e9, "frac": fl / msr / 1e9 / MFMA_BF16_PEAK_TFLOPS}}
             roofs = {"gemm_last_layer_fwd": gemm_entry(
-                "bf16 A.W^T [E,k]x[k,4096] -> bf16 (incl. the per-call cast of the fp32 master weight)",
+                "gemm_pp_kernel<NT, bias>: bf16 A.W^T [E,k]x[k,4096] -> bf16",
                 lambda: ops.linear_bf16(h2, w2, bb2, relu=False, out_bf16=True),
-                lambda: ops.linear_bf16(h2r, w2, bb2, relu=False, out_bf16=True))}
+                lambda: ops.linear_bf16(h2r, w2, bb2, relu=False, out_bf16=True), ms_cast)}
             dwe = torch.randn(E0, 4096, device=dev).to(torch.bfloat16)
-            roofs["gemm_weight_grad"] = gemm_entry("bf16 A^T.B [E,4096]^T x [E,k]", lambda: ops.gemm_atb_bf16(dwe, h2),
-                                                   lambda: ops.gemm_atb_bf16(dwe, h2r))
+            roofs["gemm_weight_grad"] = gemm_entry("gemm_pp_kernel<TN, slab>: bf16 A^T.B [E,4096]^T x [E,k]",
+                                                   lambda: ops.gemm_atb_bf16(dwe, h2), lambda: ops.gemm_atb_bf16(dwe, h2r), 0.0)
             roofs["gemm_input_grad_masked"] = gemm_entry(
-                "bf16 (h2 > 0) * (dW_e . W2) [E,4096]x[4096,k] -> bf16", lambda: ops.linear_bf16_relu_bwd(dwe, ops.transpose(w2), h2),
-                lambda: ops.linear_bf16_relu_bwd(dwe, ops.transpose(w2), h2r))
-            del h1, h2r, w2b
+                "gemm_pp_kernel<NT, mask>: bf16 (h2 > 0) * (dW_e . W2) [E,4096]x[4096,k] -> bf16",
+                lambda: ops.linear_bf16_relu_bwd(dwe, w2t, h2), lambda: ops.linear_bf16_relu_bwd(dwe, w2t, h2r), ms_cast)
+            out["weight_cast_ms"] = ms_cast
+            del h1, h2r, w2b, w2t
             g = ops.coo_to_csr(b0.edge_index, batch * N, validate=False)
             x = torch.randn(batch * N, 64, device=dev)
             root, cb = model.conv1.root.detach(), model.conv1.bias.detach()

@@ -128,6 +128,14 @@ typedef struct mdno_kernelnn_params {
 int mdno_radius_graph_csr(const float* pos, int M, int N, double cutoff,
                           int32_t* row_ptr, int32_t* src, int32_t* dst, int64_t edge_cap,
                           int32_t* num_edges, int32_t* status, void* stream);
+/* The same graph with caller-provided scratch: from 8,192 atoms per member on, a cell list (cells of edge >= cutoff,
+ * 27 cells tested per destination, sources read back in ascending order from an atom mask) replaces the N^2 pair
+ * tests — same pair test, same edges, same order, bit for bit.  mdno_radius_graph_workspace_bytes is 0 below that
+ * size (workspace may then be NULL: this entry equals mdno_radius_graph_csr). */
+size_t mdno_radius_graph_workspace_bytes(int M, int N);
+int mdno_radius_graph_csr_ws(const float* pos, int M, int N, double cutoff, int32_t* row_ptr, int32_t* src, int32_t* dst,
+                             int64_t edge_cap, int32_t* num_edges, int32_t* status, void* workspace,
+                             size_t workspace_bytes, void* stream);
 
 /* General graphs: stable sort of a COO edge list by destination — what torch_geometric's
  * scatter over edge_index[1] implies (graph_kernel.py:198 -> MessagePassing.propagate).

@@ -52,6 +52,8 @@ SIGNATURES = {
     "mdno_abi_version": (_I, []),
     "mdno_last_error": (C.c_char_p, []),
     "mdno_radius_graph_csr": (_I, [_P, _I, _I, _D, _P, _P, _P, _L, _P, _P, _P]),
+    "mdno_radius_graph_workspace_bytes": (_SZ, [_I, _I]),
+    "mdno_radius_graph_csr_ws": (_I, [_P, _I, _I, _D, _P, _P, _P, _L, _P, _P, _P, _SZ, _P]),
     "mdno_coo_to_csr_workspace_bytes": (_SZ, [_L, _I]),
     "mdno_coo_to_csr": (_I, [_P, _L, _I, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "mdno_edge_mlp_workspace_bytes": (_SZ, [_I, _I, _L, _I]),

@@ -240,8 +240,8 @@ int forward_impl(const mdno_kernelnn_params* p, const float* frames, int t0, con
 
 struct RolloutWs {
     int *row_ptr, *src, *dst, *num_edges, *t_dev, *row_done;
-    void* fwd;
-    size_t fwd_bytes, total;
+    void *fwd, *graph_scratch;
+    size_t fwd_bytes, graph_scratch_bytes, total;
 };
 
 RolloutWs carve_rollout(void* ws, const mdno_kernelnn_params* p, int M, int N, long long edge_cap) {
@@ -256,6 +256,8 @@ RolloutWs carve_rollout(void* ws, const mdno_kernelnn_params* p, int M, int N, l
     r.row_done = cv.take<int>(R <= 256 ? 256 : 0);      // short chains: parts of a row finished (FcTail::row_done)
     r.fwd_bytes = carve_fwd(nullptr, p, M, N, edge_cap, use_factored(p, M, edge_cap, true)).total;
     r.fwd = cv.take<char>(r.fwd_bytes);
+    r.graph_scratch_bytes = radius_graph_scratch_bytes(M, N);      // cell list of large members (0 otherwise)
+    r.graph_scratch = cv.take<char>(r.graph_scratch_bytes);
     r.total = cv.used();
     return r;
 }
@@ -370,7 +372,8 @@ static int plan_enqueue_step(mdno_rollout_plan* pl, hipStream_t s) {
                                  pl->status, act_flags, n_zero, s));
     else
         MDNO_TRY(radius_graph(pl->traj, W - 1, pl->r.t_dev, pl->M, pl->N, pl->threshold, pl->r.row_ptr, pl->r.src,
-                              pl->r.dst, pl->edge_cap, pl->r.num_edges, pl->status, s, act_flags, n_zero));
+                              pl->r.dst, pl->edge_cap, pl->r.num_edges, pl->status, s, act_flags, n_zero,
+                              pl->r.graph_scratch, pl->r.graph_scratch_bytes));
     const StepTail tail{pl->r.t_dev, pl->r.num_edges, pl->edges_per_step, pl->r.t_dev + 1,
                         (long long)pl->M * pl->N <= 256 ? pl->r.row_done : nullptr};
     return forward_impl(&pl->p, pl->traj, 0, pl->r.t_dev, pl->M, W, pl->N, pl->aa, pl->aa_per_member, pl->r.row_ptr,

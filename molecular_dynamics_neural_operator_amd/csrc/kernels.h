@@ -24,9 +24,12 @@ struct TimedSection {
 
 // zero_words / n_zero (<= 64): ints the graph kernels also reset — a rollout step clears the edge-MLP's
 // activation flags here instead of with a launch of its own
+// scratch (radius_graph_scratch_bytes; 0 below 8,192 atoms per member): with it a large member's graph is built
+// through a cell list instead of N^2 pair tests — the same edges in the same order
+size_t radius_graph_scratch_bytes(int M, int N);
 int radius_graph(const float* frames, int frame, const int* t_dev, int M, int N, double cutoff, int* row_ptr,
                  int* src, int* dst, long long edge_cap, int* num_edges, int* status, hipStream_t s,
-                 int* zero_words = nullptr, int n_zero = 0);
+                 int* zero_words = nullptr, int n_zero = 0, void* scratch = nullptr, size_t scratch_bytes = 0);
 
 struct EdgeMlpWeights {
     const float *w0, *b0, *w1, *b1, *w2, *b2;

@@ -36,8 +36,10 @@ class CSRGraph:
         return torch.stack([self.dst[:e], self.src[:e]]).to(torch.long)
 
 
-def radius_graph(pos: torch.Tensor, n_atoms: int, cutoff: float = 8.0, edge_cap: Optional[int] = None) -> CSRGraph:
-    """pos f32 [M*N,3] (or [M,N,3]) -> CSRGraph.  Replaces graph_kernel.py:363-368."""
+def radius_graph(pos: torch.Tensor, n_atoms: int, cutoff: float = 8.0, edge_cap: Optional[int] = None,
+                 cell_list: bool = True) -> CSRGraph:
+    """pos f32 [M*N,3] (or [M,N,3]) -> CSRGraph.  Replaces graph_kernel.py:363-368.  Members of >= 8,192 atoms go
+    through a cell list (`cell_list=False`: the N^2 pair tests; the same graph, bit for bit)."""
     lib = _lib.load()
     pos = f32(pos).reshape(-1, 3)
     R = pos.shape[0]
@@ -52,8 +54,10 @@ def radius_graph(pos: torch.Tensor, n_atoms: int, cutoff: float = 8.0, edge_cap:
     dst = torch.empty(cap, dtype=torch.int32, device=dev)
     ne = torch.zeros(1, dtype=torch.int32, device=dev)
     status = torch.zeros(1, dtype=torch.int32, device=dev)
-    check(lib.mdno_radius_graph_csr(ptr(pos), M, n_atoms, float(cutoff), ptr(row_ptr), ptr(src), ptr(dst), cap,
-                                    ptr(ne), ptr(status), stream_ptr(dev)), "mdno_radius_graph_csr")
+    nbytes = lib.mdno_radius_graph_workspace_bytes(M, n_atoms) if cell_list else 0      # > 0: large members, cell list
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev) if nbytes else None
+    check(lib.mdno_radius_graph_csr_ws(ptr(pos), M, n_atoms, float(cutoff), ptr(row_ptr), ptr(src), ptr(dst), cap,
+                                       ptr(ne), ptr(status), ptr(ws), nbytes, stream_ptr(dev)), "mdno_radius_graph_csr_ws")
     return CSRGraph(row_ptr, src, dst, ne, cap, None, status)
 
 

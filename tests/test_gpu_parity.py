@@ -68,6 +68,43 @@ def test_radius_graph_matches_reference_golden(dev):
     assert np.array_equal(pd.edge_index.cpu().numpy(), z["edge_index"])
 
 
+def test_radius_graph_cell_list_equals_brute_force(dev):
+    """From 8,192 atoms per member on the radius graph is built through a cell list (csrc/graph.hip): the same pair
+    test on 27 cells per destination, sources read back in ascending order from an atom mask — it must be the SAME
+    graph as the N^2 pair tests, bit for bit: a uniform box (two members), an elongated slab (one cell across two of
+    its axes), every atom inside one cell, a cloud wider than 32 cells per axis (cells enlarged), pairs exactly at
+    the cutoff, and an edge capacity that overflows."""
+    from molecular_dynamics_neural_operator_amd import ops, synthetic as syn
+    rng = np.random.default_rng(5)
+    cases = []
+    a = np.stack([syn.box_frame(9000, seed=31), syn.box_frame(9000, seed=32) * 1.3])          # [2,N,3]
+    cases.append(("two boxes", a, 8.0))
+    slab = (rng.random((1, 12000, 3)) * np.array([400.0, 6.0, 5.0])).astype(np.float32)
+    cases.append(("slab", slab, 8.0))
+    cases.append(("one cell", (rng.random((1, 8200, 3)) * 3.0).astype(np.float32), 8.0))
+    cases.append(("wide cloud", (rng.random((1, 20000, 3)) * 900.0).astype(np.float32), 10.0))
+    grid = np.stack(np.meshgrid(np.arange(21), np.arange(21), np.arange(21), indexing="ij"), -1).reshape(1, -1, 3).astype(np.float32) * 2.0
+    cases.append(("lattice, pairs AT the cutoff", grid, 4.0))                                  # distance exactly 4.0: strict <
+    for name, pos, cut in cases:
+        M, N = pos.shape[0], pos.shape[1]
+        x = t(pos, dev)
+        cap = M * N * N if name == "one cell" else M * N * 700          # (one cell: the complete graph, 67M edges)
+        g1 = ops.radius_graph(x, N, cut, edge_cap=cap, cell_list=True)
+        g0 = ops.radius_graph(x, N, cut, edge_cap=cap, cell_list=False)
+        e = g0.edge_count()
+        assert int(g0.status.item()) == 0 and int(g1.status.item()) == 0, name
+        assert g1.edge_count() == e and e >= M * N, (name, e, g1.edge_count())
+        assert torch.equal(g1.row_ptr, g0.row_ptr), name
+        assert torch.equal(g1.src[:e], g0.src[:e]) and torch.equal(g1.dst[:e], g0.dst[:e]), name
+        print(f"cell list == brute force: {name}: N={N} M={M} E={e}")
+    # overflow: same truncation, same status
+    x = t(cases[0][1], dev)
+    g1 = ops.radius_graph(x, 9000, 8.0, edge_cap=100000, cell_list=True)
+    g0 = ops.radius_graph(x, 9000, 8.0, edge_cap=100000, cell_list=False)
+    assert int(g1.status.item()) == int(g0.status.item()) != 0 and g1.edge_count() == g0.edge_count() == 100000
+    assert torch.equal(g1.row_ptr, g0.row_ptr) and torch.equal(g1.src[:100000], g0.src[:100000])
+
+
 def test_radius_graph_members_threshold_edge_and_overflow(dev, O):
     from molecular_dynamics_neural_operator_amd import ops, synthetic as syn
     # three independent members -> block-diagonal CSR == per-member oracle graphs, offset by m*N

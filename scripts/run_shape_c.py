@@ -85,7 +85,7 @@ print(f"workspace {eng.workspace.numel() / 2**30:.1f} GiB", flush=True)
 eng.reset(torch.from_numpy(win), aa)
 eng.step(1)
 eng.synchronize()
-eng.attach_timer(a.steps * 2000)
+eng.attach_timer(a.steps * 6000)
 t0 = torch.cuda.Event(enable_timing=True)
 t1 = torch.cuda.Event(enable_timing=True)
 t0.record(eng.stream)

@@ -504,7 +504,7 @@ def leg_cfg5_shape_c(dev, atoms=50000, cutoff=10.0, steps=2, slice_edges=2_000_0
     eng.reset(torch.from_numpy(win), aa)
     eng.step(1)
     eng.synchronize()
-    eng.attach_timer(steps * 4000)
+    eng.attach_timer(steps * 6000)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     eng.step(steps)

@@ -306,7 +306,7 @@ constexpr int PJ_SLICES = 128;
 constexpr int PJ_B_PLANE = 64 * 64;
 
 template <int PJ_ROWS>
-__global__ __launch_bounds__(PJ_ROWS * 2, 512 / PJ_ROWS * 2) void project_kernel(const float* __restrict__ S, const float* __restrict__ w3r,
+__global__ __launch_bounds__(PJ_ROWS * 2) void project_kernel(const float* __restrict__ S, const float* __restrict__ w3r,
                                                          float* __restrict__ part, int K, int cnt, int row0,
                                                          long long part_stride) {
     constexpr int PJ_A_PLANE = PJ_ROWS * 64, PJ_B_BASE = 3 * PJ_A_PLANE, NT = PJ_ROWS / 128;
@@ -330,21 +330,26 @@ __global__ __launch_bounds__(PJ_ROWS * 2, 512 / PJ_ROWS * 2) void project_kernel
     auto a_ptr = [&](int r) {
         return S + ((size_t)(NT * rg + (r >> 7)) * nkt + kt0) * 4096 + (r & 127) * 32 + scol;
     };
-    const float* A0 = a_ptr(srow);
-    const float* A1 = a_ptr(srow + RQ);
-    const float* A2 = a_ptr(srow + 2 * RQ);
-    const float* A3 = a_ptr(srow + 3 * RQ);
+    // 32-row groups past the last destination are not multiplied (wave >= live): their staging threads re-read a row
+    // of group 0 instead (always inside the image), so that every load and LDS store below is unconditional —
+    // straight-line code whose vmcnt waits the compiler can count
+    auto a_row = [&](int r) { return (r >> 5) < live ? r : (r & 31); };
+    const float* A0 = a_ptr(a_row(srow));
+    const float* A1 = a_ptr(a_row(srow + RQ));
+    const float* A2 = a_ptr(a_row(srow + 2 * RQ));
+    const float* A3 = a_ptr(a_row(srow + 3 * RQ));
     const float* Bg = w3r + (size_t)kt0 * 2048 + srow * 32 + scol;
-    const bool g0 = (srow >> 5) < live, g1 = ((srow + RQ) >> 5) < live, g2 = ((srow + 2 * RQ) >> 5) < live,
-               g3 = ((srow + 3 * RQ) >> 5) < live;
-    float4 ra0 = make_float4(0.f, 0.f, 0.f, 0.f), ra1 = ra0, ra2 = ra0, ra3 = ra0, rb0, rb1 = ra0;
-#define PJ_LOAD(KT)                                                                  \
-    if (g0) ra0 = *reinterpret_cast<const float4*>(A0 + (size_t)(KT) * 4096);        \
-    if (g1) ra1 = *reinterpret_cast<const float4*>(A1 + (size_t)(KT) * 4096);        \
-    if (g2) ra2 = *reinterpret_cast<const float4*>(A2 + (size_t)(KT) * 4096);        \
-    if (g3) ra3 = *reinterpret_cast<const float4*>(A3 + (size_t)(KT) * 4096);        \
-    rb0 = *reinterpret_cast<const float4*>(Bg + (size_t)(KT) * 2048);                \
-    if (RQ < 64) rb1 = *reinterpret_cast<const float4*>(Bg + (size_t)(KT) * 2048 + RQ * 32);
+    // TWO K-tiles in flight per thread (register sets P and Q, alternating): with one, a workgroup — one per CU at one
+    // member — had 40 KiB on its way at a time and the kernel ran at what one round trip per tile gives
+    struct Tile { float4 a0, a1, a2, a3, b0, b1; };
+    auto load = [&](Tile& r, int kt) {
+        r.a0 = *reinterpret_cast<const float4*>(A0 + (size_t)kt * 4096);
+        r.a1 = *reinterpret_cast<const float4*>(A1 + (size_t)kt * 4096);
+        r.a2 = *reinterpret_cast<const float4*>(A2 + (size_t)kt * 4096);
+        r.a3 = *reinterpret_cast<const float4*>(A3 + (size_t)kt * 4096);
+        r.b0 = *reinterpret_cast<const float4*>(Bg + (size_t)kt * 2048);
+        if (RQ < 64) r.b1 = *reinterpret_cast<const float4*>(Bg + (size_t)kt * 2048 + RQ * 32);
+    };
     auto st_off = [&](int row) { return row * 64 + ((((tid & 7) >> 1) ^ ((row >> 2) & 3)) << 4) + (tid & 1) * 8; };
     unsigned char* a_st0 = lds + st_off(srow);
     unsigned char* a_st1 = lds + st_off(srow + RQ);
@@ -352,13 +357,14 @@ __global__ __launch_bounds__(PJ_ROWS * 2, 512 / PJ_ROWS * 2) void project_kernel
     unsigned char* a_st3 = lds + st_off(srow + 3 * RQ);
     unsigned char* b_st0 = lds + PJ_B_BASE + st_off(srow);
     unsigned char* b_st1 = lds + PJ_B_BASE + st_off(srow + RQ);
-#define PJ_STORE()                                         \
-    if (g0) split_store4(ra0, a_st0, PJ_A_PLANE);          \
-    if (g1) split_store4(ra1, a_st1, PJ_A_PLANE);          \
-    if (g2) split_store4(ra2, a_st2, PJ_A_PLANE);          \
-    if (g3) split_store4(ra3, a_st3, PJ_A_PLANE);          \
-    split_store4(rb0, b_st0, PJ_B_PLANE);                  \
-    if (RQ < 64) split_store4(rb1, b_st1, PJ_B_PLANE);
+    auto store = [&](const Tile& r) {
+        split_store4(r.a0, a_st0, PJ_A_PLANE);
+        split_store4(r.a1, a_st1, PJ_A_PLANE);
+        split_store4(r.a2, a_st2, PJ_A_PLANE);
+        split_store4(r.a3, a_st3, PJ_A_PLANE);
+        split_store4(r.b0, b_st0, PJ_B_PLANE);
+        if (RQ < 64) split_store4(r.b1, b_st1, PJ_B_PLANE);
+    };
     f32x16 acc0, acc1;
 #pragma unroll
     for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
@@ -377,21 +383,32 @@ __global__ __launch_bounds__(PJ_ROWS * 2, 512 / PJ_ROWS * 2) void project_kernel
         }                                                                                                \
         MDNO_MMA6(a, b0, acc0) MDNO_MMA6(a, b1, acc1)                                                    \
     }
-    PJ_LOAD(0)
-    PJ_STORE()
-    __syncthreads();
     const bool rows_live = wave < live;
-    for (int kt = 0; kt < nk - 1; ++kt) {
-        PJ_LOAD(kt + 1)
+    Tile P, Q;
+    // nk is even (k % 128 == 0: k/64 k-tiles per slice, + the 2 of s0).  Every load below is issued whatever kt is
+    // (past the end: the last tile again, an L2 hit that is never stored) so that the number of loads in flight at
+    // each LDS store is a constant the compiler's vmcnt waits can rely on: 5 newer ones stay in flight.
+    const int last = nk - 1;
+    load(P, 0);
+    load(Q, 1);
+    store(P);
+    __syncthreads();
+    // LDS holds tile kt, the other set tile kt+1 (landed or landing), the set just stored is reloaded with tile kt+2
+    for (int kt = 0;; kt += 2) {
+        load(P, min(kt + 2, last));
         __builtin_amdgcn_sched_barrier(0);
         if (rows_live) { PJ_MMA_TILE() }
         __syncthreads();
-        PJ_STORE()
+        store(Q);
+        __syncthreads();
+        load(Q, min(kt + 3, last));
+        __builtin_amdgcn_sched_barrier(0);
+        if (rows_live) { PJ_MMA_TILE() }
+        if (kt + 2 >= nk) break;
+        __syncthreads();
+        store(P);
         __syncthreads();
     }
-    if (rows_live) { PJ_MMA_TILE() }
-#undef PJ_LOAD
-#undef PJ_STORE
 #undef PJ_MMA_TILE
     float* Po = part + (size_t)slice * part_stride;
 #pragma unroll

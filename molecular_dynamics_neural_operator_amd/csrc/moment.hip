@@ -496,8 +496,8 @@ static int moment_chunk_rows(int num_rows) {
     return padded < kMomentChunkRows ? padded : kMomentChunkRows;
 }
 
-// k % 128: what the hidden GEMM that writes H tiles by (K1 and K2 themselves only need k % 64: 64 k / 32 = 2 k k-tiles,
-// a multiple of the 128 slices)
+// k % 128: what the hidden GEMM that writes H tiles by, and what makes a K2 slice an even number of k-tiles
+// (64 k / 32 = 2 k k-tiles over 128 slices = k / 64 each; K2's loop takes them two at a time)
 bool moment_supported(int width, int ker_width) { return width == 64 && ker_width >= 128 && ker_width % 128 == 0; }
 static size_t s_chunk_floats(int num_rows, int ker_width) { return (size_t)(moment_chunk_rows(num_rows) / 128) * moment_nkt(ker_width) * 4096; }
 

@@ -6,8 +6,8 @@
 
 On-disk layout (dataset.py:112-127, 159): datasets `contact_map` (per-frame ragged flat COO
 `[rows..., cols...]`), `point_cloud` `[T,3,N]`, `rmsd` `[T]`, `amino_acids` `[N]`.  HDF5 files are
-read when `h5py` is importable (the build image has none: that branch is unexecuted here, see
-tests/test_host_logic.py::test_hdf5_container); an `.npz` with the same dataset names is read
+read through `h5py` when it is importable and otherwise through the HDF5 C library itself (`hdf5_io.py`, ctypes;
+tests/test_host_logic.py reads a file written by real h5py that way); an `.npz` with the same dataset names is read
 everywhere.  In the `.npz` twin a ragged dataset is stored without pickling, as the concatenation of
 its rows under its own name plus `<name>_offsets` (int64 [T+1]); object arrays written by older
 versions are only read with `allow_pickle=True`.  Directory mode concatenates the sorted files
@@ -112,14 +112,21 @@ def _read_container(path: str, names: Sequence[str], allow_pickle: bool = False)
                 out[n] = arr
         return out
     try:
-        import h5py  # noqa: not in the build image; used when present
-    except ImportError as e:
-        raise ImportError(f"reading {p} needs h5py; convert it to .npz with the same dataset names") from e
-    with h5py.File(p, "r", libver="latest", swmr=False) as f:
-        for n in names:
-            if n in f:
-                out[n] = np.array(f[n][...])
-    return out
+        import h5py  # noqa: used when present
+    except ImportError:
+        h5py = None
+    if h5py is not None:
+        with h5py.File(p, "r", libver="latest", swmr=False) as f:
+            for n in names:
+                if n in f:
+                    out[n] = np.array(f[n][...])
+        return out
+    # no h5py: the HDF5 C library itself through ctypes (hdf5_io.py) — the same arrays
+    from . import hdf5_io
+    if not hdf5_io.available():
+        raise ImportError(f"reading {p} needs h5py or an HDF5 C library (libhdf5.so; MDNO_HDF5_LIB names one); "
+                          "or convert the file to .npz with the same dataset names (hdf5_io.h5_to_npz where there is one)")
+    return hdf5_io.read_datasets(p, names)
 
 
 class ContactMapDataset(torch.utils.data.Dataset):

@@ -211,8 +211,8 @@ def test_npz_trajectory_is_pickle_free_and_pickled_files_are_refused(tmp_path):
 
 
 def test_hdf5_container(tmp_path):
-    """The reference's real container (dataset.py:112-127).  h5py is not in the build image, so this
-    test is skipped there and the .h5 branch of `_read_container` is unexecuted."""
+    """The reference's real container (dataset.py:112-127) through h5py, where h5py is importable (the build image's
+    main interpreter has none: there the HDF5 branch runs through hdf5_io.py — the tests below)."""
     h5py = pytest.importorskip("h5py")
     fr = syn.ou_trajectory(syn.chain_frame(9, seed=1), 5, seed=1)
     cms = [O.radius_graph_coo(f, 8.0).reshape(-1) for f in fr]
@@ -227,3 +227,84 @@ def test_hdf5_container(tmp_path):
         f.create_dataset("amino_acids", data=syn.amino_acids(9, seed=1))
     d = ContactMapDataset(str(p), window_size=2, horizon=1)
     assert np.array_equal(d[1].edge_index.numpy().reshape(-1), cms[1])
+
+
+def _need_libhdf5():
+    from molecular_dynamics_neural_operator_amd import hdf5_io
+    if not hdf5_io.available():
+        pytest.skip("no HDF5 C library on this machine (MDNO_HDF5_LIB, ldconfig, /opt/conda/lib)")
+    return hdf5_io
+
+
+def test_hdf5_file_written_by_h5py_read_without_h5py(tmp_path, monkeypatch):
+    """tests/golden/traj_h5py.h5 was written by REAL h5py 3.3.0 / HDF5 1.10.6 (oracle/gen_h5_fixture.py): variable-length
+    int16 contact maps (one of them empty), a chunked + shuffled + gzip-compressed float32 point cloud, float64 rmsd,
+    int32 residue types.  Read through the ctypes binding of libhdf5 (no h5py in this interpreter) it holds exactly the
+    arrays of its .npz twin, dtype for dtype, and `ContactMapDataset` yields the same samples from either — the
+    reference's `.h5` branch (dataset.py:110-127) and its directory mode (:134-141)."""
+    import shutil
+    from conftest import GOLDEN
+    hdf5_io = _need_libhdf5()
+    h5, twin = GOLDEN / "traj_h5py.h5", GOLDEN / "traj_h5py_twin.npz"
+    got = hdf5_io.read_datasets(str(h5), ["contact_map", "point_cloud", "rmsd", "amino_acids", "not_there"])
+    z = np.load(twin)
+    assert set(got) == {"contact_map", "point_cloud", "rmsd", "amino_acids"}
+    for n in ("point_cloud", "rmsd", "amino_acids"):
+        assert got[n].dtype == z[n].dtype and np.array_equal(got[n], z[n]), n
+    off = z["contact_map_offsets"]
+    assert got["contact_map"].dtype == object and got["contact_map"].shape == (len(off) - 1,)
+    for t in range(len(off) - 1):
+        assert got["contact_map"][t].dtype == np.int16
+        assert np.array_equal(got["contact_map"][t], z["contact_map"][off[t]:off[t + 1]]), t
+    assert got["contact_map"][6].size == 0
+    # the dataset class on the .h5 itself, with h5py made unimportable whether or not this machine has it
+    import builtins
+    real_import = builtins.__import__
+
+    def no_h5py(name, *a, **k):
+        if name == "h5py":
+            raise ImportError("h5py hidden by the test")
+        return real_import(name, *a, **k)
+
+    monkeypatch.setattr(builtins, "__import__", no_h5py)
+    a = ContactMapDataset(str(h5), window_size=3, horizon=1)
+    b = ContactMapDataset(str(twin), window_size=3, horizon=1)
+    assert len(a) == len(b) == 14 - 3 - 1 + 1
+    for i in range(len(a)):
+        for f in PairData._FIELDS:
+            assert torch.equal(getattr(a[i], f), getattr(b[i], f)), (i, f)
+    assert a[6].edge_index.shape == (2, 0) and a[6].edge_attr.shape == (0, 6)         # the frame without contacts
+    # directory mode: two copies -> the frames twice
+    d = tmp_path / "run"
+    d.mkdir()
+    shutil.copy(h5, d / "a.h5")
+    shutil.copy(h5, d / "b.h5")
+    both = ContactMapDataset(str(d), window_size=3, horizon=1)
+    assert len(both) == 28 - 3 - 1 + 1 and torch.equal(both[14].x_position, a[0].x_position)
+    # and the converter for machines with no HDF5 at all
+    hdf5_io.h5_to_npz(h5, tmp_path / "conv.npz")
+    c = ContactMapDataset(str(tmp_path / "conv.npz"), window_size=3, horizon=1)
+    assert all(torch.equal(getattr(c[4], f), getattr(a[4], f)) for f in PairData._FIELDS)
+
+
+def test_hdf5_writer_round_trip_and_errors(tmp_path):
+    """`write_trajectory_h5` (the reference's layout through the C library) -> `ContactMapDataset`, plain and
+    gzip-compressed; loud errors for a file that is not HDF5 and for a dtype the reader does not map."""
+    hdf5_io = _need_libhdf5()
+    fr = syn.ou_trajectory(syn.chain_frame(9, seed=1), 6, seed=1)
+    cms = [O.radius_graph_coo(f, 8.0).reshape(-1) for f in fr]
+    aa = syn.amino_acids(9, seed=1)
+    write_trajectory_npz(tmp_path / "t.npz", fr, cms, aa)
+    want = ContactMapDataset(str(tmp_path / "t.npz"), window_size=2, horizon=1)
+    for gz in (None, 5):
+        hdf5_io.write_trajectory_h5(tmp_path / "t.h5", fr, cms, aa, gzip=gz)
+        got = ContactMapDataset(str(tmp_path / "t.h5"), window_size=2, horizon=1)
+        assert len(got) == len(want)
+        for i in range(len(want)):
+            for f in PairData._FIELDS:
+                assert torch.equal(getattr(got[i], f), getattr(want[i], f)), (gz, i, f)
+    (tmp_path / "junk.h5").write_bytes(b"this is not an HDF5 file" * 10)
+    with pytest.raises(hdf5_io.Hdf5Error, match="cannot open"):
+        hdf5_io.read_datasets(str(tmp_path / "junk.h5"), ["contact_map"])
+    with pytest.raises(hdf5_io.Hdf5Error, match="not written"):
+        hdf5_io.write_datasets(str(tmp_path / "c.h5"), {"z": np.zeros(3, np.complex64)})

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDNO_ABI_VERSION 12
+#define MDNO_ABI_VERSION 13
 
 #define MDNO_OK            0
 #define MDNO_EINVAL       -1   /* bad argument (null pointer, non-positive size, unsupported dim) */
@@ -364,6 +364,11 @@ int mdno_nnconv_bwd_we(const float* x, const float* gs, const int32_t* src, cons
  *   mdno_nnconv_bf16w_fwd   mdno_nnconv_fwd at 64x64 with w_e bf16 [E,4096]
  *   mdno_nnconv_bwd_x_bf16w mdno_nnconv_bwd_x with w_e bf16
  *   mdno_nnconv_bwd_we_bf16 d_we bf16 [E,4096] = sum_l x_l[src p] (x) gs_l[dst p] (rounded once, at the end)
+ *   mdno_nnconv_bwd_we_bf16_colsum  the same d_we (layers <= 16: one MFMA k-step per 32 x 32 quadrant, both fp32 operands as three
+ *                           bf16 planes, six plane products) AND colsum [4096] fp32 = its column sums, the sums of the ROUNDED
+ *                           values as mdno_colsum_bf16 would take them from the stored tensor, without the second pass over it;
+ *                           workspace mdno_nnconv_bwd_we_bf16_colsum_workspace_bytes()
+ *   mdno_nnconv_bwd_we_colsum       the same with d_we and its column sums in fp32 (the fp32 training path: mdno_nnconv_bwd_we + mdno_colsum)
  *   mdno_relu_bwd_bf16      out = g * (y > 0): g fp32, y bf16, out bf16 (out_bf16) or fp32; n % 4 == 0
  *   mdno_colsum_bf16        out [n] fp32 = column sums of a bf16 [rows,n]; workspace mdno_colsum_bf16_workspace_bytes(n)
  * ---------------------------------------------------------------------------------------- */
@@ -386,6 +391,14 @@ int mdno_nnconv_bwd_x_bf16w(const float* gz, const float* gs, const int32_t* row
                             void* stream);
 int mdno_nnconv_bwd_we_bf16(const float* x, const float* gs, const int32_t* src, const int32_t* dst, int64_t E,
                             int layers, int64_t layer_stride, void* d_we, void* stream);
+size_t mdno_nnconv_bwd_we_colsum_workspace_bytes(void);
+int mdno_nnconv_bwd_we_colsum(const float* x, const float* gs, const int32_t* src, const int32_t* dst, int64_t E, int layers,
+                              int64_t layer_stride, float* d_we, float* colsum, void* workspace, size_t workspace_bytes,
+                              void* stream);
+size_t mdno_nnconv_bwd_we_bf16_colsum_workspace_bytes(void);
+int mdno_nnconv_bwd_we_bf16_colsum(const float* x, const float* gs, const int32_t* src, const int32_t* dst, int64_t E,
+                                   int layers, int64_t layer_stride, void* d_we, float* colsum, void* workspace,
+                                   size_t workspace_bytes, void* stream);
 int mdno_relu_bwd_bf16(const float* g, const void* y, int64_t rows, int n, int out_bf16, void* out, void* stream);
 size_t mdno_colsum_bf16_workspace_bytes(int n);
 int mdno_colsum_bf16(const void* a, int64_t rows, int n, float* out, void* workspace, size_t workspace_bytes,

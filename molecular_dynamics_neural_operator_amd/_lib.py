@@ -14,7 +14,7 @@ LIB_PATH = Path(os.environ.get("MDNO_LIB", _HERE / "libmdno.so"))
 OK, EINVAL, ELAUNCH, EWORKSPACE, EUNSUPPORTED = 0, -1, -2, -3, -4
 AGGR = {"add": 0, "mean": 1, "max": 2}      # "max": mdno_nnconv_fwd only (inference)
 STATUS_EDGE_OVERFLOW, STATUS_BAD_AMINOACID = 1, 2
-ABI_VERSION = 12
+ABI_VERSION = 13
 GEMM_MODES = {"split_bf16": 0, "f32": 1, "split_f16": 2}
 CONV_MODES = {"materialized": 0, "factored": 1, "auto": 2}
 STATUS_ASYMMETRIC_GRAPH = 4
@@ -106,6 +106,10 @@ SIGNATURES = {
     "mdno_nnconv_bf16w_fwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P]),
     "mdno_nnconv_bwd_x_bf16w": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
     "mdno_nnconv_bwd_we_bf16": (_I, [_P, _P, _P, _P, _L, _I, _L, _P, _P]),
+    "mdno_nnconv_bwd_we_bf16_colsum_workspace_bytes": (_SZ, []),
+    "mdno_nnconv_bwd_we_colsum_workspace_bytes": (_SZ, []),
+    "mdno_nnconv_bwd_we_colsum": (_I, [_P, _P, _P, _P, _L, _I, _L, _P, _P, _P, _SZ, _P]),
+    "mdno_nnconv_bwd_we_bf16_colsum": (_I, [_P, _P, _P, _P, _L, _I, _L, _P, _P, _P, _SZ, _P]),
     "mdno_relu_bwd_bf16": (_I, [_P, _P, _L, _I, _I, _P, _P]),
     "mdno_colsum_bf16_workspace_bytes": (_SZ, [_I]),
     "mdno_colsum_bf16": (_I, [_P, _L, _I, _P, _P, _SZ, _P]),

@@ -586,6 +586,149 @@ __global__ __launch_bounds__(256) void nnconv_bwd_we_bf16_kernel(const float* __
     for (int r = 0; r < 16; ++r) *reinterpret_cast<uint2*>(out + r * 64) = pack4_bf16(acc[r].x, acc[r].y, acc[r].z, acc[r].w);
 }
 
+// ---------------------------------------------------------------- d W_e as bf16 + its column sums, on the matrix pipe
+// dW_e[p] = sum_l gs_l[dst p] (x) x_l[src p] is a [64 x L] . [L x 64] product per edge: with L <= 16 ONE k-step of
+// v_mfma_f32_32x32x16_bf16 per 32 x 32 quadrant.  The kernel above spends 768 FMAs per lane and edge on it (115 us at
+// cfg4, twice what writing the 358 MB takes); here both fp32 operands are split exactly into three bf16 planes in
+// registers and the six leading plane products accumulated in fp32 (fp32 accuracy, as everywhere in this library):
+// 24 MFMAs per edge.  One wave per edge at a time, edges p = wave, wave + W, ..: the next edge's 32 operand words are
+// fetched before this edge's MFMAs.
+//   A = G (rows o): lane (l31, h) holds gs_l[dst][32 ob + l31], l = 8 h .. 8 h + 7;  B = X (columns i): x_l[src][32 ib + l31]
+//   acc[ob][ib][e] = dW_e[i = 32 ib + l31][o = 32 ob + (e & 3) + 8 (e >> 2) + 4 h]: four consecutive o -> one 8-B LDS write
+// and the rounded tile goes out through LDS row by row: 16 B per lane, 1 KiB contiguous per store instruction.
+// The column sums (the last layer's bias gradient: sum over edges of the ROUNDED dW_e, what mdno_colsum_bf16 computes
+// from the stored tensor in a second pass over its 358 MB) are taken on the way: every lane owns 64 fixed (i, o)
+// positions of the tile, adds each edge's rounded values in edge order, the four waves of a workgroup are added in wave
+// order through LDS and the workgroups by reduce_slices: fixed association, no atomics.
+// BF16 = false: the fp32 training path's dW_e (train.hip's nnconv_bwd_we_kernel: 180 us + a 96 us column-sum pass over
+// 716 MB at cfg4) through the same loop, the tile staged as fp32 and its column sums taken from the stored values.
+constexpr int WE_WGS = 512;                              // workgroups of the launch (whatever E: the association of the sums is fixed)
+template <bool BF16> struct WeTile {
+    static constexpr int ROW = BF16 ? 136 : 272;         // LDS bytes per row of 64 outputs (+8 / +16: the 32 rows a write touches spread over the banks)
+    static constexpr int BYTES = 64 * ROW;               // 8,704 / 17,408 B per wave
+};
+
+template <bool BF16>
+__global__ __launch_bounds__(256, 2) void nnconv_bwd_we_mfma_kernel(const float* __restrict__ x, const float* __restrict__ gs,
+                                                                   const int* __restrict__ src, const int* __restrict__ dst,
+                                                                   long long E, int L, long long layer_stride,
+                                                                   void* __restrict__ dwe_, float* __restrict__ part) {
+    constexpr int ROW = WeTile<BF16>::ROW, TILE = WeTile<BF16>::BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * TILE > 4096 * 4 ? 4 * TILE : 4096 * 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    // read-back role: 16 B per lane; bf16: 8 rows x 128 B per pass (8 passes), fp32: 4 rows x 256 B (16 passes)
+    constexpr int PASSES = BF16 ? 8 : 16, RPP = 64 / PASSES, PER = BF16 ? 8 : 4;
+    const int rr = BF16 ? lane >> 3 : lane >> 4, rc = BF16 ? lane & 7 : lane & 15;
+    unsigned char* tile = lds + wave * TILE;
+    const long long W = (long long)gridDim.x * 4;
+    float cs[64];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) cs[j] = 0.f;
+    float ga[2][8], xb[2][8];                            // this edge's operand words; next edge's while the MFMAs run
+    // (every load unconditional — a layer past L re-reads layer 0 and is zeroed by a select — so that the loop body is
+    // straight-line code: with `on ? load : 0` the compiler built a branch around each of the 32 loads)
+    auto fetch = [&](long long p, float (&g_)[2][8], float (&x_)[2][8]) {
+        const float* gq = gs + (size_t)dst[p] * 64 + l31;
+        const float* xq = x + (size_t)src[p] * 64 + l31;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int l = 8 * h + j;
+            const size_t off = (size_t)(l < L ? l : 0) * layer_stride;
+            g_[0][j] = gq[off];
+            g_[1][j] = gq[off + 32];
+            x_[0][j] = xq[off];
+            x_[1][j] = xq[off + 32];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (8 * h + j >= L) { g_[0][j] = 0.f; g_[1][j] = 0.f; x_[0][j] = 0.f; x_[1][j] = 0.f; }
+    };
+    auto split3 = [](const float (&v)[8], bf16x8 (&pl)[3]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const __bf16 hi = (__bf16)v[j];
+            const float r1 = v[j] - (float)hi;
+            const __bf16 mid = (__bf16)r1;
+            const __bf16 lo = (__bf16)(r1 - (float)mid);
+            pl[0][j] = hi; pl[1][j] = mid; pl[2][j] = lo;
+        }
+    };
+    long long p = (long long)blockIdx.x * 4 + wave;
+    if (p < E) fetch(p, ga, xb);
+    for (; p < E; p += W) {
+        bf16x8 a[2][3], b[2][3];
+        split3(ga[0], a[0]); split3(ga[1], a[1]);
+        split3(xb[0], b[0]); split3(xb[1], b[1]);
+        if (p + W < E) fetch(p + W, ga, xb);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib) {
+                const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                acc[ob][ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ob][1], b[ib][1], zero, 0, 0, 0);      // (C = inline 0)
+                acc[ob][ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ob][2], b[ib][0], acc[ob][ib], 0, 0, 0);
+                acc[ob][ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ob][0], b[ib][2], acc[ob][ib], 0, 0, 0);
+                acc[ob][ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ob][1], b[ib][0], acc[ob][ib], 0, 0, 0);
+                acc[ob][ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ob][0], b[ib][1], acc[ob][ib], 0, 0, 0);
+                acc[ob][ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ob][0], b[ib][0], acc[ob][ib], 0, 0, 0);
+            }
+        // tile -> LDS [i][o] (a wave's own tile: no workgroup barrier); four consecutive o per write
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x16& c = acc[ob][ib];
+                    unsigned char* wp = tile + (32 * ib + l31) * ROW + (32 * ob + 8 * g + 4 * h) * (BF16 ? 2 : 4);
+                    if (BF16) *reinterpret_cast<uint2*>(wp) = pack4_bf16(c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]);
+                    else *reinterpret_cast<float4*>(wp) = make_float4(c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]);
+                }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const unsigned char* rp = tile + (RPP * ps + rr) * ROW + rc * 16;
+            const size_t at = (size_t)p * 4096 + (RPP * ps + rr) * 64 + PER * rc;
+            if (BF16) {
+                const uint2 u0 = *reinterpret_cast<const uint2*>(rp), u1 = *reinterpret_cast<const uint2*>(rp + 8);
+                *reinterpret_cast<uint4*>(static_cast<__bf16*>(dwe_) + at) = make_uint4(u0.x, u0.y, u1.x, u1.y);
+                const unsigned w4[4] = {u0.x, u0.y, u1.x, u1.y};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    cs[8 * ps + 2 * j] += __builtin_bit_cast(float, w4[j] << 16);
+                    cs[8 * ps + 2 * j + 1] += __builtin_bit_cast(float, w4[j] & 0xffff0000u);
+                }
+            } else {
+                const float4 v = *reinterpret_cast<const float4*>(rp);
+                *reinterpret_cast<float4*>(static_cast<float*>(dwe_) + at) = v;
+                cs[4 * ps] += v.x; cs[4 * ps + 1] += v.y; cs[4 * ps + 2] += v.z; cs[4 * ps + 3] += v.w;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();      // the tile is rewritten by the next edge
+    }
+    // column sums: the four waves in wave order through LDS -> part[workgroup][4096]
+    float* red = reinterpret_cast<float*>(lds);
+    __syncthreads();
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int ps = 0; ps < PASSES; ++ps)
+#pragma unroll
+                for (int j = 0; j < PER; ++j) {
+                    const int idx = (RPP * ps + rr) * 64 + PER * rc + j;
+                    red[idx] = w == 0 ? cs[PER * ps + j] : red[idx] + cs[PER * ps + j];
+                }
+        }
+        __syncthreads();
+    }
+    float* po = part + (size_t)blockIdx.x * 4096;
+    for (int i = threadIdx.x; i < 1024; i += 256)
+        reinterpret_cast<float4*>(po)[i] = reinterpret_cast<const float4*>(red)[i];
+}
+
 // ---------------------------------------------------------------- elementwise / reductions on bf16
 // out = g * (y > 0): g fp32, y bf16 (the saved activation), out bf16 or fp32
 template <bool OUT_BF16>
@@ -782,6 +925,36 @@ extern "C" int mdno_nnconv_bwd_we_bf16(const float* x, const float* gs, const in
                        static_cast<hipStream_t>(stream), x, gs, src, dst, (long long)E, L, (long long)layer_stride,
                        static_cast<__bf16*>(d_we));
     return check_launch("nnconv_bwd_we_bf16_kernel");
+}
+
+extern "C" size_t mdno_nnconv_bwd_we_colsum_workspace_bytes(void) { return align_up((size_t)WE_WGS * 4096 * sizeof(float), 256); }
+extern "C" size_t mdno_nnconv_bwd_we_bf16_colsum_workspace_bytes(void) { return mdno_nnconv_bwd_we_colsum_workspace_bytes(); }
+
+template <bool BF16>
+static int bwd_we_colsum(const char* what, const float* x, const float* gs, const int32_t* src, const int32_t* dst, int64_t E, int L,
+                         int64_t layer_stride, void* d_we, float* colsum, void* workspace, size_t workspace_bytes, void* stream) {
+    MDNO_REQUIRE(x && gs && src && dst && d_we && colsum && workspace && E >= 0 && L > 0, MDNO_EINVAL, "%s: bad arguments", what);
+    MDNO_REQUIRE(L <= 16, MDNO_EUNSUPPORTED, "%s: %d conv applications (one MFMA k-step holds 16)", what, L);
+    MDNO_REQUIRE(workspace_bytes >= mdno_nnconv_bwd_we_colsum_workspace_bytes(), MDNO_EWORKSPACE, "%s: workspace too small", what);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(nnconv_bwd_we_mfma_kernel<BF16>, dim3(WE_WGS), dim3(256), 0, s, x, gs, src, dst, (long long)E, L,
+                       (long long)layer_stride, d_we, static_cast<float*>(workspace));
+    launch_reduce_slices(static_cast<const float*>(workspace), WE_WGS, 4096, colsum, 0, s);
+    return check_launch(what);
+}
+
+extern "C" int mdno_nnconv_bwd_we_bf16_colsum(const float* x, const float* gs, const int32_t* src, const int32_t* dst, int64_t E,
+                                              int L, int64_t layer_stride, void* d_we, float* colsum, void* workspace,
+                                              size_t workspace_bytes, void* stream) {
+    return bwd_we_colsum<true>("mdno_nnconv_bwd_we_bf16_colsum", x, gs, src, dst, E, L, layer_stride, d_we, colsum, workspace,
+                               workspace_bytes, stream);
+}
+
+extern "C" int mdno_nnconv_bwd_we_colsum(const float* x, const float* gs, const int32_t* src, const int32_t* dst, int64_t E, int L,
+                                         int64_t layer_stride, float* d_we, float* colsum, void* workspace, size_t workspace_bytes,
+                                         void* stream) {
+    return bwd_we_colsum<false>("mdno_nnconv_bwd_we_colsum", x, gs, src, dst, E, L, layer_stride, d_we, colsum, workspace,
+                                workspace_bytes, stream);
 }
 
 extern "C" int mdno_relu_bwd_bf16(const float* g, const void* y, int64_t rows, int n, int out_bf16, void* out,

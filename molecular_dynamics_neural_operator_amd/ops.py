@@ -406,15 +406,23 @@ def nnconv_bwd_root(x: torch.Tensor, gz: torch.Tensor) -> Tuple[torch.Tensor, to
     return d_root, d_bias
 
 
-def nnconv_bwd_we(x_layers: torch.Tensor, gs_layers: torch.Tensor, graph: CSRGraph) -> torch.Tensor:
-    """x_layers, gs_layers [L,R,64] -> d_we [E,4096]."""
+def nnconv_bwd_we(x_layers: torch.Tensor, gs_layers: torch.Tensor, graph: CSRGraph, with_colsum: bool = False):
+    """x_layers, gs_layers [L,R,64] -> d_we [E,4096]; `with_colsum`: also its column sums from the same pass (up to 16
+    conv applications: the matrix-pipe kernel; beyond, the FMA kernel and `ops.colsum`)."""
     lib = _lib.load()
     L, R, _ = x_layers.shape
     e = graph.edge_count()
     d_we = torch.empty((e, 4096), dtype=torch.float32, device=x_layers.device)
+    if with_colsum and L <= 16 and e > 0:
+        cs = torch.empty(4096, dtype=torch.float32, device=x_layers.device)
+        nb = lib.mdno_nnconv_bwd_we_colsum_workspace_bytes()
+        ws = _ws(nb, x_layers.device)
+        check(lib.mdno_nnconv_bwd_we_colsum(ptr(x_layers), ptr(gs_layers), ptr(graph.src), ptr(graph.dst), e, L, R * 64,
+                                            ptr(d_we), ptr(cs), ptr(ws), nb, stream_ptr(d_we.device)), "mdno_nnconv_bwd_we_colsum")
+        return d_we, cs
     check(lib.mdno_nnconv_bwd_we(ptr(x_layers), ptr(gs_layers), ptr(graph.src), ptr(graph.dst), e, L, R * 64, 64, 64,
                                  ptr(d_we), 0, stream_ptr(d_we.device)), "mdno_nnconv_bwd_we")
-    return d_we
+    return (d_we, colsum(d_we)) if with_colsum else d_we
 
 
 # ------------------------------------------------------------------------------------------------
@@ -517,14 +525,24 @@ def nnconv_bwd_x_bf16w(gz: torch.Tensor, gs: torch.Tensor, by_src: CSRGraph, w_e
     return g_prev
 
 
-def nnconv_bwd_we_bf16(x_layers: torch.Tensor, gs_layers: torch.Tensor, graph: CSRGraph) -> torch.Tensor:
+def nnconv_bwd_we_bf16(x_layers: torch.Tensor, gs_layers: torch.Tensor, graph: CSRGraph, with_colsum: bool = False):
+    """d_we bf16 [E,4096]; `with_colsum`: also its column sums (fp32 [4096], the sums of the rounded values) from the
+    same pass — up to 16 conv applications (depth <= 8); beyond that the plain kernel and `colsum_bf16`."""
     lib = _lib.load()
     L, R, _ = x_layers.shape
     e = graph.edge_count()
     d_we = torch.empty((e, 4096), dtype=torch.bfloat16, device=x_layers.device)
+    if with_colsum and L <= 16 and e > 0:
+        cs = torch.empty(4096, dtype=torch.float32, device=x_layers.device)
+        nb = lib.mdno_nnconv_bwd_we_bf16_colsum_workspace_bytes()
+        ws = _ws(nb, x_layers.device)
+        check(lib.mdno_nnconv_bwd_we_bf16_colsum(ptr(x_layers), ptr(gs_layers), ptr(graph.src), ptr(graph.dst), e, L, R * 64,
+                                                 ptr(d_we), ptr(cs), ptr(ws), nb, stream_ptr(d_we.device)),
+              "mdno_nnconv_bwd_we_bf16_colsum")
+        return d_we, cs
     check(lib.mdno_nnconv_bwd_we_bf16(ptr(x_layers), ptr(gs_layers), ptr(graph.src), ptr(graph.dst), e, L, R * 64,
                                       ptr(d_we), stream_ptr(d_we.device)), "mdno_nnconv_bwd_we_bf16")
-    return d_we
+    return (d_we, colsum_bf16(d_we)) if with_colsum else d_we
 
 
 def relu_bwd_bf16(g: torch.Tensor, y: torch.Tensor, out_bf16: bool = True) -> torch.Tensor:

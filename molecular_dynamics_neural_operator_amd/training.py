@@ -81,9 +81,8 @@ class KernelIntegralBlock(torch.autograd.Function):
         GZ, GS, g = ops.nnconv_chain_bwd(g_out, X, inv, by_src, w_e, root1, root2, depth)
         d_root1, d_bias1 = ops.nnconv_bwd_root(X[0:depth].reshape(-1, 64), GZ[0:depth].reshape(-1, 64))
         d_root2, d_bias2 = ops.nnconv_bwd_root(X[depth:L].reshape(-1, 64), GZ[depth:L].reshape(-1, 64))
-        d_we = ops.nnconv_bwd_we_bf16(X[0:L], GS, graph)                 # bf16 [E, 4096]
+        d_we, d_b2 = ops.nnconv_bwd_we_bf16(X[0:L], GS, graph, with_colsum=True)      # bf16 [E, 4096] and its column sums, one pass
         del GZ, GS
-        d_b2 = ops.colsum_bf16(d_we)
         d_w2 = ops.gemm_atb_bf16(d_we, h2)
         gz2 = ops.linear_bf16_relu_bwd(d_we, ops.transpose(w2), h2)        # bf16((h2 > 0) * (dW_e . W2))
         del d_we
@@ -106,10 +105,9 @@ class KernelIntegralBlock(torch.autograd.Function):
         GZ, GS, g = ops.nnconv_chain_bwd(g_out, X, inv, by_src, w_e, root1, root2, depth)
         d_root1, d_bias1 = ops.nnconv_bwd_root(X[0:depth].reshape(-1, 64), GZ[0:depth].reshape(-1, 64))
         d_root2, d_bias2 = ops.nnconv_bwd_root(X[depth:L].reshape(-1, 64), GZ[depth:L].reshape(-1, 64))
-        d_we = ops.nnconv_bwd_we(X[0:L], GS, graph)
+        d_we, d_b2 = ops.nnconv_bwd_we(X[0:L], GS, graph, with_colsum=True)        # and its column sums, one pass
         del GZ, GS
         # edge-MLP backward
-        d_b2 = ops.colsum(d_we)
         d_w2 = ops.gemm_atb(d_we, h2, gemm_mode=gemm_mode)
         gz2 = ops.relu_bwd(ops.linear(d_we, ops.transpose(w2), None, gemm_mode=gemm_mode), h2)
         del d_we

@@ -146,6 +146,43 @@ def test_colsum_atb_bf16_one_pass(dev):
         assert torch.equal(cs, cs2) and torch.equal(atb, atb2)
 
 
+@pytest.mark.parametrize("bf16", [True, False])
+@pytest.mark.parametrize("E,L", [(1, 1), (7, 12), (4001, 12), (2500, 16), (300, 5), (900, 18)])
+def test_bwd_we_on_the_matrix_pipe_with_column_sums(dev, E, L, bf16):
+    """mdno_nnconv_bwd_we[_bf16]_colsum: dW_e[p] = sum_l x_l[src p] (x) gs_l[dst p] as one MFMA k-step per quadrant (three
+    bf16 planes per fp32 operand, six products) and, from the same pass, the column sums of the stored tensor.
+    Against fp64 (fp32: accumulation error only; bf16: within half a bf16 ulp of it), against the FMA kernel (bf16: the
+    same value except where the exact sum sits on a rounding boundary — a handful of one-ulp flips), the sums against a
+    fp64 sum of the tensor the kernel itself stored, twice bitwise the same.  L > 16 takes the FMA kernel + colsum."""
+    from molecular_dynamics_neural_operator_amd import ops
+    gen = torch.Generator().manual_seed(100 + E + L)
+    R = 77
+    ei = torch.randint(0, R, (2, E), generator=gen)
+    g = ops.coo_to_csr(ei.to(dev), R)
+    X = torch.randn(L, R, 64, generator=gen).to(dev)
+    GS = (torch.randn(L, R, 64, generator=gen) * 0.3).to(dev)
+    op = ops.nnconv_bwd_we_bf16 if bf16 else ops.nnconv_bwd_we
+    d_we, cs = op(X, GS, g, with_colsum=True)
+    old = op(X, GS, g)
+    src, dst = g.src[:E].long(), g.dst[:E].long()
+    want = torch.einsum("lei,leo->eio", X.double()[:, src], GS.double()[:, dst]).reshape(E, 4096)
+    got = d_we.double()
+    mag = torch.einsum("lei,leo->eio", X.double()[:, src].abs(), GS.double()[:, dst].abs()).reshape(E, 4096)
+    ulp = 2.0 ** -8 if bf16 else 0.0
+    assert bool(((got - want).abs() <= want.abs() * ulp + mag * 2.0 ** -20).all())
+    if bf16:
+        diff = d_we != old
+        assert float(diff.float().mean()) < 2e-3
+        if bool(diff.any()):       # one bf16 ulp apart where they differ (more only where the sum cancels: fp32 accumulation)
+            a, b = d_we[diff].double(), old[diff].double()
+            assert bool(((a - b).abs() <= torch.maximum(a.abs(), b.abs()) * 2.0 ** -7 + mag[diff] * 2.0 ** -20).all())
+    else:
+        assert bool(((got - old.double()).abs() <= mag * 2.0 ** -20).all())
+    assert float((cs.double() - got.sum(0)).abs().max()) <= 1e-5 * float(got.abs().sum(0).max())
+    d2, cs2 = op(X, GS, g, with_colsum=True)
+    assert torch.equal(d2, d_we) and torch.equal(cs2, cs)
+
+
 def _as_dicts(samples):
     return [dict(x_position=s.x_position.cpu(), x_aminoacid=s.x_aminoacid.cpu(), y=s.y.cpu(),
                  edge_index=s.edge_index.cpu(), edge_attr=s.edge_attr.cpu()) for s in samples]

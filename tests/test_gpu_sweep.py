@@ -133,3 +133,39 @@ def test_eval_forward_sweep_on_dataset_samples(c, tmp_path):
             scale = max(float(want.abs().max()), 1e-30)
             torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-4 * scale, msg=lambda m: f"sample {b} {what}: {m}")
             assert float((got - want).norm() / want.norm().clamp_min(1e-300)) <= 1e-5, (b, what)
+
+
+def test_rollout_two_large_members_through_the_cell_list():
+    """Two members of 9,000 atoms (>= 8,192: the step's radius graph goes through the cell list, csrc/graph.hip), cutoff
+    4 A, k = 128, depth 1, two free-running steps: member 1 against the oracle's host loop (scipy's dense distance matrix),
+    edge counts bit-exact, and each member bitwise what it is alone."""
+    from molecular_dynamics_neural_operator_amd import _lib, synthetic as syn
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN
+    from molecular_dynamics_neural_operator_amd.rollout import RolloutEngine
+    from molecular_dynamics_neural_operator_amd.weights import near_identity_state_dict
+    from oracle import graph_kernel_oracle as O
+    _lib.load()
+    dev = torch.device("cuda:0")
+    N, M, W, steps, cutoff = 9000, 2, 3, 2, 4.0
+    sd = near_identity_state_dict(64, 128, seed=12, kernel_gain=2e-2, feature_gain=0.2, kernel_to_coords=1.0)
+    model = KernelNN(64, 128, 1, 6, 7, 3, 20, 4)
+    model.load_state_dict(sd)
+    model.eval().to(dev)
+    base = syn.jitter_window(syn.box_frame(N, seed=12), W, seed=12)
+    wins = syn.ensemble_windows(base, M, sigma=0.2, seed0=12)
+    aa = torch.from_numpy(syn.amino_acids(N, seed=12))
+    tm = torch.from_numpy(np.ascontiguousarray(wins.transpose(1, 0, 2, 3)))
+    eng = RolloutEngine(model, M, N, W, cutoff, max_steps=steps, device=dev)
+    traj = eng.run(tm, aa, steps).clone()
+    edges = eng.edges_per_step.cpu().tolist()[:steps]
+    s0 = O.construct_pairdata(wins[1], aa, cutoff)
+    fc = O.recursive_propagation(sd, 1, s0, steps, cutoff, hoist=True)
+    ref = np.stack([f["x_position"][-1].numpy() for f in fc])
+    np.testing.assert_allclose(traj[:, 1].cpu().numpy(), ref, rtol=1e-4, atol=1e-4 * float(np.abs(ref).max()))
+    solo_edges = []
+    for m in range(M):
+        e1 = RolloutEngine(model, 1, N, W, cutoff, max_steps=steps, device=dev)
+        assert torch.equal(e1.run(tm[:, m:m + 1].contiguous(), aa, steps)[:, 0], traj[:, m]), m
+        solo_edges.append(e1.edges_per_step.cpu().tolist()[:steps])
+    assert solo_edges[1] == [s0["edge_index"].shape[1]] + [f["edge_index"].shape[1] for f in fc[:-1]]
+    assert edges == [a + b for a, b in zip(*solo_edges)]

@@ -307,7 +307,8 @@ int mdno_rollout_plan_timer_detach(mdno_rollout_plan* plan);
  *   mdno_nnconv_bwd_root  d_root (+)= sum_rows x^T gz, d_bias (+)= colsum(gz); x, gz [rows,64] (layers stacked)
  *   mdno_nnconv_bwd_we    d_we[p] (+)= sum_l x_l[src p] (x) gs_l[dst p]; x, gs [layers, R, 64] (layer_stride floats)
  * Workspaces: mdno_reduce_workspace_bytes(n1, n2) for gemm_atb / colsum (n2 = 1),
- * mdno_nnconv_bwd_root_workspace_bytes(rows).
+ * mdno_nnconv_bwd_root_workspace_bytes(rows).  mdno_nnconv_bwd_root_pair: conv1's and conv2's gradients from ONE launch over
+ * x, gz [2 * rows_each, 64] (first half conv1's stacked layers, second half conv2's): bitwise the two single calls.
  * ---------------------------------------------------------------------------------------- */
 int mdno_linear_fwd(const float* a, const float* w, const float* bias, int64_t rows, int n, int k, int relu,
                     float* c, void* stream);
@@ -336,6 +337,9 @@ int mdno_nnconv_bwd_x(const float* gz, const float* gs, const int32_t* row_ptr_s
                       const int32_t* dst_s, int num_rows, const float* w_e, const float* root,
                       int Cin, int Cout, float* g_prev, void* stream);
 size_t mdno_nnconv_bwd_root_workspace_bytes(int64_t rows);
+size_t mdno_nnconv_bwd_root_pair_workspace_bytes(int64_t rows_each);
+int mdno_nnconv_bwd_root_pair(const float* x, const float* gz, int64_t rows_each, float* d_root1, float* d_bias1,
+                              float* d_root2, float* d_bias2, void* workspace, size_t workspace_bytes, void* stream);
 int mdno_nnconv_bwd_root(const float* x, const float* gz, int64_t rows, int Cin, int Cout,
                          float* d_root, float* d_bias, int accumulate,
                          void* workspace, size_t workspace_bytes, void* stream);

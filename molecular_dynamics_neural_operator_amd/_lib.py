@@ -94,6 +94,8 @@ SIGNATURES = {
     "mdno_nnconv_bwd_x": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P, _P]),
     "mdno_nnconv_bwd_root_workspace_bytes": (_SZ, [_L]),
     "mdno_nnconv_bwd_root": (_I, [_P, _P, _L, _I, _I, _P, _P, _I, _P, _SZ, _P]),
+    "mdno_nnconv_bwd_root_pair_workspace_bytes": (_SZ, [_L]),
+    "mdno_nnconv_bwd_root_pair": (_I, [_P, _P, _L, _P, _P, _P, _P, _P, _SZ, _P]),
     "mdno_nnconv_bwd_we": (_I, [_P, _P, _P, _P, _L, _I, _L, _I, _I, _P, _I, _P]),
     "mdno_cast_bf16": (_I, [_P, _L, _P, _P]),
     "mdno_linear_smallk_bf16_fwd": (_I, [_P, _P, _P, _L, _I, _I, _I, _P, _P]),

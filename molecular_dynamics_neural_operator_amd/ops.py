@@ -406,6 +406,22 @@ def nnconv_bwd_root(x: torch.Tensor, gz: torch.Tensor) -> Tuple[torch.Tensor, to
     return d_root, d_bias
 
 
+def nnconv_bwd_root_pair(x_layers: torch.Tensor, gz_layers: torch.Tensor):
+    """x_layers, gz_layers [2*depth, R, 64] (conv1's applications first, then conv2's) ->
+    (d_root1, d_bias1, d_root2, d_bias2): both convs' root / bias gradients from one launch, bitwise what two
+    `nnconv_bwd_root` calls on the halves return."""
+    lib = _lib.load()
+    x, gz = f32(x_layers), f32(gz_layers)
+    L, R, _ = x.shape
+    assert L % 2 == 0 and gz.shape == x.shape
+    rows_each = (L // 2) * R
+    outs = [torch.empty(sh, dtype=torch.float32, device=x.device) for sh in ((64, 64), (64,), (64, 64), (64,))]
+    ws = _ws(lib.mdno_nnconv_bwd_root_pair_workspace_bytes(rows_each), x.device)
+    check(lib.mdno_nnconv_bwd_root_pair(ptr(x), ptr(gz), rows_each, ptr(outs[0]), ptr(outs[1]), ptr(outs[2]), ptr(outs[3]),
+                                        ptr(ws), ws.numel(), stream_ptr(x.device)), "mdno_nnconv_bwd_root_pair")
+    return tuple(outs)
+
+
 def nnconv_bwd_we(x_layers: torch.Tensor, gs_layers: torch.Tensor, graph: CSRGraph, with_colsum: bool = False):
     """x_layers, gs_layers [L,R,64] -> d_we [E,4096]; `with_colsum`: also its column sums from the same pass (up to 16
     conv applications: the matrix-pipe kernel; beyond, the FMA kernel and `ops.colsum`)."""

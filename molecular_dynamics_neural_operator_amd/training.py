@@ -79,8 +79,7 @@ class KernelIntegralBlock(torch.autograd.Function):
         by_src = getattr(graph, "by_src", None) or ops.source_sorted(graph, R)
         inv = ops.inv_degree(graph, "mean")
         GZ, GS, g = ops.nnconv_chain_bwd(g_out, X, inv, by_src, w_e, root1, root2, depth)
-        d_root1, d_bias1 = ops.nnconv_bwd_root(X[0:depth].reshape(-1, 64), GZ[0:depth].reshape(-1, 64))
-        d_root2, d_bias2 = ops.nnconv_bwd_root(X[depth:L].reshape(-1, 64), GZ[depth:L].reshape(-1, 64))
+        d_root1, d_bias1, d_root2, d_bias2 = ops.nnconv_bwd_root_pair(X[0:L], GZ[0:L])       # both convs, one launch
         d_we, d_b2 = ops.nnconv_bwd_we_bf16(X[0:L], GS, graph, with_colsum=True)      # bf16 [E, 4096] and its column sums, one pass
         del GZ, GS
         d_w2 = ops.gemm_atb_bf16(d_we, h2)
@@ -103,8 +102,7 @@ class KernelIntegralBlock(torch.autograd.Function):
         by_src = getattr(graph, "by_src", None) or ops.source_sorted(graph, R)
         inv = ops.inv_degree(graph, "mean")
         GZ, GS, g = ops.nnconv_chain_bwd(g_out, X, inv, by_src, w_e, root1, root2, depth)
-        d_root1, d_bias1 = ops.nnconv_bwd_root(X[0:depth].reshape(-1, 64), GZ[0:depth].reshape(-1, 64))
-        d_root2, d_bias2 = ops.nnconv_bwd_root(X[depth:L].reshape(-1, 64), GZ[depth:L].reshape(-1, 64))
+        d_root1, d_bias1, d_root2, d_bias2 = ops.nnconv_bwd_root_pair(X[0:L], GZ[0:L])       # both convs, one launch
         d_we, d_b2 = ops.nnconv_bwd_we(X[0:L], GS, graph, with_colsum=True)        # and its column sums, one pass
         del GZ, GS
         # edge-MLP backward

@@ -214,13 +214,50 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PpArgs g) {
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(bv0), "+v"(bv1));      // the counted waits below must see DMA pieces only
 
     bf16x8 fa[2][4], fb[2][2];
-    auto tr_frag = [&](const unsigned char* p_) {       // two transposing reads: k rows +0..3 and +4..7
-        typedef short s16x4 __attribute__((ext_vector_type(4)));
-        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p_));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p_ + 4 * 512));
-        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    // The transposing reads (k rows +0..3, +4..7 of both k-steps of a stage: four per operand block) as inline assembly:
+    // behind an LDS-DMA the compiler puts a full vmcnt(0) in front of every ds_read_tr builtin (it cannot tell what the DMA
+    // wrote from what the read reads), i.e. in front of each load phase — after the counted wait and the barrier that
+    // already ordered them (EXPERIMENTS.md §0.2a).  The results are complete after the lgkmcnt(0) that ends the load phase.
+    const unsigned lds_addr = (unsigned)(size_t)(lds_u8*)lds;
+    typedef int i32x2 __attribute__((ext_vector_type(2)));
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    // (the waits sit inside the blocks: what the compiler does with the result registers after a block — the moves that
+    // pair two 64-bit results into one operand — must find them complete)
+#define MDNO_TR4(O, A) "ds_read_b64_tr_b16 %" #O ", %" #A "\n ds_read_b64_tr_b16 %" #O "+1, %" #A " offset:2048\n"
+    auto tr_frags_a = [&](unsigned a0, unsigned a1, unsigned a2, unsigned a3, bf16x8 (&f)[2][4]) {
+        i32x2 r[16];
+        asm volatile("ds_read_b64_tr_b16 %0, %16\n ds_read_b64_tr_b16 %1, %16 offset:2048\n"
+                     "ds_read_b64_tr_b16 %2, %16 offset:8192\n ds_read_b64_tr_b16 %3, %16 offset:10240\n"
+                     "ds_read_b64_tr_b16 %4, %17\n ds_read_b64_tr_b16 %5, %17 offset:2048\n"
+                     "ds_read_b64_tr_b16 %6, %17 offset:8192\n ds_read_b64_tr_b16 %7, %17 offset:10240\n"
+                     "ds_read_b64_tr_b16 %8, %18\n ds_read_b64_tr_b16 %9, %18 offset:2048\n"
+                     "ds_read_b64_tr_b16 %10, %18 offset:8192\n ds_read_b64_tr_b16 %11, %18 offset:10240\n"
+                     "ds_read_b64_tr_b16 %12, %19\n ds_read_b64_tr_b16 %13, %19 offset:2048\n"
+                     "ds_read_b64_tr_b16 %14, %19 offset:8192\n ds_read_b64_tr_b16 %15, %19 offset:10240\n s_waitcnt lgkmcnt(0)"
+                     : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]),
+                       "=&v"(r[8]), "=&v"(r[9]), "=&v"(r[10]), "=&v"(r[11]), "=&v"(r[12]), "=&v"(r[13]), "=&v"(r[14]), "=&v"(r[15])
+                     : "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "memory");
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[0][i] = __builtin_bit_cast(bf16x8, (i32x4){r[4 * i].x, r[4 * i].y, r[4 * i + 1].x, r[4 * i + 1].y});
+            f[1][i] = __builtin_bit_cast(bf16x8, (i32x4){r[4 * i + 2].x, r[4 * i + 2].y, r[4 * i + 3].x, r[4 * i + 3].y});
+        }
     };
+    auto tr_frags_b = [&](unsigned b0, unsigned b1, bf16x8 (&f)[2][2]) {
+        i32x2 r[8];
+        asm volatile("ds_read_b64_tr_b16 %0, %8\n ds_read_b64_tr_b16 %1, %8 offset:2048\n"
+                     "ds_read_b64_tr_b16 %2, %8 offset:8192\n ds_read_b64_tr_b16 %3, %8 offset:10240\n"
+                     "ds_read_b64_tr_b16 %4, %9\n ds_read_b64_tr_b16 %5, %9 offset:2048\n"
+                     "ds_read_b64_tr_b16 %6, %9 offset:8192\n ds_read_b64_tr_b16 %7, %9 offset:10240\n s_waitcnt lgkmcnt(0)"
+                     : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+                     : "v"(b0), "v"(b1) : "memory");
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f[0][j] = __builtin_bit_cast(bf16x8, (i32x4){r[4 * j].x, r[4 * j].y, r[4 * j + 1].x, r[4 * j + 1].y});
+            f[1][j] = __builtin_bit_cast(bf16x8, (i32x4){r[4 * j + 2].x, r[4 * j + 2].y, r[4 * j + 3].x, r[4 * j + 3].y});
+        }
+    };
+#undef MDNO_TR4
 #define MDNO_PP_LOAD(ST)                                                                          \
     {                                                                                             \
         const unsigned char* sb_ = lds + ((ST) % PP_RING) * PP_STAGE_BYTES;                       \
@@ -234,14 +271,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PpArgs g) {
                 fb[1][j] = *reinterpret_cast<const bf16x8*>(sb_ + b_off[j] + c1);                 \
             }                                                                                     \
         } else {                                                                                  \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                       \
-                fa[0][i] = tr_frag(sb_ + a_off[i]);                                               \
-                fa[1][i] = tr_frag(sb_ + a_off[i] + 16 * 512);                                    \
-            }                                                                                     \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                       \
-                fb[0][j] = tr_frag(sb_ + b_off[j]);                                               \
-                fb[1][j] = tr_frag(sb_ + b_off[j] + 16 * 512);                                    \
-            }                                                                                     \
+            const unsigned sa_ = lds_addr + ((ST) % PP_RING) * PP_STAGE_BYTES;                    \
+            tr_frags_a(sa_ + a_off[0], sa_ + a_off[1], sa_ + a_off[2], sa_ + a_off[3], fa);       \
+            tr_frags_b(sa_ + b_off[0], sa_ + b_off[1], fb);                                       \
         }                                                                                         \
     }
 #define MDNO_PP_MMA()                                                                             \

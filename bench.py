@@ -81,6 +81,10 @@ def parse(argv=None):
     ap.add_argument("--window", type=int, default=10)
     ap.add_argument("--threshold", type=float, default=8.0)
     ap.add_argument("--no-graph", action="store_true", help="plain launches instead of hipGraph replay")
+    ap.add_argument("--member-groups", type=int, default=0,
+                    help="a rank's members as this many independent engines on their own streams, stepped together "
+                         "(rollout.GroupedRolloutEngine; frames bitwise unchanged); 0 = 2 groups from 2 members of >= 256 "
+                         "atoms on (4 from 32 members on), else 1")
     ap.add_argument("--gemm-mode", choices=["split_bf16", "split_f16", "f32"], default="split_f16",
                     help="edge-MLP GEMMs: exact 3-way bf16 split (6 products, fp32 accumulate); split_f16 = the same "
                          "with the hidden layer of the factored path on 2 fp16 planes (3 products, device-side "
@@ -666,8 +670,8 @@ def worker(a):
 
     from molecular_dynamics_neural_operator_amd import synthetic as syn
     from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN, KernelNNNotebook
-    from molecular_dynamics_neural_operator_amd.rollout import (RolloutEngine, default_edge_cap, gather_trajectories,
-                                                                 shard_members)
+    from molecular_dynamics_neural_operator_amd.rollout import (GroupedRolloutEngine, RolloutEngine, default_edge_cap,
+                                                                 gather_trajectories, shard_members)
     from molecular_dynamics_neural_operator_amd.weights import near_identity_state_dict
 
     N, W = a.atoms, a.window
@@ -707,12 +711,30 @@ def worker(a):
     aa = torch.from_numpy(syn.amino_acids(N, seed=1))
     max_steps = a.warmup + a.steps + (0 if a.skip_roofline else a.steps)
     cap = default_edge_cap(M, N, a.threshold)
-    eng = RolloutEngine(model, M, N, W, a.threshold, max_steps=max_steps, edge_cap=cap, device=dev,
-                        use_graph=not a.no_graph)
+    def groups_for(members):
+        return a.member_groups if a.member_groups > 0 else ((4 if members >= 32 else 2) if members >= 2 and N >= 256 else 1)
+
+    def make_engine(members, steps_cap, edge_cap):
+        """one engine, or the members as groups on concurrent streams (same frames, another schedule: EXPERIMENTS §0.2b)"""
+        g = min(groups_for(members), members)
+        if g > 1:
+            return GroupedRolloutEngine(model, members, N, W, a.threshold, max_steps=steps_cap, edge_cap=edge_cap, device=dev,
+                                        use_graph=not a.no_graph, groups=g)
+        return RolloutEngine(model, members, N, W, a.threshold, max_steps=steps_cap, edge_cap=edge_cap, device=dev,
+                             use_graph=not a.no_graph)
+
+    def wait(engine):       # the engine's stream(s) drained, no status read
+        engine.wait() if isinstance(engine, GroupedRolloutEngine) else engine.stream.synchronize()
+
+    def ws_bytes(engine):
+        return engine.workspace_bytes if isinstance(engine, GroupedRolloutEngine) else engine.workspace.numel()
+
+    eng = make_engine(M, max_steps, cap)
+    n_groups = len(eng.engines) if isinstance(eng, GroupedRolloutEngine) else 1
     eng.reset(torch.from_numpy(wins), aa)
     mode = eng.conv_mode            # what "auto" resolved to at this edge capacity
     if rank == 0:
-        note(f"rank 0: {M} of {total_members} members, conv_mode {mode}, workspace {eng.workspace.numel() / 2**30:.1f} GiB")
+        note(f"rank 0: {M} of {total_members} members in {n_groups} group(s), conv_mode {mode}, workspace {ws_bytes(eng) / 2**30:.1f} GiB")
 
     # ---- warm-up (untimed): the step graph was captured in reset()
     eng.step(a.warmup)
@@ -730,7 +752,7 @@ def worker(a):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     eng.step(a.steps)
-    eng.stream.synchronize()
+    wait(eng)
     t_steps = time.perf_counter() - t0                                             # this rank's K steps alone
     produced = eng.traj[W + a.warmup:W + a.warmup + a.steps]                       # [K,M,N,3]
     if world > 1:
@@ -769,7 +791,9 @@ def worker(a):
     roofs = {}
     kernels = {}
     other_mode = None
-    R, C, KW = M * N, a.width, a.kernel_width
+    eng_r = eng.engines[0] if isinstance(eng, GroupedRolloutEngine) else eng      # the engine the kernel timers sit on
+    M_r = eng_r.M
+    R, C, KW = M_r * N, a.width, a.kernel_width
 
     def timed_leg(engine, first_step, members):
         engine.attach_timer(a.steps * (6 * a.depth * max(1, members) + 20))
@@ -787,7 +811,7 @@ def worker(a):
         return {"bound": "hbm", "kernel": "nnconv64_row_kernel", "conv_mode": "materialized", "achieved": alg / avg_s / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / avg_s / 1e9 / HBM_PEAK_GBS,
                 "frac_of_measured_copy_peak": alg / avg_s / 1e9 / HBM_COPY_GBS,
-                "traffic": profiled_traffic("nnconv64_row_kernel", N, M, "materialized", a.gemm_mode),
+                "traffic": profiled_traffic("nnconv64_row_kernel", N, M_r, "materialized", a.gemm_mode),
                 "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_s * 1e3, "edges_per_launch": e,
                 "rows_per_launch": R}
 
@@ -826,7 +850,7 @@ def worker(a):
         t_hbm, t_mfma = alg / (HBM_PEAK_GBS * 1e9), mfma_exec / (mfma_peak * 1e12)
         r = {"kernel": name, "conv_mode": "factored", "avg_launch_ms": avg_s * 1e3, "launches_per_application": launches_per_app,
              "algorithmic_bytes_per_launch": alg, "flops_per_launch": flops,
-             "traffic": profiled_traffic(name, N, M, "factored", a.gemm_mode),
+             "traffic": profiled_traffic(name, N, M_r, "factored", a.gemm_mode),
              "hbm_GBps": alg / avg_s / 1e9, "hbm_frac": alg / avg_s / 1e9 / HBM_PEAK_GBS,
              "frac_of_measured_copy_peak": alg / avg_s / 1e9 / HBM_COPY_GBS,
              "mfma_TFLOPs": mfma_exec / avg_s / 1e12, "mfma_frac": mfma_exec / avg_s / 1e12 / mfma_peak}
@@ -838,7 +862,7 @@ def worker(a):
 
     # rank 0 only: the other ranks idle at the final barrier through the measurement legs
     if not a.skip_roofline and rank == 0:
-        kernels, e2 = timed_leg(eng, a.warmup + a.steps, M)
+        kernels, e2 = timed_leg(eng_r, a.warmup + a.steps, M_r)
         if mode == "materialized":
             roofs["conv_materialized"] = conv_roofline(kernels, e2)
             roofs["edge_mlp_last_gemm"] = gemm_roofline(kernels, e2, "edge_mlp_gemm2", C * C)
@@ -894,21 +918,20 @@ def worker(a):
         es, ew = max(2, min(a.steps, 10)), 2
         we = member_windows(list(range(me)), perturbed=True)     # seeds 100..163
         note(f"ensemble leg: {me} members x {N} atoms")
-        enge = RolloutEngine(model, me, N, W, a.threshold, max_steps=ew + es, edge_cap=default_edge_cap(me, N, a.threshold),
-                             device=dev, use_graph=not a.no_graph)
+        enge = make_engine(me, ew + es, default_edge_cap(me, N, a.threshold))
         enge.reset(torch.from_numpy(we), aa)
         enge.step(ew)
         enge.synchronize()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         enge.step(es)
-        enge.stream.synchronize()
+        wait(enge)
         dte = time.perf_counter() - t0
         enge.synchronize()
         note(f"ensemble leg: {me} members on this GPU, {es * me / dte:.1f} frames/s")
         ensemble_leg = {"members": me, "steps": es, "warmup": ew, "frames_per_s": es * me / dte,
                         "ms_per_step": dte / es * 1e3, "ms_per_member_step": dte / es / me * 1e3,
-                        "conv_mode": enge.conv_mode,
+                        "conv_mode": enge.conv_mode, "member_groups": len(enge.engines) if isinstance(enge, GroupedRolloutEngine) else 1,
                         "note": "BASELINE configs[2] (64-member ensemble) on ONE GPU: the 1-GPU point of the "
                                 "strong-scaling series that `--gpus N` (N > 1) runs"}
         enge.close()
@@ -957,6 +980,7 @@ def worker(a):
                                    f"{total_members}-member ensemble (BASELINE {cfg}), member m on rank m mod {world}",
                        "atoms": N, "window": W, "width": a.width, "kernel_width": a.kernel_width, "depth": a.depth,
                        "members_this_rank": M, "members_per_gpu_max": m_max, "total_members": total_members,
+                       "member_groups_this_rank": n_groups, "members_in_the_profiled_group": M_r,
                        "mean_edges_per_member": e_mean / M,
                        "edges_first_last": [int(eps[0].item()), int(eps[-1].item())], "edge_cap": cap,
                        "parallelism": f"ensemble-sharded x{world}, no collective while stepping, one all-gather of "

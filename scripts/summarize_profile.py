@@ -96,8 +96,8 @@ for M in (1, 8):
         # the factored conv runs chunk by chunk over the sources: report per conv application
         launches_per_app = 1
         if kernel == "moment_kernel":
-            launches_per_app = -(-c["members_this_rank"] * c["atoms"] // 512)
-        traffic.append({"kernel": kernel, "atoms": c["atoms"], "members": c["members_this_rank"], "conv_mode": conv_mode,
+            launches_per_app = -(-c.get("members_in_the_profiled_group", c["members_this_rank"]) * c["atoms"] // 512)
+        traffic.append({"kernel": kernel, "atoms": c["atoms"], "members": c.get("members_in_the_profiled_group", c["members_this_rank"]), "conv_mode": conv_mode,
                         "gemm_mode": c["edge_mlp_gemm"], "hbm_bytes_per_launch": per_launch * launches_per_app,
                         "launches_per_application": launches_per_app, "source": f"profiles/{tag}_m{M}_pmc.json"})
 

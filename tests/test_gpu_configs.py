@@ -1002,3 +1002,31 @@ def test_ragged_member_sizes_free_run_vs_oracle(dev, O, conv_mode, gemm_mode):
                                        err_msg=f"N={N} member {m}")
             edges += np.array([s0["edge_index"].shape[1]] + [f["edge_index"].shape[1] for f in fc[:-1]])
         assert eng.edges_per_step.cpu().tolist() == edges.tolist(), (N, M)
+
+
+def test_member_groups_on_concurrent_streams_give_the_same_frames(dev):
+    """rollout.GroupedRolloutEngine: 5 members of 504 atoms as 2 groups (3 + 2) and as 5 groups of one, each group an
+    engine on its own stream with its own captured step, against ONE engine holding all five: frames bitwise equal
+    (members never interact), edge counts equal; per-member residue types; more groups than members are clamped."""
+    from molecular_dynamics_neural_operator_amd import synthetic as syn
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN
+    from molecular_dynamics_neural_operator_amd.rollout import GroupedRolloutEngine, RolloutEngine
+    from molecular_dynamics_neural_operator_amd.weights import near_identity_state_dict
+    N, W, M, steps = 504, 10, 5, 4
+    model = KernelNN(64, 256, 2, 6, 7, 3, 20, 4)
+    model.load_state_dict(near_identity_state_dict(64, 256, seed=2, kernel_gain=2e-2, feature_gain=0.2, kernel_to_coords=1.0))
+    model.eval().to(dev)
+    base = syn.jitter_window(syn.box_frame(N, seed=1), W, seed=1)
+    tm = torch.from_numpy(np.ascontiguousarray(syn.ensemble_windows(base, M, sigma=0.1, seed0=100).transpose(1, 0, 2, 3)))
+    aa = torch.cat([torch.from_numpy(syn.amino_acids(N, seed=m)) for m in range(M)])       # a different sequence per member
+    one = RolloutEngine(model, M, N, W, 8.0, max_steps=steps, device=dev)
+    want = one.run(tm, aa, steps).clone()
+    want_edges = one.edges_per_step.clone()
+    for g in (2, 5, 9):
+        eng = GroupedRolloutEngine(model, M, N, W, 8.0, max_steps=steps, device=dev, groups=g)
+        assert len(eng.engines) == min(g, M) and eng.bounds[0][0] == 0 and eng.bounds[-1][1] == M
+        got = eng.run(tm, aa, steps)
+        assert got.shape == want.shape and torch.equal(got, want), g
+        assert torch.equal(eng.edges_per_step, want_edges)
+        assert torch.equal(eng.traj[:W].cpu(), tm) and eng.steps_done == steps
+        eng.close()

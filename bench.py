@@ -874,9 +874,10 @@ def worker(a):
         if a.variant == "intree" and not a.single_mode and world == 1 and M <= 8:
             om = "materialized" if mode == "factored" else "factored"
             model.conv_mode = om
-            eng2 = RolloutEngine(model, M, N, W, a.threshold, max_steps=a.warmup + 2 * a.steps, edge_cap=cap, device=dev,
-                                 use_graph=not a.no_graph)
-            eng2.reset(torch.from_numpy(wins), aa)
+            # (one engine with the members of the profiled group: the rooflines below are per launch of that size)
+            eng2 = RolloutEngine(model, M_r, N, W, a.threshold, max_steps=a.warmup + 2 * a.steps,
+                                 edge_cap=default_edge_cap(M_r, N, a.threshold), device=dev, use_graph=not a.no_graph)
+            eng2.reset(torch.from_numpy(np.ascontiguousarray(wins[:, :M_r])), aa)
             eng2.step(a.warmup)
             eng2.synchronize()
             torch.cuda.synchronize()
@@ -884,9 +885,9 @@ def worker(a):
             eng2.step(a.steps)
             eng2.stream.synchronize()
             dt = time.perf_counter() - t0
-            k2, e3 = timed_leg(eng2, a.warmup + a.steps, M)
-            note(f"comparison leg ({om}): {a.steps * M / dt:.1f} frames/s")
-            other_mode = {"conv_mode": om, "frames_per_s_this_rank": a.steps * M / dt, "ms_per_step": dt / a.steps * 1e3,
+            k2, e3 = timed_leg(eng2, a.warmup + a.steps, M_r)
+            note(f"comparison leg ({om}, {M_r} member(s)): {a.steps * M_r / dt:.1f} frames/s")
+            other_mode = {"conv_mode": om, "members": M_r, "frames_per_s_this_rank": a.steps * M_r / dt, "ms_per_step": dt / a.steps * 1e3,
                           "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in k2.items()}}
             if om == "materialized":
                 roofs["conv_materialized"] = conv_roofline(k2, e3)

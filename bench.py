@@ -137,9 +137,22 @@ def visible_gpus() -> int:
     return n
 
 
-def launch_workers(a) -> int:
+RANK_GRACE_S = 30.0           # after the first rank fails, the others get this long before they are stopped
+INIT_TIMEOUT_S = 180          # rendezvous + every collective (the process group's timeout)
+
+
+def launch_workers(a, script=None, argv=None) -> int:
     """`python bench.py --gpus N` with no launcher around it: start N fresh worker processes (this
-    process has made no GPU call and makes none), relay rank 0's JSON line, return the worst exit code."""
+    process has made no GPU call and makes none), relay rank 0's JSON line, return the worst exit code.
+
+    Every rank is polled from the start while a thread drains rank 0's pipe: the first rank that exits
+    non-zero starts a RANK_GRACE_S clock, after which exactly the children started here are stopped
+    (SIGTERM, then SIGKILL) — a dead rank costs half a minute, not the rendezvous timeout.  A failed run
+    prints ONE JSON line {"error": ..., "rank_exit_codes": [...]} on stdout and returns non-zero.
+    (`script` / `argv`: what each rank runs — this file with this command line; tests substitute a stub.)"""
+    import threading
+    script = str(Path(__file__).resolve()) if script is None else str(script)
+    argv = sys.argv[1:] if argv is None else list(argv)
     n = a.gpus
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
         sk.bind(("127.0.0.1", 0))
@@ -153,29 +166,61 @@ def launch_workers(a) -> int:
               "(rehearsal only — RCCL needs one GPU per rank)", file=sys.stderr)
         env["MDNO_BENCH_BACKEND"] = "gloo"
     procs = []
+    try:
+        err_fd = sys.stderr.fileno()
+    except (OSError, ValueError, AttributeError):           # a replaced sys.stderr (test capture): the process's fd 2
+        err_fd = 2
     for r in range(n):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=e,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno(), text=(r == 0)))
-    out0, _ = procs[0].communicate()
-    deadline = None
-    codes = [procs[0].returncode] + [None] * (n - 1)
+        procs.append(subprocess.Popen([sys.executable, script] + argv, env=e,
+                                      stdout=subprocess.PIPE if r == 0 else err_fd, text=(r == 0)))
+    out0: list = []
+    drain = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    drain.start()
+    codes = [None] * n
+    deadline, first_bad, stopped = None, None, []
     while any(c is None for c in codes):
         for i, p in enumerate(procs):
             if codes[i] is None:
                 codes[i] = p.poll()
-        if any(c not in (None, 0) for c in codes) and deadline is None:
-            deadline = time.time() + 30.0                   # a rank failed: give the others 30 s, then stop them
+                if codes[i] not in (None, 0) and first_bad is None:
+                    first_bad = i
+                    deadline = time.time() + RANK_GRACE_S
+                    print(f"bench.py: rank {i} exited with code {codes[i]}; the other ranks get {RANK_GRACE_S:.0f} s",
+                          file=sys.stderr, flush=True)
         if deadline is not None and time.time() > deadline:
-            for i, p in enumerate(procs):
-                if codes[i] is None:
-                    p.kill()                                # exactly the children started above
-                    codes[i] = p.wait()
+            live = [i for i in range(n) if codes[i] is None]
+            for i in live:
+                procs[i].terminate()                        # exactly the children started above
+            t_kill = time.time() + 5.0
+            for i in live:
+                try:
+                    codes[i] = procs[i].wait(timeout=max(0.1, t_kill - time.time()))
+                except subprocess.TimeoutExpired:
+                    procs[i].kill()
+                    codes[i] = procs[i].wait()
+            stopped = live
         time.sleep(0.05)
-    sys.stdout.write(out0 or "")
-    sys.stdout.flush()
+    drain.join(timeout=10.0)
+    text = out0[0] if out0 else ""
     bad = [c for c in codes if c != 0]
-    return 0 if not bad else (max(bad) if max(bad) > 0 else 1)
+    if bad:
+        # rank 0's own line (if it got that far) is not relayed as a result: a failed run has no value
+        err = {"error": f"rank {first_bad} exited with code {codes[first_bad]}"
+                        + (f"; ranks {stopped} were stopped after {RANK_GRACE_S:.0f} s" if stopped else ""),
+               "rank_exit_codes": codes, "n_gpus": n}
+        for ln in (text or "").splitlines():               # rank 0's own error line, if it printed one
+            try:
+                d = json.loads(ln)
+            except ValueError:
+                continue
+            if isinstance(d, dict) and "error" in d:
+                err["rank0_error"] = d["error"]
+        print(json.dumps(err), flush=True)
+        return max(bad) if max(bad) > 0 else 1
+    sys.stdout.write(text or "")
+    sys.stdout.flush()
+    return 0
 
 
 # ----------------------------------------------------------------------------------------------- CPU leg
@@ -661,12 +706,18 @@ def worker(a):
     dev_index = local_rank % max(ndev, 1)     # rehearsal on a 1-GPU box: ranks share the card
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    if os.environ.get("MDNO_BENCH_FAIL_RANK") == str(rank):  # injected failure (tests: a rank that dies at start-up)
+        raise RuntimeError(f"MDNO_BENCH_FAIL_RANK={rank}: injected failure after set_device")
     backend = os.environ.get("MDNO_BENCH_BACKEND", "nccl")   # "gloo" only to rehearse N>1 on one GPU
     if world > 1:
+        from datetime import timedelta
+        # a rank that never arrives (or dies in a collective) fails the others after INIT_TIMEOUT_S, not after the
+        # backends' 10-30 minute defaults
+        tmo = timedelta(seconds=float(os.environ.get("MDNO_BENCH_INIT_TIMEOUT_S", INIT_TIMEOUT_S)))
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
 
     from molecular_dynamics_neural_operator_amd import synthetic as syn
     from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN, KernelNNNotebook
@@ -1014,7 +1065,21 @@ def main():
         # no launcher around us: become one.  Nothing above has touched the GPU (torch is imported, HIP
         # is not initialised), and this process never does.
         sys.exit(launch_workers(a))
-    worker(a)
+    try:
+        worker(a)
+    except BaseException as e:     # noqa: BLE001 — reported, then re-raised
+        if isinstance(e, SystemExit) and e.code in (0, None):
+            raise
+        rank = os.environ.get("RANK", "0")
+        print(f"bench.py: rank {rank} failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        if rank == "0":             # rank 0 owns stdout: the failure as one JSON line, then the non-zero exit
+            print(json.dumps({"error": f"{type(e).__name__}: {e}", "rank": 0, "n_gpus": a.gpus}), flush=True)
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            # no interpreter teardown: a process group whose peers are still waiting can block its destructor, and
+            # the launcher (ours or torch.distributed.run) is waiting for this exit code to stop the other ranks
+            sys.stderr.flush()
+            os._exit(e.code if isinstance(e, SystemExit) and isinstance(e.code, int) and e.code else 1)
+        raise
 
 
 if __name__ == "__main__":

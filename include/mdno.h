@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDNO_ABI_VERSION 13
+#define MDNO_ABI_VERSION 14
 
 #define MDNO_OK            0
 #define MDNO_EINVAL       -1   /* bad argument (null pointer, non-positive size, unsupported dim) */
@@ -89,6 +89,11 @@ extern "C" {
 
 int         mdno_abi_version(void);
 const char* mdno_last_error(void);
+/* Identity of the sources this binary was compiled from: the first 16 hex digits of sha256 over the bytes of
+ * the .hip, .h and .sh files of csrc/ and include/mdno.h in C-locale name order (csrc/build.sh computes it; the
+ * Python binding recomputes it from the tree at load time and refuses a library that was built from other
+ * sources — the built .so travels to the GPU box outside version control). */
+const char* mdno_build_id(void);
 
 /* ------------------------------------------------------------------------------------------
  * Parameters of KernelNN under the reference's state_dict key names (graph_kernel.py:246-275).

@@ -14,7 +14,7 @@ LIB_PATH = Path(os.environ.get("MDNO_LIB", _HERE / "libmdno.so"))
 OK, EINVAL, ELAUNCH, EWORKSPACE, EUNSUPPORTED = 0, -1, -2, -3, -4
 AGGR = {"add": 0, "mean": 1, "max": 2}      # "max": mdno_nnconv_fwd only (inference)
 STATUS_EDGE_OVERFLOW, STATUS_BAD_AMINOACID = 1, 2
-ABI_VERSION = 13
+ABI_VERSION = 14
 GEMM_MODES = {"split_bf16": 0, "f32": 1, "split_f16": 2}
 CONV_MODES = {"materialized": 0, "factored": 1, "auto": 2}
 STATUS_ASYMMETRIC_GRAPH = 4
@@ -51,6 +51,7 @@ _D = C.c_double
 SIGNATURES = {
     "mdno_abi_version": (_I, []),
     "mdno_last_error": (C.c_char_p, []),
+    "mdno_build_id": (C.c_char_p, []),
     "mdno_radius_graph_csr": (_I, [_P, _I, _I, _D, _P, _P, _P, _L, _P, _P, _P]),
     "mdno_radius_graph_workspace_bytes": (_SZ, [_I, _I]),
     "mdno_radius_graph_csr_ws": (_I, [_P, _I, _I, _D, _P, _P, _P, _L, _P, _P, _P, _SZ, _P]),
@@ -132,6 +133,22 @@ SIGNATURES = {
 _lib = None
 
 
+def source_build_id() -> str | None:
+    """The id csrc/build.sh compiles into the library, recomputed from the tree: sha256 over csrc/*.{hip,h,sh} and
+    include/mdno.h (bytes, C-locale name order), first 16 hex digits.  None where the sources are not beside the
+    package (a binary-only install)."""
+    import hashlib
+    csrc = _HERE / "csrc"
+    header = _HERE.parent / "include" / "mdno.h"
+    if not csrc.is_dir() or not header.exists():
+        return None
+    files = sorted([f for f in csrc.iterdir() if f.suffix in (".hip", ".h", ".sh")], key=lambda f: str(f).encode())
+    h = hashlib.sha256()
+    for f in files + [header]:
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def load() -> C.CDLL:
     """Load libmdno.so once; raise (never fall back) if it is absent or has the wrong ABI."""
     global _lib
@@ -149,6 +166,10 @@ def load() -> C.CDLL:
     ver = lib.mdno_abi_version()
     if ver != ABI_VERSION:
         raise MdnoError(f"libmdno ABI {ver} != binding {ABI_VERSION}; rebuild the library")
+    want, have = source_build_id(), lib.mdno_build_id().decode()
+    if want is not None and have != want and "MDNO_LIB" not in os.environ:
+        raise MdnoError(f"{LIB_PATH} was built from other sources (build id {have}, the tree is {want}): run "
+                        f"molecular_dynamics_neural_operator_amd/csrc/build.sh — a stale library is never used")
     _lib = lib
     return lib
 

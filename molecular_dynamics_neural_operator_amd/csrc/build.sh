@@ -1,23 +1,38 @@
 #!/usr/bin/env bash
 # Build libmdno.so for gfx950 in-tree (hipcc cross-compiles without a GPU).
 # Usage: csrc/build.sh [extra hipcc flags]
+#
+# The library is tied to its sources by CONTENT, not by timestamps: the build id is the first 16 hex digits of
+# sha256 over the bytes of csrc/*.{hip,h,sh} and include/mdno.h in C-locale name order (the Python side,
+# _lib.source_build_id(), computes the same thing).  It is compiled into the library (mdno_build_id()) and kept in
+# build/BUILD_ID; if the sources' id, the flags or the library differ from what build/ holds, EVERYTHING is rebuilt
+# from scratch (all 13 files in parallel: ~10 s) — there is no per-file incrementality to go stale.
 set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 out="$here/../libmdno.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-srcs=(engine.hip graph.hip edge_mlp.hip edge_mlp_split.hip factored.hip moment.hip nnconv.hip node_ops.hip train.hip train_bf16.hip train_nodes.hip collate.hip gemm_bf16.hip)
+export LC_ALL=C
+mapfile -t id_files < <( { ls "$here"/*.hip "$here"/*.h "$here"/*.sh | sort; echo "$here/../../include/mdno.h"; } )
+id="$(cat "${id_files[@]}" | sha256sum | cut -c1-16)"
+stamp="$id $*"
+if [[ -f "$out" && -f "$here/build/BUILD_ID" && "$(cat "$here/build/BUILD_ID")" == "$stamp" ]]; then
+  echo "up to date: $out (build id $id)"
+  exit 0
+fi
+rm -rf "$here/build"
+mkdir -p "$here/build"
 objs=()
 pids=()
-mkdir -p "$here/build"
-for f in "${srcs[@]}"; do
-  o="$here/build/${f%.hip}.o"
+for src in "$here"/*.hip; do
+  o="$here/build/$(basename "${src%.hip}").o"
   objs+=("$o")
-  if [[ ! -f "$o" || "$here/$f" -nt "$o" || "$here/common.h" -nt "$o" || "$here/kernels.h" -nt "$o" || "$here/split_layout.h" -nt "$o" || "$here/graph_small.h" -nt "$o" || "$here/mfma_f32.h" -nt "$o" || "$here/reduce.h" -nt "$o" || "$here/../../include/mdno.h" -nt "$o" ]]; then
-    "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function \
-      -c "$here/$f" -o "$o" "$@" &
-    pids+=($!)
-  fi
+  "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function \
+    -DMDNO_BUILD_ID="\"$id\"" -c "$src" -o "$o" "$@" &
+  pids+=($!)
 done
-for p in "${pids[@]:-}"; do [[ -n "$p" ]] && wait "$p"; done
+fail=0
+for p in "${pids[@]}"; do wait "$p" || fail=1; done
+[[ $fail == 0 ]] || { echo "build.sh: a compile failed" >&2; exit 1; }
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out" "${objs[@]}"
-echo "built $out"
+echo "$stamp" > "$here/build/BUILD_ID"
+echo "built $out (build id $id)"

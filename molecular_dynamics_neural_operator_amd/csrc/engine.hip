@@ -269,6 +269,11 @@ using namespace mdno;
 
 extern "C" int mdno_abi_version(void) { return MDNO_ABI_VERSION; }
 
+#ifndef MDNO_BUILD_ID
+#error "compile through csrc/build.sh: it defines MDNO_BUILD_ID (the content hash of the sources)"
+#endif
+extern "C" const char* mdno_build_id(void) { return MDNO_BUILD_ID; }
+
 extern "C" const char* mdno_last_error(void) { return g_last_error.c_str(); }
 
 extern "C" size_t mdno_kernelnn_workspace_bytes(const mdno_kernelnn_params* p, int M, int N, int64_t edge_cap) {

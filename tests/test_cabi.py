@@ -24,8 +24,9 @@ def declared_functions():
 @pytest.fixture(scope="module")
 def lib():
     from molecular_dynamics_neural_operator_amd import _lib
-    if not _lib.LIB_PATH.exists():
-        import __graft_entry__ as g
+    stamp = REPO / "molecular_dynamics_neural_operator_amd" / "csrc" / "build" / "BUILD_ID"
+    if not _lib.LIB_PATH.exists() or not stamp.exists() or stamp.read_text().split()[0] != _lib.source_build_id():
+        import __graft_entry__ as g      # (build.sh rebuilds everything when the sources' content hash moved)
         g.build()
     return _lib.load()
 
@@ -50,7 +51,7 @@ def test_exports_are_c_linkage_only_mdno(lib):
 
 def test_abi_version_struct_layout_and_error_string(lib):
     from molecular_dynamics_neural_operator_amd import _lib
-    assert lib.mdno_abi_version() == _lib.ABI_VERSION == 13
+    assert lib.mdno_abi_version() == _lib.ABI_VERSION == 14
     # 12 int32 + 27 pointers, no padding surprises
     assert ctypes.sizeof(_lib.KernelNNParams) == 12 * 4 + 27 * 8
     # argument validation happens before any device work: exercise it without a GPU
@@ -73,6 +74,21 @@ def test_abi_version_struct_layout_and_error_string(lib):
     assert lib.mdno_kernelnn_workspace_bytes(None, 1, 1, 1) == 0
     with pytest.raises(_lib.MdnoError):
         _lib.check(rc, "nnconv")
+
+
+def test_library_is_built_from_this_tree(lib, tmp_path, monkeypatch):
+    """mdno_build_id() == the content hash of csrc/* + include/mdno.h as they are now (the .so is untracked but
+    shipped to the GPU box: this is what ties it to HEAD); a library from other sources is refused at load."""
+    from molecular_dynamics_neural_operator_amd import _lib
+    want = _lib.source_build_id()
+    assert want is not None and len(want) == 16
+    assert lib.mdno_build_id().decode() == want
+    stamp = (REPO / "molecular_dynamics_neural_operator_amd" / "csrc" / "build" / "BUILD_ID").read_text().split()[0]
+    assert stamp == want
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "source_build_id", lambda: "0" * 16)
+    with pytest.raises(_lib.MdnoError, match="built from other sources"):
+        _lib.load()
 
 
 def test_conv_mode_resolution_is_host_logic(lib):

@@ -52,3 +52,62 @@ def test_member_sharding_and_allgather(world, total):
         p.join(timeout=120)
         assert p.exitcode == 0
     assert res == [(r, True) for r in range(world)]
+
+
+# ------------------------------------------------------------------------------- bench.py's own launcher
+STUB_RANK = r"""
+import json, os, sys, time
+rank = int(os.environ["RANK"])
+mode = sys.argv[1]
+if mode == "ok":
+    time.sleep(0.2 * rank)
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": 1.0, "world": int(os.environ["WORLD_SIZE"])}), flush=True)
+    sys.exit(0)
+if mode == "rank1_dies":            # rank 1 dies at start-up, every other rank waits for it "for ever"
+    if rank == 1:
+        sys.exit(3)
+    if rank == 0:
+        print("x" * 300000, flush=True)          # more than a pipe buffer: rank 0 must be drained while it waits
+    time.sleep(600)
+if mode == "rank0_dies":
+    if rank == 0:
+        print(json.dumps({"error": "RuntimeError: stub", "rank": 0}), flush=True)
+        sys.exit(1)
+    time.sleep(600)
+"""
+
+
+@pytest.mark.parametrize("mode,world", [("ok", 4), ("rank1_dies", 4), ("rank0_dies", 2)])
+def test_bench_launcher_polls_every_rank(tmp_path, monkeypatch, capsys, mode, world):
+    """bench.launch_workers with stub ranks (no GPU, no torch in the children): a clean run relays rank 0's line and
+    returns 0; a rank that dies while the others wait (rank 0 blocked with a full pipe, or rank 0 itself dead) makes
+    the launcher stop exactly its children after the grace period and print ONE JSON error line with every exit code
+    — seconds, not the rendezvous timeout."""
+    import json
+    import sys
+    import time
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    import bench
+    stub = tmp_path / "rank.py"
+    stub.write_text(STUB_RANK)
+    monkeypatch.setattr(bench, "RANK_GRACE_S", 1.5)
+    monkeypatch.setattr(bench, "visible_gpus", lambda: world)
+    a = bench.parse(["--gpus", str(world)])
+    t0 = time.time()
+    rc = bench.launch_workers(a, script=stub, argv=[mode])
+    dt = time.time() - t0
+    out = capsys.readouterr().out.strip().splitlines()
+    assert len(out) == 1, out
+    line = json.loads(out[0])
+    if mode == "ok":
+        assert rc == 0 and line == {"metric": "stub", "value": 1.0, "world": world}
+        return
+    assert rc != 0 and dt < 30.0, (rc, dt)
+    codes = line["rank_exit_codes"]
+    assert len(codes) == world and "error" in line and line["n_gpus"] == world
+    if mode == "rank1_dies":
+        assert codes[1] == 3 and all(c not in (0, None) for c in codes) and "rank 1" in line["error"]
+    else:
+        assert codes[0] == 1 and line["rank0_error"] == "RuntimeError: stub"

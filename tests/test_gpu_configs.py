@@ -890,6 +890,29 @@ def test_bench_multi_rank_line_schema(dev):
     assert a.total_members is None and bench.ENSEMBLE_MEMBERS == 64
 
 
+def test_bench_rank_failure_is_fast_and_loud(dev):
+    """`python bench.py --gpus 2` with rank 1 raising right after set_device (MDNO_BENCH_FAIL_RANK=1) while rank 0
+    waits for it in the rendezvous: the launcher polls every rank from the start, stops rank 0 after its grace period
+    and returns non-zero with ONE JSON error line — in under a minute, not the process group's timeout (the driver's
+    600 s limit would otherwise expire with nothing written)."""
+    import time
+    env = dict(os.environ, MDNO_BENCH_FAIL_RANK="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--total-members", "4", "--skip-roofline", "--skip-cpu-baseline"], capture_output=True, text=True,
+                       env=env, timeout=300)
+    dt = time.time() - t0
+    assert r.returncode != 0 and dt < 60.0, (r.returncode, dt, r.stderr[-2000:])
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert "rank 1" in line["error"] and line["rank_exit_codes"][1] not in (0, None) and line["n_gpus"] == 2
+    assert "value" not in line
+    assert "MDNO_BENCH_FAIL_RANK=1" in r.stderr
+
+
 NCCL_CHILD = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, os.environ["MDNO_REPO"])

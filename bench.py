@@ -26,16 +26,21 @@ random-init weights collapse the cloud to one point, which would change E (the c
 one step.  The architecture, arithmetic and update rule (next frame = model output) are unchanged.
 
 Extra objects on the JSON line:
-  roofline      the dominant kernel of the timed path against HBM — the per-source GEMM of the
-                factored conv (what conv_mode "auto" runs at this size; algorithmic bytes per launch
-                E*k*4 + R*C*k*4 + 2*E*C*4) or, in materialized mode, the conv (gather ->
-                per-edge matvec -> scatter-mean) kernel (16,388*E + 516*R + 4):
-                bytes / average launch duration, measured with HIP events on the launching stream over
-                K more steps of the same rollout issued as plain launches (events cannot sit inside a
-                hipGraph replay); traffic = PMC bytes per launch from profiles/roofline_traffic.json,
-                only when this run's (atoms, members, conv mode, GEMM mode) is the profiled one.
-  rooflines     the same for every leg: both conv formulations (the other one is run as a comparison
-                leg on the same start window) and the two wide split-bf16 GEMMs against the bf16 MFMA peak.
+  roofline      the dominant kernel of the timed path against HBM.  Factored conv (what conv_mode "auto" runs at
+                this size; csrc/moment.hip): K1 `moment_kernel`, S_t = sum_(e->t) x_src (x) h_e — algorithmic bytes
+                per launch E*k*4 (H in) + R*64*k*4 (S out) + E*4 (src) + (R+1)*4 (row_ptr), DESIGN.md §4.5.
+                Materialized conv: the gather -> per-edge matvec -> scatter-mean kernel (SURVEY.md §8d:
+                16,388*E + 516*R + 4).  bytes / average launch duration, measured with HIP events on the
+                launching stream over K more steps of the same rollout issued as plain launches (events cannot
+                sit inside a hipGraph replay): `avg_launch_ms_events`; `avg_launch_us_rocprof` = the same kernel's
+                average in the committed rocprofv3 trace (profiles/roofline_traffic.json), and traffic = PMC bytes
+                per launch from there, both only when this run's (atoms, members, conv mode, GEMM mode) is the
+                profiled one.
+  rooflines     the same for every leg: `conv_factored_moment` (K1) with a `per_application` object — the whole conv
+                application K1 + K2 + K3 against its COMPULSORY bytes (H + W3R + x + y: the S image and the K-slice
+                partials are intermediates), i.e. the composite and not only the best kernel —, `conv_materialized`
+                (the other formulation, run as a comparison leg on the same start window) and the two wide
+                split-plane GEMMs against the 16-bit MFMA peak.
   cpu_baseline  the oracle (CPU restatement of the reference: edge-MLP re-evaluated in all 12 conv
                 applications + scipy graph rebuild per step) timed on this box's host cores on a
                 bounded sample; rank 0, N=1 only.  A reported baseline, not the target.
@@ -138,7 +143,7 @@ def visible_gpus() -> int:
 
 
 RANK_GRACE_S = 30.0           # after the first rank fails, the others get this long before they are stopped
-INIT_TIMEOUT_S = 180          # rendezvous + every collective (the process group's timeout)
+INIT_TIMEOUT_S = 300          # rendezvous + every collective (the process group's timeout); the driver allows 600 s
 
 
 def launch_workers(a, script=None, argv=None) -> int:
@@ -547,8 +552,7 @@ def leg_cfg5_shape_c(dev, atoms=50000, cutoff=10.0, steps=2, slice_edges=2_000_0
     model.load_state_dict(sd)
     model.eval().to(dev)
     model.conv_mode = "factored"
-    eng = RolloutEngine(model, 1, N, W, cutoff, max_steps=steps + 1, edge_cap=int(E * 1.05), device=dev,
-                        max_degree=(deg_max + 127) // 128 * 128 + 128)
+    eng = RolloutEngine(model, 1, N, W, cutoff, max_steps=steps + 1, edge_cap=int(E * 1.05), device=dev)
     ws_gib = eng.workspace.numel() / 2**30
     eng.reset(torch.from_numpy(win), aa)
     eng.step(1)
@@ -677,20 +681,25 @@ def leg_shape_a(dev, a):
 
 
 # ----------------------------------------------------------------------------------------------- worker
-def profiled_traffic(kernel: str, atoms: int, members: int, conv_mode: str, gemm_mode: str):
-    """PMC HBM bytes per launch from profiles/roofline_traffic.json — only for the configuration the
-    counters were collected on (anything else would print a number that belongs to another run)."""
+def profiled_entry(kernel: str, atoms: int, members: int, conv_mode: str, gemm_mode: str) -> dict:
+    """The entry of profiles/roofline_traffic.json for this kernel and configuration ({} if none): PMC HBM bytes per
+    launch, the rocprofv3 trace's average duration, the conv application's summed traffic — only for the configuration
+    the counters were collected on (anything else would print a number that belongs to another run)."""
     tf = REPO / "profiles" / "roofline_traffic.json"
     if not tf.exists():
-        return None
+        return {}
     try:
         for ent in json.loads(tf.read_text()).get("configs", []):
             if (ent.get("kernel") == kernel and ent.get("atoms") == atoms and ent.get("members") == members
                     and ent.get("conv_mode") == conv_mode and ent.get("gemm_mode") == gemm_mode):
-                return ent.get("hbm_bytes_per_launch")
+                return ent
     except Exception:
-        return None
-    return None
+        return {}
+    return {}
+
+
+def profiled_traffic(kernel: str, atoms: int, members: int, conv_mode: str, gemm_mode: str):
+    return profiled_entry(kernel, atoms, members, conv_mode, gemm_mode).get("hbm_bytes_per_launch")
 
 
 def worker(a):
@@ -859,12 +868,13 @@ def worker(a):
     def conv_roofline(ks, e):      # the metric's kernel: gather -> per-edge matvec -> scatter-mean, HBM-bound
         avg_s = ks["nnconv"]["avg_ms"] * 1e-3
         alg = e * (C * C * 4 + 4) + (R + 1) * 4 + 2 * R * C * 4
+        prof = profiled_entry("nnconv64_row_kernel", N, M_r, "materialized", a.gemm_mode)
         return {"bound": "hbm", "kernel": "nnconv64_row_kernel", "conv_mode": "materialized", "achieved": alg / avg_s / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / avg_s / 1e9 / HBM_PEAK_GBS,
                 "frac_of_measured_copy_peak": alg / avg_s / 1e9 / HBM_COPY_GBS,
-                "traffic": profiled_traffic("nnconv64_row_kernel", N, M_r, "materialized", a.gemm_mode),
-                "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_s * 1e3, "edges_per_launch": e,
-                "rows_per_launch": R}
+                "traffic": prof.get("hbm_bytes_per_launch"),
+                "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_s * 1e3, "avg_launch_ms_events": avg_s * 1e3,
+                "avg_launch_us_rocprof": prof.get("rocprof_avg_us"), "edges_per_launch": e, "rows_per_launch": R}
 
     def gemm_roofline(ks, e, which, n_out):
         step_s = ks[which]["ms_per_step"] * 1e-3     # all launches of a step (capacity-sized chunks past E exit at once)
@@ -882,26 +892,23 @@ def worker(a):
                 "note": f"executed 16-bit MFMA flops ({products:.0f} plane products per fp32 product) vs the dense "
                         "bf16/fp16 peak"}
 
-    def per_source_roofline(ks, e):   # factored path, its dominant kernel over all launches of one conv application
+    def moment_roofline(ks, e):   # factored path (csrc/moment.hip): K1 over all launches of one conv application
         launches_per_app = max(1, round(ks["nnconv"]["launches"] / (a.steps * 2 * a.depth)))
         avg_s = ks["nnconv"]["avg_ms"] * 1e-3 * launches_per_app      # one application over all R rows
         split = a.gemm_mode != "f32"
         flops = 2.0 * e * KW * C                                                # fp32-equivalent
-        if split:
-            # destination-side form (csrc/moment.hip K1): S_t = sum_{e->t} x_src (x) h_e — H read once, S written once,
-            # the source index per edge, row_ptr (the neighbours' 384-B feature planes are gathered from L2)
-            name = "moment_kernel"
-            alg = e * KW * 4 + R * C * KW * 4 + e * 4 + (R + 1) * 4
-        else:
-            # source-side form (csrc/factored.hip): M_j = H_j . Y_j^T — H once + Y once + 2 k-slice partials out
-            name = "gemm_per_source_kernel"
-            alg = e * KW * 4 + R * C * KW * 4 + 2 * e * C * 4 + (R + 1) * 4
+        # K1: S_t = sum_{e->t} x_src (x) h_e — H read once, S written once, the source index per edge, row_ptr (the
+        # neighbours' 256-B feature rows are gathered from L2)
+        name = "moment_kernel" if split else "moment_f32_kernel"
+        alg = e * KW * 4 + R * C * KW * 4 + e * 4 + (R + 1) * 4
         # matrix-pipe work as executed: 6 bf16 plane products per fp32 product, or the fp32 MFMA itself
         mfma_exec, mfma_peak = (6.0 * flops, MFMA_BF16_PEAK_TFLOPS) if split else (flops, MFMA_F32_PEAK_TFLOPS)
         t_hbm, t_mfma = alg / (HBM_PEAK_GBS * 1e9), mfma_exec / (mfma_peak * 1e12)
-        r = {"kernel": name, "conv_mode": "factored", "avg_launch_ms": avg_s * 1e3, "launches_per_application": launches_per_app,
+        prof = profiled_entry(name, N, M_r, "factored", a.gemm_mode)
+        r = {"kernel": name, "conv_mode": "factored", "avg_launch_ms": avg_s * 1e3, "avg_launch_ms_events": avg_s * 1e3,
+             "avg_launch_us_rocprof": prof.get("rocprof_avg_us"), "launches_per_application": launches_per_app,
              "algorithmic_bytes_per_launch": alg, "flops_per_launch": flops,
-             "traffic": profiled_traffic(name, N, M_r, "factored", a.gemm_mode),
+             "traffic": prof.get("hbm_bytes_per_launch"),
              "hbm_GBps": alg / avg_s / 1e9, "hbm_frac": alg / avg_s / 1e9 / HBM_PEAK_GBS,
              "frac_of_measured_copy_peak": alg / avg_s / 1e9 / HBM_COPY_GBS,
              "mfma_TFLOPs": mfma_exec / avg_s / 1e12, "mfma_frac": mfma_exec / avg_s / 1e12 / mfma_peak}
@@ -909,6 +916,21 @@ def worker(a):
             r.update(bound="hbm", achieved=r["hbm_GBps"], peak=HBM_PEAK_GBS, unit="GB/s", frac=r["hbm_frac"])
         else:
             r.update(bound="mfma", achieved=r["mfma_TFLOPs"], peak=mfma_peak, unit="TFLOP/s", frac=r["mfma_frac"])
+        # the whole conv application (K1 + K2 + K3) against what it MUST move: H in, W3R in (+ the B3 rows), x in, y out.
+        # S (R*64*k*4 out of K1, in again to K2) and the K-slice partials are intermediates of this formulation.
+        k2 = ks.get("factored_y", {"ms_per_step": 0.0})["ms_per_step"]
+        k3 = ks.get("nnconv_combine", {"ms_per_step": 0.0})["ms_per_step"]
+        app_s = (ks["nnconv"]["ms_per_step"] + k2 + k3) * 1e-3 / (2 * a.depth)
+        compulsory = e * KW * 4 + (C * KW + C) * C * 4 + 2 * R * C * 4 + e * 4 + (R + 1) * 4
+        moved = alg + (R * C * KW * 4 + (C * KW + C) * C * 4) + 2 * 128 * R * C * 4 + R * C * 4      # + K2 in, partials out/in, y
+        r["per_application"] = {
+            "kernels": "moment_kernel (K1) + project_kernel (K2) + finish_kernel (K3)" if split else
+                       "moment_f32_kernel (K1) + project_f32_kernel (K2) + finish_kernel (K3)",
+            "ms_events": app_s * 1e3, "k1_k2_k3_ms": [ks["nnconv"]["ms_per_step"] / (2 * a.depth), k2 / (2 * a.depth), k3 / (2 * a.depth)],
+            "compulsory_bytes": compulsory, "algorithmic_bytes_moved_by_the_three_kernels": moved,
+            "traffic": prof.get("application_hbm_bytes"),
+            "achieved": compulsory / app_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": compulsory / app_s / 1e9 / HBM_PEAK_GBS,
+            "frac_of_bytes_moved": moved / app_s / 1e9 / HBM_PEAK_GBS}
         return r
 
     # rank 0 only: the other ranks idle at the final barrier through the measurement legs
@@ -918,7 +940,7 @@ def worker(a):
             roofs["conv_materialized"] = conv_roofline(kernels, e2)
             roofs["edge_mlp_last_gemm"] = gemm_roofline(kernels, e2, "edge_mlp_gemm2", C * C)
         else:
-            roofs["conv_factored_per_source_gemm"] = per_source_roofline(kernels, e2)
+            roofs["conv_factored_moment"] = moment_roofline(kernels, e2)
         roofs["edge_mlp_hidden_gemm"] = gemm_roofline(kernels, e2, "edge_mlp_gemm1", KW)
         # ---- the other conv formulation on the same start window: frames/s and, for the materialised
         # one, the HBM roofline of the gather/matvec/scatter kernel BASELINE.json's target is stated on
@@ -944,14 +966,14 @@ def worker(a):
                 roofs["conv_materialized"] = conv_roofline(k2, e3)
                 roofs["edge_mlp_last_gemm"] = gemm_roofline(k2, e3, "edge_mlp_gemm2", C * C)
             else:
-                roofs["conv_factored_per_source_gemm"] = per_source_roofline(k2, e3)
+                roofs["conv_factored_moment"] = moment_roofline(k2, e3)
             eng2.close()
             del eng2
             model.conv_mode = a.conv_mode
     # "roofline" = the dominant kernel of the TIMED path
     dominant = None
     if kernels:
-        have = {"nnconv": roofs.get("conv_materialized" if mode == "materialized" else "conv_factored_per_source_gemm"),
+        have = {"nnconv": roofs.get("conv_materialized" if mode == "materialized" else "conv_factored_moment"),
                 "edge_mlp_gemm2": roofs.get("edge_mlp_last_gemm"), "edge_mlp_gemm1": roofs.get("edge_mlp_hidden_gemm")}
         have = {k: v for k, v in have.items() if v is not None and k in kernels}
         if have:      # (tiny shapes: a latency-bound helper can top the list; the roofline is quoted on a roofline-bound kernel)

@@ -64,10 +64,9 @@ extern "C" {
 /* How a conv application is evaluated inside mdno_kernelnn_fwd / the rollout (same function either way):
  *   MATERIALIZED  the reference's formulation: W_e = net(edge_attr) [E,Cin,Cout] is written once per
  *                 forward and streamed by every conv application (HBM-bound gather/matvec/scatter).
- *   FACTORED      m_e = h_e . Y_src^T + q_src with Y = X . W3 evaluated per NODE (see csrc/factored.hip):
- *                 a reassociation of the same sums that never forms W_e.  Used only for graphs the
- *                 library builds itself from positions (symmetric radius graphs, width 64); everything
- *                 else runs MATERIALIZED. */
+ *   FACTORED      S_t = sum_{e -> t} x_src(e) (x) h_e per destination, then y_t = W3 : S_t (csrc/moment.hip): a
+ *                 reassociation of the same sums that never forms W_e.  Any destination-sorted graph at
+ *                 width 64 and ker_width % 128 == 0, in every GEMM mode; everything else runs MATERIALIZED. */
 #define MDNO_CONV_MATERIALIZED 0
 #define MDNO_CONV_FACTORED     1
 /*   AUTO          FACTORED where it applies and the graph is large enough to pay for its fixed cost
@@ -82,8 +81,7 @@ extern "C" {
 /* status word bits written by device code (read back by the caller after synchronising) */
 #define MDNO_STATUS_EDGE_OVERFLOW 1   /* radius graph found more than edge_cap edges; list truncated */
 #define MDNO_STATUS_BAD_AMINOACID 2   /* x_aminoacid outside [0, num_embeddings) */
-#define MDNO_STATUS_ASYMMETRIC_GRAPH 4 /* factored conv: an edge has no reverse edge */
-#define MDNO_STATUS_DEGREE_OVERFLOW  8 /* factored conv: a node has more edges than the max_degree bound */
+/* (bits 4 and 8 belonged to the source-side factored kernels removed with ABI 14: never set) */
 #define MDNO_STATUS_BAD_EDGE_INDEX  16 /* mdno_coo_to_csr: a node id outside [0, num_nodes) (clamped in bounds;
                                           the reference's index_select / scatter raise IndexError there) */
 
@@ -212,9 +210,7 @@ int mdno_fc_out_fwd(const float* x, const float* w, const float* b, int rows, in
  * Whole forward — replaces KernelNN.forward (graph_kernel.py:277-309) for M independent samples
  * (B=1 semantics each).  frames f32 [W,M,N,3].  Graph given as CSR over the M*N rows; edge
  * attributes by (a) edge_pos f32 [M*N,3] (the frame the graph was built on) or (b) edge_attr
- * (+perm), as in mdno_edge_mlp_fwd.  max_degree: an upper bound on any node's degree, used to size
- * the factored conv's grid (0 = N, always safe; give a tighter bound for large N — exceeding it sets
- * MDNO_STATUS_DEGREE_OVERFLOW).  out f32 [M*N,out_width]; latent f32 [M*N,width] (the
+ * (+perm), as in mdno_edge_mlp_fwd.  out f32 [M*N,out_width]; latent f32 [M*N,width] (the
  * return_latent=True output, :303) may be NULL.
  * Workspace: mdno_kernelnn_workspace_bytes(p, M, N, edge_cap).
  * ---------------------------------------------------------------------------------------- */
@@ -235,7 +231,7 @@ int mdno_conv_mode_for_graph(const mdno_kernelnn_params* p, int M, int N, int64_
 int mdno_kernelnn_fwd(const mdno_kernelnn_params* p, const float* frames, int M, int W, int N,
                       const int64_t* x_aminoacid, int aa_per_member,
                       const int32_t* row_ptr, const int32_t* src, const int32_t* dst,
-                      const int32_t* num_edges, int64_t edge_cap, int max_degree,
+                      const int32_t* num_edges, int64_t edge_cap,
                       const float* edge_pos, const float* edge_attr, const int32_t* perm,
                       float* out, float* latent, void* workspace, size_t workspace_bytes,
                       int32_t* status, void* stream);
@@ -261,13 +257,12 @@ int mdno_rollout(const mdno_kernelnn_params* p, float* traj, int M, int W, int N
  * executes), then any range of steps is replayed without re-capturing and without synchronising.
  *   traj f32 [W+max_steps, M, N, 3]; run(start_step, steps) produces frames W+start_step ..
  *   W+start_step+steps-1 from the frames before them.  The plan keeps a copy of *p (the weight
- *   pointers must stay valid) and must be destroyed only after its enqueued work has completed.
- *   max_degree as in mdno_kernelnn_fwd (0 = N). */
+ *   pointers must stay valid) and must be destroyed only after its enqueued work has completed. */
 typedef struct mdno_rollout_plan mdno_rollout_plan;
 int mdno_rollout_plan_create(mdno_rollout_plan** plan, const mdno_kernelnn_params* p, float* traj,
                              int M, int W, int N, int max_steps,
                              const int64_t* x_aminoacid, int aa_per_member, double threshold,
-                             int64_t edge_cap, int max_degree, void* workspace, size_t workspace_bytes,
+                             int64_t edge_cap, void* workspace, size_t workspace_bytes,
                              int32_t* edges_per_step, int32_t* status, int use_graph, void* stream);
 int mdno_rollout_plan_run(mdno_rollout_plan* plan, int start_step, int steps, void* stream);
 int mdno_rollout_plan_destroy(mdno_rollout_plan* plan);
@@ -459,6 +454,21 @@ int mdno_colsum_atb_bf16(const void* a, const float* b, int64_t rows, int n, int
 int mdno_collate_samples(const float* pos, const int32_t* rows, const int32_t* cols, const int64_t* meta,
                          int B, int N, int W, int horizon, int max_edges_per_sample, float* x_position, float* y,
                          int64_t* edge_index, float* edge_attr, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Training: the loss (csrc/loss.hip) — LpLoss.rel with p = 2 (graph_kernel.py:105-119; used :462, :547) and the batch
+ * MSE train() logs beside it (:465), forward and backward in three small launches instead of ~15 ATen ones.
+ *   out, y    f32 [batch, dim] (dim = atoms * 3: the flattened frame of a sample)
+ *   stats     f32 [batch, 4] (16-B aligned), written by fwd, read by bwd: {ratio_b, ||out_b - y_b||^2, ||out_b - y_b||, ||y_b||}
+ *   loss_mse  f32 [2]: loss = sum_b ratio_b (size_average != 0: / batch), mse = sum_b ||out_b - y_b||^2 / (batch dim)
+ *   bwd       grad_out [batch, dim] = g * (out_b - y_b) / (||out_b - y_b|| ||y_b||) (/ batch if size_average), 0 for a
+ *             sample with out_b == y_b (torch.norm's subgradient); grad_loss f32 [1] on the device, NULL = 1.
+ * Fixed summation orders (bitwise reproducible).
+ * ---------------------------------------------------------------------------------------- */
+int mdno_lploss_rel_fwd(const float* out, const float* y, long long batch, int dim, int size_average, float* stats,
+                        float* loss_mse, void* stream);
+int mdno_lploss_rel_bwd(const float* out, const float* y, const float* stats, const float* grad_loss, long long batch,
+                        int dim, int size_average, float* grad_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Training: backward of the per-atom ends (csrc/train_nodes.hip) — the node prologue (graph_kernel.py:279-298;

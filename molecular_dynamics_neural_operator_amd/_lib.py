@@ -17,8 +17,6 @@ STATUS_EDGE_OVERFLOW, STATUS_BAD_AMINOACID = 1, 2
 ABI_VERSION = 14
 GEMM_MODES = {"split_bf16": 0, "f32": 1, "split_f16": 2}
 CONV_MODES = {"materialized": 0, "factored": 1, "auto": 2}
-STATUS_ASYMMETRIC_GRAPH = 4
-STATUS_DEGREE_OVERFLOW = 8
 STATUS_BAD_EDGE_INDEX = 16
 
 
@@ -66,11 +64,11 @@ SIGNATURES = {
     "mdno_kernelnn_workspace_bytes": (_SZ, [C.POINTER(KernelNNParams), _I, _I, _L]),
     "mdno_resolve_conv_mode": (_I, [C.POINTER(KernelNNParams), _I, _L]),
     "mdno_conv_mode_for_graph": (_I, [C.POINTER(KernelNNParams), _I, _I, _L]),
-    "mdno_kernelnn_fwd": (_I, [C.POINTER(KernelNNParams), _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _L, _I,
+    "mdno_kernelnn_fwd": (_I, [C.POINTER(KernelNNParams), _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _L,
                                _P, _P, _P, _P, _P, _P, _SZ, _P, _P]),
     "mdno_rollout_workspace_bytes": (_SZ, [C.POINTER(KernelNNParams), _I, _I, _L]),
     "mdno_rollout": (_I, [C.POINTER(KernelNNParams), _P, _I, _I, _I, _I, _P, _I, _D, _L, _P, _SZ, _P, _P, _I, _P]),
-    "mdno_rollout_plan_create": (_I, [C.POINTER(_P), C.POINTER(KernelNNParams), _P, _I, _I, _I, _I, _P, _I, _D, _L, _I,
+    "mdno_rollout_plan_create": (_I, [C.POINTER(_P), C.POINTER(KernelNNParams), _P, _I, _I, _I, _I, _P, _I, _D, _L,
                                       _P, _SZ, _P, _P, _I, _P]),
     "mdno_rollout_plan_run": (_I, [_P, _I, _I, _P]),
     "mdno_rollout_plan_destroy": (_I, [_P]),
@@ -128,6 +126,8 @@ SIGNATURES = {
     "mdno_fc_out_bwd_workspace_bytes": (_SZ, [_I, _I, _I]),
     "mdno_fc_out_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _SZ, _P]),
     "mdno_collate_samples": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "mdno_lploss_rel_fwd": (_I, [_P, _P, _L, _I, _I, _P, _P, _P]),
+    "mdno_lploss_rel_bwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _P, _P]),
 }
 
 _lib = None
@@ -220,8 +220,4 @@ def raise_on_status(status_word: int, what: str = "") -> None:
         raise MdnoIndexError(pre + "edge_index holds a node id outside [0, num_nodes)")
     if st & STATUS_EDGE_OVERFLOW:
         raise MdnoError(pre + "radius graph exceeded edge_cap; use a larger capacity")
-    if st & STATUS_DEGREE_OVERFLOW:
-        raise MdnoError(pre + "a node has more edges than max_degree; raise the bound (0 = n_atoms)")
-    if st & STATUS_ASYMMETRIC_GRAPH:
-        raise MdnoError(pre + "factored conv met an edge without a reverse edge (graph not symmetric)")
     raise MdnoError(pre + f"device status {st:#x}")

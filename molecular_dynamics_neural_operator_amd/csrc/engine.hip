@@ -78,16 +78,10 @@ struct FwdWs {
     float *xa, *xb, *w_e, *h2;
     void *mlp, *fact;
     size_t mlp_bytes, total;
-    bool factored;
-    bool moment;      // factored, destination-side form (moment.hip): the split GEMM modes
+    bool factored;      // destination-side moment form (moment.hip), in every GEMM mode
 };
 
-// The factored conv's two forms: destination-side (moment.hip) for the split GEMM modes, source-side (factored.hip,
-// exact fp32 MFMA kernels) for gemm_mode F32.
-bool use_moment(const mdno_kernelnn_params* p) { return p->gemm_mode != MDNO_GEMM_F32; }
-bool factored_available(const mdno_kernelnn_params* p) {
-    return use_moment(p) ? moment_supported(p->width, p->ker_width) : factored_supported(p->width, p->ker_width);
-}
+bool factored_available(const mdno_kernelnn_params* p) { return moment_supported(p->width, p->ker_width); }
 
 // The factored conv applies to graphs the library builds itself (symmetric radius graphs) at width 64.
 // AUTO adds a size rule: below ~8-10k edges the factored form's fixed cost per application (Y GEMM
@@ -104,7 +98,7 @@ constexpr long long kAutoFactoredMinEdgesPerMember = 16384;
 
 bool use_factored(const mdno_kernelnn_params* p, int M, long long edge_cap, bool position_graph) {
     if (p->conv_mode == MDNO_CONV_MATERIALIZED || !factored_available(p)) return false;
-    if (p->conv_mode == MDNO_CONV_FACTORED) return true;   // (gemm_mode F32: forward_impl insists on a position graph)
+    if (p->conv_mode == MDNO_CONV_FACTORED) return true;
     return position_graph && edge_cap / (M > 0 ? M : 1) >= kAutoFactoredMinEdgeCapPerMember;
 }
 
@@ -119,9 +113,7 @@ FwdWs carve_fwd(void* ws, const mdno_kernelnn_params* p, int M, int N, long long
         // no W_e at all: the last hidden activation H [edge_cap, k] plus the per-node Y and per-edge M
         // k-tiled [e/128][k/32][128][32]: whole 128-row tiles, so the row count is rounded up
         f.h2 = cv.take<float>((size_t)((edge_cap + 127) / 128 * 128) * p->ker_width);
-        f.moment = use_moment(p);
-        f.fact = cv.take<char>(f.moment ? moment_workspace_bytes((int)R, p->ker_width)
-                                        : factored_workspace_bytes((int)R, p->ker_width, edge_cap));
+        f.fact = cv.take<char>(moment_workspace_bytes((int)R, p->ker_width));
         f.mlp_bytes = mdno_edge_mlp_workspace_bytes(p->ker_width, p->ker_width, edge_cap, p->gemm_mode);
     } else {
         f.mlp_bytes = mdno_edge_mlp_workspace_bytes(p->ker_width, p->width * p->width, edge_cap, p->gemm_mode);
@@ -136,7 +128,7 @@ FwdWs carve_fwd(void* ws, const mdno_kernelnn_params* p, int M, int N, long long
 // frames/t0/t_dev address the window; edge_frames/edge_frame the frame the graph was built on.
 int forward_impl(const mdno_kernelnn_params* p, const float* frames, int t0, const int* t_dev, int M, int W, int N,
                  const long long* aa, int aa_per_member, const int* row_ptr, const int* src, const int* dst,
-                 const int* num_edges, long long edge_cap, int max_degree, const float* edge_frames, int edge_frame,
+                 const int* num_edges, long long edge_cap, const float* edge_frames, int edge_frame,
                  const float* edge_attr, const int* perm, float* out_frames, int t_out, float* latent,
                  const FwdWs& ws, int* status, hipStream_t s, int phase = WP_BOTH, const StepTail* tail = nullptr) {
     const int R = M * N, C = p->width;
@@ -149,65 +141,35 @@ int forward_impl(const mdno_kernelnn_params* p, const float* frames, int t0, con
     bool fc_done = false;      // the output layer went out with the last conv application
     const int blocks = p->conv2_root ? 2 : 1;   // notebook-era model: conv1 only (lstm_* NULL as well)
     if (ws.factored) {
-        if (ws.moment) {
-            // destination-side form: row r = DESTINATION r with in-edges src[p] -> r, attributes [pos[src], pos[dst]]
-            // as the reference has them (graph_kernel.py:372-379) or the caller's own edge_attr (+ perm): ANY graph in
-            // destination-sorted CSR, no symmetry needed
-            MDNO_REQUIRE((edge_frames && dst) || edge_attr, MDNO_EINVAL,
-                         "factored conv needs edge attributes: positions (edge_pos, dst) or edge_attr");
-            const MomentWs mw = moment_carve(ws.fact, R, p->ker_width);
-            if (!prep_only) MDNO_TRY(moment_prepare_graph(row_ptr, R, mw, s));
-            for (int block = 0; block < blocks; ++block) {
-                const bool own = block == 1 && separate_conv2_kernel(p);
-                if (block == 0 || own) {
-                    EdgeMlpWeights w = own ? EdgeMlpWeights{p->k2_w0, p->k2_b0, p->k2_w1, p->k2_b1, p->k2_w2, p->k2_b2}
-                                           : EdgeMlpWeights{p->k_w0, p->k_b0, p->k_w1, p->k_b1, p->k_w2, p->k_b2};
-                    MDNO_TRY(edge_mlp_hidden(edge_frames, edge_frame, t_dev, R, src, dst, edge_attr, perm, num_edges, edge_cap,
-                                             p->ker_in, p->ker_width, p->gemm_mode, w, ws.h2, ws.mlp, ws.mlp_bytes, s,
-                                             block == 0 ? phase : (phase & ~WP_FLAGS_ZEROED)));
-                    if ((phase & WP_PHASE_MASK) != WP_RUN_ONLY) MDNO_TRY(moment_prepare_weights(w.w2, w.b2, p->ker_width, mw, s));
-                }
-                if (prep_only) return MDNO_OK;
-                const float* root = block == 0 ? p->conv1_root : p->conv2_root;
-                const float* bias = block == 0 ? p->conv1_bias : p->conv2_bias;
-                for (int d = 0; d < p->depth; ++d) {
-                    MDNO_TRY(moment_conv(cur, ws.h2, row_ptr, src, R, p->ker_width, root, bias, MDNO_AGGR_MEAN, /*relu=*/1, nxt,
-                                         mw, s));
-                    float* t = cur; cur = nxt; nxt = t;
-                }
-            }
-            if (latent) MDNO_HIP(hipMemcpyAsync(latent, cur, sizeof(float) * (size_t)R * C, hipMemcpyDeviceToDevice, s));
-            MDNO_TRY(fc_out(cur, p->fc2_w, p->fc2_b, R, C, p->out_width, out_frames, t_out, t_dev, s, tail));
-            return MDNO_OK;
-        }
-        MDNO_REQUIRE(edge_frames && !edge_attr && dst, MDNO_EINVAL,
-                     "factored conv with gemm_mode F32 needs a position-derived (symmetric) radius graph (edge_pos, dst)");
-        // gemm_mode F32: source-side form on the exact fp32 MFMA.  Symmetric radius graph, attributes from positions:
-        // row r = SOURCE r -> destinations src[p] (the CSR arrays' names refer to the materialised reading; here their
-        // roles are swapped)
-        const FactoredWs fw = factored_carve(ws.fact, R, p->ker_width, edge_cap);
-        if (!prep_only) MDNO_TRY(factored_prepare_graph(row_ptr, src, dst, R, edge_cap, fw, status, s));
+        // destination-side form: row r = DESTINATION r with in-edges src[p] -> r, attributes [pos[src], pos[dst]]
+        // as the reference has them (graph_kernel.py:372-379) or the caller's own edge_attr (+ perm): ANY graph in
+        // destination-sorted CSR, no symmetry needed
+        MDNO_REQUIRE((edge_frames && dst) || edge_attr, MDNO_EINVAL,
+                     "factored conv needs edge attributes: positions (edge_pos, dst) or edge_attr");
+        const MomentWs mw = moment_carve(ws.fact, R, p->ker_width);
+        if (!prep_only) MDNO_TRY(moment_prepare_graph(row_ptr, R, mw, s));
         for (int block = 0; block < blocks; ++block) {
             const bool own = block == 1 && separate_conv2_kernel(p);
             if (block == 0 || own) {
                 EdgeMlpWeights w = own ? EdgeMlpWeights{p->k2_w0, p->k2_b0, p->k2_w1, p->k2_b1, p->k2_w2, p->k2_b2}
                                        : EdgeMlpWeights{p->k_w0, p->k_b0, p->k_w1, p->k_b1, p->k_w2, p->k_b2};
-                // attr = [pos[source], pos[destination]] = [pos[row], pos[col]]: pass (dst, src) swapped
-                MDNO_TRY(edge_mlp_hidden(edge_frames, edge_frame, t_dev, R, /*src=*/dst, /*dst=*/src, nullptr, nullptr,
-                                         num_edges, edge_cap, p->ker_in, p->ker_width, p->gemm_mode, w, ws.h2, ws.mlp,
-                                         ws.mlp_bytes, s, block == 0 ? phase : (phase & ~WP_FLAGS_ZEROED)));
-                if ((phase & WP_PHASE_MASK) != WP_RUN_ONLY) MDNO_TRY(factored_prepare_weights(w.w2, p->ker_width, fw, s));
+                MDNO_TRY(edge_mlp_hidden(edge_frames, edge_frame, t_dev, R, src, dst, edge_attr, perm, num_edges, edge_cap,
+                                         p->ker_in, p->ker_width, p->gemm_mode, w, ws.h2, ws.mlp, ws.mlp_bytes, s,
+                                         block == 0 ? phase : (phase & ~WP_FLAGS_ZEROED)));
+                if ((phase & WP_PHASE_MASK) != WP_RUN_ONLY) MDNO_TRY(moment_prepare_weights(w.w2, w.b2, p->ker_width, mw, s));
             }
             if (prep_only) return MDNO_OK;
-            const float* b3 = own ? p->k2_b2 : p->k_b2;
             const float* root = block == 0 ? p->conv1_root : p->conv2_root;
             const float* bias = block == 0 ? p->conv1_bias : p->conv2_bias;
             for (int d = 0; d < p->depth; ++d) {
-                MDNO_TRY(factored_conv(cur, ws.h2, row_ptr, R, max_degree > 0 ? max_degree : N, p->ker_width, b3, root, bias,
-                                       MDNO_AGGR_MEAN, /*relu=*/1, nxt, fw, status, s));
+                MDNO_TRY(moment_conv(cur, ws.h2, row_ptr, src, R, p->ker_width, root, bias, MDNO_AGGR_MEAN, /*relu=*/1, nxt,
+                                     mw, s, /*exact_f32=*/p->gemm_mode == MDNO_GEMM_F32));
                 float* t = cur; cur = nxt; nxt = t;
             }
         }
+        if (latent) MDNO_HIP(hipMemcpyAsync(latent, cur, sizeof(float) * (size_t)R * C, hipMemcpyDeviceToDevice, s));
+        MDNO_TRY(fc_out(cur, p->fc2_w, p->fc2_b, R, C, p->out_width, out_frames, t_out, t_dev, s, tail));
+        return MDNO_OK;
     } else {
         for (int block = 0; block < blocks; ++block) {
             if (block == 0 || separate_conv2_kernel(p)) {
@@ -298,7 +260,7 @@ extern "C" int mdno_conv_mode_for_graph(const mdno_kernelnn_params* p, int M, in
 extern "C" int mdno_kernelnn_fwd(const mdno_kernelnn_params* p, const float* frames, int M, int W, int N,
                                  const int64_t* x_aminoacid, int aa_per_member, const int32_t* row_ptr,
                                  const int32_t* src, const int32_t* dst, const int32_t* num_edges,
-                                 int64_t edge_cap, int max_degree, const float* edge_pos, const float* edge_attr,
+                                 int64_t edge_cap, const float* edge_pos, const float* edge_attr,
                                  const int32_t* perm, float* out, float* latent, void* workspace,
                                  size_t workspace_bytes, int32_t* status, void* stream) {
     MDNO_TRY(validate_params(p));
@@ -310,7 +272,7 @@ extern "C" int mdno_kernelnn_fwd(const mdno_kernelnn_params* p, const float* fra
     MDNO_REQUIRE(workspace_bytes >= ws.total, MDNO_EWORKSPACE, "mdno_kernelnn_fwd: workspace %zu < %zu",
                  workspace_bytes, ws.total);
     return forward_impl(p, frames, 0, nullptr, M, W, N, (const long long*)x_aminoacid, aa_per_member, row_ptr, src,
-                        dst, num_edges, (long long)edge_cap, max_degree, edge_pos, 0, edge_attr, perm, out, 0, latent, ws,
+                        dst, num_edges, (long long)edge_cap, edge_pos, 0, edge_attr, perm, out, 0, latent, ws,
                         status, static_cast<hipStream_t>(stream));
 }
 
@@ -339,7 +301,6 @@ struct mdno_rollout_plan {
     int aa_per_member;
     double threshold;
     long long edge_cap;
-    int max_degree;
     RolloutWs r;
     FwdWs fw;
     int* edges_per_step;
@@ -357,7 +318,7 @@ struct mdno_rollout_plan {
 static int plan_prepare_weights(mdno_rollout_plan* pl, hipStream_t s) {
     const int W = pl->W;
     return forward_impl(&pl->p, pl->traj, 0, pl->r.t_dev, pl->M, W, pl->N, pl->aa, pl->aa_per_member, pl->r.row_ptr,
-                        pl->r.src, pl->r.dst, pl->r.num_edges, pl->edge_cap, pl->max_degree, pl->traj, W - 1, nullptr,
+                        pl->r.src, pl->r.dst, pl->r.num_edges, pl->edge_cap, pl->traj, W - 1, nullptr,
                         nullptr, pl->traj, W, nullptr, pl->fw, pl->status, s, WP_PREPARE_ONLY);
 }
 
@@ -382,7 +343,7 @@ static int plan_enqueue_step(mdno_rollout_plan* pl, hipStream_t s) {
     const StepTail tail{pl->r.t_dev, pl->r.num_edges, pl->edges_per_step, pl->r.t_dev + 1,
                         (long long)pl->M * pl->N <= 256 ? pl->r.row_done : nullptr};
     return forward_impl(&pl->p, pl->traj, 0, pl->r.t_dev, pl->M, W, pl->N, pl->aa, pl->aa_per_member, pl->r.row_ptr,
-                        pl->r.src, pl->r.dst, pl->r.num_edges, pl->edge_cap, pl->max_degree, pl->traj, W - 1, nullptr,
+                        pl->r.src, pl->r.dst, pl->r.num_edges, pl->edge_cap, pl->traj, W - 1, nullptr,
                         nullptr, pl->traj, W, nullptr, pl->fw, pl->status, s,
                         (pl->weights_cached ? WP_RUN_ONLY : WP_BOTH) | (act_flags ? WP_FLAGS_ZEROED : 0) |
                             (head ? WP_PROLOGUE_DONE : 0),
@@ -417,7 +378,7 @@ static int capture_steps(mdno_rollout_plan* pl, hipStream_t s, int n, hipGraph_t
 
 extern "C" int mdno_rollout_plan_create(mdno_rollout_plan** plan, const mdno_kernelnn_params* p, float* traj, int M,
                                         int W, int N, int max_steps, const int64_t* x_aminoacid, int aa_per_member,
-                                        double threshold, int64_t edge_cap, int max_degree, void* workspace,
+                                        double threshold, int64_t edge_cap, void* workspace,
                                         size_t workspace_bytes, int32_t* edges_per_step, int32_t* status,
                                         int use_graph, void* stream) {
     MDNO_REQUIRE(plan != nullptr, MDNO_EINVAL, "mdno_rollout_plan_create: null plan pointer");
@@ -439,7 +400,6 @@ extern "C" int mdno_rollout_plan_create(mdno_rollout_plan** plan, const mdno_ker
     pl->aa_per_member = aa_per_member;
     pl->threshold = threshold;
     pl->edge_cap = (long long)edge_cap;
-    pl->max_degree = max_degree;
     pl->r = r;
     pl->fw = carve_fwd(r.fwd, p, M, N, (long long)edge_cap, use_factored(p, M, (long long)edge_cap, true));
     pl->edges_per_step = edges_per_step;
@@ -559,7 +519,7 @@ extern "C" int mdno_rollout(const mdno_kernelnn_params* p, float* traj, int M, i
     if (steps == 0) return MDNO_OK;
     mdno_rollout_plan* pl = nullptr;
     MDNO_TRY(mdno_rollout_plan_create(&pl, p, traj, M, W, N, steps, x_aminoacid, aa_per_member, threshold, edge_cap,
-                                      /*max_degree=*/0, workspace, workspace_bytes, edges_per_step, status, use_graph,
+                                      workspace, workspace_bytes, edges_per_step, status, use_graph,
                                       stream));
     int rc = mdno_rollout_plan_run(pl, 0, steps, stream);
     if (pl->exec) {

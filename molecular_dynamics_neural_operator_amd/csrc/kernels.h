@@ -99,24 +99,9 @@ bool split_linear_supported(long long rows, int N, int K);
 int split_linear(const float* a, const float* w, const float* bias, long long rows, int N, int K, int relu, float* c,
                  void* workspace, hipStream_t s);
 
-// Factored conv, source-side form on the exact fp32 MFMA (factored.hip: what gemm_mode F32 runs): see the file header.
-struct FactoredWs {
-    float *w3t, *y, *m, *q;
-    int* rev;
-    long long part_stride;
-};
-bool factored_supported(int width, int ker_width);
-size_t factored_workspace_bytes(int num_rows, int ker_width, long long edge_cap);
-FactoredWs factored_carve(void* ws, int num_rows, int ker_width, long long edge_cap);
-int factored_prepare_weights(const float* w3, int ker_width, const FactoredWs& f, hipStream_t s);
-int factored_prepare_graph(const int* row_ptr, const int* col, const int* rowid, int num_rows, long long edge_cap,
-                           const FactoredWs& f, int* status, hipStream_t s);
-int factored_conv(const float* x, const float* h2, const int* row_ptr, int num_rows, int max_degree, int ker_width,
-                  const float* b3, const float* root, const float* bias, int aggr, int relu, float* y,
-                  const FactoredWs& f, int* status, hipStream_t s);
-
-// Factored conv, destination-side form (moment.hip: S_t = sum_{e->t} x_src (x) h_e, then y_t = W3 : S_t) — what the
-// split GEMM modes run; factored.hip's source-side kernels remain for gemm_mode F32.
+// Factored conv, destination-side form (moment.hip: S_t = sum_{e->t} x_src (x) h_e, then y_t = W3 : S_t), the one
+// factored formulation: on three bf16 planes per operand for the split GEMM modes, on the fp32 MFMA for gemm_mode F32
+// (`exact_f32`: h2 is then the row-major fp32 [E, k] of the fp32 hidden GEMM instead of the k-tiled image).
 struct MomentWs {
     float *w3r, *s, *part;
     int* order;               // destinations of each S chunk by decreasing degree
@@ -129,7 +114,8 @@ int moment_prepare_weights(const float* w3, const float* b3, int ker_width, cons
 int moment_prepare_graph(const int* row_ptr, int num_rows, const MomentWs& f, hipStream_t s);
 // (the last MLP layer's bias b3 is part of W3R: moment_prepare_weights)
 int moment_conv(const float* x, const float* h2, const int* row_ptr, const int* src, int num_rows, int ker_width,
-                const float* root, const float* bias, int aggr, int relu, float* y, const MomentWs& f, hipStream_t s);
+                const float* root, const float* bias, int aggr, int relu, float* y, const MomentWs& f, hipStream_t s,
+                bool exact_f32 = false);
 
 // bf16 training GEMMs (gemm_bf16.hip): 256 x 256 tiles, 8 waves, two wave groups one phase apart over an
 // LDS-DMA ring of 32-k stages.

@@ -28,6 +28,7 @@
 // Fixed summation orders everywhere: a destination's result depends on its own edges only (bitwise the same alone or
 // in any batch), no float atomics.
 #include "kernels.h"
+#include "mfma_f32.h"
 #include "split_layout.h"
 
 namespace mdno {
@@ -128,6 +129,44 @@ constexpr int MO_XROW = 64 * 2 + 64;         // the same for the 64 feature colu
 constexpr int MO_HPLANE = MO_EDGES * MO_HROW, MO_XPLANE = MO_EDGES * MO_XROW;
 constexpr int MO_LDS = 3 * MO_HPLANE + 3 * MO_XPLANE;      // 36,864 B
 
+// One more workgroup per destination in K1's launch: s0_t[i] = sum_{e -> t} x_src(e)[i] (the b3 term's operand: the last
+// MLP layer's bias seen through the summed neighbours), stored as kappa = 64 K + i of the same image, so that K2
+// multiplies it with B3 like any other slice.  16 chains x 16 lanes (4 features each), four edges in flight per chain,
+// chains added in order: a fixed order.
+__device__ __forceinline__ void moment_s0(const int* __restrict__ row_ptr, const int* __restrict__ src,
+                                          const float* __restrict__ x, float* __restrict__ S, int K, int t, int tl) {
+    __shared__ float4 sred[16][16];
+    const int tid = threadIdx.x;
+    const int beg = row_ptr[t], end = row_ptr[t + 1];
+    const int es = tid >> 4, q = tid & 15;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = beg + es; p < end; p += 64) {
+        int sj[4];
+        bool on[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            on[u] = p + 16 * u < end;
+            sj[u] = on[u] ? src[p + 16 * u] : 0;
+        }
+        float4 g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            g[u] = on[u] ? *reinterpret_cast<const float4*>(x + (size_t)sj[u] * 64 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s0.x += g[u].x; s0.y += g[u].y; s0.z += g[u].z; s0.w += g[u].w; }
+    }
+    sred[es][q] = s0;
+    __syncthreads();
+    if (es == 0) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) { const float4 v = sred[c][q]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+        const int i = 4 * q;       // features 4q..4q+3: k-tile 64K/32 + (i >> 5), columns i & 31 ..
+        float* d = S + ((size_t)(tl >> 7) * moment_nkt(K) + (size_t)64 * K / 32 + (i >> 5)) * 4096 + (tl & 127) * 32 + (i & 31);
+        *reinterpret_cast<float4*>(d) = a;
+    }
+}
+
 // Grid: (destination within the chunk, visited by decreasing degree) x (k / 256).  S chunk layout: the fp32 k-tiled
 // image K2 streams, [node/128][64k/32][128][32] with kappa = i*k + c.
 __global__ __launch_bounds__(256, 3) void moment_kernel(const float* __restrict__ Hm,
@@ -149,38 +188,7 @@ __global__ __launch_bounds__(256, 3) void moment_kernel(const float* __restrict_
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nkt = K >> 5;
     if (cq == nq - 1) {
-        // one more workgroup per destination: s0_t[i] = sum_{e -> t} x_src(e)[i] (the b3 term's operand: the last MLP
-        // layer's bias seen through the summed neighbours), stored as kappa = 64 K + i of the same image, so that K2
-        // multiplies it with B3 like any other slice.  16 chains x 16 lanes (4 features each), four edges in flight
-        // per chain, chains added in order: a fixed order.
-        __shared__ float4 sred[16][16];
-        const int es = tid >> 4, q = tid & 15;
-        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int p = beg + es; p < end; p += 64) {
-            int sj[4];
-            bool on[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                on[u] = p + 16 * u < end;
-                sj[u] = on[u] ? src[p + 16 * u] : 0;
-            }
-            float4 g[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                g[u] = on[u] ? *reinterpret_cast<const float4*>(x + (size_t)sj[u] * 64 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { s0.x += g[u].x; s0.y += g[u].y; s0.z += g[u].z; s0.w += g[u].w; }
-        }
-        sred[es][q] = s0;
-        __syncthreads();
-        if (es == 0) {
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int c = 0; c < 16; ++c) { const float4 v = sred[c][q]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
-            const int i = 4 * q;       // features 4q..4q+3: k-tile 64K/32 + (i >> 5), columns i & 31 ..
-            float* d = S + ((size_t)(tl >> 7) * moment_nkt(K) + (size_t)64 * K / 32 + (i >> 5)) * 4096 + (tl & 127) * 32 + (i & 31);
-            *reinterpret_cast<float4*>(d) = a;
-        }
+        moment_s0(row_ptr, src, x, S, K, t, tl);
         return;
     }
     // ---- staging roles
@@ -284,6 +292,86 @@ __global__ __launch_bounds__(256, 3) void moment_kernel(const float* __restrict_
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
             const int c0 = cq * MO_CQ + wave * 64 + cb * 32;      // multiple of 32
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int i = ih * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const size_t kt = ((size_t)i * K + c0) >> 5;
+                Sb[kt * 4096] = acc[ih][cb][e];
+            }
+        }
+}
+
+// ---------------------------------------------------------------- K1, exact fp32 (gemm_mode F32)
+// The same workgroup shape and the same S image, on v_mfma_f32_32x32x2_f32 (an fp32 fmaf chain over a destination's
+// edges in edge order): H is the ROW-MAJOR fp32 [E, K] that the fp32 hidden GEMM writes (edge_mlp.hip), staged as fp32
+// rows of 256 + 32 floats (the two k rows of an MFMA step fall into different bank halves), the neighbours' feature
+// rows next to it.  Not a tuned path — F32 is the reference-arithmetic mode, ~16x the matrix-pipe time of the split
+// modes — but the same formulation on any destination-sorted graph.
+constexpr int MF_HLD = MO_CQ + 32, MF_XLD = 64 + 32;
+
+__global__ __launch_bounds__(256) void moment_f32_kernel(const float* __restrict__ Hm, const int* __restrict__ row_ptr,
+                                                         const int* __restrict__ src, const int* __restrict__ order,
+                                                         float* __restrict__ S, int K, int row0, int cnt,
+                                                         const float* __restrict__ x) {
+    __shared__ __attribute__((aligned(16))) float hs[MO_EDGES * MF_HLD];
+    __shared__ __attribute__((aligned(16))) float xs_[MO_EDGES * MF_XLD];
+    const int nq = (K + MO_CQ - 1) / MO_CQ + 1;
+    const int xcd = blockIdx.x & 7, rr = blockIdx.x >> 3;
+    const int cq = rr % nq, ti = (rr / nq) * 8 + xcd;
+    if (ti >= cnt) return;
+    const int tl = order[row0 + ti];
+    const int t = row0 + tl;
+    if (cq == nq - 1) {
+        moment_s0(row_ptr, src, x, S, K, t, tl);
+        return;
+    }
+    const int beg = row_ptr[t], end = row_ptr[t + 1];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int er = tid >> 4, cc = tid & 15;       // staging: edge er of the stage, columns u*64 + cc*4 (H) / cc*4 (X)
+    const int l31 = lane & 31, h = lane >> 5;
+    const bool wave_live = cq * MO_CQ + wave * 64 < K;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    for (int e0 = beg; e0 < end; e0 += MO_EDGES) {
+        const int e = e0 + er;
+        float4 rh[4], rx = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            rh[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int c = cq * MO_CQ + u * 64 + cc * 4;
+            if (e < end && c < K) rh[u] = *reinterpret_cast<const float4*>(Hm + (size_t)e * K + c);
+        }
+        if (e < end) rx = *reinterpret_cast<const float4*>(x + (size_t)src[e] * 64 + 4 * cc);
+        __syncthreads();      // (the previous stage's fragment reads are done)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<float4*>(&hs[er * MF_HLD + u * 64 + cc * 4]) = rh[u];
+        *reinterpret_cast<float4*>(&xs_[er * MF_XLD + cc * 4]) = rx;
+        __syncthreads();
+        if (wave_live) {
+#pragma unroll
+            for (int ks = 0; ks < MO_EDGES / 2; ++ks) {      // MFMA k-step = edges 2 ks + h
+                const float a0 = xs_[(2 * ks + h) * MF_XLD + l31], a1 = xs_[(2 * ks + h) * MF_XLD + 32 + l31];
+                const float b0 = hs[(2 * ks + h) * MF_HLD + wave * 64 + l31], b1 = hs[(2 * ks + h) * MF_HLD + wave * 64 + 32 + l31];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+        }
+    }
+    if (!wave_live) return;
+    float* Sb = S + (size_t)(tl >> 7) * moment_nkt(K) * 4096 + (tl & 127) * 32 + l31;
+#pragma unroll
+    for (int ih = 0; ih < 2; ++ih)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const int c0 = cq * MO_CQ + wave * 64 + cb * 32;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int i = ih * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -421,6 +509,55 @@ __global__ __launch_bounds__(PJ_ROWS * 2) void project_kernel(const float* __res
     }
 }
 
+// ---------------------------------------------------------------- K2, exact fp32 (gemm_mode F32)
+// Workgroup (one 128-row tile of the S image, K slice): the same slices and the same partials as project_kernel, the
+// products on v_mfma_f32_32x32x2_f32 (mfma_f32.h: fp32 K-tiles as LDS rows of 36 floats).
+__global__ __launch_bounds__(256) void project_f32_kernel(const float* __restrict__ S, const float* __restrict__ w3r,
+                                                          float* __restrict__ part, int K, int cnt, int row0,
+                                                          long long part_stride) {
+    using namespace f32mma;
+    __shared__ __attribute__((aligned(16))) float As[128 * LD];
+    __shared__ __attribute__((aligned(16))) float Bs[64 * LD];
+    const int ngrp = gridDim.x / PJ_SLICES;
+    const int xcd = blockIdx.x & 7, rr = blockIdx.x >> 3;
+    const int rg = rr % ngrp, slice = (rr / ngrp) * 8 + xcd;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int srow = tid >> 3, scol = (tid & 7) * 4;
+    const int nkt = (int)moment_nkt(K), per = (nkt - 2) / PJ_SLICES;
+    const int kt0 = slice * per, nk = per + (slice == PJ_SLICES - 1 ? 2 : 0);
+    const int first = rg * 128;
+    const float* Ag = S + ((size_t)rg * nkt + kt0) * 4096 + srow * 32 + scol;      // rows srow + 32 j
+    const float* Bg = w3r + (size_t)kt0 * 2048 + srow * 32 + scol;                 // rows srow, srow + 32
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+    for (int kt = 0; kt < nk; ++kt) {
+        float4 a[4], b[2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const float4*>(Ag + (size_t)kt * 4096 + j * 32 * 32);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const float4*>(Bg + (size_t)kt * 2048 + j * 32 * 32);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(&As[(srow + 32 * j) * LD + scol]) = a[j];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) *reinterpret_cast<float4*>(&Bs[(srow + 32 * j) * LD + scol]) = b[j];
+        __syncthreads();
+        mma_32x64(acc0, acc1, &As[(wave * 32 + l31) * LD + 4 * h], &Bs[l31 * LD + 4 * h]);
+    }
+    float* Po = part + (size_t)slice * part_stride;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int m = first + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (m < cnt) {
+            Po[(size_t)(row0 + m) * 64 + l31] = acc0[e];
+            Po[(size_t)(row0 + m) * 64 + 32 + l31] = acc1[e];
+        }
+    }
+}
+
 // ---------------------------------------------------------------- K3: slices + root + bias + mean + act
 // One workgroup (32 chains x 16 lanes) per destination: chain es adds K slices es, es+32, .. in that order, the 32
 // chains are added in chain order through LDS; the root product is split over the chains the same way.  Every load
@@ -535,20 +672,30 @@ int moment_prepare_graph(const int* row_ptr, int num_rows, const MomentWs& f, hi
 }
 
 int moment_conv(const float* x, const float* h2, const int* row_ptr, const int* src, int num_rows, int ker_width,
-                const float* root, const float* bias, int aggr, int relu, float* y, const MomentWs& f, hipStream_t s) {
+                const float* root, const float* bias, int aggr, int relu, float* y, const MomentWs& f, hipStream_t s,
+                bool exact_f32) {
     MDNO_REQUIRE(moment_supported(64, ker_width), MDNO_EUNSUPPORTED, "moment conv: ker_width=%d (x128)", ker_width);
     for (int r0 = 0; r0 < num_rows; r0 += kMomentChunkRows) {
         const int cnt = num_rows - r0 < kMomentChunkRows ? num_rows - r0 : kMomentChunkRows;
         {   // K1: the chunk's destinations x the k/256 column blocks
             TimedSection ts(KID_NNCONV, s);
             const int nq = (ker_width + MO_CQ - 1) / MO_CQ + 1;
-            hipLaunchKernelGGL(moment_kernel, dim3((unsigned)(((cnt + 7) / 8) * 8 * nq)), dim3(256), 0, s, h2, row_ptr, src,
-                               (const int*)f.order, f.s, ker_width, r0, cnt, x);
+            const dim3 grid((unsigned)(((cnt + 7) / 8) * 8 * nq));
+            if (exact_f32)      // h2: row-major fp32 [E, k] (the fp32 hidden GEMM's output)
+                hipLaunchKernelGGL(moment_f32_kernel, grid, dim3(256), 0, s, h2, row_ptr, src, (const int*)f.order, f.s,
+                                   ker_width, r0, cnt, x);
+            else                // h2: the k-tiled image the split hidden GEMM writes
+                hipLaunchKernelGGL(moment_kernel, grid, dim3(256), 0, s, h2, row_ptr, src, (const int*)f.order, f.s, ker_width,
+                                   r0, cnt, x);
         }
         {   // K2: groups of row tiles x K slices
             TimedSection ts(KID_FACT_Y, s);
-            hipLaunchKernelGGL(project_kernel<256>, dim3(((cnt + 255) / 256) * PJ_SLICES), dim3(512), 0, s, (const float*)f.s,
-                               (const float*)f.w3r, f.part, ker_width, cnt, r0, f.part_stride);
+            if (exact_f32)
+                hipLaunchKernelGGL(project_f32_kernel, dim3(((cnt + 127) / 128) * PJ_SLICES), dim3(256), 0, s, (const float*)f.s,
+                                   (const float*)f.w3r, f.part, ker_width, cnt, r0, f.part_stride);
+            else
+                hipLaunchKernelGGL(project_kernel<256>, dim3(((cnt + 255) / 256) * PJ_SLICES), dim3(512), 0, s, (const float*)f.s,
+                                   (const float*)f.w3r, f.part, ker_width, cnt, r0, f.part_stride);
         }
         {   // K3
             TimedSection ts(KID_NNCONV_COMBINE, s);

@@ -62,8 +62,32 @@ def _no_training(module: nn.Module) -> None:
 
 
 # --------------------------------------------------------------------------- loss
+class _LpLossRelFn(torch.autograd.Function):
+    """relative L2 loss of a batch and its MSE on the device (csrc/loss.hip): three small launches for what costs
+    ~15 ATen ones per training batch.  Returns (loss, mse); only `loss` is differentiable."""
+
+    @staticmethod
+    def forward(ctx, x, y, size_average):
+        from . import ops
+        x, y = x.contiguous(), y.contiguous()
+        res, stats = ops.lploss_rel_fwd(x, y, size_average)
+        ctx.save_for_backward(x, y, stats)
+        ctx.size_average = bool(size_average)
+        loss, mse = res[0], res[1]
+        ctx.mark_non_differentiable(mse)
+        return loss, mse
+
+    @staticmethod
+    def backward(ctx, g, _g_mse):
+        from . import ops
+        x, y, stats = ctx.saved_tensors
+        return ops.lploss_rel_bwd(x, y, stats, g, ctx.size_average), None, None
+
+
 class LpLoss(object):
-    """Relative / absolute Lp loss (graph_kernel.py:75-122); host-side torch, not a kernel."""
+    """Relative / absolute Lp loss (graph_kernel.py:75-122).  The form train() uses — `rel` with p = 2 and a reduction,
+    on device tensors (:462, :547) — runs in libmdno (`mdno_lploss_rel_fwd/_bwd`, fixed summation orders); every other
+    form (`abs`, p != 2, reduction=False, host tensors) is the reference's torch expression."""
 
     def __init__(self, d=2, p=2, size_average=True, reduction=True):
         assert d > 0 and p > 0
@@ -80,8 +104,18 @@ class LpLoss(object):
         norms = (h ** (self.d / self.p)) * torch.norm(x.reshape(n, -1) - y.reshape(n, -1), self.p, 1)
         return self._reduce(norms)
 
+    def rel_with_mse(self, x, y):
+        """(loss, F.mse_loss(x, y)) from one pass over the batch — what one iteration of train() computes
+        (graph_kernel.py:462-465); device tensors, p = 2, with reduction."""
+        n = x.size()[0]
+        if not (x.is_cuda and self.p == 2 and self.reduction and x.dtype == torch.float32):
+            return self.rel(x, y), torch.nn.functional.mse_loss(x.detach().reshape(n, -1), y.reshape(n, -1))
+        return _LpLossRelFn.apply(x.reshape(n, -1), y.to(x.device, torch.float32).reshape(n, -1), self.size_average)
+
     def rel(self, x, y):
         n = x.size()[0]
+        if x.is_cuda and self.p == 2 and self.reduction and x.dtype == torch.float32:
+            return _LpLossRelFn.apply(x.reshape(n, -1), y.to(x.device, torch.float32).reshape(n, -1), self.size_average)[0]
         diff = torch.norm(x.reshape(n, -1) - y.reshape(n, -1), self.p, 1)
         ynorm = torch.norm(y.reshape(n, -1), self.p, 1)
         return self._reduce(diff / ynorm)
@@ -243,19 +277,19 @@ class KernelNN(nn.Module):
         # GEMMs with fp32 accumulation; fp32 master parameters)
         self.train_precision = "fp32"
         # how conv applications run inside the on-device rollout / position-graph forward
-        # (include/mdno.h MDNO_CONV_*): "factored" = the reference's sums reassociated per node, W_e
-        # never formed (csrc/factored.hip; needs width 64 and a radius graph built by the library,
-        # otherwise the library itself runs materialized); "materialized" = the reference's W_e
-        # formulation; "auto" (default) = factored once the graph is large enough to pay for its fixed
-        # cost per application (edge capacity >= 24,576), materialized below.  forward(data) with an
-        # explicit edge_index/edge_attr follows the same rule on its counted graph (split GEMM modes).
+        # (include/mdno.h MDNO_CONV_*): "factored" = the reference's sums reassociated per destination
+        # node, W_e never formed (csrc/moment.hip; needs width 64 and ker_width % 128 == 0, otherwise the
+        # library itself runs materialized); "materialized" = the reference's W_e formulation; "auto"
+        # (default) = factored once the graph is large enough to pay for its fixed cost per application
+        # (edge capacity >= 24,576), materialized below.  forward(data) with an explicit
+        # edge_index/edge_attr follows the same rule on its counted graph.
         self.conv_mode = "auto"
 
     def __getstate__(self):
         # the cached ParamPack holds device pointers in a ctypes struct: never copied or pickled
         # (copy.deepcopy(model), torch.save(model)); it is rebuilt on first use
         state = self.__dict__.copy()
-        state["_pack"], state["_pack_key"] = None, None
+        state["_pack"], state["_pack_key"], state["_packs"] = None, None, {}
         return state
 
     # -- parameter pack (device pointers) cached until a parameter changes
@@ -274,21 +308,25 @@ class KernelNN(nn.Module):
         conv2 = getattr(self, "conv2", None)
         if conv2 is not None and conv2.net is not self.conv1.net:
             key += tuple(p._version for net in (self.conv1.net, conv2.net) for p in net.parameters())
-        if self._pack is None or self._pack_key != key:
-            self._pack = ops.ParamPack(self.state_dict(), self.depth, device, self.gemm_mode, conv_mode)
-            self._pack_key = key
-        return self._pack
+        # one pack per formulation: a model that serves both (the rollout engine's factored plan and explicit-edge
+        # forwards that resolve to materialized, say) does not rebuild either on every switch
+        packs = self.__dict__.setdefault("_packs", {})
+        hit = packs.get(conv_mode)
+        if hit is None or hit[0] != key:
+            hit = packs[conv_mode] = (key, ops.ParamPack(self.state_dict(), self.depth, device, self.gemm_mode, conv_mode))
+        self._pack, self._pack_key = hit[1], key
+        return hit[1]
 
     def _conv_mode_for_edges(self, device, members: int, n_atoms: int, n_edges: int) -> str:
         """Formulation for a forward on an explicit edge list.  "auto": the library's rule on the counted graph
         (mdno_conv_mode_for_graph: factored for dense graphs — mean degree >= 40 and >= 16,384 edges per member —,
-        materialized for protein-like chains).  The factored form of the split GEMM modes (csrc/moment.hip) takes any
-        edge list; gemm_mode "f32" has the source-side form only, which needs a library-built symmetric graph, so an
-        explicit edge list runs materialized there."""
-        if self.conv_mode == "materialized" or self.gemm_mode == "f32":
+        materialized for protein-like chains).  The factored form (csrc/moment.hip) takes any edge list."""
+        if self.conv_mode == "materialized":
             return "materialized"
         from . import _lib
-        pack = self.param_pack(device, conv_mode="factored")
+        # (the rule reads the GEMM mode and the dimensions only, not the pack's conv_mode: whichever pack is cached)
+        cached = next((v[1] for v in self.__dict__.get("_packs", {}).values()), None)
+        pack = cached if cached is not None and cached.gemm_mode == self.gemm_mode else self.param_pack(device, conv_mode="materialized")
         mode = int(_lib.load().mdno_conv_mode_for_graph(pack.ref, int(members), int(n_atoms), int(n_edges)))
         if self.conv_mode == "factored":      # asked for: taken wherever the model's dimensions allow it
             return "factored" if int(_lib.load().mdno_resolve_conv_mode(pack.ref, int(members), 1 << 40)) == _lib.CONV_MODES["factored"] \

@@ -23,7 +23,6 @@ class CSRGraph:
     edge_cap: int
     perm: Optional[torch.Tensor] = None   # i32 [E]: CSR position p holds input edge perm[p]
     status: Optional[torch.Tensor] = None
-    max_degree: int = 0                   # bound on any node's degree for the factored conv (0 = N)
     n_edges: Optional[int] = None         # the edge count when the host knows it (COO input): no device read
 
     def edge_count(self) -> int:
@@ -233,7 +232,7 @@ def kernelnn_forward(pack: ParamPack, frames: torch.Tensor, x_aminoacid: torch.T
                      return_latent: bool = False, workspace: Optional[torch.Tensor] = None,
                      check_status: bool = True) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """frames f32 [W,M,N,3] (time-major) -> out [M*N,out_width] (+ latent [M*N,width]).
-    The device status word (bad amino-acid id, edge overflow, asymmetric graph, ...) is read back and
+    The device status word (bad amino-acid id, edge overflow, bad edge index) is read back and
     raised after the call — the reference's nn.Embedding raises IndexError at that point; pass
     `check_status=False` to keep the call asynchronous and read `graph.status` yourself."""
     lib = _lib.load()
@@ -257,14 +256,10 @@ def kernelnn_forward(pack: ParamPack, frames: torch.Tensor, x_aminoacid: torch.T
     status = graph.status
     ea = f32(edge_attr) if edge_attr is not None else None
     ep = f32(edge_pos).reshape(-1, 3) if edge_pos is not None else None
-    if pack.conv_mode == "factored" and pack.gemm_mode == "f32" and (ea is not None or ep is None):
-        raise MdnoError("conv_mode='factored' with gemm_mode='f32' (the source-side form) needs a symmetric radius graph "
-                        "with position-derived attributes (edge_pos); explicit edge_attr runs it with a split gemm_mode "
-                        "or conv_mode='materialized'")
     if ea is None and ep is None:
         raise MdnoError("kernelnn_forward needs edge_pos (a library-built radius graph) or edge_attr")
     check(lib.mdno_kernelnn_fwd(pack.ref, ptr(frames), M, W, N, ptr(aa), aa_pm, ptr(graph.row_ptr), ptr(graph.src),
-                                ptr(graph.dst), ptr(graph.num_edges), graph.edge_cap, int(graph.max_degree), ptr(ep),
+                                ptr(graph.dst), ptr(graph.num_edges), graph.edge_cap, ptr(ep),
                                 ptr(ea),
                                 ptr(graph.perm) if ea is not None else None, ptr(out), ptr(latent), ptr(workspace),
                                 workspace.numel(), ptr(status), stream_ptr(dev)), "mdno_kernelnn_fwd")
@@ -708,3 +703,30 @@ def collate_samples(pos: torch.Tensor, rows: torch.Tensor, cols: torch.Tensor, m
                                    ptr(x_position), ptr(y), ptr(edge_index), ptr(edge_attr), stream_ptr(dev)),
           "mdno_collate_samples")
     return x_position, y, edge_index, edge_attr
+
+
+# ------------------------------------------------------------------------------------------------
+def lploss_rel_fwd(out: torch.Tensor, y: torch.Tensor, size_average: bool):
+    """LpLoss.rel, p = 2, and the batch MSE in one pass (include/mdno.h mdno_lploss_rel_fwd): out, y f32 [B, D] ->
+    (loss_mse f32 [2] = [loss, mse], stats f32 [B, 4] for the backward)."""
+    lib = _lib.load()
+    out, y = f32(out), f32(y)
+    if out.dim() != 2 or out.shape != y.shape:
+        raise MdnoError(f"lploss_rel: out {tuple(out.shape)} and y {tuple(y.shape)} must be the same [B, D]")
+    B, D = out.shape
+    stats = torch.empty((B, 4), dtype=torch.float32, device=out.device)
+    res = torch.empty(2, dtype=torch.float32, device=out.device)
+    check(lib.mdno_lploss_rel_fwd(ptr(out), ptr(y), B, D, int(bool(size_average)), ptr(stats), ptr(res),
+                                  stream_ptr(out.device)), "mdno_lploss_rel_fwd")
+    return res, stats
+
+
+def lploss_rel_bwd(out: torch.Tensor, y: torch.Tensor, stats: torch.Tensor, grad_loss, size_average: bool) -> torch.Tensor:
+    """d loss / d out (include/mdno.h mdno_lploss_rel_bwd); grad_loss: the f32 scalar tensor autograd hands down, or None."""
+    lib = _lib.load()
+    B, D = out.shape
+    g = torch.empty_like(out)
+    gl = None if grad_loss is None else f32(grad_loss).reshape(1)
+    check(lib.mdno_lploss_rel_bwd(ptr(out), ptr(y), ptr(stats), ptr(gl), B, D, int(bool(size_average)), ptr(g),
+                                  stream_ptr(out.device)), "mdno_lploss_rel_bwd")
+    return g

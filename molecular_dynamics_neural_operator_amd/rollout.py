@@ -19,8 +19,7 @@ from typing import List, Optional, Tuple
 import torch
 
 from . import _lib, ops
-from ._lib import (MdnoError, STATUS_DEGREE_OVERFLOW, STATUS_EDGE_OVERFLOW, check, f32, ptr, raise_on_status,
-                   require_gpu)
+from ._lib import MdnoError, STATUS_EDGE_OVERFLOW, check, f32, ptr, raise_on_status, require_gpu
 
 
 def default_edge_cap(members: int, n_atoms: int, threshold: float, density: float = 0.1, slack: float = 1.6) -> int:
@@ -45,8 +44,7 @@ class RolloutEngine:
     """Owns the trajectory buffer [W+max_steps, M, N, 3], the workspace and the captured step."""
 
     def __init__(self, model, members: int, n_atoms: int, window: int, threshold: float = 8.0,
-                 max_steps: int = 1000, edge_cap: Optional[int] = None, device=None, use_graph: bool = True,
-                 max_degree: int = 0):
+                 max_steps: int = 1000, edge_cap: Optional[int] = None, device=None, use_graph: bool = True):
         self.lib = _lib.load()
         self.device = require_gpu(device if device not in (None, "cuda") else None)
         self.model = model
@@ -59,7 +57,6 @@ class RolloutEngine:
         # the window the engine is reset with (4x its edges), and the workspace allocated then — W_e at N^2 edges
         # would be 16 GB at N = 1,000 for a chain that has 30,000
         self._fit_cap = edge_cap is None and self.M * self.N * self.N > 65536
-        self.max_degree = int(max_degree)      # factored conv grid bound; 0 = n_atoms (always safe)
         self.pack = model.param_pack(self.device) if hasattr(model, "param_pack") else model
         if not isinstance(self.pack, ops.ParamPack):
             raise MdnoError("model must be a KernelNN (or an ops.ParamPack)")
@@ -133,7 +130,7 @@ class RolloutEngine:
         aa_pm = int(self.aa.numel() == self.M * self.N and self.M > 1)
         check(self.lib.mdno_rollout_plan_create(
             C.byref(self.plan), self.pack.ref, ptr(self.traj), self.M, self.W, self.N, self.max_steps,
-            ptr(self.aa), aa_pm, self.threshold, self.edge_cap, self.max_degree, ptr(self.workspace),
+            ptr(self.aa), aa_pm, self.threshold, self.edge_cap, ptr(self.workspace),
             self.workspace.numel(),
             ptr(self.edges_per_step), ptr(self.status), int(self.use_graph), self.stream.cuda_stream),
             "mdno_rollout_plan_create")
@@ -183,13 +180,8 @@ class RolloutEngine:
         if self.M != 1 or self.steps_done != 0:
             raise MdnoError("first_step_from_sample: needs M == 1 and a freshly reset engine")
         graph = ops.coo_to_csr(edge_index.to(self.device), self.N)
-        # an explicit edge list: the engine's formulation where it takes one (the destination-side factored form of the
-        # split GEMM modes does; gemm_mode "f32" has the source-side form only: materialised there)
-        pack = self.pack
-        if pack.conv_mode != "materialized" and pack.gemm_mode == "f32":
-            pack = ops.ParamPack({v: pack.tensors[k] for k, v in ops.ParamPack.KEYS.items() if k in pack.tensors},
-                                 pack.struct.depth, self.device, pack.gemm_mode, "materialized")
-        out, _ = ops.kernelnn_forward(pack, self.traj[:self.W], self.aa, graph,
+        # an explicit edge list runs in the engine's own formulation (the factored form takes any destination-sorted graph)
+        out, _ = ops.kernelnn_forward(self.pack, self.traj[:self.W], self.aa, graph,
                                       edge_attr=edge_attr.to(self.device))
         self.traj[self.W, 0].copy_(out)
         self.edges_per_step[0] = int(edge_index.shape[1])
@@ -260,8 +252,6 @@ class RolloutEngine:
             st = self._grow_and_rerun(st)
         if st & STATUS_EDGE_OVERFLOW:
             raise MdnoError(f"radius graph exceeded edge_cap={self.edge_cap}; construct the engine with a larger cap")
-        if st & STATUS_DEGREE_OVERFLOW:
-            raise MdnoError(f"a node has more than max_degree={self.max_degree} edges; raise the bound (0 = n_atoms)")
         raise_on_status(st, "rollout")
 
     def run(self, window: torch.Tensor, x_aminoacid: torch.Tensor, steps: int) -> torch.Tensor:
@@ -295,7 +285,7 @@ class GroupedRolloutEngine:
     reset / step / synchronize / run / frames interface; `traj` and `edges_per_step` are assembled on access."""
 
     def __init__(self, model, members: int, n_atoms: int, window: int, threshold: float = 8.0, max_steps: int = 1000,
-                 edge_cap: Optional[int] = None, device=None, use_graph: bool = True, max_degree: int = 0, groups: int = 2):
+                 edge_cap: Optional[int] = None, device=None, use_graph: bool = True, groups: int = 2):
         self.M, self.N, self.W = int(members), int(n_atoms), int(window)
         g = max(1, min(int(groups), self.M))
         base, extra = divmod(self.M, g)
@@ -306,7 +296,7 @@ class GroupedRolloutEngine:
             lo = hi
         self.engines = [RolloutEngine(model, hi - lo, n_atoms, window, threshold, max_steps=max_steps,
                                       edge_cap=None if edge_cap is None else max(1, -(-int(edge_cap) * (hi - lo) // self.M)),
-                                      device=device, use_graph=use_graph, max_degree=max_degree) for lo, hi in self.bounds]
+                                      device=device, use_graph=use_graph) for lo, hi in self.bounds]
         self.device = self.engines[0].device
         self.max_steps = int(max_steps)
 

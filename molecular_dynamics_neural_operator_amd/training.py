@@ -315,6 +315,7 @@ def train_epoch(model, batches, optimizer, loss_fn, batch_size: Optional[int] = 
     double precision in batch order, which is what `avg_loss += l2.item()` does."""
     model.train()
     losses, mses = [], []
+    one = None
     for batch in batches:
         if isinstance(batch, PairData):
             B = batch_size or getattr(batch, "num_graphs", 1)
@@ -323,17 +324,23 @@ def train_epoch(model, batches, optimizer, loss_fn, batch_size: Optional[int] = 
         optimizer.zero_grad()
         out = train_forward(model, batch)
         y = torch.cat([s.y for s in batch]).to(out.device) if not isinstance(batch, PairData) else batch.y.to(out.device)
-        l2 = loss_fn(out.view(B, -1), y.view(B, -1))
-        l2.backward()
+        if hasattr(loss_fn, "rel_with_mse"):      # LpLoss: loss and the logged MSE from one pass (csrc/loss.hip)
+            l2, mse = loss_fn.rel_with_mse(out.view(B, -1), y.view(B, -1))
+        else:
+            l2, mse = loss_fn(out.view(B, -1), y.view(B, -1)), F.mse_loss(out.detach(), y)
+        if one is None or one.device != l2.device:
+            one = torch.ones((), dtype=l2.dtype, device=l2.device)      # d loss / d loss, made once (not a fill per batch)
+        l2.backward(one)
         optimizer.step()
         losses.append(l2.detach())
-        mses.append(F.mse_loss(out.detach(), y))
+        mses.append(mse)
     check_train_status(model)
     n = len(losses)
     if n == 0:
         return 0.0, 0.0
-    tot = float(torch.stack(losses).double().cpu().sum())
-    tot_mse = float(torch.stack(mses).double().cpu().sum())
+    # one device->host copy per value once the pass is over, added in double precision in batch order
+    tot = sum(float(v) for v in losses)
+    tot_mse = sum(float(v) for v in mses)
     return tot / n, tot_mse / n
 
 
@@ -362,14 +369,18 @@ def validate_epoch(model, batches, loss_fn, batch_size: Optional[int] = None):
                     B = len(batch)
                     y = torch.cat([s.y for s in batch]).to(dev)
                 out = model(batch, _status=status)
-                losses.append(loss_fn(out.view(B, -1), y.view(B, -1)))
-                mses.append(F.mse_loss(out, y))
+                if hasattr(loss_fn, "rel_with_mse"):
+                    l2, mse = loss_fn.rel_with_mse(out.view(B, -1), y.view(B, -1))
+                else:
+                    l2, mse = loss_fn(out.view(B, -1), y.view(B, -1)), F.mse_loss(out, y)
+                losses.append(l2)
+                mses.append(mse)
         check_train_status(model)
     finally:
         model.train(was_training)
     n = len(losses)
     if n == 0:
         return 0.0, 0.0
-    tot = float(torch.stack(losses).double().cpu().sum())
-    tot_mse = float(torch.stack(mses).double().cpu().sum())
+    tot = sum(float(v) for v in losses)
+    tot_mse = sum(float(v) for v in mses)
     return tot / n, tot_mse / n

@@ -25,7 +25,6 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--atoms", type=int, default=50000)
 ap.add_argument("--cutoff", type=float, default=10.0)
 ap.add_argument("--steps", type=int, default=2)
-ap.add_argument("--max-degree", type=int, default=768)
 ap.add_argument("--slice-edges", type=int, default=2_000_000)
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -79,8 +78,7 @@ model = KernelNN(64, 1024, 6, 6, 7, 3, 20, 4)
 model.load_state_dict(sd)
 model.eval().to(dev)
 model.conv_mode = "factored"
-eng = RolloutEngine(model, 1, N, W, a.cutoff, max_steps=a.steps + 1, edge_cap=int(E * 1.05), device=dev,
-                    max_degree=a.max_degree)
+eng = RolloutEngine(model, 1, N, W, a.cutoff, max_steps=a.steps + 1, edge_cap=int(E * 1.05), device=dev)
 print(f"workspace {eng.workspace.numel() / 2**30:.1f} GiB", flush=True)
 eng.reset(torch.from_numpy(win), aa)
 eng.step(1)

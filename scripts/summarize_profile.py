@@ -20,7 +20,7 @@ from collections import defaultdict
 from pathlib import Path
 
 src = Path(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof")
-tag = sys.argv[2] if len(sys.argv) > 2 else "r04"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r05"
 out = Path("profiles")
 out.mkdir(exist_ok=True)
 
@@ -48,6 +48,18 @@ def kernel_stats(sub, dest):
             w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
                         r["MinNs"], r["MaxNs"], r["StdDev"]])
     print("wrote", dest)
+
+
+def trace_avg_us(sub, kernel):
+    """average duration (us) of the kernel whose short name starts with `kernel` in that trace's kernel_stats, or None"""
+    stats = glob.glob(str(src / sub / "*" / "*_kernel_stats.csv"))
+    if not stats:
+        return None
+    rows = [r for r in csv.DictReader(open(newest(stats))) if short(r["Name"]).startswith(kernel)]
+    if not rows:
+        return None
+    r = max(rows, key=lambda r_: float(r_["TotalDurationNs"]))      # (template variants: the one the run spent its time in)
+    return float(r["AverageNs"]) / 1e3
 
 
 def last_json_line(path):
@@ -97,9 +109,20 @@ for M in (1, 8):
         launches_per_app = 1
         if kernel == "moment_kernel":
             launches_per_app = -(-c.get("members_in_the_profiled_group", c["members_this_rank"]) * c["atoms"] // 512)
-        traffic.append({"kernel": kernel, "atoms": c["atoms"], "members": c.get("members_in_the_profiled_group", c["members_this_rank"]), "conv_mode": conv_mode,
-                        "gemm_mode": c["edge_mlp_gemm"], "hbm_bytes_per_launch": per_launch * launches_per_app,
-                        "launches_per_application": launches_per_app, "source": f"profiles/{tag}_m{M}_pmc.json"})
+        ent = {"kernel": kernel, "atoms": c["atoms"], "members": c.get("members_in_the_profiled_group", c["members_this_rank"]), "conv_mode": conv_mode,
+               "gemm_mode": c["edge_mlp_gemm"], "hbm_bytes_per_launch": per_launch * launches_per_app,
+               "launches_per_application": launches_per_app, "source": f"profiles/{tag}_m{M}_pmc.json",
+               "rocprof_avg_us": trace_avg_us(f"trace_m{M}", kernel), "rocprof_source": f"profiles/{tag}_m{M}_kernel_stats.csv"}
+        if kernel == "moment_kernel":      # the whole conv application: K1 + K2 + K3 (S and the partials are its intermediates)
+            tot, parts = 0.0, {}
+            for kn in ("moment_kernel", "project_kernel", "finish_kernel"):
+                nm = next((n for n in pmc if n.startswith(kn) and "hbm_bytes_per_launch_corrected" in pmc[n]), None)
+                if nm is not None:
+                    parts[kn] = pmc[nm]["hbm_bytes_per_launch_corrected"] * launches_per_app
+                    tot += parts[kn]
+            if len(parts) == 3:
+                ent["application_hbm_bytes"], ent["application_hbm_bytes_by_kernel"] = tot, parts
+        traffic.append(ent)
 
 
 # shape C (N = 50,000): the factored conv's K1 (csrc/moment.hip) per conv application (one launch per 512 destinations) and the materialised conv
@@ -175,7 +198,8 @@ if tj is not None:
 if traffic:
     (out / "roofline_traffic.json").write_text(json.dumps(
         {"note": "2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 read-side correction), separate --pmc passes; bytes per "
-                 "conv application (all chunk launches of the per-source GEMM)", "configs": traffic}, indent=1))
+                 "conv application (all chunk launches of K1, csrc/moment.hip); rocprof_avg_us = the kernel's average in the same "
+                 "collection's kernel trace", "configs": traffic}, indent=1))
     print("wrote profiles/roofline_traffic.json")
 for leg, name in (("train_fp32", "train_fp32"), ("shape_a", "shapeA_m1"), ("shape_c", "shapeC")):
     if (src / f"{leg}_trace").exists():

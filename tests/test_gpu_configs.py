@@ -656,7 +656,6 @@ def test_cfg5_50k_atoms_one_factored_step(dev):
     model = KernelNN(64, 1024, 6, 6, 7, 3, 20, 4)
     model.load_state_dict(sd)
     model.eval().to(dev)
-    g.max_degree = 768
     win = torch.from_numpy(syn.jitter_window(frame, W, sigma=0.01, seed=3)).to(dev)
     win[-1] = pos                                                          # the graph's frame is the last one
     aa = torch.from_numpy(syn.amino_acids(N, seed=3)).to(dev)

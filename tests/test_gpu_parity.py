@@ -716,37 +716,24 @@ def test_factored_conv_matches_materialized_and_reference(dev):
         res[mode] = (eng.run(tm, aa, steps).clone(), eng.edges_per_step.clone())
     assert torch.equal(res["materialized"][1], res["factored"][1])
     close(res["factored"][0], res["materialized"][0])
-    # max_degree: the destination-side form (split GEMM modes, csrc/moment.hip) has no degree tiles — a node's edges are
-    # the contraction length — so the bound is irrelevant there; the source-side fp32 form (gemm_mode "f32") honours it
-    # in 128-edge tiles and flags a bound that is too small instead of truncating (200 atoms in a 12.6 A box have
-    # ~150 neighbours each)
+    # a node's edges are the contraction length of the factored form (csrc/moment.hip): any degree, no bound to give
+    # (200 atoms in a 12.6 A box have ~150 neighbours each); the exact-fp32 twin (gemm_mode "f32") agrees
     small.conv_mode = "factored"
-    from molecular_dynamics_neural_operator_amd import MdnoError
     big = syn.jitter_window(syn.box_frame(200, seed=8), W, seed=8)
     aa_big = torch.from_numpy(syn.amino_acids(200, seed=8))
-    eng = RolloutEngine(small, 1, 200, W, 8.0, max_steps=2, device=dev, max_degree=64)
-    tight = eng.run(torch.from_numpy(big), aa_big, 2).clone()
-    eng = RolloutEngine(small, 1, 200, W, 8.0, max_steps=2, device=dev, max_degree=200)
-    assert torch.equal(eng.run(torch.from_numpy(big), aa_big, 2), tight)
+    eng = RolloutEngine(small, 1, 200, W, 8.0, max_steps=2, device=dev)
+    split = eng.run(torch.from_numpy(big), aa_big, 2).clone()
     small.gemm_mode = "f32"
-    eng = RolloutEngine(small, 1, 200, W, 8.0, max_steps=2, device=dev, max_degree=64)
-    with pytest.raises(MdnoError, match="max_degree"):
-        eng.run(torch.from_numpy(big), aa_big, 2)
-    eng = RolloutEngine(small, 1, 200, W, 8.0, max_steps=2, device=dev, max_degree=200)
-    close(eng.run(torch.from_numpy(big), aa_big, 2), tight)
+    eng = RolloutEngine(small, 1, 200, W, 8.0, max_steps=2, device=dev)
+    assert eng.conv_mode == "factored"
+    close(eng.run(torch.from_numpy(big), aa_big, 2), split)
     small.gemm_mode = "split_f16"
-    # explicit edge_attr + factored pack: the destination-side form (split GEMM modes) takes it — tested in
-    # test_factored_conv_on_an_arbitrary_edge_list —, the source-side fp32 form refuses it instead of rerouting
-    model.gemm_mode = "f32"
-    with pytest.raises(MdnoError):
-        ops.kernelnn_forward(model.param_pack(dev, conv_mode="factored"), frames.unsqueeze(1), t(z["x_aminoacid"]), g,
-                             edge_attr=torch.zeros(g.edge_count(), 6, device=dev))
 
 
-@pytest.mark.parametrize("gemm_mode", ["split_f16", "split_bf16"])
+@pytest.mark.parametrize("gemm_mode", ["split_f16", "split_bf16", "f32"])
 def test_factored_conv_on_an_arbitrary_edge_list(dev, O, gemm_mode):
-    """The destination-side factored form (csrc/moment.hip) needs no symmetric graph and no position-derived
-    attributes: a forward on a random DIRECTED edge list with duplicates, a hub, nodes without in-edges and arbitrary
+    """The factored form (csrc/moment.hip; three bf16 planes or, for gemm_mode "f32", the fp32 MFMA) needs no symmetric
+    graph and no position-derived attributes: a forward on a random DIRECTED edge list with duplicates, a hub, nodes without in-edges and arbitrary
     edge attributes, two members, against the oracle's per-edge formulation and against the materialised path."""
     from molecular_dynamics_neural_operator_amd import ops
     from molecular_dynamics_neural_operator_amd.dataset import PairData
@@ -781,11 +768,6 @@ def test_factored_conv_on_an_arbitrary_edge_list(dev, O, gemm_mode):
     want = torch.cat([O.kernelnn_forward(sd, s_.x_position.cpu(), s_.x_aminoacid.cpu(), s_.edge_index.cpu(), s_.edge_attr.cpu(), 2,
                                          hoist=True) for s_ in samples])
     close(res["factored"], want, name=f"factored vs oracle, arbitrary graph {gemm_mode}")
-    # gemm_mode "f32" has the source-side form only: an explicit edge list runs materialised there
-    model.gemm_mode, model.conv_mode = "f32", "factored"
-    assert model._conv_mode_for_edges(dev, 2, N, 2 * E) == "materialized"
-    with torch.no_grad():
-        close(model(samples), want, name="f32, arbitrary graph")
 
 
 def test_edge_cases_single_atom_window1_zero_steps_and_c_rollout(dev, O):
@@ -917,8 +899,7 @@ def test_factored_conv_large_member_source_major_order(dev):
     out = {}
     for conv in ("materialized", "factored"):
         model.conv_mode = conv
-        eng = RolloutEngine(model, 1, N, W, 8.0, max_steps=steps, edge_cap=default_edge_cap(1, N, 8.0), device=dev,
-                            max_degree=512)       # 1,100 x 8 slots = 8,800 workgroups: source-major
+        eng = RolloutEngine(model, 1, N, W, 8.0, max_steps=steps, edge_cap=default_edge_cap(1, N, 8.0), device=dev)
         out[conv] = eng.run(win, aa, steps).clone()
         assert int(eng.edges_per_step.max()) > 128 * N * 0.9          # most sources have a second tile
     close(out["factored"], out["materialized"])

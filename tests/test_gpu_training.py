@@ -753,3 +753,129 @@ def test_gemm_atb_split_f16_columns_of_any_magnitude(dev):
     assert float(ops.gemm_atb(a.to(dev), b.to(dev), gemm_mode="split_f16")[7].abs().max()) == 0.0
     # two runs, same bits (slabs are added in a fixed order)
     assert torch.equal(ops.gemm_atb(a.to(dev), b.to(dev), gemm_mode="split_f16"), ops.gemm_atb(a.to(dev), b.to(dev), gemm_mode="split_f16"))
+
+
+# ------------------------------------------------------------------------------- optimiser trajectory (cfg4)
+def _oracle_adam_trajectory(step_fn, sd0, batches, depth, lr, weight_decay, step_size, gamma):
+    """The reference's epoch loop (graph_kernel.py:583-622: train() over the loader, then scheduler.step())
+    with one batch per epoch, on the HOST in fp64: `step_fn` (the oracle's train step, or its bf16-storage
+    replica) gives loss and gradients, torch.optim.Adam + StepLR (:541-546) move fp64 copies of the
+    parameters.  conv1.net and conv2.net are one module in the reference (:271-273): one set of tensors."""
+    p = {k: v.detach().double().clone().requires_grad_(True) for k, v in sd0.items() if not k.startswith("conv2.net.")}
+    opt = torch.optim.Adam(list(p.values()), lr=lr, weight_decay=weight_decay)
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=step_size, gamma=gamma)
+    losses, lrs = [], []
+    for samples in batches:
+        sd = {k: v.detach() for k, v in p.items()}
+        loss, _, g = step_fn(sd, samples)
+        opt.zero_grad()
+        for k, v in p.items():
+            v.grad = g[k].detach().double().clone()
+        opt.step()
+        lrs.append(opt.param_groups[0]["lr"])
+        sched.step()
+        losses.append(loss)
+    final = {k: v.detach() for k, v in p.items()}
+    for k in list(final):
+        if k.startswith("conv1.net."):
+            final["conv2.net." + k[len("conv1.net."):]] = final[k]
+    return losses, final, lrs
+
+
+@pytest.mark.parametrize("precision,lr,tol_loss,tol_param", [("fp32", 3e-4, 1e-5, 1e-4), ("fp32", 1e-2, 1e-3, 1e-2),
+                                                             ("bf16", 3e-4, 1e-3, 2e-2)])
+def test_adam_trajectory_vs_oracle(dev, O, tmp_path, precision, lr, tol_loss, tol_param):
+    """SURVEY.md §8(d) cfg4, "loss ... vs the CPU restatement" over a multi-step optimiser trajectory: six epochs
+    of one batch of 4 dataset samples through training.train_epoch with the reference's optimiser set-up —
+    Adam(lr, weight_decay 5e-4) + StepLR(step_size 2, gamma 0.8), scheduler.step() after every epoch
+    (graph_kernel.py:445-474, 541-546, 622), so two decays land inside — at width 64, k = 128, depth 2.  The same
+    loop runs on the host in fp64 over the oracle's train step.
+      fp32 (GEMM mode split_f16), lr 3e-4: a smooth descent (4.02 -> 2.33); every epoch's loss within 1e-5 of the
+           oracle's, the final parameters within 1e-4 (relative L2 per tensor).
+      fp32, lr 0.01 (the reference's CLI default, graph_kernel.py:319): at this model size the first Adam step
+           moves every weight by 0.01 and the second epoch's loss is 5,641 — the map from parameters to the next
+           loss amplifies a 1e-7 perturbation of the start 50x (measured on the oracle itself), so the bar is 1e-3.
+      bf16, lr 3e-4: against the replica with the device's bf16 storage roundings (tests/bf16_replica.py), 1e-3."""
+    from molecular_dynamics_neural_operator_amd.dataset import ContactMapDataset
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN, LpLoss
+    from molecular_dynamics_neural_operator_amd.training import train_epoch
+    z = load_golden("rollout_20.npz")
+    path = tmp_path / "traj.npz"
+    write_golden_trajectory(path, z)
+    dset = ContactMapDataset(str(path), window_size=int(z["window"]), horizon=1)
+    epochs, B, depth = 6, 4, 2
+    wd, step_size, gamma = 5e-4, 2, 0.8
+    idx = [[(4 * e + 3 * j) % len(dset) for j in range(B)] for e in range(epochs)]
+    torch.manual_seed(11)
+    model = KernelNN(64, 128, depth, 6, 7, 3, 20, 4)
+    with torch.no_grad():
+        for p_ in model.conv1.net.layers[4].parameters():
+            p_.mul_(0.2)
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.to(dev)
+    model.gemm_mode, model.train_precision = "split_f16", precision
+    opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=wd)
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=step_size, gamma=gamma)
+    got, got_lr = [], []
+    for e in range(epochs):
+        loss, _ = train_epoch(model, [[dset[i] for i in idx[e]]], opt, LpLoss(size_average=False))
+        got_lr.append(opt.param_groups[0]["lr"])
+        sched.step()
+        got.append(loss)
+    if precision == "bf16":
+        from bf16_replica import train_step_bf16
+        step_fn = lambda sd, samples: train_step_bf16(O, sd, _as_dicts(samples), depth)        # noqa: E731
+    else:
+        step_fn = lambda sd, samples: O.train_step(sd, _as_dicts(samples), depth)              # noqa: E731
+    want, final, want_lr = _oracle_adam_trajectory(step_fn, sd0, [[dset[i] for i in idx[e]] for e in range(epochs)],
+                                                    depth, lr, wd, step_size, gamma)
+    assert got_lr == pytest.approx(want_lr) and got_lr[0] == lr and got_lr[-1] == pytest.approx(lr * gamma ** 2)
+    rel = [abs(a - b) / abs(b) for a, b in zip(got, want)]
+    print(precision, "loss per epoch", [f"{v:.6f}" for v in got], "rel. to the oracle", [f"{v:.1e}" for v in rel])
+    assert abs(want[-1] - want[0]) > 0.05 * want[0]          # the trajectory is a real one: the loss moves
+    assert max(rel) < tol_loss, rel
+    now = model.state_dict()
+    errs = {k: rel_err(now[k], final[k]) for k in final}
+    print(precision, "final parameters, rel. L2 vs the oracle:", {k: f"{v:.1e}" for k, v in errs.items()})
+    assert max(errs.values()) < tol_param, errs
+
+
+@pytest.mark.parametrize("B,D,size_average", [(1, 84, False), (4, 84, True), (128, 84, False), (37, 1512, False), (300, 3, True)])
+def test_lploss_rel_on_device_vs_oracle(dev, O, B, D, size_average):
+    """LpLoss.rel (p = 2) on device tensors runs in libmdno (csrc/loss.hip): loss, gradient and the batch MSE against
+    the oracle's lp_loss_rel / torch autograd in fp64 (graph_kernel.py:105-119, 462-465); a sample that is hit
+    exactly gets a zero gradient (torch.norm's subgradient); an upstream gradient scales the result; bitwise
+    reproducible."""
+    from molecular_dynamics_neural_operator_amd.graph_kernel import LpLoss
+    g = torch.Generator().manual_seed(B * 1000 + D)
+    y = torch.randn(B, D, generator=g) * 5.0
+    x = y + 0.3 * torch.randn(B, D, generator=g)
+    if B > 2:
+        x[1] = y[1]                                                  # an exact hit
+    xd = x.to(dev).requires_grad_(True)
+    fn = LpLoss(size_average=size_average)
+    loss, mse = fn.rel_with_mse(xd, y.to(dev))
+    assert loss.dim() == 0 and not mse.requires_grad
+    (loss * 3.0).backward()
+    x64 = x.double().requires_grad_(True)
+    want = O.lp_loss_rel(x64, y.double(), size_average=size_average)
+    (want * 3.0).backward()
+    assert float(loss) == pytest.approx(float(want), rel=2e-6)
+    assert float(mse) == pytest.approx(float(((x.double() - y.double()) ** 2).mean()), rel=2e-6)
+    assert rel_err(xd.grad, x64.grad) < 2e-6
+    if B > 2:
+        assert float(xd.grad[1].abs().max()) == 0.0
+    assert float(fn(xd.detach(), y.to(dev))) == float(loss)          # __call__ == rel, same bits on a second run
+    # the other forms stay the reference's torch expressions
+    per_sample = LpLoss(reduction=False)(xd.detach(), y.to(dev))
+    assert per_sample.shape == (B,)
+    torch.testing.assert_close(per_sample.cpu().double(), O.lp_loss_rel(x.double(), y.double(), reduction=False), rtol=1e-5, atol=0)
+
+
+def test_lploss_reference_golden_on_device(dev):
+    """tests/golden/lploss.npz (the reference's own LpLoss, oracle/gen_golden.py) through the device op."""
+    from molecular_dynamics_neural_operator_amd.graph_kernel import LpLoss
+    z = load_golden("lploss.npz")
+    x, y = torch.from_numpy(z["x"]).to(dev), torch.from_numpy(z["y"]).to(dev)
+    torch.testing.assert_close(LpLoss(size_average=False)(x, y).cpu(), torch.from_numpy(z["rel_sum"]), rtol=2e-6, atol=0)
+    torch.testing.assert_close(LpLoss(size_average=True)(x, y).cpu(), torch.from_numpy(z["rel_mean"]), rtol=2e-6, atol=0)

@@ -265,6 +265,11 @@ int mdno_rollout_plan_create(mdno_rollout_plan** plan, const mdno_kernelnn_param
                              int64_t edge_cap, void* workspace, size_t workspace_bytes,
                              int32_t* edges_per_step, int32_t* status, int use_graph, void* stream);
 int mdno_rollout_plan_run(mdno_rollout_plan* plan, int start_step, int steps, void* stream);
+/* How the plan replays: 0 = plain launches (no graph), 1 = one captured step per graph launch, 8 = eight steps per
+ * graph launch (short chains, M*N <= 128 rows, whose step is a few dozen launches of a few microseconds; ranges that
+ * are no multiple of 8 finish on the one-step graph).  If the eight-step capture fails at creation the plan falls
+ * back to 1 and says so once on stderr. */
+int mdno_rollout_plan_steps_per_launch(mdno_rollout_plan* plan);
 int mdno_rollout_plan_destroy(mdno_rollout_plan* plan);
 
 /* Measurement aid (bench.py roofline leg): with a timer attached, plan_run issues plain launches

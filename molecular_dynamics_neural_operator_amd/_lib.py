@@ -71,6 +71,7 @@ SIGNATURES = {
     "mdno_rollout_plan_create": (_I, [C.POINTER(_P), C.POINTER(KernelNNParams), _P, _I, _I, _I, _I, _P, _I, _D, _L,
                                       _P, _SZ, _P, _P, _I, _P]),
     "mdno_rollout_plan_run": (_I, [_P, _I, _I, _P]),
+    "mdno_rollout_plan_steps_per_launch": (_I, [_P]),
     "mdno_rollout_plan_destroy": (_I, [_P]),
     "mdno_rollout_plan_timer_attach": (_I, [_P, _I]),
     "mdno_rollout_plan_timer_read": (_I, [_P, _I, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -411,7 +411,12 @@ extern "C" int mdno_rollout_plan_create(mdno_rollout_plan** plan, const mdno_ker
         // a short chain's step is a few dozen launches of a few microseconds: several steps per graph launch
         if (rc == MDNO_OK && max_steps >= kStepsPerGraph && step_head_small_supported(M, N) &&
             capture_steps(pl, s, kStepsPerGraph, &pl->graph_n, &pl->exec_n) != MDNO_OK) {
-            // the many-steps graph is an optimisation: without it the single-step graph above replays every step
+            // the many-steps graph is an optimisation: without it the single-step graph above replays every step.  Said
+            // once on stderr (a short chain then runs at a fraction of its rate) and visible to the caller through
+            // mdno_rollout_plan_steps_per_launch; the plan itself is good, so the error string is not left behind
+            fprintf(stderr, "libmdno: the %d-steps-per-launch graph could not be built (%s); replaying single steps\n",
+                    kStepsPerGraph, mdno_last_error());
+            set_error("%s", "");
             pl->graph_n = nullptr;
             pl->exec_n = nullptr;
         }
@@ -422,6 +427,12 @@ extern "C" int mdno_rollout_plan_create(mdno_rollout_plan** plan, const mdno_ker
     }
     *plan = pl;
     return MDNO_OK;
+}
+
+extern "C" int mdno_rollout_plan_steps_per_launch(mdno_rollout_plan* plan) {
+    if (plan == nullptr) return 0;
+    if (plan->exec_n != nullptr) return kStepsPerGraph;
+    return plan->exec != nullptr ? 1 : 0;
 }
 
 extern "C" int mdno_rollout_plan_run(mdno_rollout_plan* pl, int start_step, int steps, void* stream) {

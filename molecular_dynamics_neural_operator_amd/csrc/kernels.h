@@ -105,6 +105,7 @@ int split_linear(const float* a, const float* w, const float* bias, long long ro
 struct MomentWs {
     float *w3r, *s, *part;
     int* order;               // destinations of each S chunk by decreasing degree
+    int* done;                // EXPERIMENT (K2 fold): one counter per 256-row group
     long long part_stride;
 };
 bool moment_supported(int width, int ker_width);

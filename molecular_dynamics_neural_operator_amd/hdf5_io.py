@@ -64,7 +64,12 @@ def library_path() -> Optional[str]:
 
 
 def available() -> bool:
-    return library_path() is not None
+    """An HDF5 C library is present AND binds (every symbol this module uses; version >= 1.10)."""
+    try:
+        _load()
+        return True
+    except Hdf5Error:
+        return False
 
 
 def _load():
@@ -77,7 +82,10 @@ def _load():
     lib = C.CDLL(path)
 
     def sig(name, res, *args):
-        f = getattr(lib, name)
+        try:
+            f = getattr(lib, name)
+        except AttributeError:
+            raise Hdf5Error(f"{path}: no symbol {name} (an HDF5 build this binding does not cover)") from None
         f.restype, f.argtypes = res, list(args)
         return f
 
@@ -95,7 +103,12 @@ def _load():
     sig("H5Dget_type", hid_t, hid_t)
     sig("H5Dread", C.c_int, hid_t, hid_t, hid_t, hid_t, hid_t, C.c_void_p)
     sig("H5Dwrite", C.c_int, hid_t, hid_t, hid_t, hid_t, hid_t, C.c_void_p)
-    sig("H5Dvlen_reclaim", C.c_int, hid_t, hid_t, hid_t, C.c_void_p)
+    # variable-length rows are freed by H5Treclaim (1.12+); H5Dvlen_reclaim is its deprecated predecessor, absent
+    # from libraries built without deprecated symbols and from HDF5 2.x — same signature either way
+    try:
+        lib._mdno_reclaim = sig("H5Treclaim", C.c_int, hid_t, hid_t, hid_t, C.c_void_p)
+    except Hdf5Error:
+        lib._mdno_reclaim = sig("H5Dvlen_reclaim", C.c_int, hid_t, hid_t, hid_t, C.c_void_p)
     sig("H5Screate_simple", hid_t, C.c_int, C.POINTER(hsize_t), C.POINTER(hsize_t))
     sig("H5Sget_simple_extent_ndims", C.c_int, hid_t)
     sig("H5Sget_simple_extent_dims", C.c_int, hid_t, C.POINTER(hsize_t), C.POINTER(hsize_t))
@@ -197,7 +210,7 @@ def _read_one(lib, f, name, path):
                 rows[i] = (np.frombuffer((C.c_char * (ln * dt.itemsize)).from_address(buf[i].p), dtype=dt).copy()
                            if ln else np.zeros(0, dt))
             if count:
-                lib.H5Dvlen_reclaim(mt, sp, _H5P_DEFAULT, buf)      # the library allocated the rows
+                lib._mdno_reclaim(mt, sp, _H5P_DEFAULT, buf)      # the library allocated the rows
             return rows.reshape(shape) if shape else rows[0]
         dt = _np_dtype(lib, mt)
         arr = np.empty(shape, dtype=dt)

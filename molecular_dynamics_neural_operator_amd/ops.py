@@ -86,7 +86,7 @@ def coo_to_csr(edge_index: torch.Tensor, num_nodes: int, validate: bool = True,
     if validate:
         raise_on_status(status.item(), "coo_to_csr")
     ne = torch.full((1,), E, dtype=torch.int32, device=dev)
-    return CSRGraph(row_ptr, src, dst, ne, cap, perm, status, 0, E)
+    return CSRGraph(row_ptr, src, dst, ne, cap, perm, status, n_edges=E)
 
 
 def edge_mlp(weights, ker_in: int, ker_width: int, out_dim: int, graph: CSRGraph,

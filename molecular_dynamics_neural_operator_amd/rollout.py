@@ -78,6 +78,9 @@ class RolloutEngine:
         self.use_graph = bool(use_graph)
         self.steps_done = 0
         self._sample_first_step = False
+        self._timer_records = 0        # capacity of the attached per-kernel timer (0 = none): re-attached to a rebuilt plan
+        self.regrown = []              # (first re-run step, old edge_cap, new edge_cap) per growth of a fitted capacity
+        self.mode_changes = []         # (step, from, to): "auto" changed formulation when the capacity grew mid-trajectory
         # "auto": what the edge capacity suggests until a window is known; reset() decides on its graph
         self._auto = (getattr(model, "conv_mode", None) if hasattr(model, "param_pack") else self.pack.conv_mode) == "auto"
 
@@ -104,13 +107,16 @@ class RolloutEngine:
         self.edge_cap = cap
         return True
 
-    def _resolve_auto(self, e: int, over: bool) -> bool:
-        """conv_mode "auto" on the graph of the window's last frame (AUTO_FACTORED_* above).  Returns True if the
-        engine changed formulation (its plan must then be rebuilt)."""
+    def _wanted_mode(self, e: int, over: bool) -> str:
+        """conv_mode "auto" on a counted graph of this engine's members (AUTO_FACTORED_* above)."""
         if over:
             e = max(e, self.M * max(AUTO_FACTORED_MIN_DEGREE * self.N, AUTO_FACTORED_MIN_EDGES))
-        want = {v: k for k, v in _lib.CONV_MODES.items()}[
+        return {v: k for k, v in _lib.CONV_MODES.items()}[
             int(self.lib.mdno_conv_mode_for_graph(self.pack.ref, self.M, self.N, int(e)))]
+
+    def _apply_mode(self, want: str) -> bool:
+        """Switch to formulation `want` where the model's dimensions (and, for materialized, the workspace bound) allow
+        it.  Returns True if the engine changed formulation (its plan must then be rebuilt)."""
         if want == self.conv_mode:
             return False
         pack = self._pack_for(want)
@@ -120,8 +126,13 @@ class RolloutEngine:
         need = self.lib.mdno_rollout_workspace_bytes(pack.ref, self.M, self.N, self.edge_cap)
         if want == "materialized" and need > AUTO_MATERIALIZED_MAX_WORKSPACE:
             return False                 # W_e at this edge capacity does not fit: stay factored
+        if self.steps_done and self.conv_mode != want:
+            self.mode_changes.append((self.steps_done, self.conv_mode, want))
         self.pack, self.conv_mode = pack, want
         return True
+
+    def _resolve_auto(self, e: int, over: bool) -> bool:
+        return self._apply_mode(self._wanted_mode(e, over))
 
     def _create_plan(self):
         if self.plan:
@@ -134,9 +145,17 @@ class RolloutEngine:
             self.workspace.numel(),
             ptr(self.edges_per_step), ptr(self.status), int(self.use_graph), self.stream.cuda_stream),
             "mdno_rollout_plan_create")
+        if self._timer_records:          # the timer lived in the plan just destroyed: its records are gone, the attachment is not
+            check(self.lib.mdno_rollout_plan_timer_attach(self.plan, self._timer_records), "timer_attach")
 
-    def reset(self, window: torch.Tensor, x_aminoacid: torch.Tensor) -> None:
-        """window: f32 [W,M,N,3] (time-major), [W,N,3] for M=1; x_aminoacid i64 [N] or [M*N]."""
+    @property
+    def steps_per_launch(self) -> int:
+        """0 = plain launches, 1 = one captured step per graph launch, 8 = eight (short chains); include/mdno.h."""
+        return int(self.lib.mdno_rollout_plan_steps_per_launch(self.plan)) if self.plan else 0
+
+    def reset(self, window: torch.Tensor, x_aminoacid: torch.Tensor, _conv_mode: Optional[str] = None) -> None:
+        """window: f32 [W,M,N,3] (time-major), [W,N,3] for M=1; x_aminoacid i64 [N] or [M*N].
+        (_conv_mode: what "auto" resolved to for the whole shard this engine is a group of — GroupedRolloutEngine.)"""
         w = f32(window.to(self.device))
         if w.dim() == 3:
             w = w.unsqueeze(1)
@@ -156,12 +175,13 @@ class RolloutEngine:
             self.aa.copy_(aa)
         torch.cuda.current_stream(self.device).synchronize()
         changed = False
-        if self._auto or self._fit_cap:
+        e, over = 0, False
+        if self._fit_cap or (self._auto and not _conv_mode):
             e, over = self._probe_edges()
-            if self._fit_cap:
-                changed |= self._fit_capacity(e, over)
-            if self._auto:
-                changed |= self._resolve_auto(e, over)
+        if self._fit_cap:
+            changed |= self._fit_capacity(e, over)
+        if self._auto:
+            changed |= self._apply_mode(_conv_mode) if _conv_mode else self._resolve_auto(e, over)
         need = self.lib.mdno_rollout_workspace_bytes(self.pack.ref, self.M, self.N, self.edge_cap)
         if self.workspace is None or need > self.workspace.numel() or 2 * need < self.workspace.numel():
             self.workspace = None        # (release before allocating: the two could be tens of GB each)
@@ -171,6 +191,7 @@ class RolloutEngine:
             self._create_plan()
         self.steps_done = 0
         self._sample_first_step = False
+        self.regrown, self.mode_changes = [], []
 
     def first_step_from_sample(self, edge_index: torch.Tensor, edge_attr: torch.Tensor) -> None:
         """Produce frame W from the start sample's OWN graph and edge attributes, as the reference's
@@ -204,6 +225,7 @@ class RolloutEngine:
         """Per-kernel HIP-event timing (measurement aid): subsequent step() calls issue plain
         launches bracketed by events on the engine's stream."""
         check(self.lib.mdno_rollout_plan_timer_attach(self.plan, int(max_records)), "timer_attach")
+        self._timer_records = int(max_records)
 
     def read_timer(self) -> dict:
         """{kernel: (total_ms, launches)}; synchronises the engine's stream first."""
@@ -218,12 +240,16 @@ class RolloutEngine:
     def detach_timer(self) -> None:
         self.stream.synchronize()
         check(self.lib.mdno_rollout_plan_timer_detach(self.plan), "timer_detach")
+        self._timer_records = 0
 
     def _grow_and_rerun(self, st: int) -> int:
         """The radius graph of some step outgrew a capacity that was FITTED to the start window (no `edge_cap` given,
         N > 256): the reference keeps building the denser graph (graph_kernel.py:363-368), so the engine does too —
         capacity x4 (at most the complete graph), new workspace and plan, and the steps from the first truncated one
-        on are run again (frames before it are untouched: their graphs fitted).  Returns the new status word."""
+        on are run again (frames before it are untouched: their graphs fitted).  Recorded in `self.regrown`; with
+        conv_mode "auto" the larger graph can take the other formulation from that step on (`self.mode_changes`; the
+        two agree to fp32 reassociation, not bitwise).  An attached timer is re-attached to the new plan (its records
+        up to here are lost with the old one).  Returns the new status word."""
         target = self.steps_done
         eps = self.edges_per_step[:target].cpu()
         hit = (eps >= self.edge_cap).nonzero()
@@ -232,6 +258,8 @@ class RolloutEngine:
             first = max(first, 1)                # step 0 ran on the sample's own edge list (cannot overflow)
         old = self.edge_cap
         self.edge_cap = min(self.M * self.N * self.N, 4 * old)
+        self.regrown.append((first, old, self.edge_cap))
+        self.steps_done = first                  # (what a formulation change below is recorded at)
         if self._auto:
             self._resolve_auto(old, False)       # the graph now has at least `old` edges
         need = self.lib.mdno_rollout_workspace_bytes(self.pack.ref, self.M, self.N, self.edge_cap)
@@ -280,7 +308,9 @@ class RolloutEngine:
 class GroupedRolloutEngine:
     """The members of a shard as `groups` independent `RolloutEngine`s (contiguous member ranges), each with its own
     stream and its own captured step, stepped together.  Members never interact, so the frames are bitwise those of one
-    engine holding them all; what changes is the schedule: one group's edge-MLP (matrix-pipe-bound) and launch tails run
+    engine holding them all — conv_mode "auto" is resolved ONCE, on the graph of the whole shard, and given to every group
+    (a group deciding on its own members could take the other formulation when densities differ) —; what changes is the
+    schedule: one group's edge-MLP (matrix-pipe-bound) and launch tails run
     beside another group's convs (fabric-bound) — 5 % at 8 x 504 atoms, 3 % at 64 (EXPERIMENTS.md section 0.2b).  Same
     reset / step / synchronize / run / frames interface; `traj` and `edges_per_step` are assembled on access."""
 
@@ -302,11 +332,16 @@ class GroupedRolloutEngine:
 
     @property
     def conv_mode(self):
-        return self.engines[0].conv_mode
+        modes = {e.conv_mode for e in self.engines}
+        return self.engines[0].conv_mode if len(modes) == 1 else "mixed:" + ",".join(sorted(modes))
 
     @property
     def steps_done(self):
         return self.engines[0].steps_done
+
+    @property
+    def regrown(self):
+        return [(g,) + r for g, e in enumerate(self.engines) for r in e.regrown]
 
     @property
     def workspace_bytes(self) -> int:
@@ -321,8 +356,21 @@ class GroupedRolloutEngine:
         if x_aminoacid.numel() not in (self.N, self.M * self.N):
             raise MdnoError(f"x_aminoacid has {x_aminoacid.numel()} entries, expected {self.N} or {self.M * self.N}")
         per_member = x_aminoacid.numel() == self.M * self.N and self.M > 1
+        want = None
+        if any(e._auto for e in self.engines):      # the rule one engine holding every member would apply
+            e0 = self.engines[0]
+            R = self.M * self.N
+            probe_cap = max(AUTO_FACTORED_MIN_DEGREE * R, self.M * AUTO_FACTORED_MIN_EDGES) + R
+            last = f32(window[self.W - 1].to(self.device)).reshape(R, 3)
+            g = ops.radius_graph(last, self.N, e0.threshold, edge_cap=probe_cap)
+            n_e, over = int(g.num_edges.item()), bool(int(g.status.item()) & STATUS_EDGE_OVERFLOW)
+            if over:
+                n_e = max(n_e, self.M * max(AUTO_FACTORED_MIN_DEGREE * self.N, AUTO_FACTORED_MIN_EDGES))
+            want = {v: k for k, v in _lib.CONV_MODES.items()}[
+                int(e0.lib.mdno_conv_mode_for_graph(e0.pack.ref, self.M, self.N, n_e))]
         for e, (lo, hi) in zip(self.engines, self.bounds):
-            e.reset(window[:, lo:hi].contiguous(), x_aminoacid[lo * self.N:hi * self.N] if per_member else x_aminoacid)
+            e.reset(window[:, lo:hi].contiguous(), x_aminoacid[lo * self.N:hi * self.N] if per_member else x_aminoacid,
+                    _conv_mode=want)
 
     def step(self, steps: int) -> None:
         for e in self.engines:      # asynchronous on each engine's own stream

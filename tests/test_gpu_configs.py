@@ -362,6 +362,20 @@ def test_recursive_propagation_outgrows_fitted_capacity(dev, O):
     eng.synchronize()
     assert eng.edge_cap > cap0 and eng.edges_per_step.cpu().tolist() == [e0] + e_ref[:-1]
     assert torch.equal(eng.frames()[:, 0].cpu(), torch.stack([f.x_position[-1] for f in fc]))
+    # the growth is on record (first re-run step, old and new capacity) ...
+    assert eng.regrown and eng.regrown[0][1] == cap0 and eng.regrown[-1][2] == eng.edge_cap and eng.regrown[0][0] >= 1
+    eng.close()
+    # ... and a per-kernel timer attached before it survives the plan that was rebuilt (it was lost and
+    # read_timer failed): its records restart at the re-run
+    eng = RolloutEngine(model, 1, N, W, thr, max_steps=steps, device=dev)
+    eng.reset(torch.from_numpy(win), aa)
+    eng.attach_timer(4096)
+    eng.step(steps)
+    eng.synchronize()
+    assert eng.regrown
+    tm = eng.read_timer()
+    assert tm["nnconv"][1] > 0 and tm["nnconv"][0] > 0.0
+    eng.detach_timer()
     eng.close()
     # a capacity the CALLER chose is a contract: overflow raises
     eng = RolloutEngine(model, 1, N, W, thr, max_steps=steps, edge_cap=cap0, device=dev)
@@ -1024,6 +1038,62 @@ def test_ragged_member_sizes_free_run_vs_oracle(dev, O, conv_mode, gemm_mode):
                                        err_msg=f"N={N} member {m}")
             edges += np.array([s0["edge_index"].shape[1]] + [f["edge_index"].shape[1] for f in fc[:-1]])
         assert eng.edges_per_step.cpu().tolist() == edges.tolist(), (N, M)
+
+
+def test_member_groups_resolve_auto_once_for_the_shard(dev):
+    """conv_mode "auto" in a GroupedRolloutEngine is decided on the graph of the WHOLE shard and given to every group
+    (ADVICE r4): two members of very different density — a 504-atom box at 0.1 atoms/A^3 (~118 neighbours: factored on
+    its own) and the same atoms spread 3x wider (~6 neighbours: materialized on its own) — as two groups of one take
+    the formulation one engine holding both picks, and give its frames bitwise."""
+    from molecular_dynamics_neural_operator_amd import synthetic as syn
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN
+    from molecular_dynamics_neural_operator_amd.rollout import GroupedRolloutEngine, RolloutEngine
+    from molecular_dynamics_neural_operator_amd.weights import near_identity_state_dict
+    N, W, steps = 504, 4, 2
+    model = KernelNN(64, 256, 2, 6, 7, 3, 20, 4)
+    model.load_state_dict(near_identity_state_dict(64, 256, seed=2, kernel_gain=2e-2, feature_gain=0.2, kernel_to_coords=1.0))
+    model.eval().to(dev)
+    assert model.conv_mode == "auto"
+    dense = syn.jitter_window(syn.box_frame(N, seed=1), W, seed=1)
+    centre = dense.mean(axis=(0, 1), keepdims=True)
+    sparse = (dense - centre) * 3.0 + centre
+    aa = torch.from_numpy(syn.amino_acids(N, seed=1))
+    alone = {}
+    for name, w in (("dense", dense), ("sparse", sparse)):
+        e = RolloutEngine(model, 1, N, W, 8.0, max_steps=steps, device=dev)
+        e.reset(torch.from_numpy(w), aa)
+        alone[name] = e.conv_mode
+        e.close()
+    assert alone == {"dense": "factored", "sparse": "materialized"}, alone
+    tm = torch.from_numpy(np.ascontiguousarray(np.stack([dense, sparse], axis=1)))              # [W, 2, N, 3]
+    one = RolloutEngine(model, 2, N, W, 8.0, max_steps=steps, device=dev)
+    want = one.run(tm, aa, steps).clone()
+    grp = GroupedRolloutEngine(model, 2, N, W, 8.0, max_steps=steps, device=dev, groups=2)
+    got = grp.run(tm, aa, steps)
+    assert grp.conv_mode == one.conv_mode and {e.conv_mode for e in grp.engines} == {one.conv_mode}
+    assert torch.equal(got, want)
+    one.close()
+    grp.close()
+
+
+def test_short_chain_plan_replays_eight_steps_per_launch(dev):
+    """The N = 28 configuration's plan holds the eight-steps-per-launch graph (a failed capture used to be
+    swallowed and would only have shown as a slower shape A); a 504-atom plan replays single steps, a plan without
+    graphs reports 0."""
+    from molecular_dynamics_neural_operator_amd import synthetic as syn
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN
+    from molecular_dynamics_neural_operator_amd.rollout import RolloutEngine
+    from molecular_dynamics_neural_operator_amd.weights import near_identity_state_dict
+    model = KernelNN(64, 128, 2, 6, 7, 3, 20, 4)
+    model.load_state_dict(near_identity_state_dict(64, 128, seed=2, kernel_gain=2e-2, feature_gain=0.2, kernel_to_coords=1.0))
+    model.eval().to(dev)
+    for N, use_graph, want in ((28, True, 8), (504, True, 1), (28, False, 0)):
+        frame = syn.chain_frame(N, seed=1) if N == 28 else syn.box_frame(N, seed=1)
+        eng = RolloutEngine(model, 1, N, 4, 8.0, max_steps=16, device=dev, use_graph=use_graph)
+        assert eng.steps_per_launch == 0                        # no plan before reset
+        eng.reset(torch.from_numpy(syn.jitter_window(frame, 4, seed=1)), torch.from_numpy(syn.amino_acids(N, seed=1)))
+        assert eng.steps_per_launch == want, (N, use_graph, eng.steps_per_launch)
+        eng.close()
 
 
 def test_member_groups_on_concurrent_streams_give_the_same_frames(dev):

@@ -148,11 +148,20 @@ int mdno_radius_graph_csr_ws(const float* pos, int M, int N, double cutoff, int3
  *   unique edge ids): deterministic, no vendor sort.  Node ids outside [0, num_nodes) — where the
  *   reference's index_select / scatter raise — set MDNO_STATUS_BAD_EDGE_INDEX in `status`
  *   (i32 [1] device, OR-ed; may be NULL) and are clamped so that nothing is read out of bounds.
+ *   num_edges i32 [1] out (device, may be NULL): E, for the entry points that take the count from the device.
  *   Workspace size from mdno_coo_to_csr_workspace_bytes. */
 size_t mdno_coo_to_csr_workspace_bytes(int64_t E, int num_nodes);
 int mdno_coo_to_csr(const int64_t* edge_index, int64_t E, int num_nodes,
-                    int32_t* row_ptr, int32_t* src, int32_t* dst, int32_t* perm, int32_t* status,
-                    void* workspace, size_t workspace_bytes, void* stream);
+                    int32_t* row_ptr, int32_t* src, int32_t* dst, int32_t* perm, int32_t* num_edges,
+                    int32_t* status, void* workspace, size_t workspace_bytes, void* stream);
+/* The edges of a destination-sorted CSR (its src / dst arrays, E entries) grouped by SOURCE — what the input
+ * gradient of a conv application walks (training; autograd's scatter in the reference, graph_kernel.py:198
+ * differentiated): row j lists, in ascending CSR position, the targets nbr[q] of source j; rowid[q] = j (may be
+ * NULL); perm[q] = the position of that edge in the destination-sorted CSR (and in W_e).  Same sort, same
+ * workspace size as mdno_coo_to_csr. */
+int mdno_csr_by_source(const int32_t* csr_src, const int32_t* csr_dst, int64_t E, int num_nodes,
+                       int32_t* row_ptr, int32_t* nbr, int32_t* rowid, int32_t* perm, int32_t* status,
+                       void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K2  edge-MLP — replaces DenseNet.forward (graph_kernel.py:239-242) as called from
@@ -459,6 +468,9 @@ int mdno_colsum_atb_bf16(const void* a, const float* b, int64_t rows, int n, int
 int mdno_collate_samples(const float* pos, const int32_t* rows, const int32_t* cols, const int64_t* meta,
                          int B, int N, int W, int horizon, int max_edges_per_sample, float* x_position, float* y,
                          int64_t* edge_index, float* edge_attr, void* stream);
+/* out[p][0..width) = in[perm[p]][0..width): per-edge rows (edge attributes) put into the destination-sorted order of a
+ * graph built by mdno_coo_to_csr (its perm) — torch's index_select on the path edge_attr -> DenseNet (graph_kernel.py:200). */
+int mdno_permute_rows(const float* in, const int32_t* perm, int64_t rows, int width, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Training: the loss (csrc/loss.hip) — LpLoss.rel with p = 2 (graph_kernel.py:105-119; used :462, :547) and the batch
@@ -479,8 +491,9 @@ int mdno_lploss_rel_bwd(const float* out, const float* y, const float* stats, co
  * Training: backward of the per-atom ends (csrc/train_nodes.hip) — the node prologue (graph_kernel.py:279-298;
  * forward = mdno_node_prologue_fwd) and fc2 (:305; forward = mdno_fc_out_fwd).  Fixed-order reductions.
  *   mdno_node_prologue_bwd   x0, g0 f32 [M*N,width]: the forward's output and dLoss/dx0.  Outputs (overwritten):
- *                            d_lstm f32 [96] = [w_ih 36 | w_hh 36 | bias 12 (the gradient of b_ih AND of b_hh) |
- *                            lstm_fc.weight 9 | lstm_fc.bias 3] (NULL for the notebook-era model), d_emb
+ *                            d_lstm f32 [108] = [w_ih 36 | w_hh 36 | b_ih 12 | lstm_fc.weight 9 | lstm_fc.bias 3 |
+ *                            b_hh 12 (the same values as b_ih, a second copy: every parameter's gradient has its
+ *                            own 12 floats)] (NULL for the notebook-era model), d_emb
  *                            [num_embeddings, embedding_dim], d_fc1_w [width, in_width], d_fc1_b [width].
  *                            window <= 16.
  *   mdno_fc_out_bwd          out = x . w^T + b:  dx [rows,width] = g . w,  d_w [out_width,width] = g^T . x,

@@ -54,7 +54,9 @@ SIGNATURES = {
     "mdno_radius_graph_workspace_bytes": (_SZ, [_I, _I]),
     "mdno_radius_graph_csr_ws": (_I, [_P, _I, _I, _D, _P, _P, _P, _L, _P, _P, _P, _SZ, _P]),
     "mdno_coo_to_csr_workspace_bytes": (_SZ, [_L, _I]),
-    "mdno_coo_to_csr": (_I, [_P, _L, _I, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "mdno_coo_to_csr": (_I, [_P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "mdno_csr_by_source": (_I, [_P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "mdno_permute_rows": (_I, [_P, _P, _L, _I, _P, _P]),
     "mdno_edge_mlp_workspace_bytes": (_SZ, [_I, _I, _L, _I]),
     "mdno_edge_mlp_fwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _SZ,
                                _P]),

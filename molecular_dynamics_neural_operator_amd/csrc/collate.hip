@@ -57,10 +57,30 @@ __global__ __launch_bounds__(256) void collate_edges_kernel(const float* __restr
     }
 }
 
+// out[p][:] = in[perm[p]][:]  — rows of `width` floats (edge attributes put into CSR order: edge p of the
+// destination-sorted graph is input edge perm[p])
+__global__ __launch_bounds__(256) void permute_rows_kernel(const float* __restrict__ in, const int* __restrict__ perm,
+                                                           long long rows, int width, float* __restrict__ out) {
+    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= rows * width) return;
+    const long long p = id / width;
+    out[id] = in[(size_t)perm[p] * width + (int)(id - p * width)];
+}
+
 }  // namespace
 }  // namespace mdno
 
 using namespace mdno;
+
+extern "C" int mdno_permute_rows(const float* in, const int32_t* perm, int64_t rows, int width, float* out, void* stream) {
+    MDNO_REQUIRE(rows >= 0 && width > 0, MDNO_EINVAL, "mdno_permute_rows: rows=%lld width=%d", (long long)rows, width);
+    if (rows == 0) return MDNO_OK;
+    MDNO_REQUIRE(in && perm && out && in != out, MDNO_EINVAL, "mdno_permute_rows: null pointer (or in == out)");
+    const long long n = (long long)rows * width;
+    hipLaunchKernelGGL(permute_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       in, perm, (long long)rows, width, out);
+    return check_launch("mdno_permute_rows");
+}
 
 extern "C" int mdno_collate_samples(const float* pos, const int32_t* rows, const int32_t* cols, const int64_t* meta,
                                     int B, int N, int W, int horizon, int max_edges_per_sample, float* x_position,

@@ -375,39 +375,49 @@ __device__ __forceinline__ int clamp_node(long long v, int num_nodes, bool& bad)
     return (int)v;
 }
 
-__global__ __launch_bounds__(256) void coo_count_kernel(const long long* __restrict__ edge_index, long long E,
+// The edge list the sort reads: i64 [2,E] (row 0 = source, row 1 = target) as torch_geometric has it, or two i32
+// arrays (mdno_csr_by_source: the arrays of an existing CSR with their roles swapped).
+struct EdgeView {
+    const long long* ei;      // i64 [2,E], or NULL
+    const int *s32, *t32;     // i32 [E] each
+    long long E;
+    __device__ __forceinline__ long long source(long long e) const { return ei ? ei[e] : (long long)s32[e]; }
+    __device__ __forceinline__ long long target(long long e) const { return ei ? ei[E + e] : (long long)t32[e]; }
+};
+
+__global__ __launch_bounds__(256) void coo_count_kernel(const EdgeView edge_index, long long E,
                                                         int num_nodes, int* __restrict__ deg,
                                                         int* __restrict__ status) {
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
     if (e >= E) return;
     bool bad = false;
-    (void)clamp_node(edge_index[e], num_nodes, bad);
-    const int d = clamp_node(edge_index[E + e], num_nodes, bad);
+    (void)clamp_node(edge_index.source(e), num_nodes, bad);
+    const int d = clamp_node(edge_index.target(e), num_nodes, bad);
     if (bad && status) atomicOr(status, MDNO_STATUS_BAD_EDGE_INDEX);
     atomicAdd(&deg[d], 1);
 }
 
-__global__ __launch_bounds__(256) void coo_slot_kernel(const long long* __restrict__ edge_index, long long E,
+__global__ __launch_bounds__(256) void coo_slot_kernel(const EdgeView edge_index, long long E,
                                                        int num_nodes, const int* __restrict__ row_ptr,
                                                        int* __restrict__ cursor, int* __restrict__ ids) {
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
     if (e >= E) return;
     bool bad = false;
-    const int d = clamp_node(edge_index[E + e], num_nodes, bad);
+    const int d = clamp_node(edge_index.target(e), num_nodes, bad);
     ids[row_ptr[d] + atomicAdd(&cursor[d], 1)] = (int)e;
 }
 
 // rank of an id = number of smaller ids in its row; `ids` is read-only here, results go to perm/src/dst
-__device__ __forceinline__ void coo_place(const long long* __restrict__ edge_index, int num_nodes, int row, int beg,
+__device__ __forceinline__ void coo_place(const EdgeView& edge_index, int num_nodes, int row, int beg,
                                           int rank, int id, int* __restrict__ perm, int* __restrict__ src,
                                           int* __restrict__ dst) {
     bool bad = false;
     perm[beg + rank] = id;
-    src[beg + rank] = clamp_node(edge_index[id], num_nodes, bad);
+    src[beg + rank] = clamp_node(edge_index.source(id), num_nodes, bad);
     if (dst) dst[beg + rank] = row;
 }
 
-__global__ __launch_bounds__(256) void coo_row_sort_kernel(const long long* __restrict__ edge_index, int num_nodes,
+__global__ __launch_bounds__(256) void coo_row_sort_kernel(const EdgeView edge_index, int num_nodes,
                                                            const int* __restrict__ row_ptr,
                                                            const int* __restrict__ ids, int* __restrict__ perm,
                                                            int* __restrict__ src, int* __restrict__ dst) {
@@ -423,7 +433,7 @@ __global__ __launch_bounds__(256) void coo_row_sort_kernel(const long long* __re
     }
 }
 
-__global__ __launch_bounds__(1024) void coo_big_row_sort_kernel(const long long* __restrict__ edge_index,
+__global__ __launch_bounds__(1024) void coo_big_row_sort_kernel(const EdgeView edge_index,
                                                                 int num_nodes, const int* __restrict__ row_ptr,
                                                                 const int* __restrict__ ids, int* __restrict__ perm,
                                                                 int* __restrict__ src, int* __restrict__ dst) {
@@ -540,33 +550,48 @@ extern "C" size_t mdno_coo_to_csr_workspace_bytes(int64_t E, int num_nodes) {
     return carve_coo(nullptr, E, num_nodes).total;
 }
 
-extern "C" int mdno_coo_to_csr(const int64_t* edge_index, int64_t E, int num_nodes, int32_t* row_ptr,
-                               int32_t* src, int32_t* dst, int32_t* perm, int32_t* status, void* workspace,
-                               size_t workspace_bytes, void* stream) {
-    MDNO_REQUIRE(row_ptr && num_nodes > 0 && E >= 0, MDNO_EINVAL, "mdno_coo_to_csr: bad arguments");
-    MDNO_REQUIRE(E < (1ll << 31) - 1, MDNO_EUNSUPPORTED, "mdno_coo_to_csr: E exceeds int32 indexing");
-    hipStream_t s = static_cast<hipStream_t>(stream);
+static int coo_sort(const EdgeView ei, long long E, int num_nodes, int32_t* row_ptr, int32_t* src, int32_t* dst,
+                    int32_t* perm, int32_t* num_edges, int32_t* status, void* workspace, size_t workspace_bytes,
+                    hipStream_t s, const char* who) {
+    MDNO_REQUIRE(row_ptr && num_nodes > 0 && E >= 0, MDNO_EINVAL, "%s: bad arguments", who);
+    MDNO_REQUIRE(E < (1ll << 31) - 1, MDNO_EUNSUPPORTED, "%s: E exceeds int32 indexing", who);
     if (E == 0) {
         MDNO_HIP(hipMemsetAsync(row_ptr, 0, sizeof(int) * (size_t)(num_nodes + 1), s));
+        if (num_edges) MDNO_HIP(hipMemsetAsync(num_edges, 0, sizeof(int), s));
         return MDNO_OK;
     }
-    MDNO_REQUIRE(edge_index && src && perm && workspace, MDNO_EINVAL, "mdno_coo_to_csr: null pointer");
+    MDNO_REQUIRE((ei.ei || (ei.s32 && ei.t32)) && src && perm && workspace, MDNO_EINVAL, "%s: null pointer", who);
     CooWs c = carve_coo(workspace, E, num_nodes);
-    MDNO_REQUIRE(workspace_bytes >= c.total, MDNO_EWORKSPACE, "mdno_coo_to_csr: workspace %zu < %zu",
-                 workspace_bytes, c.total);
-    const long long* ei = (const long long*)edge_index;
+    MDNO_REQUIRE(workspace_bytes >= c.total, MDNO_EWORKSPACE, "%s: workspace %zu < %zu", who, workspace_bytes, c.total);
     const unsigned nb = (unsigned)((E + 255) / 256);
     MDNO_HIP(hipMemsetAsync(c.deg, 0, sizeof(int) * 2 * (size_t)num_nodes, s));
-    hipLaunchKernelGGL(coo_count_kernel, dim3(nb), dim3(256), 0, s, ei, (long long)E, num_nodes, c.deg, status);
-    hipLaunchKernelGGL(scan_rows_kernel, dim3(1), dim3(1024), 0, s, (const int*)c.deg, num_nodes, (long long)E,
-                       row_ptr, c.scratch, (int*)nullptr, (int*)nullptr, 0);
-    hipLaunchKernelGGL(coo_slot_kernel, dim3(nb), dim3(256), 0, s, ei, (long long)E, num_nodes, (const int*)row_ptr,
-                       c.cursor, c.ids);
+    hipLaunchKernelGGL(coo_count_kernel, dim3(nb), dim3(256), 0, s, ei, E, num_nodes, c.deg, status);
+    // (the scan also leaves the edge count on the device for the caller: no fill launch on the host side)
+    hipLaunchKernelGGL(scan_rows_kernel, dim3(1), dim3(1024), 0, s, (const int*)c.deg, num_nodes, E, row_ptr,
+                       num_edges ? num_edges : c.scratch, (int*)nullptr, (int*)nullptr, 0);
+    hipLaunchKernelGGL(coo_slot_kernel, dim3(nb), dim3(256), 0, s, ei, E, num_nodes, (const int*)row_ptr, c.cursor, c.ids);
     hipLaunchKernelGGL(coo_row_sort_kernel, dim3((num_nodes + 3) / 4), dim3(256), 0, s, ei, num_nodes,
                        (const int*)row_ptr, (const int*)c.ids, perm, src, dst);
     // rows above kBigRow entries exist only if E does
     if (E > kBigRow)
         hipLaunchKernelGGL(coo_big_row_sort_kernel, dim3(num_nodes), dim3(1024), 0, s, ei, num_nodes,
                            (const int*)row_ptr, (const int*)c.ids, perm, src, dst);
-    return check_launch("mdno_coo_to_csr");
+    return check_launch(who);
+}
+
+extern "C" int mdno_coo_to_csr(const int64_t* edge_index, int64_t E, int num_nodes, int32_t* row_ptr,
+                               int32_t* src, int32_t* dst, int32_t* perm, int32_t* num_edges, int32_t* status,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+    const EdgeView ev{(const long long*)edge_index, nullptr, nullptr, (long long)E};
+    return coo_sort(ev, (long long)E, num_nodes, row_ptr, src, dst, perm, num_edges, status, workspace, workspace_bytes,
+                    static_cast<hipStream_t>(stream), "mdno_coo_to_csr");
+}
+
+extern "C" int mdno_csr_by_source(const int32_t* csr_src, const int32_t* csr_dst, int64_t E, int num_nodes,
+                                  int32_t* row_ptr, int32_t* nbr, int32_t* rowid, int32_t* perm, int32_t* status,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+    // the same sort with the two arrays' roles swapped: rows = SOURCES, row entries = the targets they send to
+    const EdgeView ev{nullptr, csr_dst, csr_src, (long long)E};
+    return coo_sort(ev, (long long)E, num_nodes, row_ptr, nbr, rowid, perm, nullptr, status, workspace, workspace_bytes,
+                    static_cast<hipStream_t>(stream), "mdno_csr_by_source");
 }

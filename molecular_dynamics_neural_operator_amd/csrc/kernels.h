@@ -101,11 +101,10 @@ int split_linear(const float* a, const float* w, const float* bias, long long ro
 
 // Factored conv, destination-side form (moment.hip: S_t = sum_{e->t} x_src (x) h_e, then y_t = W3 : S_t), the one
 // factored formulation: on three bf16 planes per operand for the split GEMM modes, on the fp32 MFMA for gemm_mode F32
-// (`exact_f32`: h2 is then the row-major fp32 [E, k] of the fp32 hidden GEMM instead of the k-tiled image).
+// (`exact_f32`; h2 is the k-tiled fp32 image [e/128][k/32][128][32] either way).
 struct MomentWs {
     float *w3r, *s, *part;
     int* order;               // destinations of each S chunk by decreasing degree
-    int* done;                // EXPERIMENT (K2 fold): one counter per 256-row group
     long long part_stride;
 };
 bool moment_supported(int width, int ker_width);

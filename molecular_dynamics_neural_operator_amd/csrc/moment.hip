@@ -99,11 +99,10 @@ __global__ __launch_bounds__(256) void w3_moment_kernel(const float* __restrict_
 // together, and a CU then gets one destination from every quarter of the sorted list instead of four of any size.
 template <int CH>
 __global__ __launch_bounds__(CH) void degree_order_kernel(const int* __restrict__ row_ptr, int num_rows,
-                                                          int* __restrict__ order, int* __restrict__ done) {
+                                                          int* __restrict__ order) {
     __shared__ __attribute__((aligned(16))) int key[CH];      // degree * CH + (CH - 1 - index): all distinct
     const int base = blockIdx.x * CH, t = threadIdx.x;
     const int cnt = num_rows - base < CH ? num_rows - base : CH;
-    if (done != nullptr && t < CH / 256) done[blockIdx.x * (CH / 256) + t] = 0;      // (EXPERIMENT: K2-fold counters)
     int dg = t < cnt ? row_ptr[base + t + 1] - row_ptr[base + t] : 0;
     dg = dg < (1 << 20) ? dg : (1 << 20);      // (the key must fit an int; beyond that the order does not matter)
     const int mine = t < cnt ? dg * CH + (CH - 1 - t) : -1;
@@ -304,8 +303,8 @@ __global__ __launch_bounds__(256, 3) void moment_kernel(const float* __restrict_
 
 // ---------------------------------------------------------------- K1, exact fp32 (gemm_mode F32)
 // The same workgroup shape and the same S image, on v_mfma_f32_32x32x2_f32 (an fp32 fmaf chain over a destination's
-// edges in edge order): H is the ROW-MAJOR fp32 [E, K] that the fp32 hidden GEMM writes (edge_mlp.hip), staged as fp32
-// rows of 256 + 32 floats (the two k rows of an MFMA step fall into different bank halves), the neighbours' feature
+// edges in edge order): H is the same k-tiled fp32 image (the fp32 hidden GEMM writes it too, edge_mlp.hip), staged as
+// fp32 rows of 256 + 32 floats (the two k rows of an MFMA step fall into different bank halves), the neighbours' feature
 // rows next to it.  Not a tuned path — F32 is the reference-arithmetic mode, ~16x the matrix-pipe time of the split
 // modes — but the same formulation on any destination-sorted graph.
 constexpr int MF_HLD = MO_CQ + 32, MF_XLD = 64 + 32;
@@ -346,7 +345,8 @@ __global__ __launch_bounds__(256) void moment_f32_kernel(const float* __restrict
         for (int u = 0; u < 4; ++u) {
             rh[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             const int c = cq * MO_CQ + u * 64 + cc * 4;
-            if (e < end && c < K) rh[u] = *reinterpret_cast<const float4*>(Hm + (size_t)e * K + c);
+            if (e < end && c < K)
+                rh[u] = *reinterpret_cast<const float4*>(Hm + ((size_t)(e >> 7) * (K >> 5) + (c >> 5)) * 4096 + (e & 127) * 32 + (c & 31));
         }
         if (e < end) rx = *reinterpret_cast<const float4*>(x + (size_t)src[e] * 64 + 4 * cc);
         __syncthreads();      // (the previous stage's fragment reads are done)
@@ -394,19 +394,10 @@ constexpr int PJ_SLICES = 128;
                                    // went through it was W3R (L2 hits): 34 us; (64 rows: 43 us)
 constexpr int PJ_B_PLANE = 64 * 64;
 
-// EXPERIMENT (MDNO_K2_FOLD=1): FOLD = the row group's last-arriving workgroup does K3's work
-struct FoldArgs {
-    int* done;                 // [row groups] zeroed, self-resetting
-    const int* row_ptr;
-    const float *x, *root, *bias;
-    float* y;
-    int aggr, relu;
-};
-
-template <int PJ_ROWS, bool FOLD = false>
+template <int PJ_ROWS>
 __global__ __launch_bounds__(PJ_ROWS * 2) void project_kernel(const float* __restrict__ S, const float* __restrict__ w3r,
                                                          float* __restrict__ part, int K, int cnt, int row0,
-                                                         long long part_stride, FoldArgs fa = FoldArgs{}) {
+                                                         long long part_stride) {
     constexpr int PJ_A_PLANE = PJ_ROWS * 64, PJ_B_BASE = 3 * PJ_A_PLANE, NT = PJ_ROWS / 128;
     constexpr int RQ = PJ_ROWS / 4;       // staging: thread (srow < RQ, 4 columns) takes A rows srow + RQ j and B rows srow (+ RQ)
     __shared__ __attribute__((aligned(16))) unsigned char lds[3 * PJ_A_PLANE + 3 * PJ_B_PLANE];
@@ -515,62 +506,6 @@ __global__ __launch_bounds__(PJ_ROWS * 2) void project_kernel(const float* __res
         if (m < cnt) {
             Po[(size_t)(row0 + m) * 64 + l31] = acc0[e];
             Po[(size_t)(row0 + m) * 64 + 32 + l31] = acc1[e];
-        }
-    }
-    if constexpr (FOLD) {
-        // the row group's last workgroup to get here adds the K slices (finish_kernel's association: chain c = slices
-        // c, c+32, c+64, c+96 in that order, chains in chain order) and applies mean / root / bias / ReLU
-        __shared__ int last_s;
-        __syncthreads();                                   // every wave's partial stores issued
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            last_s = __hip_atomic_fetch_add(fa.done + (row0 / PJ_ROWS) + rg, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == PJ_SLICES - 1;
-            if (last_s) fa.done[(row0 / PJ_ROWS) + rg] = 0;
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        __syncthreads();
-        if (!last_s) return;
-        const int q = tid & 15;
-        for (int r = tid >> 4; r < rows_here; r += PJ_ROWS * 2 / 16) {
-            const int t = row0 + first + r;
-            const float* pp = part + (size_t)t * 64 + 4 * q;
-            float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 4
-            for (int c = 0; c < 32; ++c) {
-                f32x4 v[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pp + (size_t)(c + 32 * u) * part_stride));
-                float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { z.x += v[u].x; z.y += v[u].y; z.z += v[u].z; z.w += v[u].w; }
-                sum.x += z.x; sum.y += z.y; sum.z += z.z; sum.w += z.w;
-            }
-            float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (fa.root != nullptr) {
-                for (int c = 0; c < 32; ++c) {          // chain c: features 2c, 2c+1 (fmaf chain), chains in order
-                    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const float xv = fa.x[(size_t)t * 64 + 2 * c + i];
-                        const float4 rv = *reinterpret_cast<const float4*>(fa.root + (2 * c + i) * 64 + 4 * q);
-                        ra.x = fmaf(xv, rv.x, ra.x); ra.y = fmaf(xv, rv.y, ra.y); ra.z = fmaf(xv, rv.z, ra.z); ra.w = fmaf(xv, rv.w, ra.w);
-                    }
-                    rs.x += ra.x; rs.y += ra.y; rs.z += ra.z; rs.w += ra.w;
-                }
-            }
-            if (fa.aggr == MDNO_AGGR_MEAN) {
-                const int deg = fa.row_ptr[t + 1] - fa.row_ptr[t];
-                const float inv = (float)(deg > 1 ? deg : 1);
-                sum.x /= inv; sum.y /= inv; sum.z /= inv; sum.w /= inv;
-            }
-            if (fa.root != nullptr) { sum.x += rs.x; sum.y += rs.y; sum.z += rs.z; sum.w += rs.w; }
-            if (fa.bias != nullptr) {
-                const float4 bv = *reinterpret_cast<const float4*>(fa.bias + 4 * q);
-                sum.x += bv.x; sum.y += bv.y; sum.z += bv.z; sum.w += bv.w;
-            }
-            if (fa.relu) { sum.x = fmaxf(sum.x, 0.f); sum.y = fmaxf(sum.y, 0.f); sum.z = fmaxf(sum.z, 0.f); sum.w = fmaxf(sum.w, 0.f); }
-            *reinterpret_cast<float4*>(fa.y + (size_t)t * 64 + 4 * q) = sum;
         }
     }
 }
@@ -710,7 +645,6 @@ size_t moment_workspace_bytes(int num_rows, int ker_width) {
     cv.take<float>(s_chunk_floats(num_rows, ker_width));                           // S (+ s0), one chunk of destinations
     cv.take<float>((size_t)PJ_SLICES * num_rows * 64);                             // K-slice partials of z
     cv.take<int>((size_t)num_rows);                                                // destinations of each chunk by decreasing degree
-    cv.take<int>((size_t)(num_rows + kMomentChunkRows - 1) / kMomentChunkRows * (kMomentChunkRows / 256));
     return cv.used();
 }
 
@@ -722,7 +656,6 @@ MomentWs moment_carve(void* ws, int num_rows, int ker_width) {
     f.part = cv.take<float>((size_t)PJ_SLICES * num_rows * 64);
     f.part_stride = (long long)num_rows * 64;
     f.order = cv.take<int>((size_t)num_rows);
-    f.done = cv.take<int>((size_t)(num_rows + kMomentChunkRows - 1) / kMomentChunkRows * (kMomentChunkRows / 256));
     return f;
 }
 
@@ -735,7 +668,7 @@ int moment_prepare_weights(const float* w3, const float* b3, int ker_width, cons
 int moment_prepare_graph(const int* row_ptr, int num_rows, const MomentWs& f, hipStream_t s) {
     TimedSection ts(KID_GRAPH, s);
     hipLaunchKernelGGL(degree_order_kernel<kMomentChunkRows>, dim3((num_rows + kMomentChunkRows - 1) / kMomentChunkRows),
-                       dim3(kMomentChunkRows), 0, s, row_ptr, num_rows, f.order, f.done);
+                       dim3(kMomentChunkRows), 0, s, row_ptr, num_rows, f.order);
     return check_launch("degree_order_kernel");
 }
 
@@ -743,18 +676,16 @@ int moment_conv(const float* x, const float* h2, const int* row_ptr, const int* 
                 const float* root, const float* bias, int aggr, int relu, float* y, const MomentWs& f, hipStream_t s,
                 bool exact_f32) {
     MDNO_REQUIRE(moment_supported(64, ker_width), MDNO_EUNSUPPORTED, "moment conv: ker_width=%d (x128)", ker_width);
-    static const bool fold_env = getenv("MDNO_K2_FOLD") != nullptr && getenv("MDNO_K2_FOLD")[0] == '1';      // EXPERIMENT
-    const bool fold = fold_env && !exact_f32;
     for (int r0 = 0; r0 < num_rows; r0 += kMomentChunkRows) {
         const int cnt = num_rows - r0 < kMomentChunkRows ? num_rows - r0 : kMomentChunkRows;
         {   // K1: the chunk's destinations x the k/256 column blocks
             TimedSection ts(KID_NNCONV, s);
             const int nq = (ker_width + MO_CQ - 1) / MO_CQ + 1;
             const dim3 grid((unsigned)(((cnt + 7) / 8) * 8 * nq));
-            if (exact_f32)      // h2: row-major fp32 [E, k] (the fp32 hidden GEMM's output)
+            if (exact_f32)      // (h2: the k-tiled image in every GEMM mode)
                 hipLaunchKernelGGL(moment_f32_kernel, grid, dim3(256), 0, s, h2, row_ptr, src, (const int*)f.order, f.s,
                                    ker_width, r0, cnt, x);
-            else                // h2: the k-tiled image the split hidden GEMM writes
+            else
                 hipLaunchKernelGGL(moment_kernel, grid, dim3(256), 0, s, h2, row_ptr, src, (const int*)f.order, f.s, ker_width,
                                    r0, cnt, x);
         }
@@ -763,15 +694,11 @@ int moment_conv(const float* x, const float* h2, const int* row_ptr, const int* 
             if (exact_f32)
                 hipLaunchKernelGGL(project_f32_kernel, dim3(((cnt + 127) / 128) * PJ_SLICES), dim3(256), 0, s, (const float*)f.s,
                                    (const float*)f.w3r, f.part, ker_width, cnt, r0, f.part_stride);
-            else if (fold)
-                hipLaunchKernelGGL((project_kernel<256, true>), dim3(((cnt + 255) / 256) * PJ_SLICES), dim3(512), 0, s, (const float*)f.s,
-                                   (const float*)f.w3r, f.part, ker_width, cnt, r0, f.part_stride,
-                                   FoldArgs{f.done, row_ptr, x, root, bias, y, aggr, relu});
             else
-                hipLaunchKernelGGL((project_kernel<256, false>), dim3(((cnt + 255) / 256) * PJ_SLICES), dim3(512), 0, s, (const float*)f.s,
-                                   (const float*)f.w3r, f.part, ker_width, cnt, r0, f.part_stride, FoldArgs{});
+                hipLaunchKernelGGL(project_kernel<256>, dim3(((cnt + 255) / 256) * PJ_SLICES), dim3(512), 0, s, (const float*)f.s,
+                                   (const float*)f.w3r, f.part, ker_width, cnt, r0, f.part_stride);
         }
-        if (!fold) {   // K3
+        {   // K3
             TimedSection ts(KID_NNCONV_COMBINE, s);
             hipLaunchKernelGGL(finish_kernel, dim3(cnt), dim3(FN_CHAINS * 16), 0, s, (const float*)f.part, f.part_stride,
                                row_ptr, x, root, bias, y, r0, aggr, relu);

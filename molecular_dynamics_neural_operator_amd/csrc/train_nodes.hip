@@ -415,7 +415,10 @@ extern "C" int mdno_node_prologue_bwd(const mdno_kernelnn_params* p, const float
         hipLaunchKernelGGL(reduce_blocks_kernel, dim3((count + 255) / 256), dim3(256), 0, s, (const float*)part + off,
                            blocks, tot, count, out);
     };
-    if (lstm) reduce(0, N_LSTM, d_lstm);
+    if (lstm) {
+        reduce(0, N_LSTM, d_lstm);
+        reduce(72, 12, d_lstm + N_LSTM);      // b_hh's gradient = b_ih's: its own 12 floats (no two .grad tensors alias)
+    }
     reduce(N_LSTM, ne, d_emb);
     reduce(N_LSTM + ne, nw, d_fc1_w);
     reduce(N_LSTM + ne + nw, p->width, d_fc1_b);

@@ -81,11 +81,11 @@ def coo_to_csr(edge_index: torch.Tensor, num_nodes: int, validate: bool = True,
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     if status is None:
         status = torch.zeros(1, dtype=torch.int32, device=dev)
-    check(lib.mdno_coo_to_csr(ptr(ei), E, num_nodes, ptr(row_ptr), ptr(src), ptr(dst), ptr(perm), ptr(status),
+    ne = torch.empty(1, dtype=torch.int32, device=dev)       # written by the sort itself (no fill launch)
+    check(lib.mdno_coo_to_csr(ptr(ei), E, num_nodes, ptr(row_ptr), ptr(src), ptr(dst), ptr(perm), ptr(ne), ptr(status),
                               ptr(ws), nbytes, stream_ptr(dev)), "mdno_coo_to_csr")
     if validate:
         raise_on_status(status.item(), "coo_to_csr")
-    ne = torch.full((1,), E, dtype=torch.int32, device=dev)
     return CSRGraph(row_ptr, src, dst, ne, cap, perm, status, n_edges=E)
 
 
@@ -202,7 +202,7 @@ class ParamPack:
 
 
 def node_prologue(pack: ParamPack, frames: torch.Tensor, x_aminoacid: torch.Tensor,
-                  status: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  status: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """frames f32 [W,M,N,3] -> x0 f32 [M*N,width]: LSTM over the window, lstm_fc, Embedding, concat, fc1,
     ReLU (graph_kernel.py:279-298).  Raises on an amino-acid id outside [0, num_embeddings) — unless the
     caller passes its own `status` word (int32 [1] on the device): the bit is then left there for it to
@@ -216,7 +216,9 @@ def node_prologue(pack: ParamPack, frames: torch.Tensor, x_aminoacid: torch.Tens
     aa = x_aminoacid.to(device=dev, dtype=torch.long).contiguous()
     if aa.numel() not in (N, M * N):
         raise MdnoError(f"x_aminoacid has {aa.numel()} entries, expected {N} or {M * N}")
-    x0 = torch.empty((M * N, pack.struct.width), dtype=torch.float32, device=dev)
+    x0 = out if out is not None else torch.empty((M * N, pack.struct.width), dtype=torch.float32, device=dev)
+    if tuple(x0.shape) != (M * N, pack.struct.width) or x0.dtype != torch.float32:
+        raise MdnoError(f"node_prologue: out must be f32 {(M * N, pack.struct.width)}")
     deferred = status is not None
     if not deferred:
         status = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -369,12 +371,33 @@ def inv_degree(graph: CSRGraph, aggr: str = "mean") -> torch.Tensor:
     return inv
 
 
-def source_sorted(graph: CSRGraph, num_nodes: int) -> CSRGraph:
-    """The same edges grouped by SOURCE: row_ptr over sources, `src` field = destination of each
-    out-edge, `perm` = the edge's position in the destination-sorted arrays (and in W_e)."""
-    e = graph.edge_count()
-    swapped = torch.stack([graph.dst[:e], graph.src[:e]]).to(torch.long)   # "target" := source
-    return coo_to_csr(swapped, num_nodes, validate=False)     # (ids come from a CSR that was validated when built)
+def source_sorted(graph: CSRGraph, num_nodes: int, status: Optional[torch.Tensor] = None) -> CSRGraph:
+    """The same edges grouped by SOURCE (include/mdno.h mdno_csr_by_source): row_ptr over sources, `src` field =
+    destination of each out-edge, `perm` = the edge's position in the destination-sorted arrays (and in W_e)."""
+    lib = _lib.load()
+    E = graph.edge_count()
+    dev = graph.row_ptr.device
+    cap = max(E, 1)
+    row_ptr = torch.empty(num_nodes + 1, dtype=torch.int32, device=dev)
+    nbr = torch.empty(cap, dtype=torch.int32, device=dev)
+    rowid = torch.empty(cap, dtype=torch.int32, device=dev)
+    perm = torch.empty(cap, dtype=torch.int32, device=dev)
+    nbytes = lib.mdno_coo_to_csr_workspace_bytes(E, num_nodes)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    st = status if status is not None else graph.status        # (ids come from a CSR that was validated when built)
+    check(lib.mdno_csr_by_source(ptr(graph.src), ptr(graph.dst), E, num_nodes, ptr(row_ptr), ptr(nbr), ptr(rowid), ptr(perm),
+                                 ptr(st), ptr(ws), nbytes, stream_ptr(dev)), "mdno_csr_by_source")
+    return CSRGraph(row_ptr, nbr, rowid, graph.num_edges, cap, perm, st, n_edges=E)
+
+
+def permute_rows(x: torch.Tensor, perm: torch.Tensor, rows: int) -> torch.Tensor:
+    """out[p] = x[perm[p]] for p < rows (include/mdno.h mdno_permute_rows): per-edge rows into a graph's CSR order."""
+    lib = _lib.load()
+    x = f32(x)
+    out = torch.empty((rows,) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
+    width = int(x[0].numel()) if x.shape[0] else 1
+    check(lib.mdno_permute_rows(ptr(x), ptr(perm), rows, width, ptr(out), stream_ptr(x.device)), "mdno_permute_rows")
+    return out
 
 
 def nnconv_bwd_x(gz: torch.Tensor, gs: torch.Tensor, by_src: CSRGraph, w_e: torch.Tensor,
@@ -668,7 +691,7 @@ def node_prologue_bwd(pack: ParamPack, frames: torch.Tensor, x_aminoacid: torch.
     aa = x_aminoacid.to(device=dev, dtype=torch.long).contiguous()
     p = pack.struct
     has_lstm = "lstm_w_ih" in pack.tensors
-    d_lstm = torch.empty(96, dtype=torch.float32, device=dev) if has_lstm else None
+    d_lstm = torch.empty(108, dtype=torch.float32, device=dev) if has_lstm else None
     d_emb = torch.empty((p.num_embeddings, p.embedding_dim), dtype=torch.float32, device=dev)
     d_w = torch.empty((p.width, p.in_width), dtype=torch.float32, device=dev)
     d_b = torch.empty(p.width, dtype=torch.float32, device=dev)
@@ -678,13 +701,12 @@ def node_prologue_bwd(pack: ParamPack, frames: torch.Tensor, x_aminoacid: torch.
                                      ws.numel(), stream_ptr(dev)), "mdno_node_prologue_bwd")
     out = {"emb.weight": d_emb, "fc1.weight": d_w, "fc1.bias": d_b}
     if has_lstm:
-        # every gradient owns its storage: autograd's AccumulateGrad keeps the tensor it is handed, so
-        # views of one buffer (bias_ih and bias_hh have the SAME gradient) would alias .grad tensors —
-        # clip_grad_norm_ and a second backward without zero_grad(set_to_none=True) then count it twice
-        out.update({"lstm.weight_ih_l0": d_lstm[0:36].reshape(12, 3).clone(),
-                    "lstm.weight_hh_l0": d_lstm[36:72].reshape(12, 3).clone(),
-                    "lstm.bias_ih_l0": d_lstm[72:84].clone(), "lstm.bias_hh_l0": d_lstm[72:84].clone(),
-                    "lstm_fc.weight": d_lstm[84:93].reshape(3, 3).clone(), "lstm_fc.bias": d_lstm[93:96].clone()})
+        # six DISJOINT slices of one buffer (the kernel writes b_hh's gradient — the same values as b_ih's — a second
+        # time at [96:108]): autograd's AccumulateGrad keeps the tensor it is handed, so no two .grad tensors may
+        # share memory (clip_grad_norm_, accumulation without zero_grad), and none of them needs a copy
+        out.update({"lstm.weight_ih_l0": d_lstm[0:36].view(12, 3), "lstm.weight_hh_l0": d_lstm[36:72].view(12, 3),
+                    "lstm.bias_ih_l0": d_lstm[72:84], "lstm.bias_hh_l0": d_lstm[96:108],
+                    "lstm_fc.weight": d_lstm[84:93].view(3, 3), "lstm_fc.bias": d_lstm[93:96]})
     return out
 
 

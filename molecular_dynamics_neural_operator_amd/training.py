@@ -38,38 +38,39 @@ class KernelIntegralBlock(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x0, edge_attr, graph, depth, gemm_mode, w0, b0, w1, b1, w2, b2, root1, bias1, root2, bias2):
+        """graph.x_stack (optional): f32 [2*depth+1, R, 64] whose layer 0 IS x0 — train_forward lets the node prologue
+        write there, so the block copies nothing in.  Returns layer 2*depth of the stack (a view: the stack is kept
+        for the backward anyway)."""
         R = x0.shape[0]
+        X = getattr(graph, "x_stack", None)
         E = graph.edge_count()
-        ea = ops.f32(edge_attr)[graph.perm[:E].long()] if graph.perm is not None else ops.f32(edge_attr)
-        ea = ea.contiguous()
+        ea = ops.permute_rows(edge_attr, graph.perm, E) if graph.perm is not None else ops.f32(edge_attr).contiguous()
+        L = 2 * depth
+        if X is None or X.data_ptr() != x0.data_ptr() or tuple(X.shape) != (L + 1, R, 64):
+            X = torch.empty((L + 1, R, 64), dtype=torch.float32, device=x0.device)
+            X[0].copy_(x0)
         ctx.bf16 = gemm_mode == "bf16"
         if ctx.bf16:
-            return KernelIntegralBlock._forward_bf16(ctx, x0, ea, graph, depth, w0, b0, w1, b1, w2, b2, root1, bias1,
+            return KernelIntegralBlock._forward_bf16(ctx, X, ea, graph, depth, w0, b0, w1, b1, w2, b2, root1, bias1,
                                                      root2, bias2)
         h1 = ops.linear(ea, w0, b0, relu=True)
         h2 = ops.linear(h1, w1, b1, relu=True, gemm_mode=gemm_mode)
         w_e = ops.linear(h2, w2, b2, relu=False, gemm_mode=gemm_mode)
-        L = 2 * depth
-        X = torch.empty((L + 1, R, 64), dtype=torch.float32, device=x0.device)
-        X[0].copy_(x0)
         ops.nnconv_chain_fwd(X, graph, w_e, root1, bias1, root2, bias2, depth)        # the 2*depth applications, one call
         ctx.graph, ctx.depth, ctx.gemm_mode = graph, depth, gemm_mode
         ctx.save_for_backward(ea, h1, h2, w_e, X, w0, w1, w2, root1, root2)
-        return X[L].clone()
+        return X[L]
 
     @staticmethod
-    def _forward_bf16(ctx, x0, ea, graph, depth, w0, b0, w1, b1, w2, b2, root1, bias1, root2, bias2):
-        R = x0.shape[0]
+    def _forward_bf16(ctx, X, ea, graph, depth, w0, b0, w1, b1, w2, b2, root1, bias1, root2, bias2):
         h1 = ops.linear_smallk_bf16(ea, w0, b0, relu=True)               # K = 6: fp32 fmaf chains, stored bf16
         h2 = ops.linear_bf16(h1, w1, b1, relu=True, out_bf16=True)
         w_e = ops.linear_bf16(h2, w2, b2, relu=False, out_bf16=True)     # [E, 4096] bf16: 8 KiB per edge
         L = 2 * depth
-        X = torch.empty((L + 1, R, 64), dtype=torch.float32, device=x0.device)
-        X[0].copy_(x0)
         ops.nnconv_chain_fwd(X, graph, w_e, root1, bias1, root2, bias2, depth)
         ctx.graph, ctx.depth, ctx.gemm_mode = graph, depth, "bf16"
         ctx.save_for_backward(ea, h1, h2, w_e, X, w0, w1, w2, root1, root2)
-        return X[L].clone()
+        return X[L]
 
     @staticmethod
     def _backward_bf16(ctx, g_out):
@@ -123,7 +124,7 @@ class NodePrologue(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pack, frames, aa, *params):
-        x0 = ops.node_prologue(pack, frames, aa, status=pack.train_status)
+        x0 = ops.node_prologue(pack, frames, aa, status=pack.train_status, out=getattr(pack, "prologue_out", None))
         ctx.pack, ctx.names = pack, pack.prologue_names
         ctx.save_for_backward(frames, aa, x0)
         return x0
@@ -268,18 +269,23 @@ def train_forward(model, data) -> torch.Tensor:
     if status is None or status.device != dev:
         status = model._train_status = torch.zeros(1, dtype=torch.int32, device=dev)
     pack.train_status = status
+    conv2 = getattr(model, "conv2", None)
+    depth = model.depth if conv2 is not None else model.depth // 2
+    # the feature stack of the kernel-integral block [2*depth+1, R, 64]: the prologue writes layer 0 in place and the
+    # block returns its last layer as a view — no copy on either side
+    X = torch.empty((2 * depth + 1, R, model.fc1.out_features), dtype=torch.float32, device=dev) \
+        if model.fc1.out_features == 64 else None
+    pack.prologue_out = X[0] if X is not None else None
     x0 = NodePrologue.apply(pack, xp.unsqueeze(1).contiguous(), aa, *[sd[k] for k in names])
+    pack.prologue_out = None
     ei = batch.edge_index.to(dev)
     graph = ops.coo_to_csr(ei, R, validate=False, status=status)
     # the same edges grouped by source, for the input-gradient kernel: built now, next to the forward's sort
     # (ids already validated by it), so that the backward starts with everything in place
-    E = graph.n_edges
-    graph.by_src = ops.coo_to_csr(torch.stack([graph.dst[:E], graph.src[:E]]).to(torch.long), R, validate=False,
-                                  status=status) if torch.is_grad_enabled() else None
+    graph.by_src = ops.source_sorted(graph, R, status=status) if torch.is_grad_enabled() else None
+    graph.x_stack = X
     net = model.conv1.net
     w0, b0, w1, b1, w2, b2 = net.hip_weights()
-    conv2 = getattr(model, "conv2", None)
-    depth = model.depth if conv2 is not None else model.depth // 2
     if conv2 is None and model.depth % 2:
         raise NotImplementedError("notebook-era variant: training needs an even depth")
     c2 = conv2 if conv2 is not None else model.conv1

@@ -68,8 +68,8 @@ for ev in prof.events():
     ops[ev.name] += 1
     frame = "?"
     for fr in (ev.stack or []):
-        if str(REPO) in fr and "train_aten_audit" not in fr:
-            frame = fr.replace(str(REPO) + "/", "")
+        if "molecular_dynamics_neural_operator_amd/" in fr:
+            frame = fr[fr.index("molecular_dynamics_neural_operator_amd/"):]
             break
     where[ev.name][frame] += 1
 print(f"precision {a.precision}, {a.batches} batches of {B}: ATen operators per batch (innermost repo frame)")

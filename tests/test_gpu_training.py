@@ -879,3 +879,28 @@ def test_lploss_reference_golden_on_device(dev):
     x, y = torch.from_numpy(z["x"]).to(dev), torch.from_numpy(z["y"]).to(dev)
     torch.testing.assert_close(LpLoss(size_average=False)(x, y).cpu(), torch.from_numpy(z["rel_sum"]), rtol=2e-6, atol=0)
     torch.testing.assert_close(LpLoss(size_average=True)(x, y).cpu(), torch.from_numpy(z["rel_mean"]), rtol=2e-6, atol=0)
+
+
+def test_csr_by_source_and_permute_rows(dev):
+    """mdno_csr_by_source == mdno_coo_to_csr on the swapped (dst, src) arrays of the destination-sorted graph (what the
+    training forward did through torch.stack(...).to(long)), bitwise, on a graph with a hub row above the big-row
+    threshold, duplicates and empty rows; mdno_permute_rows == x[perm]; the edge count is written by the sort itself."""
+    from molecular_dynamics_neural_operator_amd import ops
+    gen = torch.Generator().manual_seed(9)
+    R, E = 700, 30000
+    ei = torch.randint(0, R, (2, E), generator=gen)
+    ei[0, :2600] = 3                                  # a hub SOURCE: a by-source row beyond kBigRow = 2,048
+    ei[1, 2600:5300] = 11                             # and a hub target
+    ei[:, 6000:6100] = ei[:, 5900:6000]               # duplicates
+    ei[0, ei[0] == 50] = 51                           # node 50: no out-edge
+    g = ops.coo_to_csr(ei.to(dev), R)
+    assert int(g.num_edges.item()) == E == g.edge_count()
+    want = ops.coo_to_csr(torch.stack([g.dst[:E], g.src[:E]]).to(torch.long), R)
+    got = ops.source_sorted(g, R)
+    for f in ("row_ptr", "src", "dst", "perm"):
+        assert torch.equal(getattr(got, f)[:E + 1 if f == "row_ptr" else E], getattr(want, f)[:E + 1 if f == "row_ptr" else E]), f
+    assert int(got.row_ptr[51]) == int(got.row_ptr[50])        # the empty row
+    x = torch.randn(E, 6, generator=gen).to(dev)
+    assert torch.equal(ops.permute_rows(x, g.perm, E), x[g.perm[:E].long()])
+    x1 = torch.randn(E, generator=gen).to(dev)
+    assert torch.equal(ops.permute_rows(x1, g.perm, E), x1[g.perm[:E].long()])

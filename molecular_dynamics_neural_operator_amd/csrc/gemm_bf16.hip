@@ -92,8 +92,15 @@ struct PpArgs {
 //   and the fragments come out of gfx950's transposing read ds_read_b64_tr_b16 (a 16-lane group gets a 4-row x
 //   16-column block column-major: 4 consecutive k of its own m; two reads make the 8-k MFMA operand).  The four
 //   rows of a block sit in four different 64-B quarters of the 256-B bank row: conflict free.
-template <bool TN, int EPI, bool RELU, bool OUT_BF16, bool F16 = false>
+// PERSIST (NT with bf16 output only): the grid is one workgroup per CU (a multiple of 8) and a workgroup walks the
+// tiles of its XCD's range j, j + G/8, j + 2 G/8, ..; the first two stages of the NEXT tile are put in flight by every
+// wave right after its last multiply phase, under its epilogue stores (the epilogue's LDS patches live in ring slot 2,
+// which the next tile does not touch before the barrier that ends its prologue), so that a tile no longer starts with
+// every CU's first 64 KB arriving at once (EXPERIMENTS.md §0.3: 6.7k of a K = 1,024 tile's 64.5k cycles).  Same MFMAs
+// in the same order per output element: bit-identical results.
+template <bool TN, int EPI, bool RELU, bool OUT_BF16, bool F16 = false, bool PERSIST = false>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PpArgs g) {
+    static_assert(!PERSIST || (!TN && OUT_BF16 && EPI != EPI_SLAB && !F16), "persistent form: A . W^T with bf16 output");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const __bf16* const opA = (F16 && blockIdx.z == 1) ? g.A2 : g.A;
     const __bf16* const opW = (F16 && blockIdx.z == 2) ? g.W2 : g.W;
@@ -102,9 +109,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PpArgs g) {
     const long long nwg = g.tiles_m * g.tiles_n;
     const long long orig = blockIdx.x;
     const long long xcd = orig & 7, q = nwg >> 3, r8 = nwg & 7;
-    const long long tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
-    const long long bm = (tile / g.tiles_n) * PP_T;
-    const int bn = (int)(tile % g.tiles_n) * PP_T;
+    const long long xcd_first = xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q;      // this XCD's first tile
+    const long long xcd_count = q + (xcd < r8 ? 1 : 0);
+    const long long per_xcd = PERSIST ? (long long)(gridDim.x >> 3) : 0;      // workgroups per XCD (stride of the walk)
+    long long loc = orig >> 3;                          // index inside the XCD's range
+    if (PERSIST && loc >= xcd_count) return;
+    long long tile = xcd_first + loc;
+    long long bm = (tile / g.tiles_n) * PP_T;
+    int bn = (int)(tile % g.tiles_n) * PP_T;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -132,16 +144,21 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PpArgs g) {
     unsigned voff[PP_PIECES_PER_WAVE];
     unsigned stride_a, stride_b;                 // bytes from one stage to the next, per operand
     __amdgpu_buffer_rsrc_t rsrc_a, rsrc_b;
+    // (NT) the two descriptors of the tile at (row bm_, column bn_)
+    auto nt_descriptors = [&](long long bm_, int bn_) {
+        const size_t ldk = (size_t)g.K * 2;
+        long long live = g.rows - bm_;
+        if (live > PP_T) live = PP_T;
+        rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const unsigned char*>(g.A) + (size_t)bm_ * ldk), 0,
+                                                   (int)(live * (long long)ldk), 0x00020000);
+        rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const unsigned char*>(g.W) + (size_t)bn_ * ldk), 0,
+                                                   (int)(PP_T * ldk), 0x00020000);
+    };
     if (!TN) {
         const int pr = lane >> 2, pc = (lane & 3) ^ ((lane >> 4) & 3);
         const size_t ldk = (size_t)g.K * 2;
         stride_a = stride_b = PP_ROW_BYTES;
-        long long live = g.rows - bm;
-        if (live > PP_T) live = PP_T;
-        rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const unsigned char*>(g.A) + (size_t)bm * ldk), 0,
-                                                   (int)(live * (long long)ldk), 0x00020000);
-        rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const unsigned char*>(g.W) + (size_t)bn * ldk), 0,
-                                                   (int)(PP_T * ldk), 0x00020000);
+        nt_descriptors(bm, bn);
 #pragma unroll
         for (int t = 0; t < PP_PIECES_PER_WAVE; ++t) {
             const int piece = wave + 8 * t;                      // 0..31; < 16: A, else B
@@ -200,12 +217,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PpArgs g) {
     }
 
     f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     float bv0 = 0.f, bv1 = 0.f;      // fetched before the K loop and pinned (edge_mlp_split.hip, epilogue stores)
     if (EPI == EPI_BIAS && g.bias) {
         bv0 = g.bias[bn + wn * 64 + l31];
@@ -294,8 +305,18 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PpArgs g) {
     // prologue: stages 0 and 1 in flight, stage 0 landed for everybody
     if (T > 0) { MDNO_PP_DMA(0) }
     if (T > 1) { MDNO_PP_DMA(1) }
-    if (T > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bool first_tile = true;
+tile_loop:      // (PERSIST: one pass per tile of this workgroup; otherwise a single pass)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    // a later tile's first two stages went out under the previous epilogue, with that epilogue's stores behind them in
+    // the queue: everything is waited for (stage 1 landed long ago: an epilogue is longer than a stage's flight)
+    if (T > 1 && first_tile) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(bv0), "+v"(bv1) :: "memory");      // (and this tile's bias is pinned here)
     MDNO_PP_BARRIER()
     if (grp == 1) { MDNO_PP_BARRIER() }          // the stagger: waves 4-7 run one phase behind
     for (int t = 0; t < T; ++t) {
@@ -316,10 +337,32 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PpArgs g) {
         if (grp == 0 || t + 1 < T) { MDNO_PP_BARRIER() }
     }
     if (T == 0 && grp == 0) { MDNO_PP_BARRIER() }   // (an empty slice: pair the stagger barrier)
-#undef MDNO_PP_DMA
-#undef MDNO_PP_LOAD
-#undef MDNO_PP_MMA
-#undef MDNO_PP_BARRIER
+
+    // ---- PERSIST: this wave's share of the next tile's stages 0 and 1, now (every fragment read of the tile just
+    // multiplied completed before the last barrier this wave passed: any slot may be overwritten; slot 2 is left to
+    // the epilogue's patches).  The next tile's bias first — older in the queue than the pieces, pinned after its K loop.
+    const long long cur_bm = bm;
+    const int cur_bn = bn;
+    float bn0 = 0.f, bn1 = 0.f;
+    bool more_tiles = false;
+    if (PERSIST) {
+        loc += per_xcd;
+        more_tiles = loc < xcd_count;
+        if (more_tiles) {
+            tile = xcd_first + loc;
+            bm = (tile / g.tiles_n) * PP_T;
+            bn = (int)(tile % g.tiles_n) * PP_T;
+            if (EPI == EPI_BIAS && g.bias) {
+                bn0 = g.bias[bn + wn * 64 + l31];
+                bn1 = g.bias[bn + wn * 64 + 32 + l31];
+            }
+            nt_descriptors(bm, bn);
+            __builtin_amdgcn_sched_barrier(0);
+            MDNO_PP_DMA(0)
+            if (T > 1) { MDNO_PP_DMA(1) }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
 
     // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5): a lane holds
     // ONE column of 16 rows, so storing from the accumulators is 2-byte (or 4-byte) pieces 2*N apart — 128 store
@@ -330,9 +373,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PpArgs g) {
     constexpr bool OBF = OUT_BF16 && EPI != EPI_SLAB;
     constexpr int ESZ = OBF ? 2 : 4;
     constexpr int PATCH_ROW = 64 * ESZ;                    // bytes per patch row (the wave's 64 columns)
-    unsigned char* patch = lds + wave * (32 * 64 * 4);    // 8 KiB apart (fp32 size) for either type
+    // (PERSIST: bf16 patches of 4 KiB per wave in ring slot 2 — slots 0 and 1 are receiving the next tile)
+    unsigned char* patch = PERSIST ? lds + 2 * PP_STAGE_BYTES + wave * (32 * 64 * 2) : lds + wave * (32 * 64 * 4);    // else 8 KiB apart (fp32 size) for either type
     const size_t ldc = (size_t)g.N * ESZ;
-    unsigned char* cbase = static_cast<unsigned char*>(g.C) + (size_t)(bn + wn * 64) * ESZ;
+    unsigned char* cbase = static_cast<unsigned char*>(g.C) + (size_t)(cur_bn + wn * 64) * ESZ;
     // slab (product z, slice y) = [n1 = K][n2 = N] fp32
     if (EPI == EPI_SLAB) cbase += ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * (size_t)g.K * g.N * 4;
     const long long out_rows = TN ? (long long)g.K : g.rows;
@@ -341,7 +385,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PpArgs g) {
     const int orow = lane / LANES_PER_ROW, ochunk = lane % LANES_PER_ROW;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const long long m0 = bm + grp * 128 + i * 32;
+        const long long m0 = cur_bm + grp * 128 + i * 32;
         // EPI_MASK: this lane's 16 B of the stored activation Y, one load per output store, issued first
         uint4 yv[32 / ROWS_PER_INSTR];
         if (EPI == EPI_MASK) {
@@ -350,7 +394,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PpArgs g) {
                 long long m = m0 + rr + orow;
                 if (m >= out_rows) m = out_rows - 1;
                 yv[rr / ROWS_PER_INSTR] = *reinterpret_cast<const uint4*>(
-                    reinterpret_cast<const unsigned char*>(g.Y) + ((size_t)m * g.N + bn + wn * 64) * 2 + ochunk * 16);
+                    reinterpret_cast<const unsigned char*>(g.Y) + ((size_t)m * g.N + cur_bn + wn * 64) * 2 + ochunk * 16);
             }
         }
 #pragma unroll
@@ -383,6 +427,20 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PpArgs g) {
             if (m < out_rows) *reinterpret_cast<uint4*>(cbase + (size_t)m * ldc + ochunk * 16) = v;
         }
     }
+    if (PERSIST && more_tiles) {
+        bv0 = bn0;
+        bv1 = bn1;
+        first_tile = false;
+        // this wave's patch reads are done before anybody's stage-2 pieces can reach slot 2: they are issued after the
+        // prologue barrier of the next tile, which this wave enters only after its LDS operations have been issued in
+        // order (lgkmcnt(0) makes it explicit)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        goto tile_loop;
+    }
+#undef MDNO_PP_DMA
+#undef MDNO_PP_LOAD
+#undef MDNO_PP_MMA
+#undef MDNO_PP_BARRIER
 }
 
 // out[i] = sum over slices (in order) of slab[z][i]
@@ -412,12 +470,43 @@ bool gemm_nt_pp_supported(long long rows, int N, int K) {
     return rows > 0 && N % PP_T == 0 && K % PP_BK == 0 && K >= 2 * PP_BK;
 }
 
+// compute units of the current device (a persistent launch is one workgroup per CU)
+static int device_cus() {
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int n = cached[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
+// MDNO_GEMM_PP_PERSIST=0: one workgroup per tile for the bf16-output products too (A/B switch of the persistent form)
+static bool pp_persist_enabled() {
+    static const bool on = !(getenv("MDNO_GEMM_PP_PERSIST") && getenv("MDNO_GEMM_PP_PERSIST")[0] == '0');
+    return on;
+}
+
 template <bool TN, int EPI, bool RELU, bool OUT_BF16, bool F16 = false>
 static int launch_pp(const PpArgs& g, unsigned slices, hipStream_t s) {
-    static std::atomic<unsigned long long> raised{0};
-    MDNO_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(&gemm_pp_kernel<TN, EPI, RELU, OUT_BF16, F16>), PP_LDS_BYTES, raised));
     const long long nwg = g.tiles_m * g.tiles_n;
     MDNO_REQUIRE(nwg < (1ll << 31), MDNO_EUNSUPPORTED, "gemm_pp: too many tiles");
+    if constexpr (!TN && OUT_BF16 && EPI != EPI_SLAB && !F16) {
+        // more tiles than CUs: the persistent form (one workgroup per CU walking its XCD's tiles)
+        const int cus = device_cus() / 8 * 8;
+        if (pp_persist_enabled() && cus >= 8 && nwg > cus) {
+            static std::atomic<unsigned long long> raised_p{0};
+            MDNO_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(&gemm_pp_kernel<TN, EPI, RELU, OUT_BF16, F16, true>),
+                                       PP_LDS_BYTES, raised_p));
+            hipLaunchKernelGGL((gemm_pp_kernel<TN, EPI, RELU, OUT_BF16, F16, true>), dim3((unsigned)cus), dim3(512), PP_LDS_BYTES,
+                               s, g);
+            return check_launch("gemm_pp_kernel (persistent)");
+        }
+    }
+    static std::atomic<unsigned long long> raised{0};
+    MDNO_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(&gemm_pp_kernel<TN, EPI, RELU, OUT_BF16, F16>), PP_LDS_BYTES, raised));
     hipLaunchKernelGGL((gemm_pp_kernel<TN, EPI, RELU, OUT_BF16, F16>), dim3((unsigned)nwg, slices, F16 ? 3 : 1), dim3(512),
                        PP_LDS_BYTES, s, g);
     return check_launch("gemm_pp_kernel");

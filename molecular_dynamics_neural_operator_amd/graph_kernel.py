@@ -70,6 +70,7 @@ class _LpLossRelFn(torch.autograd.Function):
     def forward(ctx, x, y, size_average):
         from . import ops
         x, y = x.contiguous(), y.contiguous()
+        ctx.set_materialize_grads(False)       # (no zeros tensor — a fill launch — for the MSE output's absent gradient)
         res, stats = ops.lploss_rel_fwd(x, y, size_average)
         ctx.save_for_backward(x, y, stats)
         ctx.size_average = bool(size_average)
@@ -81,6 +82,8 @@ class _LpLossRelFn(torch.autograd.Function):
     def backward(ctx, g, _g_mse):
         from . import ops
         x, y, stats = ctx.saved_tensors
+        if g is None:
+            return None, None, None
         return ops.lploss_rel_bwd(x, y, stats, g, ctx.size_average), None, None
 
 

@@ -92,7 +92,7 @@ def test_live504_teacher_forced_reference_golden(dev, live504, gemm_mode):
     for i in range(z["teacher_forced_out"].shape[0]):
         s = dset[i].to(dev)
         # model(sample) on the sample's own edge list: the reference's formulation, and what "auto" picks for this
-        # graph (120 neighbours per atom: the factored form — for the split GEMM modes, which take any edge list)
+        # graph (120 neighbours per atom: the factored form, which takes any edge list in every GEMM mode)
         for conv_mode in ("materialized", "auto"):
             model.conv_mode = conv_mode
             with torch.no_grad():
@@ -101,7 +101,7 @@ def test_live504_teacher_forced_reference_golden(dev, live504, gemm_mode):
             if i == 0:
                 close(lat, lat0, name=f"latent0 model(sample) {conv_mode}")
         picked = model._conv_mode_for_edges(dev, 1, s.x_aminoacid.shape[0], s.edge_index.shape[1])
-        assert picked == ("materialized" if gemm_mode == "f32" else "factored")
+        assert picked == "factored"
         # factored: the sample's graph is the radius graph of its FIRST window frame (dataset.py:189-201)
         first = s.x_position[0].contiguous()
         g = ops.radius_graph(first, first.shape[0], thr)

@@ -500,6 +500,49 @@ def leg_cfg4_training(dev, frames=10000, batch=128, kernel_width=1024, depth=6, 
     out["cpu_baseline"] = {"value": cpu_samples / dt, "unit": "samples/s", "cores": _cores(), "kind": "port",
                            "sample": f"forward + LpLoss + backward of {cpu_samples} samples, torch autograd over the oracle's "
                                      "formulas (edge-MLP evaluated once per sample, not 12x), no optimizer step"}
+    # ---- "loss after 1 epoch vs the CPU restatement" (SURVEY.md §8d cfg4): a 16-batch mini-epoch of the reference's
+    # loop (graph_kernel.py:445-474: forward, LpLoss(size_average=False), backward, Adam step per batch; the epoch's
+    # average loss is what train() returns), same start parameters and batches, on the device in both precisions and
+    # on the host in fp64 over the oracle's train step
+    try:
+        mb, mbs = 16, 4
+        ep_idx = [list(range(200 + b_ * mbs, 200 + (b_ + 1) * mbs)) for b_ in range(mb)]
+        sd0 = {k: v.clone() for k, v in ref.state_dict().items()}
+        with torch.no_grad():
+            for k_ in ("conv1.net.layers.4.weight", "conv1.net.layers.4.bias"):
+                sd0[k_] = sd0[k_] * 0.05
+                sd0[k_.replace("conv1", "conv2")] = sd0[k_]
+        ep = {"batches": mb, "batch_size": mbs, "optimizer": "Adam(lr=1e-4, weight_decay=5e-4)"}
+        for precision in ("fp32", "bf16"):
+            m_ = KernelNN(64, kernel_width, depth, 6, 7, 3, 20, 4)
+            m_.load_state_dict(sd0)
+            m_.to(dev)
+            m_.train_precision = precision
+            o_ = torch.optim.Adam(m_.parameters(), lr=1e-4, weight_decay=5e-4)
+            ep[f"hip_{precision}"], _ = train_epoch(m_, (dtraj.batch(i) for i in ep_idx), o_, LpLoss(size_average=False))
+            del m_, o_
+        t0 = time.perf_counter()
+        pp = {k: v.detach().double().clone().requires_grad_(True) for k, v in sd0.items() if not k.startswith("conv2.net.")}
+        o_ = torch.optim.Adam(list(pp.values()), lr=1e-4, weight_decay=5e-4)
+        tot = 0.0
+        for i in ep_idx:
+            dd = [dict(x_position=s_.x_position, x_aminoacid=s_.x_aminoacid, y=s_.y, edge_index=s_.edge_index,
+                       edge_attr=s_.edge_attr) for s_ in (dset[j] for j in i)]
+            l_, _, g_ = O.train_step({k: v.detach() for k, v in pp.items()}, dd, depth)
+            o_.zero_grad()
+            for k, v in pp.items():
+                v.grad = g_[k].detach().double().clone()
+            o_.step()
+            tot += l_
+        ep["oracle_fp64"] = tot / mb
+        ep["oracle_seconds"] = time.perf_counter() - t0
+        ep["rel_diff_fp32"] = abs(ep["hip_fp32"] - ep["oracle_fp64"]) / abs(ep["oracle_fp64"])
+        ep["rel_diff_bf16"] = abs(ep["hip_bf16"] - ep["oracle_fp64"]) / abs(ep["oracle_fp64"])
+        out["loss_after_1_epoch"] = ep
+        note(f"cfg4 mini-epoch loss: hip fp32 {ep['hip_fp32']:.6f} bf16 {ep['hip_bf16']:.6f} oracle {ep['oracle_fp64']:.6f} "
+             f"({ep['oracle_seconds']:.0f} s on the host)")
+    except Exception as e:     # noqa: BLE001 — recorded in the line
+        out["loss_after_1_epoch"] = {"error": f"{type(e).__name__}: {e}"}
     return out
 
 

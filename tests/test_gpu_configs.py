@@ -1071,6 +1071,9 @@ def test_member_groups_resolve_auto_once_for_the_shard(dev):
     grp = GroupedRolloutEngine(model, 2, N, W, 8.0, max_steps=steps, device=dev, groups=2)
     got = grp.run(tm, aa, steps)
     assert grp.conv_mode == one.conv_mode and {e.conv_mode for e in grp.engines} == {one.conv_mode}
+    for m in range(2):
+        d = (got[:, m] - want[:, m]).abs().max().item()
+        print(f"member {m}: max |grouped - one engine| = {d:.3e}, edges/step {[int(e.edges_per_step[0]) for e in grp.engines]}")
     assert torch.equal(got, want)
     one.close()
     grp.close()

@@ -537,8 +537,17 @@ constexpr int F16_STAGE_BYTES = 3 * F16_TILE_BYTES;       // A tile 0 | A tile 1
 // ROW_SCALE: the rows of A carry their own power-of-two scale as well (g.a_unscale; split_linear_f16) — its own
 // instantiation: the 32 extra registers and multiplies in the epilogue cost the inference kernels 12 % (353 -> 400 us
 // for the hidden GEMM at N = 504) when they sat in the common one
-template <int OUT, int MI, bool ROW_SCALE = false>
+// PERSIST (the factored conv's hidden GEMM: OUT 2, MI 2): the launch is one workgroup per CU (a multiple of 8) and a
+// workgroup walks the tiles of its XCD's range j, j + G/8, ..  Two things change at a tile's end, none in its sums
+// (same MFMAs in the same order per output element: bit-identical results):
+//   * after a barrier that ends the last stage's fragment reads, every wave puts its pieces of the NEXT tile's stages 0
+//     and 1 in flight, so that they travel under the epilogue instead of in front of the next K loop;
+//   * the epilogue turns each 32 x 32 accumulator block through a 4.5 KiB LDS patch (ring slot 2, idle until the next
+//     tile's first barrier) and stores it as the 4 KiB contiguous run it is in the k-tiled image — 16 B per lane, four
+//     1 KiB store instructions per block — instead of 16 stores of 4 B per lane (two 128-B rows per instruction).
+template <int OUT, int MI, bool ROW_SCALE = false, bool PERSIST = false>
 __global__ __launch_bounds__(1024 / MI) void gemm_split_f16_kernel(SplitGemmArgs g) {
+    static_assert(!PERSIST || (OUT == 2 && !ROW_SCALE), "persistent form: the k-tiled fp32 output");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int TM = F16_TM, WAVES = 16 / MI;
     constexpr int PPW = F16_STAGE_BYTES / 1024 / WAVES;   // one-KiB DMA pieces per wave per stage: 6 or 12
@@ -548,12 +557,17 @@ __global__ __launch_bounds__(1024 / MI) void gemm_split_f16_kernel(SplitGemmArgs
     if (valid <= 0) return;
     const int nwg = g.tiles_n * (int)((valid + TM - 1) / TM);
     const int orig = blockIdx.x;
-    if (orig >= nwg) return;
+    if (!PERSIST && orig >= nwg) return;
     const int xcd = orig & 7, q = nwg >> 3, r8 = nwg & 7;
-    const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
+    const int xcd_first = xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q;      // this XCD's first tile
+    const int xcd_count = q + (xcd < r8 ? 1 : 0);
+    const int per_xcd = PERSIST ? (int)(gridDim.x >> 3) : 0;
+    int loc = orig >> 3;                           // index inside the XCD's range
+    if (PERSIST && loc >= xcd_count) return;
+    int tile = xcd_first + loc;
     const int tiles_mv = nwg / g.tiles_n;
-    const int bm = (g.m_fastest ? tile % tiles_mv : tile / g.tiles_n) * TM;
-    const int bn = (g.m_fastest ? tile / tiles_mv : tile % g.tiles_n) * TN;
+    int bm = (g.m_fastest ? tile % tiles_mv : tile / g.tiles_n) * TM;
+    int bn = (g.m_fastest ? tile / tiles_mv : tile % g.tiles_n) * TN;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -567,8 +581,8 @@ __global__ __launch_bounds__(1024 / MI) void gemm_split_f16_kernel(SplitGemmArgs
     // this tile's first byte, a per-lane 32-bit offset that never changes, the stage as the scalar offset — no
     // 64-bit address arithmetic per piece (gemm_bf16.hip measured 8 % on its DMA-bound loop)
     const size_t a_tile_stride = (size_t)nkt * 2 << 12;
-    const unsigned char* const a_panel = g.Ap + (size_t)(bm >> 7) * a_tile_stride;      // two row tiles
-    const unsigned char* const b_panel = g.Bp + (size_t)(bn >> 7) * a_tile_stride;
+    const unsigned char* a_panel = g.Ap + (size_t)(bm >> 7) * a_tile_stride;      // two row tiles
+    const unsigned char* b_panel = g.Bp + (size_t)(bn >> 7) * a_tile_stride;
     const int a_bytes = (int)(2 * a_tile_stride), b_bytes = (int)a_tile_stride;
     unsigned voff[PPW];
 #pragma unroll
@@ -595,12 +609,6 @@ __global__ __launch_bounds__(1024 / MI) void gemm_split_f16_kernel(SplitGemmArgs
     const int b_rd = 2 * F16_TILE_BYTES + (wn * 64 + l31) * 32 + hsw;
 
     f32x16 acc[MI][2], accx[MI][2];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.f; accx[i][j][e] = 0.f; }
     float bv0 = 0.f, bv1 = 0.f;      // fetched before the K loop and pinned (see gemm_split_bf16_kernel)
     float us0 = 1.f, us1 = 1.f;      // undo the power-of-two scale of the weight rows behind these two columns
     if (g.bias) {
@@ -615,10 +623,22 @@ __global__ __launch_bounds__(1024 / MI) void gemm_split_f16_kernel(SplitGemmArgs
 
     MDNO_DMA_STAGE(0, 0)
     if (nst > 1) MDNO_DMA_STAGE(1, 1)
+    bool first_tile = true;
+tile_loop:      // (PERSIST: one pass per tile of this workgroup; otherwise a single pass)
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.f; accx[i][j][e] = 0.f; }
     int slot = 0, slot_in = 2;       // slot being multiplied; slot the next DMA goes to
     for (int st = 0; st < nst; ++st) {
         // this wave's pieces of stage st have landed (the next stage's PPW pieces may still be in flight) ...
-        if (st + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        // (a later tile's stages 0 and 1 went out under the previous epilogue, whose stores sit behind them in the
+        // queue: everything is waited for once, and this tile's bias / scale values are pinned there)
+        if (PERSIST && st == 0 && !first_tile)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(bv0), "+v"(bv1), "+v"(us0), "+v"(us1) :: "memory");
+        else if (st + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // ... and so have everybody's; nobody still reads the slot stage st+2 goes to (multiplied at st-1:
         // a wave's fragment reads feed its MFMAs, so they have returned before it gets here).  The bare
@@ -659,6 +679,67 @@ __global__ __launch_bounds__(1024 / MI) void gemm_split_f16_kernel(SplitGemmArgs
 #undef MDNO_F16_KSTEP_DMA
         slot = slot == F16_RING - 1 ? 0 : slot + 1;
         slot_in = slot_in == F16_RING - 1 ? 0 : slot_in + 1;
+    }
+    if constexpr (PERSIST) {
+        // every wave's fragment reads of the last stage are done: any slot may be written
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int cur_bm = bm, cur_bn = bn;
+        float nb0 = 0.f, nb1 = 0.f, nu0 = 1.f, nu1 = 1.f;
+        loc += per_xcd;
+        const bool more_tiles = loc < xcd_count;
+        if (more_tiles) {
+            tile = xcd_first + loc;
+            bm = (g.m_fastest ? tile % tiles_mv : tile / g.tiles_n) * TM;
+            bn = (g.m_fastest ? tile / tiles_mv : tile % g.tiles_n) * TN;
+            if (g.bias) {
+                nb0 = g.bias[bn + wn * 64 + l31];
+                nb1 = g.bias[bn + wn * 64 + 32 + l31];
+            }
+            if (g.b_unscale) {
+                nu0 = g.b_unscale[bn + wn * 64 + l31];
+                nu1 = g.b_unscale[bn + wn * 64 + 32 + l31];
+            }
+            a_panel = g.Ap + (size_t)(bm >> 7) * a_tile_stride;
+            b_panel = g.Bp + (size_t)(bn >> 7) * a_tile_stride;
+            __builtin_amdgcn_sched_barrier(0);
+            MDNO_DMA_STAGE(0, 0)
+            if (nst > 1) MDNO_DMA_STAGE(1, 1)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- epilogue through a per-wave LDS patch in ring slot 2: 32 rows of 36 floats (144 B: 16-B aligned rows)
+        constexpr int PLD = 36;
+        float* patch = reinterpret_cast<float*>(lds + 2 * F16_STAGE_BYTES) + wave * (32 * PLD);
+        const int prow = lane >> 3, pchunk = lane & 7;       // read-back: 8 rows x 8 chunks of 16 B per instruction
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float bv = j ? bv1 : bv0, us = j ? us1 : us0;
+            const int n0 = cur_bn + wn * 64 + j * 32;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int m0 = cur_bm + wm * (MI * 32) + i * 32;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float v = (acc[i][j][e] + accx[i][j][e] * F16_LO_UNSCALE) * us + bv;
+                    patch[((e & 3) + 8 * (e >> 2) + 4 * h) * PLD + l31] = fmaxf(v, 0.f);
+                }
+                float* cb = g.C + ((size_t)(m0 >> 7) * (g.N >> 5) + (n0 >> 5)) * 4096 + (m0 & 127) * 32;
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int r = it * 8 + prow;
+                    const float4 v4 = *reinterpret_cast<const float4*>(&patch[r * PLD + pchunk * 4]);
+                    if (m0 + r < valid) *reinterpret_cast<float4*>(cb + r * 32 + pchunk * 4) = v4;
+                }
+            }
+        }
+        if (more_tiles) {
+            bv0 = nb0; bv1 = nb1; us0 = nu0; us1 = nu1;
+            first_tile = false;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my patch reads are done before the next tile's first barrier
+            goto tile_loop;
+        }
+        return;
     }
 #undef MDNO_DMA_STAGE
 #undef MDNO_PIECE_DMA
@@ -952,6 +1033,21 @@ int launch_split_f16_gemm(SplitGemmArgs g, hipStream_t s) {
         MDNO_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(&gemm_split_f16_kernel<OUT, MI, true>), lds_bytes, lds_raised_rs));
         hipLaunchKernelGGL((gemm_split_f16_kernel<OUT, MI, true>), dim3(g.tiles_n * g.tiles_m), dim3(1024 / MI), lds_bytes, s, g);
         return check_launch("split-f16 GEMM");
+    }
+    if constexpr (OUT == 2 && MI == 2) {
+        // more tiles than CUs (by the launch's row capacity): one workgroup per CU walking its XCD's tiles
+        // (MDNO_GEMM_F16_PERSIST=0: one workgroup per tile, the A/B switch)
+        static const bool persist_on = !(getenv("MDNO_GEMM_F16_PERSIST") && getenv("MDNO_GEMM_F16_PERSIST")[0] == '0');
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        cus = cus / 8 * 8;
+        if (persist_on && cus >= 8 && (long long)g.tiles_n * g.tiles_m > cus) {
+            static std::atomic<unsigned long long> lds_raised_p{0};
+            MDNO_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(&gemm_split_f16_kernel<OUT, MI, false, true>), lds_bytes,
+                                       lds_raised_p));
+            hipLaunchKernelGGL((gemm_split_f16_kernel<OUT, MI, false, true>), dim3(cus), dim3(1024 / MI), lds_bytes, s, g);
+            return check_launch("split-f16 GEMM (persistent)");
+        }
     }
     hipLaunchKernelGGL((gemm_split_f16_kernel<OUT, MI>), dim3(g.tiles_n * g.tiles_m), dim3(1024 / MI), lds_bytes, s, g);
     return check_launch("split-f16 GEMM");

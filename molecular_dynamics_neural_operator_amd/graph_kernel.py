@@ -327,13 +327,16 @@ class KernelNN(nn.Module):
         if self.conv_mode == "materialized":
             return "materialized"
         from . import _lib
-        # (the rule reads the GEMM mode and the dimensions only, not the pack's conv_mode: whichever pack is cached)
-        cached = next((v[1] for v in self.__dict__.get("_packs", {}).values()), None)
-        pack = cached if cached is not None and cached.gemm_mode == self.gemm_mode else self.param_pack(device, conv_mode="materialized")
-        mode = int(_lib.load().mdno_conv_mode_for_graph(pack.ref, int(members), int(n_atoms), int(n_edges)))
+        lib = _lib.load()
         if self.conv_mode == "factored":      # asked for: taken wherever the model's dimensions allow it
-            return "factored" if int(_lib.load().mdno_resolve_conv_mode(pack.ref, int(members), 1 << 40)) == _lib.CONV_MODES["factored"] \
+            pack = self.param_pack(device, conv_mode="factored")      # (the pack the forward then runs with)
+            return "factored" if int(lib.mdno_resolve_conv_mode(pack.ref, int(members), 1 << 40)) == _lib.CONV_MODES["factored"] \
                 else "materialized"
+        # "auto": the rule reads the GEMM mode and the dimensions only, not the pack's conv_mode — whichever pack is
+        # cached serves (asking for a "factored" pack here evicted the materialized one on every forward)
+        cached = next((v[1] for v in self.__dict__.get("_packs", {}).values() if v[1].gemm_mode == self.gemm_mode), None)
+        pack = cached if cached is not None else self.param_pack(device, conv_mode="materialized")
+        mode = int(lib.mdno_conv_mode_for_graph(pack.ref, int(members), int(n_atoms), int(n_edges)))
         return {v: k for k, v in _lib.CONV_MODES.items()}[mode]
 
     def forward(self, data, return_latent: bool = False, single_example: bool = False, _status=None):

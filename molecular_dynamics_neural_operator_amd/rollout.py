@@ -307,10 +307,12 @@ class RolloutEngine:
 
 class GroupedRolloutEngine:
     """The members of a shard as `groups` independent `RolloutEngine`s (contiguous member ranges), each with its own
-    stream and its own captured step, stepped together.  Members never interact, so the frames are bitwise those of one
-    engine holding them all — conv_mode "auto" is resolved ONCE, on the graph of the whole shard, and given to every group
-    (a group deciding on its own members could take the other formulation when densities differ) —; what changes is the
-    schedule: one group's edge-MLP (matrix-pipe-bound) and launch tails run
+    stream and its own captured step, stepped together.  Members never interact and conv_mode "auto" is resolved ONCE,
+    on the graph of the whole shard, and given to every group (a group deciding on its own members could take the other
+    formulation when densities differ), so the frames are those of one engine holding them all: bitwise for members of
+    like magnitude (the ensemble case: perturbed copies of one system), and to fp32 rounding in general — the edge-MLP
+    chooses between its fp16 and bf16 plane products per launch from the magnitudes it sees (split_layout.h), and a
+    group can see other magnitudes than the whole shard.  What changes is the schedule: one group's edge-MLP (matrix-pipe-bound) and launch tails run
     beside another group's convs (fabric-bound) — 5 % at 8 x 504 atoms, 3 % at 64 (EXPERIMENTS.md section 0.2b).  Same
     reset / step / synchronize / run / frames interface; `traj` and `edges_per_step` are assembled on access."""
 

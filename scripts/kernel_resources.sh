@@ -6,7 +6,7 @@ root="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 src="$root/molecular_dynamics_neural_operator_amd/csrc/$1"
 tmp="$(mktemp -d)"
 trap 'rm -rf "$tmp"' EXIT
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off --cuda-device-only -c "$src" -o "$tmp/dev.bundle"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DMDNO_BUILD_ID=\"x\" --cuda-device-only -c "$src" -o "$tmp/dev.bundle"
 /opt/rocm/lib/llvm/bin/clang-offload-bundler --unbundle --type=o --input="$tmp/dev.bundle" \
     --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --output="$tmp/dev.co"
 /opt/rocm/lib/llvm/bin/llvm-readelf --notes "$tmp/dev.co" | awk -v f="${2:-}" '

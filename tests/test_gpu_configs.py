@@ -1044,7 +1044,7 @@ def test_member_groups_resolve_auto_once_for_the_shard(dev):
     """conv_mode "auto" in a GroupedRolloutEngine is decided on the graph of the WHOLE shard and given to every group
     (ADVICE r4): two members of very different density — a 504-atom box at 0.1 atoms/A^3 (~118 neighbours: factored on
     its own) and the same atoms spread 3x wider (~6 neighbours: materialized on its own) — as two groups of one take
-    the formulation one engine holding both picks, and give its frames bitwise."""
+    the formulation one engine holding both picks, and give its frames (to fp32 rounding: see the class docstring)."""
     from molecular_dynamics_neural_operator_amd import synthetic as syn
     from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN
     from molecular_dynamics_neural_operator_amd.rollout import GroupedRolloutEngine, RolloutEngine
@@ -1074,7 +1074,10 @@ def test_member_groups_resolve_auto_once_for_the_shard(dev):
     for m in range(2):
         d = (got[:, m] - want[:, m]).abs().max().item()
         print(f"member {m}: max |grouped - one engine| = {d:.3e}, edges/step {[int(e.edges_per_step[0]) for e in grp.engines]}")
-    assert torch.equal(got, want)
+    # same formulation, same sums; the sparse member alone takes the edge-MLP's bf16 plane products (no activation of
+    # its few edges reaches 2^-10: split_layout.h) where the shard as a whole takes the fp16 ones: fp32 rounding apart
+    assert torch.equal(got[:, 0], want[:, 0])
+    torch.testing.assert_close(got, want, rtol=2e-6, atol=2e-6 * float(want.abs().max()))
     one.close()
     grp.close()
 

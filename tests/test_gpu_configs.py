@@ -903,6 +903,47 @@ def test_bench_multi_rank_line_schema(dev):
     assert a.total_members is None and bench.ENSEMBLE_MEMBERS == 64
 
 
+def _torchrun_bench(args, env_extra, timeout=600):
+    """bench.py under the DRIVER's launcher and command line: python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ... (ranks share the one card here,
+    so the collective runs over gloo; with one GPU per rank the same command runs RCCL)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    n = args[args.index("--gpus") + 1]
+    env = dict(os.environ, **env_extra)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(REPO / "bench.py")] + args
+    return subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout)
+
+
+def test_bench_under_torch_distributed_run(dev):
+    """The scaling series' own command line (one process per rank started by torch.distributed.run, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* from its environment): two ranks, the 4-member ensemble split 2 + 2, one JSON line from rank 0
+    on stdout; and the same launch with rank 1 failing at start-up ends non-zero in well under a minute instead of
+    sitting in the rendezvous."""
+    import time
+    gloo = {} if torch.cuda.device_count() >= 2 else {"MDNO_BENCH_BACKEND": "gloo"}
+    args = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--total-members", "4", "--skip-roofline", "--skip-cpu-baseline"]
+    r = _torchrun_bench(args, gloo)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["total_members"] == 4
+    assert line["config"]["members_this_rank"] == 2 and len(line["multi_gpu_timing"]["per_rank_steps_ms"]) == 2
+    t0 = time.time()
+    r = _torchrun_bench(args, dict(gloo, MDNO_BENCH_FAIL_RANK="1"), timeout=300)
+    dt = time.time() - t0
+    assert r.returncode != 0 and dt < 90.0, (r.returncode, dt, r.stderr[-2000:])
+    assert "MDNO_BENCH_FAIL_RANK=1" in r.stderr
+    assert not [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{") and '"value"' in ln]
+
+
 def test_bench_rank_failure_is_fast_and_loud(dev):
     """`python bench.py --gpus 2` with rank 1 raising right after set_device (MDNO_BENCH_FAIL_RANK=1) while rank 0
     waits for it in the rendezvous: the launcher polls every rank from the start, stops rank 0 after its grace period

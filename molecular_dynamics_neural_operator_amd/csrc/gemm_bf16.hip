@@ -98,18 +98,9 @@ struct PpArgs {
 // which the next tile does not touch before the barrier that ends its prologue), so that a tile no longer starts with
 // every CU's first 64 KB arriving at once (EXPERIMENTS.md §0.3: 6.7k of a K = 1,024 tile's 64.5k cycles).  Same MFMAs
 // in the same order per output element: bit-identical results.
-// BD (with PERSIST): the B operand (W: 256 rows x K, L2-resident and shared by every tile of a column) does not pass
-// through LDS at all.  A lane's MFMA fragment of W — row n, eight consecutive k — is 16 contiguous bytes of the
-// row-major weight: four buffer_load_dwordx4 per wave and stage bring stage t+1's fragments straight into registers
-// while stage t multiplies.  The load phase — what the two wave groups wait for each other on (EXPERIMENTS.md §0.3:
-// ≈770 cycles against 512 of MFMA issue) — then holds 8 fragment reads and 2 LDS-DMA pieces per wave instead of
-// 12 and 4.  Issued and waited for by inline assembly (counted vmcnt: the compiler's own wait in front of the first
-// use of a loaded register would be a vmcnt(0) behind the conditional DMA issue, i.e. a wait for the pieces just
-// sent).  Same products in the same order: bit-identical results.
-template <bool TN, int EPI, bool RELU, bool OUT_BF16, bool F16 = false, bool PERSIST = false, bool BD = false>
+template <bool TN, int EPI, bool RELU, bool OUT_BF16, bool F16 = false, bool PERSIST = false>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PpArgs g) {
     static_assert(!PERSIST || (!TN && OUT_BF16 && EPI != EPI_SLAB && !F16), "persistent form: A . W^T with bf16 output");
-    static_assert(!BD || PERSIST, "direct B fragments: only with the persistent form");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const __bf16* const opA = (F16 && blockIdx.z == 1) ? g.A2 : g.A;
     const __bf16* const opW = (F16 && blockIdx.z == 2) ? g.W2 : g.W;
@@ -163,23 +154,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PpArgs g) {
         rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const unsigned char*>(g.W) + (size_t)bn_ * ldk), 0,
                                                    (int)(PP_T * ldk), 0x00020000);
     };
-    // (BD) W's tile as a raw descriptor for the inline-assembly loads, and this lane's two row offsets (j = 0, 1): row
-    // bn + wn*64 + j*32 + l31, k-half h -> + h*16 bytes; k-step 1 is "offset:32", the stage the scalar offset
-    typedef int i32x4 __attribute__((ext_vector_type(4)));
-    i32x4 wdesc = {0, 0, 0, 0};
-    unsigned bvoff0 = 0, bvoff1 = 0;
-    auto w_descriptor = [&](int bn_) {
-        const unsigned long long wa = (unsigned long long)(reinterpret_cast<const unsigned char*>(g.W) + (size_t)bn_ * g.K * 2);
-        wdesc.x = __builtin_amdgcn_readfirstlane((int)(wa & 0xffffffffull));
-        wdesc.y = __builtin_amdgcn_readfirstlane((int)((wa >> 32) & 0xffffull));
-        wdesc.z = __builtin_amdgcn_readfirstlane((int)((size_t)PP_T * g.K * 2));
-        wdesc.w = 0x00020000;
-    };
-    if (BD) {
-        bvoff0 = (unsigned)((size_t)(wn * 64 + l31) * g.K * 2 + h * 16);
-        bvoff1 = (unsigned)((size_t)(wn * 64 + 32 + l31) * g.K * 2 + h * 16);
-        w_descriptor(bn);
-    }
     if (!TN) {
         const int pr = lane >> 2, pc = (lane & 3) ^ ((lane >> 4) & 3);
         const size_t ldk = (size_t)g.K * 2;
@@ -210,7 +184,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PpArgs g) {
 #define MDNO_PP_DMA(ST)                                                                                         \
     {                                                                                                           \
         const int st_ = (ST), slot_ = st_ % PP_RING;       /* (ST may name the caller's loop variable) */       \
-        _Pragma("unroll") for (int pi_ = 0; pi_ < (BD ? 2 : PP_PIECES_PER_WAVE); ++pi_)                         \
+        _Pragma("unroll") for (int pi_ = 0; pi_ < PP_PIECES_PER_WAVE; ++pi_)                                    \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(pi_ < 2 ? rsrc_a : rsrc_b,                                 \
                                                      (lds_u8*)(lds + slot_ * PP_STAGE_BYTES + piece_base + pi_ * 8192), 16, \
                                                      voff[pi_], (unsigned)st_ * (pi_ < 2 ? stride_a : stride_b), 0, 0); \
@@ -303,11 +277,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PpArgs g) {
                 fa[0][i] = *reinterpret_cast<const bf16x8*>(sb_ + a_off[i] + c0);                 \
                 fa[1][i] = *reinterpret_cast<const bf16x8*>(sb_ + a_off[i] + c1);                 \
             }                                                                                     \
-            if (!BD) {                                                                            \
-                _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                   \
-                    fb[0][j] = *reinterpret_cast<const bf16x8*>(sb_ + b_off[j] + c0);             \
-                    fb[1][j] = *reinterpret_cast<const bf16x8*>(sb_ + b_off[j] + c1);             \
-                }                                                                                 \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                       \
+                fb[0][j] = *reinterpret_cast<const bf16x8*>(sb_ + b_off[j] + c0);                 \
+                fb[1][j] = *reinterpret_cast<const bf16x8*>(sb_ + b_off[j] + c1);                 \
             }                                                                                     \
         } else {                                                                                  \
             const unsigned sa_ = lds_addr + ((ST) % PP_RING) * PP_STAGE_BYTES;                    \
@@ -330,30 +302,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PpArgs g) {
     asm volatile("" ::: "memory");                   \
     __builtin_amdgcn_sched_barrier(0);
 
-    // (BD) stage ST's four B fragments of this lane -> fbn (registers), by inline assembly: no compiler-tracked waits
-    i32x4 fbn00, fbn10, fbn01, fbn11;      // [k-step][j]
-#define MDNO_PP_BLOAD(ST)                                                                                          \
-    {                                                                                                              \
-        const int so_ = __builtin_amdgcn_readfirstlane((int)((ST) * PP_ROW_BYTES));                                \
-        asm volatile("buffer_load_dwordx4 %0, %4, %6, %7 offen\n buffer_load_dwordx4 %1, %4, %6, %7 offen offset:32\n" \
-                     "buffer_load_dwordx4 %2, %5, %6, %7 offen\n buffer_load_dwordx4 %3, %5, %6, %7 offen offset:32"  \
-                     : "=&v"(fbn00), "=&v"(fbn10), "=&v"(fbn01), "=&v"(fbn11)                                      \
-                     : "v"(bvoff0), "v"(bvoff1), "s"(wdesc), "s"(so_) : "memory");                                 \
-    }
-    // fbn -> fb once the loads have landed: vmcnt(N) leaves the N youngest operations (this wave's DMA pieces of stage
-    // t+2, issued after the loads) in flight
-#define MDNO_PP_BTAKE(N)                                                                                           \
-    {                                                                                                              \
-        asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(fbn00), "+v"(fbn10), "+v"(fbn01), "+v"(fbn11) :: "memory");  \
-        fb[0][0] = __builtin_bit_cast(bf16x8, fbn00);                                                              \
-        fb[1][0] = __builtin_bit_cast(bf16x8, fbn10);                                                              \
-        fb[0][1] = __builtin_bit_cast(bf16x8, fbn01);                                                              \
-        fb[1][1] = __builtin_bit_cast(bf16x8, fbn11);                                                              \
-    }
     // prologue: stages 0 and 1 in flight, stage 0 landed for everybody
     if (T > 0) { MDNO_PP_DMA(0) }
     if (T > 1) { MDNO_PP_DMA(1) }
-    if (BD) { MDNO_PP_BLOAD(0) }
     bool first_tile = true;
 tile_loop:      // (PERSIST: one pass per tile of this workgroup; otherwise a single pass)
 #pragma unroll
@@ -364,20 +315,14 @@ tile_loop:      // (PERSIST: one pass per tile of this workgroup; otherwise a si
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     // a later tile's first two stages went out under the previous epilogue, with that epilogue's stores behind them in
     // the queue: everything is waited for (stage 1 landed long ago: an epilogue is longer than a stage's flight)
-    if (!BD && T > 1 && first_tile) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (T > 1 && first_tile) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" : "+v"(bv0), "+v"(bv1) :: "memory");      // (and this tile's bias is pinned here)
     MDNO_PP_BARRIER()
     if (grp == 1) { MDNO_PP_BARRIER() }          // the stagger: waves 4-7 run one phase behind
     for (int t = 0; t < T; ++t) {
         // ---- load phase of stage t (the other group multiplies meanwhile)
         MDNO_PP_LOAD(t)
-        if (BD) {
-            // in flight on entry: my 2 pieces of A(t+1) and the 4 loads of B(t), in that order.  B(t) is taken into fb
-            // first (vmcnt(0): both are a whole phase old), then A(t+2) and B(t+1) go out and stay in flight
-            MDNO_PP_BTAKE(0)
-            if (t + 2 < T) { MDNO_PP_DMA(t + 2) }
-            if (t + 1 < T) { MDNO_PP_BLOAD(t + 1) }
-        } else if (t + 2 < T) {
+        if (t + 2 < T) {
             MDNO_PP_DMA(t + 2)
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // my pieces of stage t+1 have landed
         } else {
@@ -412,11 +357,9 @@ tile_loop:      // (PERSIST: one pass per tile of this workgroup; otherwise a si
                 bn1 = g.bias[bn + wn * 64 + 32 + l31];
             }
             nt_descriptors(bm, bn);
-            if (BD) w_descriptor(bn);
             __builtin_amdgcn_sched_barrier(0);
             MDNO_PP_DMA(0)
             if (T > 1) { MDNO_PP_DMA(1) }
-            if (BD) { MDNO_PP_BLOAD(0) }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -498,8 +441,6 @@ tile_loop:      // (PERSIST: one pass per tile of this workgroup; otherwise a si
 #undef MDNO_PP_LOAD
 #undef MDNO_PP_MMA
 #undef MDNO_PP_BARRIER
-#undef MDNO_PP_BLOAD
-#undef MDNO_PP_BTAKE
 }
 
 // out[i] = sum over slices (in order) of slab[z][i]
@@ -556,16 +497,6 @@ static int launch_pp(const PpArgs& g, unsigned slices, hipStream_t s) {
         // more tiles than CUs: the persistent form (one workgroup per CU walking its XCD's tiles)
         const int cus = device_cus() / 8 * 8;
         if (pp_persist_enabled() && cus >= 8 && nwg > cus) {
-            static const bool bdirect = !(getenv("MDNO_GEMM_PP_BDIRECT") && getenv("MDNO_GEMM_PP_BDIRECT")[0] == '0');
-            // (the W tile is addressed through 32-bit offsets: 256 rows of K bf16)
-            if (bdirect && (size_t)PP_T * g.K * 2 < (1ull << 31)) {
-                static std::atomic<unsigned long long> raised_b{0};
-                MDNO_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(&gemm_pp_kernel<TN, EPI, RELU, OUT_BF16, F16, true, true>),
-                                           PP_LDS_BYTES, raised_b));
-                hipLaunchKernelGGL((gemm_pp_kernel<TN, EPI, RELU, OUT_BF16, F16, true, true>), dim3((unsigned)cus), dim3(512),
-                                   PP_LDS_BYTES, s, g);
-                return check_launch("gemm_pp_kernel (persistent, direct B)");
-            }
             static std::atomic<unsigned long long> raised_p{0};
             MDNO_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(&gemm_pp_kernel<TN, EPI, RELU, OUT_BF16, F16, true>),
                                        PP_LDS_BYTES, raised_p));

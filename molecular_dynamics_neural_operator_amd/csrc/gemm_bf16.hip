@@ -410,9 +410,30 @@ tile_loop:      // (PERSIST: one pass per tile of this workgroup; otherwise a si
                 else *reinterpret_cast<float*>(dst) = v;
             }
         }
+        // The read-backs by inline assembly, all of the block's at once: in front of a plain LDS load behind an LDS-DMA
+        // the compiler puts s_waitcnt vmcnt(0) — in this loop a wait for every store issued so far (a store round trip
+        // per KiB stored: what made the epilogue 8.1k cycles of a K = 1,024 tile, EXPERIMENTS.md §00.5) and, in the
+        // persistent form, for the next tile's pieces just sent.  (EPI_MASK: the Y loads above are waited for by the
+        // compiler where `keep` first uses them — once per block.)
+        uint4 pv[32 / ROWS_PER_INSTR];
+        {
+            const unsigned pa = (unsigned)(size_t)(lds_u8*)patch + (unsigned)(orow * PATCH_ROW + ochunk * 16);
+            constexpr int RS = ROWS_PER_INSTR * PATCH_ROW;      // bytes between the rows of two consecutive read-backs
+            asm volatile("ds_read_b128 %0, %4\n ds_read_b128 %1, %4 offset:%5\n ds_read_b128 %2, %4 offset:%6\n"
+                         "ds_read_b128 %3, %4 offset:%7"
+                         : "=&v"(pv[0]), "=&v"(pv[1]), "=&v"(pv[2]), "=&v"(pv[3])
+                         : "v"(pa), "n"(RS), "n"(2 * RS), "n"(3 * RS) : "memory");
+            if constexpr (ROWS_PER_INSTR == 4)
+                asm volatile("ds_read_b128 %0, %4 offset:%5\n ds_read_b128 %1, %4 offset:%6\n ds_read_b128 %2, %4 offset:%7\n"
+                             "ds_read_b128 %3, %4 offset:%8"
+                             : "=&v"(pv[(32 / ROWS_PER_INSTR) - 4]), "=&v"(pv[(32 / ROWS_PER_INSTR) - 3]),
+                               "=&v"(pv[(32 / ROWS_PER_INSTR) - 2]), "=&v"(pv[(32 / ROWS_PER_INSTR) - 1])
+                             : "v"(pa), "n"(4 * RS), "n"(5 * RS), "n"(6 * RS), "n"(7 * RS) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
 #pragma unroll
         for (int rr = 0; rr < 32; rr += ROWS_PER_INSTR) {
-            uint4 v = *reinterpret_cast<const uint4*>(patch + (rr + orow) * PATCH_ROW + ochunk * 16);
+            uint4 v = pv[rr / ROWS_PER_INSTR];
             if (EPI == EPI_MASK) {      // eight bf16 per lane: keep where the stored activation is positive
                 const uint4 y = yv[rr / ROWS_PER_INSTR];
                 auto keep = [](unsigned vv, unsigned yy) {

@@ -595,6 +595,12 @@ __global__ __launch_bounds__(1024 / MI) void gemm_split_f16_kernel(SplitGemmArgs
     const int b_rd = 2 * F16_TILE_BYTES + (wn * 64 + l31) * 32 + hsw;
 
     f32x16 acc[MI][2], accx[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.f; accx[i][j][e] = 0.f; }
     float bv0 = 0.f, bv1 = 0.f;      // fetched before the K loop and pinned (see gemm_split_bf16_kernel)
     float us0 = 1.f, us1 = 1.f;      // undo the power-of-two scale of the weight rows behind these two columns
     if (g.bias) {
@@ -607,12 +613,6 @@ __global__ __launch_bounds__(1024 / MI) void gemm_split_f16_kernel(SplitGemmArgs
     }
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(bv0), "+v"(bv1), "+v"(us0), "+v"(us1));   // the counted waits below must see DMA pieces only
 
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.f; accx[i][j][e] = 0.f; }
     MDNO_DMA_STAGE(0, 0)
     if (nst > 1) MDNO_DMA_STAGE(1, 1)
     int slot = 0, slot_in = 2;       // slot being multiplied; slot the next DMA goes to
@@ -707,244 +707,6 @@ __global__ __launch_bounds__(1024 / MI) void gemm_split_f16_kernel(SplitGemmArgs
     }
     if (OUT == 4 && bad) atomicOr(const_cast<int*>(g.f16_flags) + 1, 1);
     if (OUT == 4 && seen) const_cast<int*>(g.f16_flags)[3] = 1;
-}
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-// four 16-B LDS reads `stride` bytes apart, complete on return — by inline assembly (see the epilogue below)
-__device__ __forceinline__ void lds_read4_b128(unsigned addr, int stride, f32x4 (&v)[4]) {
-    asm volatile("ds_read_b128 %0, %4\n ds_read_b128 %1, %5\n ds_read_b128 %2, %6\n ds_read_b128 %3, %7\n s_waitcnt lgkmcnt(0)"
-                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
-                 : "v"(addr), "v"(addr + stride), "v"(addr + 2 * stride), "v"(addr + 3 * stride)
-                 : "memory");
-}
-
-// ---- the factored conv's hidden GEMM (OUT 2: H as the k-tiled fp32 image), "ping-pong" form
-// The kernel above runs its 8 waves in lockstep: a barrier at every stage start, then every wave reads its fragments
-// (the LDS pipe busy, the matrix pipes idle), then every wave multiplies (the reverse).  Measured on the chip
-// (EXPERIMENTS.md §00.5): per stage, time = LDS time + MFMA time, 2,900 cycles against 1,536 of MFMA issue per SIMD
-// — the two never overlap, and with the MFMAs compiled out the kernel still takes half its time.  Here the two waves
-// of every SIMD (w and w + 4) run the same program ONE PHASE APART, as gemm_bf16.hip's kernel does: while waves 0-3
-// multiply stage t out of registers (24 MFMAs back to back, the stage's six LDS-DMA pieces of a later stage going out
-// one behind each of the first six MFMA groups), waves 4-7 read the 16 fragments of stage t from LDS, and vice versa.
-// A SIMD's matrix pipe sees an MFMA phase at all times and the fragment reads sit beside them.  Phases are separated
-// by raw s_barrier (never __syncthreads(): its fence drains vmcnt and with it the DMA in flight).
-//   ring of three 48 KiB stages (32 k each); slot of stage s = s % 3.  Slot s % 3 is read last by waves 4-7 in
-//   phase 2s+1 and first again (stage s+3) by waves 0-3 in phase 2s+6:
-//     waves 0-3 issue stage q+2 during MMA(q) (phase 2q+1) and wait for it at the end of MMA(q+1) — vmcnt(6): the six
-//               pieces of stage q+3, just issued, stay in flight;
-//     waves 4-7 issue stage q+3 during MMA(q) (phase 2q+2: the slot is free one phase after their own last read) and
-//               wait for it at the end of LOAD(q+2) — vmcnt(6) again; their pieces get three phases of flight.
-// Persistent (one workgroup per CU walking its XCD's tiles), next tile's stages 0 and 1 in flight under the epilogue,
-// epilogue through LDS patches in slot 2 as in the kernel above.  Per output element the same MFMAs in the same
-// order (k-steps ascending; a_lo b_hi, a_hi b_lo, then a_hi b_hi): bit-identical to every other kernel of the family.
-__global__ __launch_bounds__(512) void gemm_split_f16_pp_kernel(SplitGemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    constexpr int TM = F16_TM, WAVES = 8, MI = 2;
-    constexpr int PPW = F16_STAGE_BYTES / 1024 / WAVES;   // 6 one-KiB DMA pieces per wave per stage
-    if (g.f16_flags != nullptr && f16_blocked(g.f16_flags, g.f16_need)) return;   // out of fp16 range: the bf16 launch behind us runs
-    long long valid = g.num_edges ? (long long)(*g.num_edges) - g.row_begin : (long long)g.rows_valid;
-    if (valid > g.rows) valid = g.rows;
-    if (valid <= 0) return;
-    const int nwg = g.tiles_n * (int)((valid + TM - 1) / TM);
-    const int orig = blockIdx.x;
-    const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
-    const int xcd_first = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-    const int xcd_count = q8 + (xcd < r8 ? 1 : 0);
-    const int per_xcd = (int)(gridDim.x >> 3);
-    int loc = orig >> 3;
-    if (loc >= xcd_count) return;
-    int tile = xcd_first + loc;
-    const int tiles_mv = nwg / g.tiles_n;
-    int bm = (g.m_fastest ? tile % tiles_mv : tile / g.tiles_n) * TM;
-    int bn = (g.m_fastest ? tile / tiles_mv : tile % g.tiles_n) * TN;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2;                            // 0: waves 0-3, 1: waves 4-7 (one phase behind)
-    const int wm = wave >> 1, wn = wave & 1;
-    const int l31 = lane & 31, h = lane >> 5;
-    const int nkt = g.K / TK, nst = g.K / 32;
-    const size_t a_tile_stride = (size_t)nkt * 2 << 12;
-    const unsigned char* a_panel = g.Ap + (size_t)(bm >> 7) * a_tile_stride;
-    const unsigned char* b_panel = g.Bp + (size_t)(bn >> 7) * a_tile_stride;
-    const int a_bytes = (int)(2 * a_tile_stride), b_bytes = (int)a_tile_stride;
-    unsigned voff[PPW];
-#pragma unroll
-    for (int t = 0; t < PPW; ++t) {
-        const int qq = wave + t * WAVES, blk = qq >> 4;
-        voff[t] = (unsigned)((blk == 1 ? a_tile_stride : 0) + (qq & 15) * 1024 + lane * 16);
-    }
-    const int d0 = wave * 1024;
-#define MDNO_PPF_PIECE(T, ST)                                                                                        \
-    dma_piece_buffer((((T) * WAVES) >> 4) < 2 ? a_panel : b_panel, (((T) * WAVES) >> 4) < 2 ? a_bytes : b_bytes,     \
-                     (lds_u8*)(lds + ((ST) % F16_RING) * F16_STAGE_BYTES + d0 + (T) * WAVES * 1024), voff[T],        \
-                     (unsigned)(ST) * F16_TILE_BYTES)
-#define MDNO_PPF_STAGE(ST)                                                       \
-    {                                                                            \
-        const int st_ = (ST);                                                    \
-        _Pragma("unroll") for (int t = 0; t < PPW; ++t) MDNO_PPF_PIECE(t, st_);  \
-    }
-#define MDNO_PPF_BARRIER()                           \
-    __builtin_amdgcn_sched_barrier(0);               \
-    __builtin_amdgcn_s_barrier();                    \
-    asm volatile("" ::: "memory");                   \
-    __builtin_amdgcn_sched_barrier(0);
-
-    const int hsw = (h ^ ((l31 >> 3) & 1)) << 4;
-    const int arow = wm * (MI * 32) + l31;
-    const int a_rd = (arow >> 7) * F16_TILE_BYTES + (arow & 127) * 32 + hsw;
-    const int b_rd = 2 * F16_TILE_BYTES + (wn * 64 + l31) * 32 + hsw;
-    const int lead = grp ? 3 : 2;                         // which later stage a wave's MMA phase sends out
-
-    f32x16 acc[MI][2], accx[MI][2];
-    float bv0 = 0.f, bv1 = 0.f, us0 = 1.f, us1 = 1.f;
-    if (g.bias) {
-        bv0 = g.bias[bn + wn * 64 + l31];
-        bv1 = g.bias[bn + wn * 64 + 32 + l31];
-    }
-    if (g.b_unscale) {
-        us0 = g.b_unscale[bn + wn * 64 + l31];
-        us1 = g.b_unscale[bn + wn * 64 + 32 + l31];
-    }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bv0), "+v"(bv1), "+v"(us0), "+v"(us1));   // the counted waits below must see DMA pieces only
-
-    MDNO_PPF_STAGE(0)
-    if (nst > 1) MDNO_PPF_STAGE(1)
-    bool first_tile = true;
-tile_loop:
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.f; accx[i][j][e] = 0.f; }
-    // stage 0 has landed (first tile: stage 1's six pieces may stay in flight; a later tile's stages 0 and 1 went out
-    // under the previous epilogue, whose stores sit behind them in the queue: everything is waited for, and this tile's
-    // bias / scale values are pinned there)
-    if (first_tile && nst > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(bv0), "+v"(bv1), "+v"(us0), "+v"(us1) :: "memory");
-    MDNO_PPF_BARRIER()
-    if (grp == 1) {
-        // slot 2 is free now (the previous tile's epilogue patches are done: everybody passed the barrier above):
-        // waves 4-7 send their share of stage 2 (their MMA phases send stage q + 3; waves 0-3 send it in MMA(0))
-        if (nst > 2) MDNO_PPF_STAGE(2)
-        MDNO_PPF_BARRIER()                                // the stagger
-    }
-    for (int st = 0; st < nst; ++st) {
-        // ---- load phase: the 16 fragments of stage st (the other group multiplies meanwhile)
-        const unsigned char* sb = lds + (st % F16_RING) * F16_STAGE_BYTES;
-        f16x8 fa[2][MI][2], fb[2][2][2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-                    fa[ks][i][p] = *reinterpret_cast<const f16x8*>(sb + ks * 2 * PLANE_BYTES + p * PLANE_BYTES + a_rd + i * 32 * 32);
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    fb[ks][j][p] = *reinterpret_cast<const f16x8*>(sb + ks * 2 * PLANE_BYTES + p * PLANE_BYTES + b_rd + j * 32 * 32);
-            }
-        if (grp == 1) {      // waves 4-7: my pieces of stage st+1 have landed (those of st+2, sent in MMA(st-1), may fly on)
-            if (st + 2 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // my fragments are in registers
-        MDNO_PPF_BARRIER()
-        // ---- multiply phase: 8 groups of three MFMAs; one DMA piece of stage st + lead behind each of the first six
-        {
-            const int sst = st + lead;
-            const bool more = sst < nst;
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks][i][1], fb[ks][j][0], accx[i][j], 0, 0, 0);
-                        accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks][i][0], fb[ks][j][1], accx[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks][i][0], fb[ks][j][0], acc[i][j], 0, 0, 0);
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (more && ks * 4 + i * 2 + j < PPW) MDNO_PPF_PIECE(ks * 4 + i * 2 + j, sst);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-            __builtin_amdgcn_s_setprio(0);
-        }
-        if (grp == 0) {      // waves 0-3: my pieces of stage st+1 (sent in MMA(st-1) / the prologue) have landed
-            if (st + 2 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        // (the last barrier of waves 4-7 — the one the stagger added to their count — is left out: nothing follows it
-        // but the epilogue, which waves 0-3 then start while waves 4-7 are still multiplying)
-        if (grp == 0 || st + 1 < nst) { MDNO_PPF_BARRIER() }
-    }
-
-    // ---- this wave's share of the next tile's stages 0 and 1 (every fragment read of this tile completed before the
-    // last barrier this wave passed; slot 2 is left to the patches), the next tile's bias / scale in front of them
-    const int cur_bm = bm, cur_bn = bn;
-    float nb0 = 0.f, nb1 = 0.f, nu0 = 1.f, nu1 = 1.f;
-    loc += per_xcd;
-    const bool more_tiles = loc < xcd_count;
-    if (more_tiles) {
-        tile = xcd_first + loc;
-        bm = (g.m_fastest ? tile % tiles_mv : tile / g.tiles_n) * TM;
-        bn = (g.m_fastest ? tile / tiles_mv : tile % g.tiles_n) * TN;
-        if (g.bias) {
-            nb0 = g.bias[bn + wn * 64 + l31];
-            nb1 = g.bias[bn + wn * 64 + 32 + l31];
-        }
-        if (g.b_unscale) {
-            nu0 = g.b_unscale[bn + wn * 64 + l31];
-            nu1 = g.b_unscale[bn + wn * 64 + 32 + l31];
-        }
-        a_panel = g.Ap + (size_t)(bm >> 7) * a_tile_stride;
-        b_panel = g.Bp + (size_t)(bn >> 7) * a_tile_stride;
-        __builtin_amdgcn_sched_barrier(0);
-        MDNO_PPF_STAGE(0)
-        if (nst > 1) MDNO_PPF_STAGE(1)
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    // ---- epilogue through a per-wave LDS patch in ring slot 2: 32 rows of 36 floats; a 32 x 32 block of the k-tiled
-    // image is one 4 KiB run: four 1 KiB store instructions
-    constexpr int PLD = 36;
-    float* patch = reinterpret_cast<float*>(lds + 2 * F16_STAGE_BYTES) + wave * (32 * PLD);
-    const unsigned patch_addr = (unsigned)(size_t)(lds_u8*)patch;
-    const int prow = lane >> 3, pchunk = lane & 7;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const float bv = j ? bv1 : bv0, us = j ? us1 : us0;
-        const int n0 = cur_bn + wn * 64 + j * 32;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int m0 = cur_bm + wm * (MI * 32) + i * 32;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float v = (acc[i][j][e] + accx[i][j][e] * F16_LO_UNSCALE) * us + bv;
-                patch[((e & 3) + 8 * (e >> 2) + 4 * h) * PLD + l31] = fmaxf(v, 0.f);
-            }
-            float* cb = g.C + ((size_t)(m0 >> 7) * (g.N >> 5) + (n0 >> 5)) * 4096 + (m0 & 127) * 32;
-            // the four read-backs by inline assembly: in front of a plain LDS load behind an LDS-DMA the compiler puts
-            // s_waitcnt vmcnt(0) — here that is a wait for the next tile's pieces just sent AND for every store issued
-            // so far, i.e. a store round trip per 1 KiB stored (EXPERIMENTS.md §00.5)
-            f32x4 pv[4];
-            lds_read4_b128(patch_addr + (unsigned)((prow * PLD + pchunk * 4) * 4), 8 * PLD * 4, pv);
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int r = it * 8 + prow;
-                if (m0 + r < valid) *reinterpret_cast<f32x4*>(cb + r * 32 + pchunk * 4) = pv[it];
-            }
-        }
-    }
-    if (more_tiles) {
-        bv0 = nb0; bv1 = nb1; us0 = nu0; us1 = nu1;
-        first_tile = false;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my patch reads are done before the next tile's first barrier
-        goto tile_loop;
-    }
-#undef MDNO_PPF_PIECE
-#undef MDNO_PPF_STAGE
-#undef MDNO_PPF_BARRIER
 }
 
 // ---- the same product for a FEW rows (a 28-atom chain has 330 edges): (32 WM) x 64 tiles, WM x 2 waves of 32 x 32.
@@ -1190,22 +952,6 @@ int launch_split_f16_gemm(SplitGemmArgs g, hipStream_t s) {
         MDNO_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(&gemm_split_f16_kernel<OUT, MI, true>), lds_bytes, lds_raised_rs));
         hipLaunchKernelGGL((gemm_split_f16_kernel<OUT, MI, true>), dim3(g.tiles_n * g.tiles_m), dim3(1024 / MI), lds_bytes, s, g);
         return check_launch("split-f16 GEMM");
-    }
-    if constexpr (OUT == 2 && MI == 2) {
-        // more tiles than CUs (by the launch's row capacity): the ping-pong kernel, one workgroup per CU walking its
-        // XCD's tiles (MDNO_GEMM_F16_PINGPONG=0: the lockstep kernel, one workgroup per tile — the A/B switch)
-        static const bool persist_on = !(getenv("MDNO_GEMM_F16_PINGPONG") && getenv("MDNO_GEMM_F16_PINGPONG")[0] == '0');
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        cus = cus / 8 * 8;
-        if (persist_on && cus >= 8 && (long long)g.tiles_n * g.tiles_m > cus) {
-            if (g.K >= 96) {
-                static std::atomic<unsigned long long> lds_raised_pp{0};
-                MDNO_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(&gemm_split_f16_pp_kernel), lds_bytes, lds_raised_pp));
-                hipLaunchKernelGGL(gemm_split_f16_pp_kernel, dim3(cus), dim3(512), lds_bytes, s, g);
-                return check_launch("split-f16 GEMM (ping-pong)");
-            }
-        }
     }
     hipLaunchKernelGGL((gemm_split_f16_kernel<OUT, MI>), dim3(g.tiles_n * g.tiles_m), dim3(1024 / MI), lds_bytes, s, g);
     return check_launch("split-f16 GEMM");

@@ -309,7 +309,8 @@ def check_train_status(model) -> None:
     if st is None:
         return
     word = int(st.item())
-    st.zero_()
+    if word:                     # (cleared only when something was raised: no fill launch per epoch otherwise)
+        st.zero_()
     raise_on_status(word, "training forward")
 
 

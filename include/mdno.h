@@ -283,10 +283,11 @@ int mdno_rollout_plan_destroy(mdno_rollout_plan* plan);
 
 /* Measurement aid (bench.py roofline leg): with a timer attached, plan_run issues plain launches
  * (never the captured graph) and brackets every kernel with two HIP events on `stream`.
- * kernel_id: 0 conv (materialized: the gather/matvec/scatter kernel K3-K6; factored: the per-source
- * GEMM), 1 edge-MLP GEMM layer 1, 2 edge-MLP GEMM layer 2 (materialized only), 3 edge-MLP layer 0
- * (+ weight splits when not cached), 4 radius graph (+ reverse-edge index), 5 node prologue, 6 fc2,
- * 7 factored conv: aggregation, 8 factored conv: Y GEMM.  Read after synchronising the stream. */
+ * kernel_id: 0 conv (materialized: the gather/matvec/scatter kernel; factored: K1, the edge-moment kernel of
+ * csrc/moment.hip), 1 edge-MLP GEMM layer 1, 2 edge-MLP GEMM layer 2 (materialized only), 3 edge-MLP layer 0
+ * (+ weight splits when not cached), 4 radius graph (+ the factored conv's degree order), 5 node prologue, 6 fc2,
+ * 7 factored conv: K3 (slices + root + bias + mean + ReLU), 8 factored conv: K2 (projection on W3).  Read after
+ * synchronising the stream. */
 int mdno_rollout_plan_timer_attach(mdno_rollout_plan* plan, int max_records);
 int mdno_rollout_plan_timer_read(mdno_rollout_plan* plan, int kernel_id, double* total_ms, int64_t* count);
 int mdno_rollout_plan_timer_detach(mdno_rollout_plan* plan);

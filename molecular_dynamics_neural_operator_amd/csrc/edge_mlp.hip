@@ -92,7 +92,7 @@ struct GemmArgs {
     long long row_begin;  // global edge index of local row 0
     int rows;             // chunk rows (capacity)
     int N, K;
-    int tiled_out;        // 1: C written k-tiled [rows/128][N/32][128][32] (csrc/factored.hip step (2))
+    int tiled_out;        // 1: C written k-tiled [rows/128][N/32][128][32] (what csrc/moment.hip K1 streams)
 };
 
 // One K-tile of MFMA work for a wave: 2x2 tiles of 32x32 (mfma_f32.h)

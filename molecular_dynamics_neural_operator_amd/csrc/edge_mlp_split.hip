@@ -23,7 +23,7 @@
 //   layer 1      H1 x W1 -> relu -> split  ---------> H2 tiled planes        (epilogue emits planes)
 //   layer 2      H2 x W2 + b  -> fp32 W_e[E, Cin*Cout]  (row-major, what the conv streams)
 // so no fp32 activation is ever stored (materialized conv).  The factored conv stops after layer 1,
-// whose epilogue then writes H as k-tiled fp32 (OUT 2: what csrc/moment.hip and csrc/factored.hip stream)
+// whose epilogue then writes H as k-tiled fp32 (OUT 2: what csrc/moment.hip streams)
 // (split_gemm_rows); the training ops use it through split_linear (OUT 0 / 3).
 //
 // GEMM kernel: 256x128 block tile, k-step 16 per stage, 8 waves (4x2), wave tile 64x64 = 2x2
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(TM * 2, 2) void gemm_split_bf16_kernel(SplitGemmArg
                 const int m = bm + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (m < valid) {
                     const float v = acc[i][j][e] + bv;
-                    if (OUT == 2) {   // k-tiled fp32 image [m/128][n/32][128][32] (csrc/moment.hip K1, csrc/factored.hip step (2))
+                    if (OUT == 2) {   // k-tiled fp32 image [m/128][n/32][128][32] (csrc/moment.hip K1)
                         g.C[((size_t)(m >> 7) * (g.N >> 5) + (n >> 5)) * 4096 + (m & 127) * 32 + (n & 31)] = fmaxf(v, 0.f);
                     } else if (OUT == 1) {
                         __bf16 ph, pm, pl;

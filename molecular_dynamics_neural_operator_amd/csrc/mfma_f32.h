@@ -1,4 +1,4 @@
-// Exact-fp32 MFMA tile helpers shared by the fp32 GEMM kernels (edge_mlp.hip, factored.hip, train.hip):
+// Exact-fp32 MFMA tile helpers shared by the fp32 GEMM kernels (edge_mlp.hip, moment.hip, train.hip):
 // v_mfma_f32_32x32x2_f32 over K-tiles of 32 staged in LDS as rows of 36 floats (144 B: conflict-free
 // ds_read_b128).  Bit-for-bit an fmaf chain in k order.
 #pragma once

@@ -6,10 +6,10 @@
 //     z_t[o]    = sum_{i,c} S_t[i][c] * W3[i*64 + o][c] + sum_i s0_t[i] * B3[i][o]      (K2)  one tall GEMM
 //                 [R, 64 k + 64] x [64 k + 64, 64], K-sliced;  s0_t = sum_{e -> t} x_src(e), B3 = reshape(b3, [64, 64])
 //     y_t       = act( z_t / max(deg_t, 1) + x_t . root + bias )                                   (K3)
-// Against the source-side form of factored.hip (Y_j = x_j . W3T per source, M_j = H_j . Y_j^T per source, gather of
-// the 256-B messages per destination) this needs no reverse-edge index and no symmetric graph, has no 128-row tiles
-// of a node's edges (a destination's edges are the contraction length: any degree, H read exactly once — the
-// source-side form re-read Y_j once per 128 edges of a source: 1.33x the algorithmic bytes at degree 362), writes
+// Against the source-side form of rounds 1-3 (Y_j = x_j . W3T per source, M_j = H_j . Y_j^T per source, gather of the
+// 256-B messages per destination; removed in round 5) this needs no reverse-edge index and no symmetric graph, has no
+// 128-row tiles of a node's edges (a destination's edges are the contraction length: any degree, H read exactly once
+// — the source-side form re-read Y_j once per 128 edges of a source: 1.33x the algorithmic bytes at degree 362), writes
 // no per-edge partial messages (62 MB per application at N = 504) and ends in a per-node epilogue instead of a
 // gather: HBM bytes per application  E k 4 (H) + 2 R 64 k 4 (S out, S in) + 64 k 64 4 (W3)  — 529 MB at N = 504,
 // E = 60.6k, k = 1024 against 692 MB measured for the three source-side kernels.
@@ -23,7 +23,7 @@
 //                         transposing read ds_read_b64_tr_b16; register prefetch of the next stage under the MFMAs.
 //                         One more workgroup per destination sums the neighbours' features (s0, the b3 term).
 //   K2  project_kernel    workgroup = (128 destinations, 1/128 of the 64 k contraction): S and W3 tiles fp32 -> planes
-//                         on the fly (the loop of factored.hip's per-source kernel); partial sums per K slice.
+//                         on the fly; partial sums per K slice.
 //   K3  finish_kernel     per destination: K slices added in slice order, root / bias / mean / ReLU.
 // Fixed summation orders everywhere: a destination's result depends on its own edges only (bitwise the same alone or
 // in any batch), no float atomics.
@@ -384,9 +384,8 @@ __global__ __launch_bounds__(256) void moment_f32_kernel(const float* __restrict
 
 // ---------------------------------------------------------------- K2: z = S . W3R, K-sliced
 // Workgroup (256 destinations = two row tiles of the S image, slice): partial[slice][row][64] = S[rows][kappa in slice] . W3R[kappa][:].
-// The loop of factored.hip's gemm_per_source_split_kernel (fp32 K-tiles of both operands -> three bf16 planes on the
-// fly, XOR-swizzled 64-B LDS rows, six plane products), with the row tile's S in the role of H_j and W3R in the role
-// of Y_j.  PJ_SLICES is a constant and a slice's k-tiles a function of k alone: the association of a destination's
+// fp32 K-tiles of both operands (S rows, W3R rows) are split into three bf16 planes on the fly and staged in
+// XOR-swizzled 64-B LDS rows; six plane products per pair.  PJ_SLICES is a constant and a slice's k-tiles a function of k alone: the association of a destination's
 // sum does not depend on the launch.  The last slice also takes the two s0 k-tiles (x B3).
 constexpr int PJ_SLICES = 128;
 // 256 destinations per workgroup: two 128-row tiles of the S image against ONE W3R tile —

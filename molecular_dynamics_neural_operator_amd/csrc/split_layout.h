@@ -1,5 +1,5 @@
-// Shared by the kernels that produce or consume the split-bf16 operand images (edge_mlp_split.hip
-// owns the layout; factored.hip's aggregation writes the node features of the next layer in it).
+// Shared by the kernels that produce or consume the split operand images (edge_mlp_split.hip owns the layout;
+// gemm_bf16.hip's fp32 training products use the fp16 row scales).
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -33,7 +33,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/shape_a_trace -- py
 echo "shape A trace done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/shape_c_trace -- python3 $ROOT/scripts/run_shape_c.py --steps 2 > $OUT/shape_c.json 2> $OUT/shape_c.err
 echo "shape C trace done"
-# shape C counters (HBM bytes of the per-source GEMM and of the materialised conv kernel on the 2.0M-edge slice): own passes
+# shape C counters (HBM bytes of K1, csrc/moment.hip, and of the materialised conv kernel on the 2.0M-edge slice): own passes
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_shape_c -- python3 $ROOT/scripts/run_shape_c.py --steps 1 > $OUT/pmc_fetch_shape_c.json 2> $OUT/pmc_fetch_shape_c.err
 echo "shape C fetch done"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_shape_c -- python3 $ROOT/scripts/run_shape_c.py --steps 1 > $OUT/pmc_write_shape_c.json 2> $OUT/pmc_write_shape_c.err

@@ -681,8 +681,8 @@ def test_rollout_vs_oracle_full_width(dev, O):
 
 # ------------------------------------------------------------------------------- factored conv
 def test_factored_conv_matches_materialized_and_reference(dev):
-    """conv_mode='factored' (per-node Y = X.W3, per-source GEMM, reverse-edge gather) computes the
-    same forward as the materialised W_e formulation: against the REFERENCE's golden at the benchmark
+    """conv_mode='factored' (S_t = sum over a destination's in-edges of x_src (x) h_e, then y_t = W3 : S_t; csrc/moment.hip)
+    computes the same forward as the materialised W_e formulation: against the REFERENCE's golden at the benchmark
     shape (N=504, full model) and against the materialised path on a 3-member ensemble."""
     from molecular_dynamics_neural_operator_amd import ops, synthetic as syn
     from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN
@@ -883,9 +883,8 @@ def test_factored_conv_many_row_tiles(dev):
 
 
 def test_factored_conv_large_member_source_major_order(dev):
-    """Members with more than 1,024 atoms take the other launch shape of the per-source GEMM (uniform
-    2-way k split; with >= 8,192 workgroups also source-major dispatch with rotated slots):
-    factored == materialized at N = 1,100."""
+    """A member of more than 512 atoms spans several S chunks of the factored conv (512 destinations each, three
+    here, the last one partial) and most atoms have more than 128 neighbours: factored == materialized at N = 1,100."""
     from molecular_dynamics_neural_operator_amd import synthetic as syn
     from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN
     from molecular_dynamics_neural_operator_amd.rollout import RolloutEngine, default_edge_cap

@@ -88,8 +88,8 @@ def parse(argv=None):
     ap.add_argument("--no-graph", action="store_true", help="plain launches instead of hipGraph replay")
     ap.add_argument("--member-groups", type=int, default=0,
                     help="a rank's members as this many independent engines on their own streams, stepped together "
-                         "(rollout.GroupedRolloutEngine; frames bitwise unchanged); 0 = 2 groups from 2 members of >= 256 "
-                         "atoms on (4 from 32 members on), else 1")
+                         "(rollout.GroupedRolloutEngine; frames bitwise unchanged); 0 = groups of four members (at least 2 "
+                         "groups, at most 16) from 2 members of >= 256 atoms on, else 1")
     ap.add_argument("--gemm-mode", choices=["split_bf16", "split_f16", "f32"], default="split_f16",
                     help="edge-MLP GEMMs: exact 3-way bf16 split (6 products, fp32 accumulate); split_f16 = the same "
                          "with the hidden layer of the factored path on 2 fp16 planes (3 products, device-side "
@@ -815,7 +815,9 @@ def worker(a):
     max_steps = a.warmup + a.steps + (0 if a.skip_roofline else a.steps)
     cap = default_edge_cap(M, N, a.threshold)
     def groups_for(members):
-        return a.member_groups if a.member_groups > 0 else ((4 if members >= 32 else 2) if members >= 2 and N >= 256 else 1)
+        # four members per group (8 members: 2 groups 582 vs 4 groups 577 frames/s; 64 members: 4 / 8 / 16 groups
+        # 577 / 589 / 594 on one box)
+        return a.member_groups if a.member_groups > 0 else (max(2, min(16, members // 4)) if members >= 2 and N >= 256 else 1)
 
     def make_engine(members, steps_cap, edge_cap):
         """one engine, or the members as groups on concurrent streams (same frames, another schedule: EXPERIMENTS §0.2b)"""

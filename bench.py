@@ -67,6 +67,10 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s mea
 HBM_COPY_GBS = 6290.0
 MFMA_F32_PEAK_TFLOPS = 157.3  # fp32-input MFMA = vector fp32 peak
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (MI355X_MICROARCH.md)
+# what the chip SUSTAINS on v_mfma_f32_32x32x16_f16 beside one 1-KiB LDS-DMA piece per 4 MFMAs and wave from beyond L2 —
+# the hidden GEMM's data-movement intensity — measured by scripts/micro/mfma_sustained.hip (EXPERIMENTS.md §00.6;
+# MFMAs alone: 1.5-1.7 PF): context beside the nominal peak, as HBM_COPY_GBS is beside HBM_PEAK_GBS
+MFMA_16BIT_SUSTAINED_TFLOPS = 1480.0
 ENSEMBLE_MEMBERS = 64         # BASELINE.json configs[2]
 
 
@@ -934,8 +938,10 @@ def worker(a):
         return {"bound": "mfma", "kernel": "gemm_split_f16_kernel" if f16 else "gemm_split_bf16_kernel", "achieved": ach,
                 "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
                 "fp32_equivalent_tflops": flops32 / step_s / 1e12, "ms_per_step": step_s * 1e3,
+                "frac_of_measured_sustained_rate": ach / MFMA_16BIT_SUSTAINED_TFLOPS,
                 "note": f"executed 16-bit MFMA flops ({products:.0f} plane products per fp32 product) vs the dense "
-                        "bf16/fp16 peak"}
+                        "bf16/fp16 peak; frac_of_measured_sustained_rate: vs the 1.48 PF the chip sustains on fp16 MFMAs at "
+                        "this kernel's LDS-DMA intensity (scripts/micro/mfma_sustained.hip)"}
 
     def moment_roofline(ks, e):   # factored path (csrc/moment.hip): K1 over all launches of one conv application
         launches_per_app = max(1, round(ks["nnconv"]["launches"] / (a.steps * 2 * a.depth)))

@@ -122,6 +122,11 @@ __global__ __launch_bounds__(CH) void degree_order_kernel(const int* __restrict_
 // k-tiles (32 kappa) of a destination's row of the S image: 64 k / 32 for S_t itself + 2 for s0_t (kappa = 64 k + i)
 __host__ __device__ constexpr size_t moment_nkt(int K) { return (size_t)64 * K / 32 + 2; }
 constexpr int MO_EDGES = 16;                 // edges per stage = one MFMA k-step
+// The first bytes of H are loaded with the default cache policy, the rest non-temporally: the 2 x depth applications of
+// a forward stream the same H, and what of it stays in the 256 MiB Infinity Cache between two of them is read faster
+// (scripts/micro/mall_partial_residency.hip: 248 MB at 5.5 TB/s all non-temporal, 6.3 TB/s with 64 MiB kept — and no
+// further gain from more, while S (written by K1, read back by K2 out of the same cache) and W3R need their share).
+constexpr size_t kMomentCachedBytes = (size_t)64 << 20;
 constexpr int MO_CQ = 256;                   // hidden units per workgroup
 constexpr int MO_HROW = MO_CQ * 2 + 64;      // LDS bytes per edge row of an H plane (64 B of padding: the four rows of a
                                              // transposing read's block fall into four different 64-B bank quarters)
@@ -172,7 +177,7 @@ __device__ __forceinline__ void moment_s0(const int* __restrict__ row_ptr, const
 __global__ __launch_bounds__(256, 3) void moment_kernel(const float* __restrict__ Hm,
                                                         const int* __restrict__ row_ptr, const int* __restrict__ src,
                                                         const int* __restrict__ order, float* __restrict__ S, int K,
-                                                        int row0, int cnt, const float* __restrict__ x) {
+                                                        int row0, int cnt, const float* __restrict__ x, int cache_e) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[MO_LDS];
     // workgroup ids b, b+8, b+16, .. share an XCD: a destination's k/256 column blocks (and its s0 workgroup) run there
     // back to back, so that the neighbours' feature rows they all gather come through that L2 once (at N = 50,000 the
@@ -210,10 +215,18 @@ __global__ __launch_bounds__(256, 3) void moment_kernel(const float* __restrict_
     }
     auto load_stage = [&](int e0) {       // edges e0 .. e0+15 of this row -> registers (zeros past the end)
         const int e = e0 + er;
+        if (e0 + MO_EDGES <= cache_e) {    // the part of H kept in the Infinity Cache (moment_conv): default-policy loads
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {      // (u: the 64 hidden units of wave u; none past k — k % 64 == 0)
-            rh[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < end && cq * MO_CQ + u * 64 < K) MO_NT(rh[u], h_ptr(e, u))
+            for (int u = 0; u < 4; ++u) {
+                rh[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < end && cq * MO_CQ + u * 64 < K) rh[u] = *reinterpret_cast<const float4*>(h_ptr(e, u));
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {      // (u: the 64 hidden units of wave u; none past k — k % 64 == 0)
+                rh[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < end && cq * MO_CQ + u * 64 < K) MO_NT(rh[u], h_ptr(e, u))
+            }
         }
         rx = make_float4(0.f, 0.f, 0.f, 0.f);
         if (e0 + xe < end) rx = *reinterpret_cast<const float4*>(x + (size_t)sidx * 64 + 4 * xs);
@@ -675,6 +688,11 @@ int moment_conv(const float* x, const float* h2, const int* row_ptr, const int* 
                 const float* root, const float* bias, int aggr, int relu, float* y, const MomentWs& f, hipStream_t s,
                 bool exact_f32) {
     MDNO_REQUIRE(moment_supported(64, ker_width), MDNO_EUNSUPPORTED, "moment conv: ker_width=%d (x128)", ker_width);
+    size_t cached_bytes = kMomentCachedBytes;
+#ifdef MDNO_EXP_CACHE_ENV
+    if (const char* v = getenv("MDNO_EXP_CACHE_MIB")) cached_bytes = (size_t)atoi(v) << 20;
+#endif
+    const int cache_e = (int)(cached_bytes / ((size_t)ker_width * sizeof(float))) & ~127;      // whole 128-edge tiles of the image
     for (int r0 = 0; r0 < num_rows; r0 += kMomentChunkRows) {
         const int cnt = num_rows - r0 < kMomentChunkRows ? num_rows - r0 : kMomentChunkRows;
         {   // K1: the chunk's destinations x the k/256 column blocks
@@ -686,7 +704,7 @@ int moment_conv(const float* x, const float* h2, const int* row_ptr, const int* 
                                    ker_width, r0, cnt, x);
             else
                 hipLaunchKernelGGL(moment_kernel, grid, dim3(256), 0, s, h2, row_ptr, src, (const int*)f.order, f.s, ker_width,
-                                   r0, cnt, x);
+                                   r0, cnt, x, cache_e);
         }
         {   // K2: groups of row tiles x K slices
             TimedSection ts(KID_FACT_Y, s);

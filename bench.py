@@ -952,8 +952,10 @@ def worker(a):
         # neighbours' 256-B feature rows are gathered from L2)
         name = "moment_kernel" if split else "moment_f32_kernel"
         alg = e * KW * 4 + R * C * KW * 4 + e * 4 + (R + 1) * 4
-        # matrix-pipe work as executed: 6 bf16 plane products per fp32 product, or the fp32 MFMA itself
-        mfma_exec, mfma_peak = (6.0 * flops, MFMA_BF16_PEAK_TFLOPS) if split else (flops, MFMA_F32_PEAK_TFLOPS)
+        # matrix-pipe work as executed: 3 fp16 (split_f16) or 6 bf16 (split_bf16) plane products per fp32 product, or the
+        # fp32 MFMA itself
+        products = {"split_f16": 3.0, "split_bf16": 6.0}.get(a.gemm_mode, 1.0)
+        mfma_exec, mfma_peak = (products * flops, MFMA_BF16_PEAK_TFLOPS) if split else (flops, MFMA_F32_PEAK_TFLOPS)
         t_hbm, t_mfma = alg / (HBM_PEAK_GBS * 1e9), mfma_exec / (mfma_peak * 1e12)
         prof = profiled_entry(name, N, M_r, "factored", a.gemm_mode)
         r = {"kernel": name, "conv_mode": "factored", "avg_launch_ms": avg_s * 1e3, "avg_launch_ms_events": avg_s * 1e3,
@@ -975,8 +977,9 @@ def worker(a):
         compulsory = e * KW * 4 + (C * KW + C) * C * 4 + 2 * R * C * 4 + e * 4 + (R + 1) * 4
         moved = alg + (R * C * KW * 4 + (C * KW + C) * C * 4) + 2 * 128 * R * C * 4 + R * C * 4      # + K2 in, partials out/in, y
         r["per_application"] = {
-            "kernels": "moment_kernel (K1) + project_kernel (K2) + finish_kernel (K3)" if split else
-                       "moment_f32_kernel (K1) + project_f32_kernel (K2) + finish_kernel (K3)",
+            "kernels": {"split_f16": "moment_kernel<true> (K1) + project_f16_kernel (K2) + finish_kernel (K3)",
+                        "split_bf16": "moment_kernel<false> (K1) + project_kernel<256> (K2) + finish_kernel (K3)"}.get(
+                            a.gemm_mode, "moment_f32_kernel (K1) + project_f32_kernel (K2) + finish_kernel (K3)"),
             "ms_events": app_s * 1e3, "k1_k2_k3_ms": [ks["nnconv"]["ms_per_step"] / (2 * a.depth), k2 / (2 * a.depth), k3 / (2 * a.depth)],
             "compulsory_bytes": compulsory, "algorithmic_bytes_moved_by_the_three_kernels": moved,
             "traffic": prof.get("application_hbm_bytes"),

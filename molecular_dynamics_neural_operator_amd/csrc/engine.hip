@@ -156,14 +156,14 @@ int forward_impl(const mdno_kernelnn_params* p, const float* frames, int t0, con
                 MDNO_TRY(edge_mlp_hidden(edge_frames, edge_frame, t_dev, R, src, dst, edge_attr, perm, num_edges, edge_cap,
                                          p->ker_in, p->ker_width, p->gemm_mode, w, ws.h2, ws.mlp, ws.mlp_bytes, s,
                                          block == 0 ? phase : (phase & ~WP_FLAGS_ZEROED)));
-                if ((phase & WP_PHASE_MASK) != WP_RUN_ONLY) MDNO_TRY(moment_prepare_weights(w.w2, w.b2, p->ker_width, mw, s));
+                if ((phase & WP_PHASE_MASK) != WP_RUN_ONLY) MDNO_TRY(moment_prepare_weights(w.w2, w.b2, p->ker_width, mw, s, p->gemm_mode));
             }
             if (prep_only) return MDNO_OK;
             const float* root = block == 0 ? p->conv1_root : p->conv2_root;
             const float* bias = block == 0 ? p->conv1_bias : p->conv2_bias;
             for (int d = 0; d < p->depth; ++d) {
                 MDNO_TRY(moment_conv(cur, ws.h2, row_ptr, src, R, p->ker_width, root, bias, MDNO_AGGR_MEAN, /*relu=*/1, nxt,
-                                     mw, s, /*exact_f32=*/p->gemm_mode == MDNO_GEMM_F32));
+                                     mw, s, p->gemm_mode));
                 float* t = cur; cur = nxt; nxt = t;
             }
         }

@@ -106,16 +106,21 @@ struct MomentWs {
     float *w3r, *s, *part;
     int* order;               // destinations of each S chunk by decreasing degree
     long long part_stride;
+    // gemm_mode SPLIT_F16: W3R on two fp16 planes with its columns' inverse scales, and the row maxima of the S chunk
+    _Float16* w3h;
+    float* colinv;
+    int* colmax_bits;
+    float* rowmax;
 };
 bool moment_supported(int width, int ker_width);
 size_t moment_workspace_bytes(int num_rows, int ker_width);
 MomentWs moment_carve(void* ws, int num_rows, int ker_width);
-int moment_prepare_weights(const float* w3, const float* b3, int ker_width, const MomentWs& f, hipStream_t s);
+int moment_prepare_weights(const float* w3, const float* b3, int ker_width, const MomentWs& f, hipStream_t s, int gemm_mode);
 int moment_prepare_graph(const int* row_ptr, int num_rows, const MomentWs& f, hipStream_t s);
 // (the last MLP layer's bias b3 is part of W3R: moment_prepare_weights)
 int moment_conv(const float* x, const float* h2, const int* row_ptr, const int* src, int num_rows, int ker_width,
                 const float* root, const float* bias, int aggr, int relu, float* y, const MomentWs& f, hipStream_t s,
-                bool exact_f32 = false);
+                int gemm_mode);
 
 // bf16 training GEMMs (gemm_bf16.hip): 256 x 256 tiles, 8 waves, two wave groups one phase apart over an
 // LDS-DMA ring of 32-k stages.

@@ -14,19 +14,31 @@
 // gather: HBM bytes per application  E k 4 (H) + 2 R 64 k 4 (S out, S in) + 64 k 64 4 (W3)  — 529 MB at N = 504,
 // E = 60.6k, k = 1024 against 692 MB measured for the three source-side kernels.
 //
-// All three products run on the bf16 matrix pipe at fp32 accuracy: every fp32 operand is split exactly into three
-// bf16 planes (x = hi + mid + lo) and the six leading plane products are accumulated in fp32 (edge_mlp_split.hip).
+// The products run on the 16-bit matrix pipe at fp32 accuracy, every fp32 operand split into planes on the way to LDS:
+//   gemm_mode SPLIT_BF16  three bf16 planes (x = hi + mid + lo, exact for any fp32 x), six leading plane products;
+//   gemm_mode SPLIT_F16   two fp16 planes (x = hi + lo), three products — half the matrix work, which in K1 and K2 is
+//                         ADDED to the stream time rather than hidden under it (EXPERIMENTS 00.10, 00.11).  fp16 has 30
+//                         binades, so operands are put high in its range first by exact powers of two (K2: every row
+//                         of S by its own maximum, every column of W3R by its own — no input is out of range; K1: x and
+//                         H by 2^8, and a workgroup whose staged values leave [2^-10, 255.87] reruns its destination on
+//                         the bf16 planes: the decision depends on that destination's own edges only);
+//   gemm_mode F32         the fp32 MFMA (moment_f32_kernel, project_f32_kernel): reference arithmetic.
 //   K1  moment_kernel     workgroup = (destination t, 256 of the k hidden units); stage = 16 edges: H rows (fp32,
-//                         k-tiled image written by the hidden GEMM, streamed once, non-temporal) and the neighbours'
-//                         fp32 feature rows (gathered from L2) are split into planes on the way to LDS, edge-major,
-//                         i.e. with the contraction index SLOWEST, and the MFMA fragments come out of gfx950's
-//                         transposing read ds_read_b64_tr_b16; register prefetch of the next stage under the MFMAs.
-//                         One more workgroup per destination sums the neighbours' features (s0, the b3 term).
-//   K2  project_kernel    workgroup = (128 destinations, 1/128 of the 64 k contraction): S and W3 tiles fp32 -> planes
-//                         on the fly; partial sums per K slice.
-//   K3  finish_kernel     per destination: K slices added in slice order, root / bias / mean / ReLU.
+//                         k-tiled image written by the hidden GEMM, streamed once per application, non-temporal but
+//                         for the first 64 MiB, kept in the Infinity Cache) and the neighbours' fp32 feature rows
+//                         (gathered from L2) are split into planes on the way to LDS, edge-major, i.e. with the
+//                         contraction index SLOWEST, and the MFMA fragments come out of gfx950's transposing read
+//                         ds_read_b64_tr_b16; register prefetch of the next stage under the MFMAs.  One more workgroup
+//                         per destination sums the neighbours' features (s0, the b3 term).
+//   K2  project_kernel / project_f16_kernel
+//                         workgroup = (256 destinations, 1/128 of the 64 k contraction): S tiles fp32 -> planes on the
+//                         fly, W3R's likewise (bf16) or pre-split (fp16); partial sums per K slice.
+//   K3  finish_kernel     per destination: K slices added in slice order, (fp16: the row's and columns' scales out
+//                         again,) root / bias / mean / ReLU.
 // Fixed summation orders everywhere: a destination's result depends on its own edges only (bitwise the same alone or
 // in any batch), no float atomics.
+#include <type_traits>
+
 #include "kernels.h"
 #include "mfma_f32.h"
 #include "split_layout.h"
@@ -39,6 +51,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 // (a, b) -> packed bf16 pair (one v_cvt_pk_bf16_f32) and the pair's values back in fp32
 __device__ __forceinline__ unsigned pack_bf16(float a, float b, float& fa, float& fb) {
@@ -75,6 +89,40 @@ __device__ __forceinline__ void split_store4(const float4 v, unsigned char* dst,
     ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[1], ACC, 0, 0, 0);        \
     ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[0], ACC, 0, 0, 0);
 
+// ---- two fp16 planes (gemm_mode SPLIT_F16; split_layout.h): x = hi + lo with hi = fp16(x), lo = fp16(x - hi), the lo
+// plane NOT scaled here, so that the three leading products share one accumulator (K1 has no registers for a second
+// one at three workgroups per CU).  |x - (hi + lo)| <= max(2^-23 |x|, 2^-25): the absolute floor is kept out of sight by
+// putting the operands high in fp16's range first, with exact powers of two that are taken out again afterwards —
+// K2: every row of S by its own maximum (K1 records it) and every column of W3R by its own, to [2^13, 2^14): floor
+// 2^-38 of the row's / column's largest entry; K1: x and H by 2^8 (floor 2^-33; a workgroup whose x or H holds a value
+// >= 255 or none >= 2^-10 redoes its destination on the bf16 planes — a decision that depends on that destination's own
+// edges only).  (a, b) -> packed fp16 pair (one v_cvt_pk_f16_f32 on gfx950) and the pair's values back in fp32
+__device__ __forceinline__ unsigned pack_f16(float a, float b, float& fa, float& fb) {
+    const f32x2 v = {a, b};
+    const f16x2 p = __builtin_convertvector(v, f16x2);
+    fa = (float)p.x;
+    fb = (float)p.y;
+    return __builtin_bit_cast(unsigned, p);
+}
+
+// four fp32 (already scaled) -> 2 x four fp16 (hi, lo), 8 bytes per plane at dst + p * plane_bytes
+__device__ __forceinline__ void split2_store4(const float4 v, unsigned char* dst, int plane_bytes) {
+    float h0, h1, h2, h3, t0, t1;
+    uint2 hi, lo;
+    hi.x = pack_f16(v.x, v.y, h0, h1);
+    hi.y = pack_f16(v.z, v.w, h2, h3);
+    lo.x = pack_f16(v.x - h0, v.y - h1, t0, t1);
+    lo.y = pack_f16(v.z - h2, v.w - h3, t0, t1);
+    *reinterpret_cast<uint2*>(dst) = hi;
+    *reinterpret_cast<uint2*>(dst + plane_bytes) = lo;
+}
+
+// the three leading plane products of (a0 + a1)(b0 + b1), smallest first
+#define MDNO_MMA3H(A, B, ACC)                                                       \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1], B[0], ACC, 0, 0, 0);         \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], B[1], ACC, 0, 0, 0);         \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], B[0], ACC, 0, 0, 0);
+
 // ---------------------------------------------------------------- W3 [64*64, k] -> W3R tiled [64k/32][64 o][32]
 // W3R[kappa][o] = W3[(i*64 + o)*k + c] with kappa = i*k + c (and B3[i][o] at kappa = 64 k + i): the B operand of K2,
 // one 8 KiB run per 32 kappa
@@ -91,6 +139,46 @@ __global__ __launch_bounds__(256) void w3_moment_kernel(const float* __restrict_
     }
     const int i = (int)(kappa / k), c = (int)(kappa - (long long)i * k);
     w3r[id] = w3[((size_t)i * 64 + o) * k + c];
+}
+
+// W3R on two fp16 planes (gemm_mode SPLIT_F16): column o (one output channel: 64 k + 64 entries) times the power of two
+// that puts its largest entry in [2^13, 2^14), split; tile [kappa/32][plane][64 o][32 kappa] of fp16, 8 KiB like the fp32
+// tile.  colinv[o] = the power of two that takes the scale out again (K3).
+__global__ __launch_bounds__(256) void w3_colmax_kernel(const float* __restrict__ w3r, long long ntiles, int* __restrict__ colmax_bits) {
+    __shared__ int red[4][64];
+    const int o = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    float m = 0.f;
+    for (long long t = (long long)blockIdx.x * 4 + sub; t < ntiles; t += (long long)gridDim.x * 4) {
+        const float4* row = reinterpret_cast<const float4*>(w3r + (t * 64 + o) * 32);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4 v = row[j];
+            // (not fmaxf: a NaN must win, so that a non-finite weight reaches the output as the other paths have it)
+            const float a = fabsf(v.x), b = fabsf(v.y), c = fabsf(v.z), d = fabsf(v.w);
+            m = !(a <= m) ? a : m; m = !(b <= m) ? b : m; m = !(c <= m) ? c : m; m = !(d <= m) ? d : m;
+        }
+    }
+    red[sub][o] = __builtin_bit_cast(int, m);      // non-negative floats (and NaN above Inf) order like their bits
+    __syncthreads();
+    if (sub == 0) {
+        int v = red[0][o];
+        for (int u = 1; u < 4; ++u) v = red[u][o] > v ? red[u][o] : v;
+        atomicMax(colmax_bits + o, v);
+    }
+}
+
+__global__ __launch_bounds__(256) void w3_planes_f16_kernel(const float* __restrict__ w3r, long long total,
+                                                            const int* __restrict__ colmax_bits, _Float16* __restrict__ w3h,
+                                                            float* __restrict__ colinv) {
+    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;      // over (kappa tile, o, kappa & 31), as w3r
+    if (id < 64) colinv[id] = 1.f / f16_row_scale(__builtin_bit_cast(float, colmax_bits[id]));
+    if (id >= total) return;
+    const int kl = (int)(id & 31), o = (int)((id >> 5) & 63);
+    const long long tile = id >> 11;
+    const float v = w3r[id] * f16_row_scale(__builtin_bit_cast(float, colmax_bits[o]));
+    const _Float16 h = (_Float16)v;
+    w3h[(tile * 2 + 0) * 2048 + o * 32 + kl] = h;
+    w3h[(tile * 2 + 1) * 2048 + o * 32 + kl] = (_Float16)(v - (float)h);
 }
 
 // ---------------------------------------------------------------- destinations by decreasing degree
@@ -138,8 +226,15 @@ constexpr int MO_LDS = 3 * MO_HPLANE + 3 * MO_XPLANE;      // 36,864 B
 // MLP layer's bias seen through the summed neighbours), stored as kappa = 64 K + i of the same image, so that K2
 // multiplies it with B3 like any other slice.  16 chains x 16 lanes (4 features each), four edges in flight per chain,
 // chains added in order: a fixed order.
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
 __device__ __forceinline__ void moment_s0(const int* __restrict__ row_ptr, const int* __restrict__ src,
-                                          const float* __restrict__ x, float* __restrict__ S, int K, int t, int tl) {
+                                          const float* __restrict__ x, float* __restrict__ S, int K, int t, int tl,
+                                          float* __restrict__ rowmax_slot) {
     __shared__ float4 sred[16][16];
     const int tid = threadIdx.x;
     const int beg = row_ptr[t], end = row_ptr[t + 1];
@@ -162,23 +257,40 @@ __device__ __forceinline__ void moment_s0(const int* __restrict__ row_ptr, const
     }
     sred[es][q] = s0;
     __syncthreads();
+    float4 s0r = make_float4(0.f, 0.f, 0.f, 0.f);
     if (es == 0) {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int c = 0; c < 16; ++c) { const float4 v = sred[c][q]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+        s0r = a;
         const int i = 4 * q;       // features 4q..4q+3: k-tile 64K/32 + (i >> 5), columns i & 31 ..
         float* d = S + ((size_t)(tl >> 7) * moment_nkt(K) + (size_t)64 * K / 32 + (i >> 5)) * 4096 + (tl & 127) * 32 + (i & 31);
         *reinterpret_cast<float4*>(d) = a;
+    }
+    if (rowmax_slot != nullptr && tid < 64) {      // wave 0: its first 16 lanes hold s0
+        float m = es == 0 ? fmaxf(fmaxf(fabsf(s0r.x), fabsf(s0r.y)), fmaxf(fabsf(s0r.z), fabsf(s0r.w))) : 0.f;
+        m = wave_max(m);
+        if (tid == 0) *rowmax_slot = m;
     }
 }
 
 // Grid: (destination within the chunk, visited by decreasing degree) x (k / 256).  S chunk layout: the fp32 k-tiled
 // image K2 streams, [node/128][64k/32][128][32] with kappa = i*k + c.
+// F16 (gemm_mode SPLIT_F16): the stage loop runs on two fp16 planes of 2^8 x and 2^8 H (three products instead of six:
+// the matrix work of this kernel is added to its stream time, not hidden under it — EXPERIMENTS 00.10, 00.11), and the
+// workgroup checks afterwards what it has staged: if a |value| reached 2^-8 of fp16's largest (255.87) or none reached
+// 2^-10 (split_layout.h's rule for activations), it runs the loop again on the three bf16 planes.  The decision is the
+// workgroup's own — one destination's edges —, so a destination's bits are the same alone or in any batch.
+constexpr float MO_F16_PRE = 256.f, MO_F16_UNPRE2 = 1.f / 65536.f;
+
+template <bool F16>
 __global__ __launch_bounds__(256, 3) void moment_kernel(const float* __restrict__ Hm,
                                                         const int* __restrict__ row_ptr, const int* __restrict__ src,
                                                         const int* __restrict__ order, float* __restrict__ S, int K,
-                                                        int row0, int cnt, const float* __restrict__ x, int cache_e) {
+                                                        int row0, int cnt, const float* __restrict__ x, int cache_e,
+                                                        float* __restrict__ rowmax) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[MO_LDS];
+    __shared__ float wg_red[12];
     // workgroup ids b, b+8, b+16, .. share an XCD: a destination's k/256 column blocks (and its s0 workgroup) run there
     // back to back, so that the neighbours' feature rows they all gather come through that L2 once (at N = 50,000 the
     // features are 12.8 MB — beyond an XCD's 4 MiB — and each block fetched them again through the fabric)
@@ -193,14 +305,14 @@ __global__ __launch_bounds__(256, 3) void moment_kernel(const float* __restrict_
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nkt = K >> 5;
     if (cq == nq - 1) {
-        moment_s0(row_ptr, src, x, S, K, t, tl);
+        moment_s0(row_ptr, src, x, S, K, t, tl, rowmax ? rowmax + (size_t)tl * nq + cq : nullptr);
         return;
     }
     // ---- staging roles
     // H: thread (edge er = tid >> 4, column group cc = tid & 15) loads four float4: hidden units cq*256 + u*64 + cc*4 ..
     const int er = tid >> 4, cc = tid & 15;
     // X: thread (edge xe = tid >> 4, xs = tid & 15): four fp32 features 4*xs .. of the edge's source row (from L2: the
-    // features of a member are 129 KB), split into the three planes on the way to LDS like H
+    // features of a member are 129 KB), split into the planes on the way to LDS like H
     const int xe = tid >> 4, xs = tid & 15;
     auto h_ptr = [&](int e, int u) {      // element (edge e, hidden unit cq*256 + u*64 + cc*4) of the k-tiled H
         const int c = cq * MO_CQ + u * 64 + cc * 4;
@@ -231,36 +343,54 @@ __global__ __launch_bounds__(256, 3) void moment_kernel(const float* __restrict_
         rx = make_float4(0.f, 0.f, 0.f, 0.f);
         if (e0 + xe < end) rx = *reinterpret_cast<const float4*>(x + (size_t)sidx * 64 + 4 * xs);
     };
-    auto store_stage = [&]() {
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            split_store4(rh[u], lds + er * MO_HROW + (u * 64 + cc * 4) * 2, MO_HPLANE);
-        split_store4(rx, lds + 3 * MO_HPLANE + xe * MO_XROW + xs * 8, MO_XPLANE);
-    };
     // ---- fragment addresses (ds_read_b64_tr_b16): 16-lane group gq, lane = 4*qq + pp inside it reads row 8*(gq>>1) + qq
     // (+4 for the second half), 8 B at column 16*(gq&1) + 4*pp of the block; lane i of the group receives column i
     const int gq = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
     const int frow = 8 * (gq >> 1) + qq, fcol = 16 * (gq & 1) + 4 * pp;
     const unsigned char* hb = lds + frow * MO_HROW + (wave * 64 + fcol) * 2;                  // + cb*64 B, + plane
     const unsigned char* xb = lds + 3 * MO_HPLANE + frow * MO_XROW + fcol * 2;               // + ih*64 B, + plane
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
     auto tr_frag = [&](const unsigned char* p_, int row_bytes) {
         typedef short s16x4 __attribute__((ext_vector_type(4)));
         typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p_));
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p_ + 4 * row_bytes));
-        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     };
     f32x16 acc[2][2];      // [feature half ih][hidden block cb of this wave's 64]
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
     const int stages = (end - beg + MO_EDGES - 1) / MO_EDGES;
     const bool wave_live = cq * MO_CQ + wave * 64 < K;      // this wave's 64 hidden units exist
-    if (stages > 0) {
+    float hmax = 0.f, xmax = 0.f;      // (F16) the largest |H| and |x| this thread has staged
+    auto max4 = [](const float4 v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); };
+    auto pre = [](const float4 v) { return make_float4(v.x * MO_F16_PRE, v.y * MO_F16_PRE, v.z * MO_F16_PRE, v.w * MO_F16_PRE); };
+
+    // the stage loop on two fp16 planes (HALF) or three bf16 planes
+    auto run = [&](auto half_tag) {
+        constexpr bool HALF = decltype(half_tag)::value;
+        auto store_stage = [&]() {
+            if constexpr (HALF) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    hmax = fmaxf(hmax, max4(rh[u]));
+                    split2_store4(pre(rh[u]), lds + er * MO_HROW + (u * 64 + cc * 4) * 2, MO_HPLANE);
+                }
+                xmax = fmaxf(xmax, max4(rx));
+                split2_store4(pre(rx), lds + 3 * MO_HPLANE + xe * MO_XROW + xs * 8, MO_XPLANE);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    split_store4(rh[u], lds + er * MO_HROW + (u * 64 + cc * 4) * 2, MO_HPLANE);
+                split_store4(rx, lds + 3 * MO_HPLANE + xe * MO_XROW + xs * 8, MO_XPLANE);
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        if (stages == 0) return;
+        sidx = 0;
         if (beg + xe < end) sidx = src[beg + xe];
         load_stage(beg);
         if (beg + MO_EDGES + xe < end) sidx = src[beg + MO_EDGES + xe];
@@ -274,17 +404,34 @@ __global__ __launch_bounds__(256, 3) void moment_kernel(const float* __restrict_
             }
             __builtin_amdgcn_sched_barrier(0);      // keep the prefetch above the MFMAs
             if (wave_live) {
-                bf16x8 a[2][3], b[3];
+                if constexpr (HALF) {
+                    f16x8 a[2][2], b[2];
 #pragma unroll
-                for (int ih = 0; ih < 2; ++ih)
+                    for (int ih = 0; ih < 2; ++ih)
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) a[ih][p] = tr_frag(xb + p * MO_XPLANE + ih * 64, MO_XROW);
+                        for (int p = 0; p < 2; ++p)
+                            a[ih][p] = __builtin_bit_cast(f16x8, tr_frag(xb + p * MO_XPLANE + ih * 64, MO_XROW));
 #pragma unroll
-                for (int cb = 0; cb < 2; ++cb) {
+                    for (int cb = 0; cb < 2; ++cb) {
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) b[p] = tr_frag(hb + p * MO_HPLANE + cb * 64, MO_HROW);
-                    MDNO_MMA6(a[0], b, acc[0][cb])
-                    MDNO_MMA6(a[1], b, acc[1][cb])
+                        for (int p = 0; p < 2; ++p) b[p] = __builtin_bit_cast(f16x8, tr_frag(hb + p * MO_HPLANE + cb * 64, MO_HROW));
+                        MDNO_MMA3H(a[0], b, acc[0][cb])
+                        MDNO_MMA3H(a[1], b, acc[1][cb])
+                    }
+                } else {
+                    bf16x8 a[2][3], b[3];
+#pragma unroll
+                    for (int ih = 0; ih < 2; ++ih)
+#pragma unroll
+                        for (int p = 0; p < 3; ++p)
+                            a[ih][p] = __builtin_bit_cast(bf16x8, tr_frag(xb + p * MO_XPLANE + ih * 64, MO_XROW));
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(bf16x8, tr_frag(hb + p * MO_HPLANE + cb * 64, MO_HROW));
+                        MDNO_MMA6(a[0], b, acc[0][cb])
+                        MDNO_MMA6(a[1], b, acc[1][cb])
+                    }
                 }
             }
             if (st + 1 < stages) {
@@ -293,25 +440,59 @@ __global__ __launch_bounds__(256, 3) void moment_kernel(const float* __restrict_
                 __syncthreads();
             }
         }
+    };
+    // workgroup-wide maxima of two per-thread values in one round (wg_red is touched by nothing else)
+    auto wg_max2 = [&](float a, float b, float& ra, float& rb) {
+        a = wave_max(a); b = wave_max(b);
+        if (lane == 0) { wg_red[wave] = a; wg_red[4 + wave] = b; }
+        __syncthreads();
+        ra = fmaxf(fmaxf(wg_red[0], wg_red[1]), fmaxf(wg_red[2], wg_red[3]));
+        rb = fmaxf(fmaxf(wg_red[4], wg_red[5]), fmaxf(wg_red[6], wg_red[7]));
+    };
+    float out_scale = 1.f;
+    if constexpr (F16) {
+        run(std::true_type{});
+        float mh, mx;
+        wg_max2(hmax, xmax, mh, mx);
+        constexpr float LIM = F16_MAX / MO_F16_PRE;
+        const bool ok = stages == 0 || (mh < LIM && mx < LIM && mh >= F16_ACT_MIN && mx >= F16_ACT_MIN);
+        if (ok) out_scale = MO_F16_UNPRE2;
+        else {
+            __syncthreads();      // (every wave has read wg_red; the stage buffers were free already)
+            run(std::false_type{});
+        }
+    } else {
+        run(std::false_type{});
     }
 #undef MO_NT
     // ---- S_t[i][c] -> the k-tiled image: kappa = i*K + c, tile (t >> 7, kappa >> 5), row t & 127, column kappa & 31
     // (a lane holds one hidden unit c = column l31 of the block, 16 feature rows: 128-B runs per half wave)
-    if (!wave_live) return;
-    const int l31 = lane & 31, h = lane >> 5;
-    float* Sb = S + (size_t)(tl >> 7) * moment_nkt(K) * 4096 + (tl & 127) * 32 + l31;
+    float smax = 0.f;      // the largest |S_t[i][c]| this thread holds
+    if (wave_live) {
+        const int l31 = lane & 31, h = lane >> 5;
+        float* Sb = S + (size_t)(tl >> 7) * moment_nkt(K) * 4096 + (tl & 127) * 32 + l31;
 #pragma unroll
-    for (int ih = 0; ih < 2; ++ih)
+        for (int ih = 0; ih < 2; ++ih)
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            const int c0 = cq * MO_CQ + wave * 64 + cb * 32;      // multiple of 32
+            for (int cb = 0; cb < 2; ++cb) {
+                const int c0 = cq * MO_CQ + wave * 64 + cb * 32;      // multiple of 32
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int i = ih * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                const size_t kt = ((size_t)i * K + c0) >> 5;
-                Sb[kt * 4096] = acc[ih][cb][e];
+                for (int e = 0; e < 16; ++e) {
+                    const int i = ih * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const size_t kt = ((size_t)i * K + c0) >> 5;
+                    const float v = acc[ih][cb][e] * out_scale;
+                    Sb[kt * 4096] = v;
+                    smax = fmaxf(smax, fabsf(v));
+                }
             }
-        }
+    }
+    // K2 on fp16 planes scales a row of S by its own maximum: this block's share of it, behind the stores
+    if (rowmax != nullptr) {
+        __syncthreads();      // (wg_red is free again)
+        float m, d;
+        wg_max2(smax, 0.f, m, d);
+        if (tid == 0) rowmax[(size_t)tl * nq + cq] = m;
+    }
 }
 
 // ---------------------------------------------------------------- K1, exact fp32 (gemm_mode F32)
@@ -335,7 +516,7 @@ __global__ __launch_bounds__(256) void moment_f32_kernel(const float* __restrict
     const int tl = order[row0 + ti];
     const int t = row0 + tl;
     if (cq == nq - 1) {
-        moment_s0(row_ptr, src, x, S, K, t, tl);
+        moment_s0(row_ptr, src, x, S, K, t, tl, nullptr);
         return;
     }
     const int beg = row_ptr[t], end = row_ptr[t + 1];
@@ -522,6 +703,125 @@ __global__ __launch_bounds__(PJ_ROWS * 2) void project_kernel(const float* __res
     }
 }
 
+// ---------------------------------------------------------------- K2 on two fp16 planes (gemm_mode SPLIT_F16)
+// project_kernel's loop with half the matrix work: S's rows times the power of two that puts the row's largest entry
+// (rowmax: K1's record, one value per column block of the row) in [2^13, 2^14), split into two fp16 planes on the way
+// to LDS; W3R comes pre-split (w3_planes_f16_kernel: 16 B per thread and plane tile, no vector work); three plane
+// products per pair in ONE accumulator.  K3 takes both scales out again (exact powers of two).  The same slices, the
+// same partials layout, the same fixed association as project_kernel.
+__global__ __launch_bounds__(512) void project_f16_kernel(const float* __restrict__ S, const _Float16* __restrict__ w3h,
+                                                          float* __restrict__ part, int K, int cnt, int row0,
+                                                          long long part_stride, const float* __restrict__ rowmax, int nq) {
+    constexpr int PJ_ROWS = 256, PJ_A_PLANE = PJ_ROWS * 64, PJ_B_BASE = 2 * PJ_A_PLANE, NT = 2, RQ = 64;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * PJ_A_PLANE + 2 * PJ_B_PLANE];      // 40 KiB
+    const int ngrp = gridDim.x / PJ_SLICES;
+    const int xcd = blockIdx.x & 7, rr = blockIdx.x >> 3;
+    const int rg = rr % ngrp, slice = (rr / ngrp) * 8 + xcd;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int srow = tid >> 3, scol = (tid & 7) * 4;
+    const int nkt = (int)moment_nkt(K), per = (nkt - 2) / PJ_SLICES;
+    const int kt0 = slice * per, nk = per + (slice == PJ_SLICES - 1 ? 2 : 0);
+    const int first = rg * PJ_ROWS;
+    const int rows_here = cnt - first < PJ_ROWS ? cnt - first : PJ_ROWS;
+    const int live = (rows_here + 31) >> 5;
+    auto a_row = [&](int r) { return (r >> 5) < live ? r : (r & 31); };
+    auto a_ptr = [&](int r) {
+        return S + ((size_t)(NT * rg + (r >> 7)) * nkt + kt0) * 4096 + (r & 127) * 32 + scol;
+    };
+    // the scale of a row: from the maxima of its nq column blocks (rows past the last destination: whatever is there —
+    // f16_row_scale returns a power of two for any bits, and nothing of those rows is stored)
+    auto row_scale = [&](int r) {
+        const float* m = rowmax + (size_t)(first + r) * nq;
+        float v = 0.f;
+        for (int q = 0; q < nq; ++q) v = fmaxf(v, m[q]);
+        return f16_row_scale(v);
+    };
+    const int r0_ = a_row(srow), r1_ = a_row(srow + RQ), r2_ = a_row(srow + 2 * RQ), r3_ = a_row(srow + 3 * RQ);
+    const float* A0 = a_ptr(r0_);
+    const float* A1 = a_ptr(r1_);
+    const float* A2 = a_ptr(r2_);
+    const float* A3 = a_ptr(r3_);
+    const float sc0 = row_scale(r0_), sc1 = row_scale(r1_), sc2 = row_scale(r2_), sc3 = row_scale(r3_);
+    // W3R's plane tiles: thread (plane bp, row bo, 16-B chunk bc)
+    const int bp = tid >> 8, bo = (tid >> 2) & 63, bc = tid & 3;
+    const _Float16* Bg = w3h + ((size_t)kt0 * 2 + bp) * 2048 + bo * 32 + bc * 8;
+    struct Tile { float4 a0, a1, a2, a3; uint4 b; };
+    auto load = [&](Tile& r, int kt) {
+        r.a0 = *reinterpret_cast<const float4*>(A0 + (size_t)kt * 4096);
+        r.a1 = *reinterpret_cast<const float4*>(A1 + (size_t)kt * 4096);
+        r.a2 = *reinterpret_cast<const float4*>(A2 + (size_t)kt * 4096);
+        r.a3 = *reinterpret_cast<const float4*>(A3 + (size_t)kt * 4096);
+        r.b = *reinterpret_cast<const uint4*>(Bg + (size_t)kt * 4096);
+    };
+    auto st_off = [&](int row) { return row * 64 + ((((tid & 7) >> 1) ^ ((row >> 2) & 3)) << 4) + (tid & 1) * 8; };
+    unsigned char* a_st0 = lds + st_off(srow);
+    unsigned char* a_st1 = lds + st_off(srow + RQ);
+    unsigned char* a_st2 = lds + st_off(srow + 2 * RQ);
+    unsigned char* a_st3 = lds + st_off(srow + 3 * RQ);
+    unsigned char* b_st = lds + PJ_B_BASE + bp * PJ_B_PLANE + bo * 64 + ((bc ^ ((bo >> 2) & 3)) << 4);
+    auto scaled = [](const float4 v, float sc) { return make_float4(v.x * sc, v.y * sc, v.z * sc, v.w * sc); };
+    auto store = [&](const Tile& r) {
+        split2_store4(scaled(r.a0, sc0), a_st0, PJ_A_PLANE);
+        split2_store4(scaled(r.a1, sc1), a_st1, PJ_A_PLANE);
+        split2_store4(scaled(r.a2, sc2), a_st2, PJ_A_PLANE);
+        split2_store4(scaled(r.a3, sc3), a_st3, PJ_A_PLANE);
+        *reinterpret_cast<uint4*>(b_st) = r.b;
+    };
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+    const int arow = wave * 32 + l31, brow0 = l31, brow1 = 32 + l31;
+    const int a_sw = (arow >> 2) & 3, b_sw0 = (brow0 >> 2) & 3, b_sw1 = (brow1 >> 2) & 3;
+    const unsigned char* a_rd = lds + arow * 64;
+    const unsigned char* b_rd0 = lds + PJ_B_BASE + brow0 * 64;
+    const unsigned char* b_rd1 = lds + PJ_B_BASE + brow1 * 64;
+#define PJ_MMA_TILE()                                                                                    \
+    _Pragma("unroll") for (int st = 0; st < 2; ++st) {                                                   \
+        f16x8 a[2], b0[2], b1[2];                                                                        \
+        _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                                  \
+            a[p] = *reinterpret_cast<const f16x8*>(a_rd + p * PJ_A_PLANE + (((2 * st + h) ^ a_sw) << 4));    \
+            b0[p] = *reinterpret_cast<const f16x8*>(b_rd0 + p * PJ_B_PLANE + (((2 * st + h) ^ b_sw0) << 4)); \
+            b1[p] = *reinterpret_cast<const f16x8*>(b_rd1 + p * PJ_B_PLANE + (((2 * st + h) ^ b_sw1) << 4)); \
+        }                                                                                                \
+        MDNO_MMA3H(a, b0, acc0) MDNO_MMA3H(a, b1, acc1)                                                  \
+    }
+    const bool rows_live = wave < live;
+    Tile P, Q;
+    // (as project_kernel: nk even, every load unconditional, two K-tiles in flight per thread)
+    const int last = nk - 1;
+    load(P, 0);
+    load(Q, 1);
+    store(P);
+    __syncthreads();
+    for (int kt = 0;; kt += 2) {
+        load(P, min(kt + 2, last));
+        __builtin_amdgcn_sched_barrier(0);
+        if (rows_live) { PJ_MMA_TILE() }
+        __syncthreads();
+        store(Q);
+        __syncthreads();
+        load(Q, min(kt + 3, last));
+        __builtin_amdgcn_sched_barrier(0);
+        if (rows_live) { PJ_MMA_TILE() }
+        if (kt + 2 >= nk) break;
+        __syncthreads();
+        store(P);
+        __syncthreads();
+    }
+#undef PJ_MMA_TILE
+    float* Po = part + (size_t)slice * part_stride;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int m = first + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (m < cnt) {
+            Po[(size_t)(row0 + m) * 64 + l31] = acc0[e];
+            Po[(size_t)(row0 + m) * 64 + 32 + l31] = acc1[e];
+        }
+    }
+}
+
 // ---------------------------------------------------------------- K2, exact fp32 (gemm_mode F32)
 // Workgroup (one 128-row tile of the S image, K slice): the same slices and the same partials as project_kernel, the
 // products on v_mfma_f32_32x32x2_f32 (mfma_f32.h: fp32 K-tiles as LDS rows of 36 floats).
@@ -580,7 +880,9 @@ constexpr int FN_CHAINS = 32;
 __global__ __launch_bounds__(FN_CHAINS * 16) void finish_kernel(const float* __restrict__ part, long long part_stride,
                                                                 const int* __restrict__ row_ptr, const float* __restrict__ x,
                                                                 const float* __restrict__ root, const float* __restrict__ bias,
-                                                                float* __restrict__ y, int row0, int aggr, int relu) {
+                                                                float* __restrict__ y, int row0, int aggr, int relu,
+                                                                const float* __restrict__ rowmax, int nq,
+                                                                const float* __restrict__ colinv) {
     constexpr int CPT = 64 / FN_CHAINS;
     __shared__ float4 red[FN_CHAINS][16];
     __shared__ float4 red2[FN_CHAINS][16];
@@ -599,6 +901,13 @@ __global__ __launch_bounds__(FN_CHAINS * 16) void finish_kernel(const float* __r
         }
     }
     if (bias != nullptr && es == 0) biasv = *reinterpret_cast<const float4*>(bias + 4 * q);
+    float rmax = 0.f;      // (K2 on fp16 planes) the row's largest |S|, and the columns' inverse scales: loaded up front
+    float4 ci = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (rowmax != nullptr && es == 0) {
+        const float* m = rowmax + (size_t)blockIdx.x * nq;
+        for (int u = 0; u < nq; ++u) rmax = fmaxf(rmax, m[u]);
+        ci = *reinterpret_cast<const float4*>(colinv + 4 * q);
+    }
     float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     {
         float4 v[PJ_SLICES / FN_CHAINS];
@@ -625,6 +934,10 @@ __global__ __launch_bounds__(FN_CHAINS * 16) void finish_kernel(const float* __r
             s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
             rs.x += b.x; rs.y += b.y; rs.z += b.z; rs.w += b.w;
         }
+        if (rowmax != nullptr) {      // K2 on fp16 planes: the row's and the columns' powers of two out again (exact)
+            const float ri = 1.f / f16_row_scale(rmax);
+            s.x = s.x * ri * ci.x; s.y = s.y * ri * ci.y; s.z = s.z * ri * ci.z; s.w = s.w * ri * ci.w;
+        }
         if (aggr == MDNO_AGGR_MEAN) {
             const float inv = (float)(deg > 1 ? deg : 1);
             s.x /= inv; s.y /= inv; s.z /= inv; s.w /= inv;
@@ -649,6 +962,7 @@ static int moment_chunk_rows(int num_rows) {
 // k % 128: what the hidden GEMM that writes H tiles by, and what makes a K2 slice an even number of k-tiles
 // (64 k / 32 = 2 k k-tiles over 128 slices = k / 64 each; K2's loop takes them two at a time)
 bool moment_supported(int width, int ker_width) { return width == 64 && ker_width >= 128 && ker_width % 128 == 0; }
+static int moment_nq(int ker_width) { return (ker_width + MO_CQ - 1) / MO_CQ + 1; }      // K1's column blocks + the s0 block
 static size_t s_chunk_floats(int num_rows, int ker_width) { return (size_t)(moment_chunk_rows(num_rows) / 128) * moment_nkt(ker_width) * 4096; }
 
 size_t moment_workspace_bytes(int num_rows, int ker_width) {
@@ -657,6 +971,10 @@ size_t moment_workspace_bytes(int num_rows, int ker_width) {
     cv.take<float>(s_chunk_floats(num_rows, ker_width));                           // S (+ s0), one chunk of destinations
     cv.take<float>((size_t)PJ_SLICES * num_rows * 64);                             // K-slice partials of z
     cv.take<int>((size_t)num_rows);                                                // destinations of each chunk by decreasing degree
+    cv.take<_Float16>((size_t)(64 * ker_width + 64) * 64 * 2);                     // W3R on two fp16 planes (SPLIT_F16)
+    cv.take<float>(64);                                                            // its columns' inverse scales
+    cv.take<int>(64);                                                              // (their maxima, as bits)
+    cv.take<float>((size_t)(moment_chunk_rows(num_rows) + 256) * moment_nq(ker_width));   // row maxima of the S chunk
     return cv.used();
 }
 
@@ -668,12 +986,22 @@ MomentWs moment_carve(void* ws, int num_rows, int ker_width) {
     f.part = cv.take<float>((size_t)PJ_SLICES * num_rows * 64);
     f.part_stride = (long long)num_rows * 64;
     f.order = cv.take<int>((size_t)num_rows);
+    f.w3h = cv.take<_Float16>((size_t)(64 * ker_width + 64) * 64 * 2);
+    f.colinv = cv.take<float>(64);
+    f.colmax_bits = cv.take<int>(64);
+    f.rowmax = cv.take<float>((size_t)(moment_chunk_rows(num_rows) + 256) * moment_nq(ker_width));
     return f;
 }
 
-int moment_prepare_weights(const float* w3, const float* b3, int ker_width, const MomentWs& f, hipStream_t s) {
+int moment_prepare_weights(const float* w3, const float* b3, int ker_width, const MomentWs& f, hipStream_t s, int gemm_mode) {
     const long long total = (long long)(64 * ker_width + 64) * 64;
     hipLaunchKernelGGL(w3_moment_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w3, b3, ker_width, f.w3r);
+    if (gemm_mode == MDNO_GEMM_SPLIT_F16) {
+        MDNO_HIP(hipMemsetAsync(f.colmax_bits, 0, 64 * sizeof(int), s));
+        hipLaunchKernelGGL(w3_colmax_kernel, dim3(256), dim3(256), 0, s, (const float*)f.w3r, total / 2048, f.colmax_bits);
+        hipLaunchKernelGGL(w3_planes_f16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)f.w3r, total,
+                           (const int*)f.colmax_bits, f.w3h, f.colinv);
+    }
     return check_launch("w3_moment_kernel");
 }
 
@@ -686,8 +1014,10 @@ int moment_prepare_graph(const int* row_ptr, int num_rows, const MomentWs& f, hi
 
 int moment_conv(const float* x, const float* h2, const int* row_ptr, const int* src, int num_rows, int ker_width,
                 const float* root, const float* bias, int aggr, int relu, float* y, const MomentWs& f, hipStream_t s,
-                bool exact_f32) {
+                int gemm_mode) {
     MDNO_REQUIRE(moment_supported(64, ker_width), MDNO_EUNSUPPORTED, "moment conv: ker_width=%d (x128)", ker_width);
+    const bool exact_f32 = gemm_mode == MDNO_GEMM_F32, f16 = gemm_mode == MDNO_GEMM_SPLIT_F16;
+    const int nq = moment_nq(ker_width);
     size_t cached_bytes = kMomentCachedBytes;
 #ifdef MDNO_EXP_CACHE_ENV
     if (const char* v = getenv("MDNO_EXP_CACHE_MIB")) cached_bytes = (size_t)atoi(v) << 20;
@@ -697,20 +1027,25 @@ int moment_conv(const float* x, const float* h2, const int* row_ptr, const int* 
         const int cnt = num_rows - r0 < kMomentChunkRows ? num_rows - r0 : kMomentChunkRows;
         {   // K1: the chunk's destinations x the k/256 column blocks
             TimedSection ts(KID_NNCONV, s);
-            const int nq = (ker_width + MO_CQ - 1) / MO_CQ + 1;
             const dim3 grid((unsigned)(((cnt + 7) / 8) * 8 * nq));
             if (exact_f32)      // (h2: the k-tiled image in every GEMM mode)
                 hipLaunchKernelGGL(moment_f32_kernel, grid, dim3(256), 0, s, h2, row_ptr, src, (const int*)f.order, f.s,
                                    ker_width, r0, cnt, x);
+            else if (f16)
+                hipLaunchKernelGGL(moment_kernel<true>, grid, dim3(256), 0, s, h2, row_ptr, src, (const int*)f.order, f.s, ker_width,
+                                   r0, cnt, x, cache_e, f.rowmax);
             else
-                hipLaunchKernelGGL(moment_kernel, grid, dim3(256), 0, s, h2, row_ptr, src, (const int*)f.order, f.s, ker_width,
-                                   r0, cnt, x, cache_e);
+                hipLaunchKernelGGL(moment_kernel<false>, grid, dim3(256), 0, s, h2, row_ptr, src, (const int*)f.order, f.s, ker_width,
+                                   r0, cnt, x, cache_e, (float*)nullptr);
         }
         {   // K2: groups of row tiles x K slices
             TimedSection ts(KID_FACT_Y, s);
             if (exact_f32)
                 hipLaunchKernelGGL(project_f32_kernel, dim3(((cnt + 127) / 128) * PJ_SLICES), dim3(256), 0, s, (const float*)f.s,
                                    (const float*)f.w3r, f.part, ker_width, cnt, r0, f.part_stride);
+            else if (f16)
+                hipLaunchKernelGGL(project_f16_kernel, dim3(((cnt + 255) / 256) * PJ_SLICES), dim3(512), 0, s, (const float*)f.s,
+                                   (const _Float16*)f.w3h, f.part, ker_width, cnt, r0, f.part_stride, (const float*)f.rowmax, nq);
             else
                 hipLaunchKernelGGL(project_kernel<256>, dim3(((cnt + 255) / 256) * PJ_SLICES), dim3(512), 0, s, (const float*)f.s,
                                    (const float*)f.w3r, f.part, ker_width, cnt, r0, f.part_stride);
@@ -718,7 +1053,8 @@ int moment_conv(const float* x, const float* h2, const int* row_ptr, const int* 
         {   // K3
             TimedSection ts(KID_NNCONV_COMBINE, s);
             hipLaunchKernelGGL(finish_kernel, dim3(cnt), dim3(FN_CHAINS * 16), 0, s, (const float*)f.part, f.part_stride,
-                               row_ptr, x, root, bias, y, r0, aggr, relu);
+                               row_ptr, x, root, bias, y, r0, aggr, relu, f16 ? (const float*)f.rowmax : (const float*)nullptr, nq,
+                               (const float*)f.colinv);
         }
     }
     return check_launch("moment_conv");

@@ -116,7 +116,9 @@ for M in (1, 8):
         if kernel == "moment_kernel":      # the whole conv application: K1 + K2 + K3 (S and the partials are its intermediates)
             tot, parts = 0.0, {}
             for kn in ("moment_kernel", "project_kernel", "finish_kernel"):
-                nm = next((n for n in pmc if n.startswith(kn) and "hbm_bytes_per_launch_corrected" in pmc[n]), None)
+                # (K2 is project_f16_kernel in gemm_mode split_f16, project_kernel<256> in split_bf16)
+                pref = ("project_f16_kernel", "project_kernel") if kn == "project_kernel" else (kn,)
+                nm = next((n for pf in pref for n in pmc if n.startswith(pf) and "hbm_bytes_per_launch_corrected" in pmc[n]), None)
                 if nm is not None:
                     parts[kn] = pmc[nm]["hbm_bytes_per_launch_corrected"] * launches_per_app
                     tot += parts[kn]
@@ -188,7 +190,7 @@ def mfma_summary(sub, dest, what, keep):
 
 mfma_summary("pmc_mfma_m1", out / f"{tag}_m1_pmc_mfma.json",
              "python3 bench.py --skip-cpu-baseline --skip-ensemble-leg --single-mode --steps 3 --warmup 1 --no-graph "
-             "(1 member, N=504, split_f16)", ("gemm_split_f16_kernel", "moment_kernel", "project_kernel"))
+             "(1 member, N=504, split_f16)", ("gemm_split_f16_kernel", "moment_kernel", "project_f16_kernel", "project_kernel"))
 mfma_summary("pmc_mfma_train", out / f"{tag}_train_pmc_mfma.json",
              "python3 scripts/train_synthetic.py --frames 600 (cfg4 batch: 43.7k edges, k=1024, bf16)", ("gemm_pp_kernel",))
 kernel_stats("train_trace", out / f"{tag}_train_kernel_stats.csv")

@@ -732,7 +732,7 @@ def test_factored_conv_matches_materialized_and_reference(dev):
 
 @pytest.mark.parametrize("gemm_mode", ["split_f16", "split_bf16", "f32"])
 def test_factored_conv_on_an_arbitrary_edge_list(dev, O, gemm_mode):
-    """The factored form (csrc/moment.hip; three bf16 planes or, for gemm_mode "f32", the fp32 MFMA) needs no symmetric
+    """The factored form (csrc/moment.hip; two fp16 planes, three bf16 planes or, for gemm_mode "f32", the fp32 MFMA) needs no symmetric
     graph and no position-derived attributes: a forward on a random DIRECTED edge list with duplicates, a hub, nodes without in-edges and arbitrary
     edge attributes, two members, against the oracle's per-edge formulation and against the materialised path."""
     from molecular_dynamics_neural_operator_amd import ops
@@ -768,6 +768,72 @@ def test_factored_conv_on_an_arbitrary_edge_list(dev, O, gemm_mode):
     want = torch.cat([O.kernelnn_forward(sd, s_.x_position.cpu(), s_.x_aminoacid.cpu(), s_.edge_index.cpu(), s_.edge_attr.cpu(), 2,
                                          hoist=True) for s_ in samples])
     close(res["factored"], want, name=f"factored vs oracle, arbitrary graph {gemm_mode}")
+
+
+def test_factored_conv_fp16_planes_range_rules(dev, O):
+    """gemm_mode "split_f16" runs K1 and K2 of the factored conv on two fp16 planes (csrc/moment.hip).  K2 scales every
+    row of S and every column of W3R by its own power of two, so it has no range limit; a K1 workgroup whose staged x
+    or H holds a value >= 255.87 or none >= 2^-10 reruns its destination on the three bf16 planes — a decision that
+    depends on that destination's edges only.  Here: a batch whose second member's hidden activations are out of
+    range (its edge attributes times 2^12) while the first member's are not, hidden activations that are all tiny, and
+    node features that are all huge — each against the oracle, and each member bit for bit what it is alone."""
+    from molecular_dynamics_neural_operator_amd.dataset import PairData
+    from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN
+    from molecular_dynamics_neural_operator_amd.weights import near_identity_state_dict
+    gen = torch.Generator().manual_seed(33)
+    N, W, E = 150, 10, 9000
+    base = near_identity_state_dict(64, 384, seed=4, kernel_gain=3e-2, feature_gain=0.3, kernel_to_coords=1.0)
+
+    def hidden(sd, ea):
+        h = torch.relu(ea.double() @ sd["conv1.net.layers.0.weight"].double().T + sd["conv1.net.layers.0.bias"].double())
+        return torch.relu(h @ sd["conv1.net.layers.2.weight"].double().T + sd["conv1.net.layers.2.bias"].double())
+
+    def build(scale_member1):
+        out = []
+        for m in range(2):
+            ei = torch.randint(0, N, (2, E), generator=gen)
+            ei[1, :500] = 9 + m                                  # a hub
+            xp = torch.randn(W, N, 3, generator=gen) * 4
+            ea = torch.randn(E, 6, generator=gen) * 3 * (scale_member1 if m == 1 else 1.0)
+            out.append(PairData(x_aminoacid=torch.randint(0, 20, (N,), generator=gen), x_position=xp, y=torch.zeros(N, 3),
+                                edge_attr=ea, edge_index=ei))
+        return out
+
+    def run(sd, samples, name):
+        model = KernelNN(64, 384, 2, 6, 7, 3, 20, 4)
+        model.load_state_dict(sd)
+        model.eval().to(dev)
+        model.gemm_mode, model.conv_mode = "split_f16", "factored"
+        with torch.no_grad():
+            both = model(samples)
+            alone = [model(s_.to(dev)) for s_ in samples]
+        assert torch.equal(both[:N], alone[0]) and torch.equal(both[N:], alone[1])
+        want = torch.cat([O.kernelnn_forward(sd, s_.x_position.cpu(), s_.x_aminoacid.cpu(), s_.edge_index.cpu(),
+                                             s_.edge_attr.cpu(), 2, hoist=True) for s_ in samples])
+        assert bool(torch.isfinite(want).all())
+        # per member: the two differ by orders of magnitude in the first scenario
+        close(both[:N], want[:N], name=name + " member 0")
+        close(both[N:], want[N:], name=name + " member 1")
+
+    # (1) member 1's hidden activations beyond the fp16 planes' range, member 0's inside
+    samples = build(4096.0)
+    h0, h1 = hidden(base, samples[0].edge_attr), hidden(base, samples[1].edge_attr)
+    assert 2.0 ** -10 <= float(h0.max()) < 255.0 and float(h1.max()) >= 255.875
+    run(base, samples, "H of member 1 out of range")
+    # (2) hidden activations all below 2^-10 (layer 1 times 2^-20, layer 2's weight times 2^20: the same W_e)
+    tiny = {k: v.clone() for k, v in base.items()}
+    for conv in ("conv1", "conv2"):
+        tiny[f"{conv}.net.layers.2.weight"] *= 2.0 ** -20
+        tiny[f"{conv}.net.layers.2.bias"] *= 2.0 ** -20
+        tiny[f"{conv}.net.layers.4.weight"] *= 2.0 ** 20
+    samples = build(1.0)
+    assert float(hidden(tiny, samples[0].edge_attr).max()) < 2.0 ** -10
+    run(tiny, samples, "H all tiny")
+    # (3) node features times 2^12
+    huge = {k: v.clone() for k, v in base.items()}
+    huge["fc1.weight"] *= 4096.0
+    huge["fc1.bias"] *= 4096.0
+    run(huge, samples, "x huge")
 
 
 def test_edge_cases_single_atom_window1_zero_steps_and_c_rollout(dev, O):

@@ -226,6 +226,9 @@ constexpr int MO_LDS = 3 * MO_HPLANE + 3 * MO_XPLANE;      // 36,864 B
 // MLP layer's bias seen through the summed neighbours), stored as kappa = 64 K + i of the same image, so that K2
 // multiplies it with B3 like any other slice.  16 chains x 16 lanes (4 features each), four edges in flight per chain,
 // chains added in order: a fixed order.
+// the exponent e of a power of two 2^e held in a normal float
+__device__ __forceinline__ int f32_exponent(float p2) { return (int)((__builtin_bit_cast(unsigned, p2) >> 23) & 0xffu) - 127; }
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
@@ -934,9 +937,11 @@ __global__ __launch_bounds__(FN_CHAINS * 16) void finish_kernel(const float* __r
             s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
             rs.x += b.x; rs.y += b.y; rs.z += b.z; rs.w += b.w;
         }
-        if (rowmax != nullptr) {      // K2 on fp16 planes: the row's and the columns' powers of two out again (exact)
-            const float ri = 1.f / f16_row_scale(rmax);
-            s.x = s.x * ri * ci.x; s.y = s.y * ri * ci.y; s.z = s.z * ri * ci.z; s.w = s.w * ri * ci.w;
+        if (rowmax != nullptr) {      // K2 on fp16 planes: the row's and the columns' powers of two out again — as ONE
+            // exponent (ldexp: exact over the whole range; the two factors one after the other can overflow on the way)
+            const int er = f32_exponent(1.f / f16_row_scale(rmax));
+            s.x = ldexpf(s.x, er + f32_exponent(ci.x)); s.y = ldexpf(s.y, er + f32_exponent(ci.y));
+            s.z = ldexpf(s.z, er + f32_exponent(ci.z)); s.w = ldexpf(s.w, er + f32_exponent(ci.w));
         }
         if (aggr == MDNO_AGGR_MEAN) {
             const float inv = (float)(deg > 1 ? deg : 1);

@@ -52,13 +52,15 @@ extern "C" {
  *   F32         v_mfma_f32_32x32x2_f32: bit-for-bit an fp32 fmaf chain. */
 #define MDNO_GEMM_SPLIT_BF16 0
 #define MDNO_GEMM_F32        1
-/*   SPLIT_F16   as SPLIT_BF16, except that the k x k hidden layer of the edge-MLP in the factored conv runs
- *               on TWO fp16 planes (x = hi + 2^-11 lo', 22-23 mantissa bits) and three plane products
- *               with fp32 accumulation: half the matrix work, error vs fp64 still below a plain fp32
- *               GEMM's.  Exact only for |x| < 65504: producers raise a device flag on a value out of
- *               fp16 range and the chunk is then redone by the SPLIT_BF16 kernels inside the same
- *               forward (no host involvement), so results are fp32-accurate for any input.  The Python
- *               host side's default. */
+/*   SPLIT_F16   as SPLIT_BF16, except that the wide edge-MLP GEMMs and the two products of the factored conv
+ *               (csrc/moment.hip: K1, K2) run on TWO fp16 planes (22-23 mantissa bits) and three plane
+ *               products with fp32 accumulation: half the matrix work, error vs fp64 still below a plain
+ *               fp32 GEMM's.  fp16 has 30 binades, so every use keeps its operands in range by exact powers
+ *               of two (weight rows / columns and the rows of the conv's moment image by their own maxima)
+ *               or checks them on the device: an edge-MLP chunk with a value out of range is redone by the
+ *               SPLIT_BF16 kernels inside the same forward, a conv workgroup reruns its own destination on
+ *               the bf16 planes (no host involvement either way), so results are fp32-accurate for any
+ *               input that fp32 itself can carry.  The Python host side's default. */
 #define MDNO_GEMM_SPLIT_F16  2
 
 /* How a conv application is evaluated inside mdno_kernelnn_fwd / the rollout (same function either way):

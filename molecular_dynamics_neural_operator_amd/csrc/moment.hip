@@ -33,8 +33,7 @@
 //   K2  project_kernel / project_f16_kernel
 //                         workgroup = (256 destinations, 1/128 of the 64 k contraction): S tiles fp32 -> planes on the
 //                         fly, W3R's likewise (bf16) or pre-split (fp16); partial sums per K slice.
-//   K3  finish_kernel     per destination: K slices added in slice order, (fp16: the row's and columns' scales out
-//                         again,) root / bias / mean / ReLU.
+//   K3  finish_kernel     per destination: K slices added in slice order, root / bias / mean / ReLU.
 // Fixed summation orders everywhere: a destination's result depends on its own edges only (bitwise the same alone or
 // in any batch), no float atomics.
 #include <type_traits>
@@ -710,13 +709,17 @@ __global__ __launch_bounds__(PJ_ROWS * 2) void project_kernel(const float* __res
 // project_kernel's loop with half the matrix work: S's rows times the power of two that puts the row's largest entry
 // (rowmax: K1's record, one value per column block of the row) in [2^13, 2^14), split into two fp16 planes on the way
 // to LDS; W3R comes pre-split (w3_planes_f16_kernel: 16 B per thread and plane tile, no vector work); three plane
-// products per pair in ONE accumulator.  K3 takes both scales out again (exact powers of two).  The same slices, the
+// products per pair in ONE accumulator; the epilogue takes both scales out again (exact powers of two).  The same slices, the
 // same partials layout, the same fixed association as project_kernel.
-__global__ __launch_bounds__(512) void project_f16_kernel(const float* __restrict__ S, const _Float16* __restrict__ w3h,
+__global__ __launch_bounds__(512) void project_f16_kernel(const float* __restrict__ S, const unsigned short* __restrict__ w3h_bits,
                                                           float* __restrict__ part, int K, int cnt, int row0,
-                                                          long long part_stride, const float* __restrict__ rowmax, int nq) {
+                                                          long long part_stride, const float* __restrict__ rowmax, int nq,
+                                                          const float* __restrict__ colinv) {
+    // (w3h_bits: the fp16 planes as raw 16-bit words — a _Float16 in the signature leaves the name mangled in traces)
+    const _Float16* __restrict__ w3h = reinterpret_cast<const _Float16*>(w3h_bits);
     constexpr int PJ_ROWS = 256, PJ_A_PLANE = PJ_ROWS * 64, PJ_B_BASE = 2 * PJ_A_PLANE, NT = 2, RQ = 64;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * PJ_A_PLANE + 2 * PJ_B_PLANE];      // 40 KiB
+    __shared__ int rowexp[PJ_ROWS];      // exponent of each row's scale: taken out again in the epilogue
     const int ngrp = gridDim.x / PJ_SLICES;
     const int xcd = blockIdx.x & 7, rr = blockIdx.x >> 3;
     const int rg = rr % ngrp, slice = (rr / ngrp) * 8 + xcd;
@@ -747,6 +750,10 @@ __global__ __launch_bounds__(512) void project_f16_kernel(const float* __restric
     const float* A2 = a_ptr(r2_);
     const float* A3 = a_ptr(r3_);
     const float sc0 = row_scale(r0_), sc1 = row_scale(r1_), sc2 = row_scale(r2_), sc3 = row_scale(r3_);
+    if ((tid & 7) == 0) {      // (read in the epilogue, behind the loop's barriers)
+        rowexp[srow] = f32_exponent(sc0); rowexp[srow + RQ] = f32_exponent(sc1);
+        rowexp[srow + 2 * RQ] = f32_exponent(sc2); rowexp[srow + 3 * RQ] = f32_exponent(sc3);
+    }
     // W3R's plane tiles: thread (plane bp, row bo, 16-B chunk bc)
     const int bp = tid >> 8, bo = (tid >> 2) & 63, bc = tid & 3;
     const _Float16* Bg = w3h + ((size_t)kt0 * 2 + bp) * 2048 + bo * 32 + bc * 8;
@@ -814,13 +821,17 @@ __global__ __launch_bounds__(512) void project_f16_kernel(const float* __restric
         __syncthreads();
     }
 #undef PJ_MMA_TILE
+    // the row's and the column's powers of two out again — as ONE exponent per element (ldexp: exact over the whole range;
+    // the two factors one after the other could overflow on the way): the partials K3 adds are in S . W3R's own units
+    const int ec0 = f32_exponent(colinv[l31]), ec1 = f32_exponent(colinv[32 + l31]);
     float* Po = part + (size_t)slice * part_stride;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-        const int m = first + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int ml = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h, m = first + ml;
         if (m < cnt) {
-            Po[(size_t)(row0 + m) * 64 + l31] = acc0[e];
-            Po[(size_t)(row0 + m) * 64 + 32 + l31] = acc1[e];
+            const int er = rowexp[ml];
+            Po[(size_t)(row0 + m) * 64 + l31] = ldexpf(acc0[e], ec0 - er);
+            Po[(size_t)(row0 + m) * 64 + 32 + l31] = ldexpf(acc1[e], ec1 - er);
         }
     }
 }
@@ -883,9 +894,7 @@ constexpr int FN_CHAINS = 32;
 __global__ __launch_bounds__(FN_CHAINS * 16) void finish_kernel(const float* __restrict__ part, long long part_stride,
                                                                 const int* __restrict__ row_ptr, const float* __restrict__ x,
                                                                 const float* __restrict__ root, const float* __restrict__ bias,
-                                                                float* __restrict__ y, int row0, int aggr, int relu,
-                                                                const float* __restrict__ rowmax, int nq,
-                                                                const float* __restrict__ colinv) {
+                                                                float* __restrict__ y, int row0, int aggr, int relu) {
     constexpr int CPT = 64 / FN_CHAINS;
     __shared__ float4 red[FN_CHAINS][16];
     __shared__ float4 red2[FN_CHAINS][16];
@@ -904,13 +913,6 @@ __global__ __launch_bounds__(FN_CHAINS * 16) void finish_kernel(const float* __r
         }
     }
     if (bias != nullptr && es == 0) biasv = *reinterpret_cast<const float4*>(bias + 4 * q);
-    float rmax = 0.f;      // (K2 on fp16 planes) the row's largest |S|, and the columns' inverse scales: loaded up front
-    float4 ci = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (rowmax != nullptr && es == 0) {
-        const float* m = rowmax + (size_t)blockIdx.x * nq;
-        for (int u = 0; u < nq; ++u) rmax = fmaxf(rmax, m[u]);
-        ci = *reinterpret_cast<const float4*>(colinv + 4 * q);
-    }
     float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     {
         float4 v[PJ_SLICES / FN_CHAINS];
@@ -936,12 +938,6 @@ __global__ __launch_bounds__(FN_CHAINS * 16) void finish_kernel(const float* __r
             const float4 a = red[c][q], b = red2[c][q];
             s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
             rs.x += b.x; rs.y += b.y; rs.z += b.z; rs.w += b.w;
-        }
-        if (rowmax != nullptr) {      // K2 on fp16 planes: the row's and the columns' powers of two out again — as ONE
-            // exponent (ldexp: exact over the whole range; the two factors one after the other can overflow on the way)
-            const int er = f32_exponent(1.f / f16_row_scale(rmax));
-            s.x = ldexpf(s.x, er + f32_exponent(ci.x)); s.y = ldexpf(s.y, er + f32_exponent(ci.y));
-            s.z = ldexpf(s.z, er + f32_exponent(ci.z)); s.w = ldexpf(s.w, er + f32_exponent(ci.w));
         }
         if (aggr == MDNO_AGGR_MEAN) {
             const float inv = (float)(deg > 1 ? deg : 1);
@@ -1050,7 +1046,8 @@ int moment_conv(const float* x, const float* h2, const int* row_ptr, const int* 
                                    (const float*)f.w3r, f.part, ker_width, cnt, r0, f.part_stride);
             else if (f16)
                 hipLaunchKernelGGL(project_f16_kernel, dim3(((cnt + 255) / 256) * PJ_SLICES), dim3(512), 0, s, (const float*)f.s,
-                                   (const _Float16*)f.w3h, f.part, ker_width, cnt, r0, f.part_stride, (const float*)f.rowmax, nq);
+                                   reinterpret_cast<const unsigned short*>(f.w3h), f.part, ker_width, cnt, r0, f.part_stride,
+                                   (const float*)f.rowmax, nq, (const float*)f.colinv);
             else
                 hipLaunchKernelGGL(project_kernel<256>, dim3(((cnt + 255) / 256) * PJ_SLICES), dim3(512), 0, s, (const float*)f.s,
                                    (const float*)f.w3r, f.part, ker_width, cnt, r0, f.part_stride);
@@ -1058,8 +1055,7 @@ int moment_conv(const float* x, const float* h2, const int* row_ptr, const int* 
         {   // K3
             TimedSection ts(KID_NNCONV_COMBINE, s);
             hipLaunchKernelGGL(finish_kernel, dim3(cnt), dim3(FN_CHAINS * 16), 0, s, (const float*)f.part, f.part_stride,
-                               row_ptr, x, root, bias, y, r0, aggr, relu, f16 ? (const float*)f.rowmax : (const float*)nullptr, nq,
-                               (const float*)f.colinv);
+                               row_ptr, x, root, bias, y, r0, aggr, relu);
         }
     }
     return check_launch("moment_conv");

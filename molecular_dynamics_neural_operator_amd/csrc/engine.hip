@@ -148,6 +148,8 @@ int forward_impl(const mdno_kernelnn_params* p, const float* frames, int t0, con
                      "factored conv needs edge attributes: positions (edge_pos, dst) or edge_attr");
         const MomentWs mw = moment_carve(ws.fact, R, p->ker_width);
         if (!prep_only) MDNO_TRY(moment_prepare_graph(row_ptr, R, mw, s));
+        if (!prep_only && p->gemm_mode == MDNO_GEMM_SPLIT_F16) MDNO_TRY(moment_row_absmax(cur, R, mw, s));
+        int application = 0;
         for (int block = 0; block < blocks; ++block) {
             const bool own = block == 1 && separate_conv2_kernel(p);
             if (block == 0 || own) {
@@ -163,7 +165,7 @@ int forward_impl(const mdno_kernelnn_params* p, const float* frames, int t0, con
             const float* bias = block == 0 ? p->conv1_bias : p->conv2_bias;
             for (int d = 0; d < p->depth; ++d) {
                 MDNO_TRY(moment_conv(cur, ws.h2, row_ptr, src, R, p->ker_width, root, bias, MDNO_AGGR_MEAN, /*relu=*/1, nxt,
-                                     mw, s, p->gemm_mode));
+                                     mw, s, p->gemm_mode, application++));
                 float* t = cur; cur = nxt; nxt = t;
             }
         }

@@ -111,6 +111,7 @@ struct MomentWs {
     float* colinv;
     int* colmax_bits;
     float* rowmax;
+    float* xm[2];             // every node's largest |feature|: of a conv application's input and of its output
 };
 bool moment_supported(int width, int ker_width);
 size_t moment_workspace_bytes(int num_rows, int ker_width);
@@ -120,7 +121,9 @@ int moment_prepare_graph(const int* row_ptr, int num_rows, const MomentWs& f, hi
 // (the last MLP layer's bias b3 is part of W3R: moment_prepare_weights)
 int moment_conv(const float* x, const float* h2, const int* row_ptr, const int* src, int num_rows, int ker_width,
                 const float* root, const float* bias, int aggr, int relu, float* y, const MomentWs& f, hipStream_t s,
-                int gemm_mode);
+                int gemm_mode, int application);
+// SPLIT_F16, before a forward's application 0: every row's largest |x| (the later applications get it from the one before)
+int moment_row_absmax(const float* x, int num_rows, const MomentWs& f, hipStream_t s);
 
 // bf16 training GEMMs (gemm_bf16.hip): 256 x 256 tiles, 8 waves, two wave groups one phase apart over an
 // LDS-DMA ring of 32-k stages.

@@ -19,9 +19,10 @@
 //   gemm_mode SPLIT_F16   two fp16 planes (x = hi + lo), three products — half the matrix work, which in K1 and K2 is
 //                         ADDED to the stream time rather than hidden under it (EXPERIMENTS 00.10, 00.11).  fp16 has 30
 //                         binades, so operands are put high in its range first by exact powers of two (K2: every row
-//                         of S by its own maximum, every column of W3R by its own — no input is out of range; K1: x and
-//                         H by 2^8, and a workgroup whose staged values leave [2^-10, 255.87] reruns its destination on
-//                         the bf16 planes: the decision depends on that destination's own edges only);
+//                         of S by its own maximum, every column of W3R by its own; K1: the feature rows by the largest
+//                         |feature| among the destination's own neighbours — no input of these is out of range —, H
+//                         by 2^5, and a workgroup whose staged |H| leave [2^-7, 2047) reruns its destination on the
+//                         bf16 planes: every decision depends on that destination's own edges only);
 //   gemm_mode F32         the fp32 MFMA (moment_f32_kernel, project_f32_kernel): reference arithmetic.
 //   K1  moment_kernel     workgroup = (destination t, 256 of the k hidden units); stage = 16 edges: H rows (fp32,
 //                         k-tiled image written by the hidden GEMM, streamed once per application, non-temporal but
@@ -93,9 +94,10 @@ __device__ __forceinline__ void split_store4(const float4 v, unsigned char* dst,
 // one at three workgroups per CU).  |x - (hi + lo)| <= max(2^-23 |x|, 2^-25): the absolute floor is kept out of sight by
 // putting the operands high in fp16's range first, with exact powers of two that are taken out again afterwards —
 // K2: every row of S by its own maximum (K1 records it) and every column of W3R by its own, to [2^13, 2^14): floor
-// 2^-38 of the row's / column's largest entry; K1: x and H by 2^8 (floor 2^-33; a workgroup whose x or H holds a value
-// >= 255 or none >= 2^-10 redoes its destination on the bf16 planes — a decision that depends on that destination's own
-// edges only).  (a, b) -> packed fp16 pair (one v_cvt_pk_f16_f32 on gfx950) and the pair's values back in fp32
+// 2^-38 of the row's / column's largest entry; K1: the feature rows by the largest |feature| among the destination's
+// neighbours (likewise), H by 2^5 (floor 2^-30; a workgroup whose H holds a value >= 2047 or none >= 2^-7 redoes its
+// destination on the bf16 planes — a decision that depends on that destination's own edges only).
+// (a, b) -> packed fp16 pair (one v_cvt_pk_f16_f32 on gfx950) and the pair's values back in fp32
 __device__ __forceinline__ unsigned pack_f16(float a, float b, float& fa, float& fb) {
     const f32x2 v = {a, b};
     const f16x2 p = __builtin_convertvector(v, f16x2);
@@ -236,7 +238,7 @@ __device__ __forceinline__ float wave_max(float v) {
 
 __device__ __forceinline__ void moment_s0(const int* __restrict__ row_ptr, const int* __restrict__ src,
                                           const float* __restrict__ x, float* __restrict__ S, int K, int t, int tl,
-                                          float* __restrict__ rowmax_slot) {
+                                          float* __restrict__ rowmax_slot, float scale) {
     __shared__ float4 sred[16][16];
     const int tid = threadIdx.x;
     const int beg = row_ptr[t], end = row_ptr[t + 1];
@@ -264,6 +266,7 @@ __device__ __forceinline__ void moment_s0(const int* __restrict__ row_ptr, const
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int c = 0; c < 16; ++c) { const float4 v = sred[c][q]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+        a.x *= scale; a.y *= scale; a.z *= scale; a.w *= scale;      // (fp16 planes: the row's power of two, as K1's blocks)
         s0r = a;
         const int i = 4 * q;       // features 4q..4q+3: k-tile 64K/32 + (i >> 5), columns i & 31 ..
         float* d = S + ((size_t)(tl >> 7) * moment_nkt(K) + (size_t)64 * K / 32 + (i >> 5)) * 4096 + (tl & 127) * 32 + (i & 31);
@@ -278,19 +281,25 @@ __device__ __forceinline__ void moment_s0(const int* __restrict__ row_ptr, const
 
 // Grid: (destination within the chunk, visited by decreasing degree) x (k / 256).  S chunk layout: the fp32 k-tiled
 // image K2 streams, [node/128][64k/32][128][32] with kappa = i*k + c.
-// F16 (gemm_mode SPLIT_F16): the stage loop runs on two fp16 planes of 2^8 x and 2^8 H (three products instead of six:
-// the matrix work of this kernel is added to its stream time, not hidden under it — EXPERIMENTS 00.10, 00.11), and the
-// workgroup checks afterwards what it has staged: if a |value| reached 2^-8 of fp16's largest (255.87) or none reached
-// 2^-10 (split_layout.h's rule for activations), it runs the loop again on the three bf16 planes.  The decision is the
+// F16 (gemm_mode SPLIT_F16): the stage loop runs on two fp16 planes (three products instead of six: the matrix work of
+// this kernel is added to its stream time, not hidden under it — EXPERIMENTS 00.10, 00.11).  The feature rows are scaled
+// by the power of two that puts the largest |x| among THIS destination's neighbours in [2^13, 2^14) (xm: every node's
+// largest |feature|, written by K3 — by row_absmax_kernel for a forward's first application — and gathered over the
+// edge list before the first stage: no x is out of range, floor 2^-38 of that maximum) and H by 2^5; the S image of this
+// mode holds 2^(ex + 5) S — K2 scales every row by its own maximum anyway and takes the row's ex + 5 (recorded next to
+// the row's maxima) out with its own scale.  The workgroup checks afterwards what it has staged: if an |H| reached 2047
+// or none reached 2^-7 (floor 2^-30: split_layout.h's rule for activations — at most 2^-23 of the largest value), it runs
+// the loop again on the three bf16 planes (of the same scaled operands: exact scalings).  Both decisions are the
 // workgroup's own — one destination's edges —, so a destination's bits are the same alone or in any batch.
-constexpr float MO_F16_PRE = 256.f, MO_F16_UNPRE2 = 1.f / 65536.f;
+constexpr int MO_F16_PRE_H_EXP = 5;      // H times 2^5: a workgroup's largest |H| may lie in [2^-7, 2047] (typical: 1 .. 10)
+constexpr float MO_F16_PRE_H = 32.f, MO_F16_H_LIM = F16_MAX / 32.f, MO_F16_H_MIN = 0.25f / 32.f;
 
 template <bool F16>
 __global__ __launch_bounds__(256, 3) void moment_kernel(const float* __restrict__ Hm,
                                                         const int* __restrict__ row_ptr, const int* __restrict__ src,
                                                         const int* __restrict__ order, float* __restrict__ S, int K,
                                                         int row0, int cnt, const float* __restrict__ x, int cache_e,
-                                                        float* __restrict__ rowmax) {
+                                                        float* __restrict__ rowmax, const float* __restrict__ xm) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[MO_LDS];
     __shared__ float wg_red[12];
     // workgroup ids b, b+8, b+16, .. share an XCD: a destination's k/256 column blocks (and its s0 workgroup) run there
@@ -306,8 +315,26 @@ __global__ __launch_bounds__(256, 3) void moment_kernel(const float* __restrict_
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nkt = K >> 5;
+    // rowmax: nq maxima per destination of the chunk and, behind them, the exponent ex + 5 of the row's scale
+    float xsc = 1.f, hsc = 1.f;      // (F16) the powers of two the neighbours' features and H are multiplied with
+    bool x_plain = false;
+    if constexpr (F16) {
+        float m = 0.f;
+        for (int e = beg + tid; e < end; e += 256) m = fmaxf(m, xm[src[e]]);
+        m = wave_max(m);
+        if (lane == 0) wg_red[wave] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(wg_red[0], wg_red[1]), fmaxf(wg_red[2], wg_red[3]));
+        // (no neighbour feature, or one beyond 2^+-100: operands as they are — S would overflow scaled —, and the bf16
+        // planes, exact for any x; a property of the destination, so all its column blocks agree on the row's scale)
+        x_plain = !(m >= 0x1p-100f && m < 0x1p100f);
+        xsc = x_plain ? 1.f : __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, f16_row_scale(m))));
+        hsc = x_plain ? 1.f : MO_F16_PRE_H;
+        __syncthreads();      // (wg_red is free again)
+        if (cq == 0 && tid == 0) rowmax[(size_t)tl * (nq + 1) + nq] = x_plain ? 0.f : (float)(f32_exponent(xsc) + MO_F16_PRE_H_EXP);
+    }
     if (cq == nq - 1) {
-        moment_s0(row_ptr, src, x, S, K, t, tl, rowmax ? rowmax + (size_t)tl * nq + cq : nullptr);
+        moment_s0(row_ptr, src, x, S, K, t, tl, rowmax ? rowmax + (size_t)tl * (nq + 1) + cq : nullptr, xsc * hsc);
         return;
     }
     // ---- staging roles
@@ -362,9 +389,17 @@ __global__ __launch_bounds__(256, 3) void moment_kernel(const float* __restrict_
     f32x16 acc[2][2];      // [feature half ih][hidden block cb of this wave's 64]
     const int stages = (end - beg + MO_EDGES - 1) / MO_EDGES;
     const bool wave_live = cq * MO_CQ + wave * 64 < K;      // this wave's 64 hidden units exist
-    float hmax = 0.f, xmax = 0.f;      // (F16) the largest |H| and |x| this thread has staged
+    float hmax = 0.f;      // (F16) the largest |H| this thread has staged
     auto max4 = [](const float4 v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); };
-    auto pre = [](const float4 v) { return make_float4(v.x * MO_F16_PRE, v.y * MO_F16_PRE, v.z * MO_F16_PRE, v.w * MO_F16_PRE); };
+    auto pre = [](const float4 v, float sc) { return make_float4(v.x * sc, v.y * sc, v.z * sc, v.w * sc); };
+    // workgroup-wide maxima of two per-thread values in one round (wg_red is touched by nothing else)
+    auto wg_max2 = [&](float a, float b, float& ra, float& rb) {
+        a = wave_max(a); b = wave_max(b);
+        if (lane == 0) { wg_red[wave] = a; wg_red[4 + wave] = b; }
+        __syncthreads();
+        ra = fmaxf(fmaxf(wg_red[0], wg_red[1]), fmaxf(wg_red[2], wg_red[3]));
+        rb = fmaxf(fmaxf(wg_red[4], wg_red[5]), fmaxf(wg_red[6], wg_red[7]));
+    };
 
     // the stage loop on two fp16 planes (HALF) or three bf16 planes
     auto run = [&](auto half_tag) {
@@ -374,10 +409,14 @@ __global__ __launch_bounds__(256, 3) void moment_kernel(const float* __restrict_
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     hmax = fmaxf(hmax, max4(rh[u]));
-                    split2_store4(pre(rh[u]), lds + er * MO_HROW + (u * 64 + cc * 4) * 2, MO_HPLANE);
+                    split2_store4(pre(rh[u], hsc), lds + er * MO_HROW + (u * 64 + cc * 4) * 2, MO_HPLANE);
                 }
-                xmax = fmaxf(xmax, max4(rx));
-                split2_store4(pre(rx), lds + 3 * MO_HPLANE + xe * MO_XROW + xs * 8, MO_XPLANE);
+                split2_store4(pre(rx, xsc), lds + 3 * MO_HPLANE + xe * MO_XROW + xs * 8, MO_XPLANE);
+            } else if constexpr (F16) {      // the rerun: the same scaled operands on three bf16 planes
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    split_store4(pre(rh[u], hsc), lds + er * MO_HROW + (u * 64 + cc * 4) * 2, MO_HPLANE);
+                split_store4(pre(rx, xsc), lds + 3 * MO_HPLANE + xe * MO_XROW + xs * 8, MO_XPLANE);
             } else {
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
@@ -443,23 +482,11 @@ __global__ __launch_bounds__(256, 3) void moment_kernel(const float* __restrict_
             }
         }
     };
-    // workgroup-wide maxima of two per-thread values in one round (wg_red is touched by nothing else)
-    auto wg_max2 = [&](float a, float b, float& ra, float& rb) {
-        a = wave_max(a); b = wave_max(b);
-        if (lane == 0) { wg_red[wave] = a; wg_red[4 + wave] = b; }
-        __syncthreads();
-        ra = fmaxf(fmaxf(wg_red[0], wg_red[1]), fmaxf(wg_red[2], wg_red[3]));
-        rb = fmaxf(fmaxf(wg_red[4], wg_red[5]), fmaxf(wg_red[6], wg_red[7]));
-    };
-    float out_scale = 1.f;
     if constexpr (F16) {
         run(std::true_type{});
-        float mh, mx;
-        wg_max2(hmax, xmax, mh, mx);
-        constexpr float LIM = F16_MAX / MO_F16_PRE;
-        const bool ok = stages == 0 || (mh < LIM && mx < LIM && mh >= F16_ACT_MIN && mx >= F16_ACT_MIN);
-        if (ok) out_scale = MO_F16_UNPRE2;
-        else {
+        float mh, d;
+        wg_max2(hmax, 0.f, mh, d);
+        if (stages != 0 && (x_plain || !(mh < MO_F16_H_LIM && mh >= MO_F16_H_MIN))) {
             __syncthreads();      // (every wave has read wg_red; the stage buffers were free already)
             run(std::false_type{});
         }
@@ -482,7 +509,7 @@ __global__ __launch_bounds__(256, 3) void moment_kernel(const float* __restrict_
                 for (int e = 0; e < 16; ++e) {
                     const int i = ih * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                     const size_t kt = ((size_t)i * K + c0) >> 5;
-                    const float v = acc[ih][cb][e] * out_scale;
+                    const float v = acc[ih][cb][e];
                     Sb[kt * 4096] = v;
                     smax = fmaxf(smax, fabsf(v));
                 }
@@ -493,7 +520,7 @@ __global__ __launch_bounds__(256, 3) void moment_kernel(const float* __restrict_
         __syncthreads();      // (wg_red is free again)
         float m, d;
         wg_max2(smax, 0.f, m, d);
-        if (tid == 0) rowmax[(size_t)tl * nq + cq] = m;
+        if (tid == 0) rowmax[(size_t)tl * (nq + 1) + cq] = m;
     }
 }
 
@@ -518,7 +545,7 @@ __global__ __launch_bounds__(256) void moment_f32_kernel(const float* __restrict
     const int tl = order[row0 + ti];
     const int t = row0 + tl;
     if (cq == nq - 1) {
-        moment_s0(row_ptr, src, x, S, K, t, tl, nullptr);
+        moment_s0(row_ptr, src, x, S, K, t, tl, nullptr, 1.f);
         return;
     }
     const int beg = row_ptr[t], end = row_ptr[t + 1];
@@ -719,7 +746,7 @@ __global__ __launch_bounds__(512) void project_f16_kernel(const float* __restric
     const _Float16* __restrict__ w3h = reinterpret_cast<const _Float16*>(w3h_bits);
     constexpr int PJ_ROWS = 256, PJ_A_PLANE = PJ_ROWS * 64, PJ_B_BASE = 2 * PJ_A_PLANE, NT = 2, RQ = 64;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * PJ_A_PLANE + 2 * PJ_B_PLANE];      // 40 KiB
-    __shared__ int rowexp[PJ_ROWS];      // exponent of each row's scale: taken out again in the epilogue
+    __shared__ int rowexp[PJ_ROWS];      // exponent of each row's scale (K1's and this kernel's): taken out again in the epilogue
     const int ngrp = gridDim.x / PJ_SLICES;
     const int xcd = blockIdx.x & 7, rr = blockIdx.x >> 3;
     const int rg = rr % ngrp, slice = (rr / ngrp) * 8 + xcd;
@@ -739,11 +766,12 @@ __global__ __launch_bounds__(512) void project_f16_kernel(const float* __restric
     // the scale of a row: from the maxima of its nq column blocks (rows past the last destination: whatever is there —
     // f16_row_scale returns a power of two for any bits, and nothing of those rows is stored)
     auto row_scale = [&](int r) {
-        const float* m = rowmax + (size_t)(first + r) * nq;
+        const float* m = rowmax + (size_t)(first + r) * (nq + 1);
         float v = 0.f;
         for (int q = 0; q < nq; ++q) v = fmaxf(v, m[q]);
         return f16_row_scale(v);
     };
+    auto row_exp = [&](int r) { return (int)rowmax[(size_t)(first + r) * (nq + 1) + nq]; };      // K1's ex + 5 of the row
     const int r0_ = a_row(srow), r1_ = a_row(srow + RQ), r2_ = a_row(srow + 2 * RQ), r3_ = a_row(srow + 3 * RQ);
     const float* A0 = a_ptr(r0_);
     const float* A1 = a_ptr(r1_);
@@ -751,8 +779,8 @@ __global__ __launch_bounds__(512) void project_f16_kernel(const float* __restric
     const float* A3 = a_ptr(r3_);
     const float sc0 = row_scale(r0_), sc1 = row_scale(r1_), sc2 = row_scale(r2_), sc3 = row_scale(r3_);
     if ((tid & 7) == 0) {      // (read in the epilogue, behind the loop's barriers)
-        rowexp[srow] = f32_exponent(sc0); rowexp[srow + RQ] = f32_exponent(sc1);
-        rowexp[srow + 2 * RQ] = f32_exponent(sc2); rowexp[srow + 3 * RQ] = f32_exponent(sc3);
+        rowexp[srow] = f32_exponent(sc0) + row_exp(r0_); rowexp[srow + RQ] = f32_exponent(sc1) + row_exp(r1_);
+        rowexp[srow + 2 * RQ] = f32_exponent(sc2) + row_exp(r2_); rowexp[srow + 3 * RQ] = f32_exponent(sc3) + row_exp(r3_);
     }
     // W3R's plane tiles: thread (plane bp, row bo, 16-B chunk bc)
     const int bp = tid >> 8, bo = (tid >> 2) & 63, bc = tid & 3;
@@ -894,7 +922,8 @@ constexpr int FN_CHAINS = 32;
 __global__ __launch_bounds__(FN_CHAINS * 16) void finish_kernel(const float* __restrict__ part, long long part_stride,
                                                                 const int* __restrict__ row_ptr, const float* __restrict__ x,
                                                                 const float* __restrict__ root, const float* __restrict__ bias,
-                                                                float* __restrict__ y, int row0, int aggr, int relu) {
+                                                                float* __restrict__ y, int row0, int aggr, int relu,
+                                                                float* __restrict__ xm_out) {
     constexpr int CPT = 64 / FN_CHAINS;
     __shared__ float4 red[FN_CHAINS][16];
     __shared__ float4 red2[FN_CHAINS][16];
@@ -947,7 +976,26 @@ __global__ __launch_bounds__(FN_CHAINS * 16) void finish_kernel(const float* __r
         if (bias != nullptr) { s.x += biasv.x; s.y += biasv.y; s.z += biasv.z; s.w += biasv.w; }
         if (relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
         *reinterpret_cast<float4*>(y + (size_t)t * 64 + 4 * q) = s;
+        if (xm_out != nullptr) {      // the row's largest |feature|: K1 on fp16 planes scales a destination's neighbours by it
+            float m = fmaxf(fmaxf(fabsf(s.x), fabsf(s.y)), fmaxf(fabsf(s.z), fabsf(s.w)));
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));      // (es == 0: lanes 0..15 of wave 0)
+            if (q == 0) xm_out[t] = m;
+        }
     }
+}
+
+// every node's largest |feature| for a forward's FIRST conv application (the later ones get it from K3)
+__global__ __launch_bounds__(256) void row_absmax_kernel(const float* __restrict__ x, int num_rows, float* __restrict__ xm) {
+    const int r = blockIdx.x * 16 + (threadIdx.x >> 4), q = threadIdx.x & 15;
+    float m = 0.f;
+    if (r < num_rows) {
+        const float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * 64 + 4 * q);
+        m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if (q == 0 && r < num_rows) xm[r] = m;
 }
 
 }  // namespace
@@ -975,7 +1023,8 @@ size_t moment_workspace_bytes(int num_rows, int ker_width) {
     cv.take<_Float16>((size_t)(64 * ker_width + 64) * 64 * 2);                     // W3R on two fp16 planes (SPLIT_F16)
     cv.take<float>(64);                                                            // its columns' inverse scales
     cv.take<int>(64);                                                              // (their maxima, as bits)
-    cv.take<float>((size_t)(moment_chunk_rows(num_rows) + 256) * moment_nq(ker_width));   // row maxima of the S chunk
+    cv.take<float>((size_t)(moment_chunk_rows(num_rows) + 256) * (moment_nq(ker_width) + 1));   // row maxima of the S chunk (+ the rows' scale exponents)
+    cv.take<float>((size_t)num_rows * 2);                                          // every node's largest |feature|: in, out
     return cv.used();
 }
 
@@ -990,7 +1039,9 @@ MomentWs moment_carve(void* ws, int num_rows, int ker_width) {
     f.w3h = cv.take<_Float16>((size_t)(64 * ker_width + 64) * 64 * 2);
     f.colinv = cv.take<float>(64);
     f.colmax_bits = cv.take<int>(64);
-    f.rowmax = cv.take<float>((size_t)(moment_chunk_rows(num_rows) + 256) * moment_nq(ker_width));
+    f.rowmax = cv.take<float>((size_t)(moment_chunk_rows(num_rows) + 256) * (moment_nq(ker_width) + 1));
+    f.xm[0] = cv.take<float>((size_t)num_rows);
+    f.xm[1] = cv.take<float>((size_t)num_rows);
     return f;
 }
 
@@ -1013,12 +1064,20 @@ int moment_prepare_graph(const int* row_ptr, int num_rows, const MomentWs& f, hi
     return check_launch("degree_order_kernel");
 }
 
+int moment_row_absmax(const float* x, int num_rows, const MomentWs& f, hipStream_t s) {
+    hipLaunchKernelGGL(row_absmax_kernel, dim3((num_rows + 15) / 16), dim3(256), 0, s, x, num_rows, f.xm[0]);
+    return check_launch("row_absmax_kernel");
+}
+
 int moment_conv(const float* x, const float* h2, const int* row_ptr, const int* src, int num_rows, int ker_width,
                 const float* root, const float* bias, int aggr, int relu, float* y, const MomentWs& f, hipStream_t s,
-                int gemm_mode) {
+                int gemm_mode, int application) {
     MDNO_REQUIRE(moment_supported(64, ker_width), MDNO_EUNSUPPORTED, "moment conv: ker_width=%d (x128)", ker_width);
     const bool exact_f32 = gemm_mode == MDNO_GEMM_F32, f16 = gemm_mode == MDNO_GEMM_SPLIT_F16;
     const int nq = moment_nq(ker_width);
+    // (fp16 planes) the nodes' largest |feature|: application a reads xm[a & 1] (x's) and writes xm[(a + 1) & 1] (y's)
+    const float* xm_in = f.xm[application & 1];
+    float* xm_out = f16 ? f.xm[(application + 1) & 1] : nullptr;
     size_t cached_bytes = kMomentCachedBytes;
 #ifdef MDNO_EXP_CACHE_ENV
     if (const char* v = getenv("MDNO_EXP_CACHE_MIB")) cached_bytes = (size_t)atoi(v) << 20;
@@ -1034,10 +1093,10 @@ int moment_conv(const float* x, const float* h2, const int* row_ptr, const int* 
                                    ker_width, r0, cnt, x);
             else if (f16)
                 hipLaunchKernelGGL(moment_kernel<true>, grid, dim3(256), 0, s, h2, row_ptr, src, (const int*)f.order, f.s, ker_width,
-                                   r0, cnt, x, cache_e, f.rowmax);
+                                   r0, cnt, x, cache_e, f.rowmax, xm_in);
             else
                 hipLaunchKernelGGL(moment_kernel<false>, grid, dim3(256), 0, s, h2, row_ptr, src, (const int*)f.order, f.s, ker_width,
-                                   r0, cnt, x, cache_e, (float*)nullptr);
+                                   r0, cnt, x, cache_e, (float*)nullptr, (const float*)nullptr);
         }
         {   // K2: groups of row tiles x K slices
             TimedSection ts(KID_FACT_Y, s);
@@ -1055,7 +1114,7 @@ int moment_conv(const float* x, const float* h2, const int* row_ptr, const int* 
         {   // K3
             TimedSection ts(KID_NNCONV_COMBINE, s);
             hipLaunchKernelGGL(finish_kernel, dim3(cnt), dim3(FN_CHAINS * 16), 0, s, (const float*)f.part, f.part_stride,
-                               row_ptr, x, root, bias, y, r0, aggr, relu);
+                               row_ptr, x, root, bias, y, r0, aggr, relu, xm_out);
         }
     }
     return check_launch("moment_conv");

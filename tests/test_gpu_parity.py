@@ -772,9 +772,10 @@ def test_factored_conv_on_an_arbitrary_edge_list(dev, O, gemm_mode):
 
 def test_factored_conv_fp16_planes_range_rules(dev, O):
     """gemm_mode "split_f16" runs K1 and K2 of the factored conv on two fp16 planes (csrc/moment.hip).  K2 scales every
-    row of S and every column of W3R by its own power of two, so it has no range limit; a K1 workgroup whose staged x
-    or H holds a value >= 255.87 or none >= 2^-10 reruns its destination on the three bf16 planes — a decision that
-    depends on that destination's edges only.  Here: a batch whose second member's hidden activations are out of
+    row of S and every column of W3R by its own power of two and K1 the feature rows by the largest |feature| among
+    the destination's own neighbours, so none of these has a range limit; H is scaled by 2^5, and a K1 workgroup whose
+    staged H holds a value >= 2047 or none >= 2^-7 reruns its destination on the three bf16 planes — decisions that
+    depend on that destination's edges only.  Here: a batch whose second member's hidden activations are out of
     range (its edge attributes times 2^12) while the first member's are not, hidden activations that are all tiny, and
     node features that are all huge — each against the oracle, and each member bit for bit what it is alone."""
     from molecular_dynamics_neural_operator_amd.dataset import PairData
@@ -818,16 +819,16 @@ def test_factored_conv_fp16_planes_range_rules(dev, O):
     # (1) member 1's hidden activations beyond the fp16 planes' range, member 0's inside
     samples = build(4096.0)
     h0, h1 = hidden(base, samples[0].edge_attr), hidden(base, samples[1].edge_attr)
-    assert 2.0 ** -10 <= float(h0.max()) < 255.0 and float(h1.max()) >= 255.875
+    assert 2.0 ** -7 <= float(h0.max()) < 2047.0 and float(h1.max()) >= 2047.0
     run(base, samples, "H of member 1 out of range")
-    # (2) hidden activations all below 2^-10 (layer 1 times 2^-20, layer 2's weight times 2^20: the same W_e)
+    # (2) hidden activations all below 2^-7 (layer 1 times 2^-20, layer 2's weight times 2^20: the same W_e)
     tiny = {k: v.clone() for k, v in base.items()}
     for conv in ("conv1", "conv2"):
         tiny[f"{conv}.net.layers.2.weight"] *= 2.0 ** -20
         tiny[f"{conv}.net.layers.2.bias"] *= 2.0 ** -20
         tiny[f"{conv}.net.layers.4.weight"] *= 2.0 ** 20
     samples = build(1.0)
-    assert float(hidden(tiny, samples[0].edge_attr).max()) < 2.0 ** -10
+    assert float(hidden(tiny, samples[0].edge_attr).max()) < 2.0 ** -7
     run(tiny, samples, "H all tiny")
     # (3) node features times 2^12
     huge = {k: v.clone() for k, v in base.items()}

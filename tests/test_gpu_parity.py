@@ -776,8 +776,9 @@ def test_factored_conv_fp16_planes_range_rules(dev, O):
     the destination's own neighbours, so none of these has a range limit; H is scaled by 2^5, and a K1 workgroup whose
     staged H holds a value >= 2047 or none >= 2^-7 reruns its destination on the three bf16 planes — decisions that
     depend on that destination's edges only.  Here: a batch whose second member's hidden activations are out of
-    range (its edge attributes times 2^12) while the first member's are not, hidden activations that are all tiny, and
-    node features that are all huge — each against the oracle, and each member bit for bit what it is alone."""
+    range (its edge attributes times 2^12) while the first member's are not, hidden activations that are all tiny, node
+    features that are all huge, and node features that are all zero — each against the oracle, and each member bit for
+    bit what it is alone."""
     from molecular_dynamics_neural_operator_amd.dataset import PairData
     from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN
     from molecular_dynamics_neural_operator_amd.weights import near_identity_state_dict
@@ -835,6 +836,12 @@ def test_factored_conv_fp16_planes_range_rules(dev, O):
     huge["fc1.weight"] *= 4096.0
     huge["fc1.bias"] *= 4096.0
     run(huge, samples, "x huge")
+    # (4) no feature at all in the first application (fc1 = 0: every neighbourhood's maximum is 0 — K1 then takes the
+    # operands as they are, on the bf16 planes), features from the conv biases afterwards
+    zero = {k: v.clone() for k, v in base.items()}
+    zero["fc1.weight"].zero_()
+    zero["fc1.bias"].zero_()
+    run(zero, samples, "x = 0 in the first application")
 
 
 def test_edge_cases_single_atom_window1_zero_steps_and_c_rollout(dev, O):

@@ -110,6 +110,9 @@ def parse(argv=None):
     ap.add_argument("--skip-roofline", action="store_true")
     ap.add_argument("--skip-ensemble-leg", action="store_true",
                     help="N=1 default run: skip the 64-member single-GPU leg (cfg3's like-for-like baseline)")
+    ap.add_argument("--skip-rank-share-leg", action="store_true",
+                    help="N=1 default run: skip the leg that runs 8 members (one rank's share of configs[2] at 8 GPUs) in a "
+                         "child process through a world-size-1 RCCL group")
     ap.add_argument("--skip-config-legs", action="store_true",
                     help="N=1 default run: skip the cfg4 (training), cfg5 (50k-atom box) and shape-A (N=28) legs")
     ap.add_argument("--cpu-budget-s", type=float, default=120.0,
@@ -727,6 +730,52 @@ def leg_shape_a(dev, a):
     return out
 
 
+def leg_rank_share(a, ensemble_leg, members=8, timeout_s=240):
+    """What ONE rank of the 8-GPU run of BASELINE configs[2] does — 8 of the 64 members, K steps, then the trajectory
+    all-gather — run as a child `python bench.py --gpus 1 --total-members 8` with MDNO_BENCH_FORCE_DIST=1: a
+    world-size-1 nccl (= RCCL) process group on this GPU, so the collective path of the timed region (barrier,
+    all_gather_into_tensor, all_reduce MAX) executes through librccl.  A failure is recorded, not fatal."""
+    env = dict(os.environ, MDNO_BENCH_FORCE_DIST="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "MDNO_BENCH_BACKEND"):
+        env.pop(k, None)
+    cmd = [sys.executable, str(Path(__file__).resolve()), "--gpus", "1", "--total-members", str(members),
+           "--steps", str(a.steps), "--warmup", str(a.warmup), "--atoms", str(a.atoms), "--window", str(a.window),
+           "--kernel-width", str(a.kernel_width), "--depth", str(a.depth), "--gemm-mode", a.gemm_mode,
+           "--conv-mode", a.conv_mode, "--skip-roofline", "--skip-cpu-baseline", "--single-mode"]
+    if a.no_graph:
+        cmd.append("--no-graph")
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {"error": f"child did not finish in {timeout_s} s"}
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": f"child exit code {r.returncode}", "stderr_tail": r.stderr[-1500:]}
+    d = json.loads(lines[-1])
+    if "value" not in d:
+        return {"error": d.get("error", "no value on the child's line"), "stderr_tail": r.stderr[-1500:]}
+    mg = d.get("multi_gpu_timing") or {}
+    out = {"members": members, "steps": d["steps"], "warmup": d["warmup"], "frames_per_s": d["value"], "ms_per_step": d["ms_per_step"],
+           "member_groups": d["config"]["member_groups_this_rank"], "conv_mode": d["config"]["conv_mode"],
+           "collective": {"backend": mg.get("backend"), "world_size": mg.get("world_size"),
+                          "init_process_group_s": mg.get("init_process_group_s"), "first_gather_s": mg.get("first_gather_s"),
+                          "timed_gather_ms": (mg.get("per_rank_gather_ms") or [None])[0],
+                          "gathered_bytes": mg.get("gathered_bytes_per_rank"),
+                          "what": "barrier + all_gather_into_tensor + all_reduce(MAX) of the timed region through a "
+                                  "world-size-1 nccl (RCCL) group in a child process"},
+           "child_seconds": time.perf_counter() - t0,
+           "note": "one rank's share of BASELINE configs[2] at 8 GPUs (8 of 64 members), inside the same timed region "
+                   "an N > 1 rank runs"}
+    if ensemble_leg and ensemble_leg.get("frames_per_s"):
+        out["baseline_1gpu_same_workload"] = ensemble_leg["frames_per_s"]
+        out["projected_speedup_8gpu"] = 8.0 * d["value"] / ensemble_leg["frames_per_s"]
+        out["projected_value_8gpu"] = 8.0 * d["value"]
+    note(f"per-rank share: {d['value']:.1f} frames/s with {members} members"
+         + (f", projected 8-GPU speed-up {out['projected_speedup_8gpu']:.2f}x" if "projected_speedup_8gpu" in out else ""))
+    return out
+
+
 # ----------------------------------------------------------------------------------------------- worker
 def profiled_entry(kernel: str, atoms: int, members: int, conv_mode: str, gemm_mode: str) -> dict:
     """The entry of profiles/roofline_traffic.json for this kernel and configuration ({} if none): PMC HBM bytes per
@@ -750,6 +799,11 @@ def profiled_traffic(kernel: str, atoms: int, members: int, conv_mode: str, gemm
 
 
 def worker(a):
+    # Before the first HIP call of this process (HSA reads it when the runtime opens): the host driver of this pool
+    # only supports dmabuf IPC, and RCCL's / torch's cross-process device-memory handles fail with
+    # `hipIpcGetMemHandle: invalid argument` without it (the environment's own instructions export it; a launcher
+    # that does not pass it on — torch.distributed.run under a scrubbed environment — must not lose it).
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -765,15 +819,28 @@ def worker(a):
     if os.environ.get("MDNO_BENCH_FAIL_RANK") == str(rank):  # injected failure (tests: a rank that dies at start-up)
         raise RuntimeError(f"MDNO_BENCH_FAIL_RANK={rank}: injected failure after set_device")
     backend = os.environ.get("MDNO_BENCH_BACKEND", "nccl")   # "gloo" only to rehearse N>1 on one GPU
-    if world > 1:
+    # MDNO_BENCH_FORCE_DIST=1 on a one-rank run: a world-size-1 process group, so that the timed region's barrier,
+    # all-gather and max-over-ranks run through the backend (RCCL: communicator init + all_gather_into_tensor through
+    # librccl on this GPU) exactly as a rank of an N > 1 run issues them
+    force_dist = world == 1 and os.environ.get("MDNO_BENCH_FORCE_DIST") == "1"
+    use_dist = world > 1 or force_dist
+    t_init = None
+    if use_dist:
         from datetime import timedelta
         # a rank that never arrives (or dies in a collective) fails the others after INIT_TIMEOUT_S, not after the
         # backends' 10-30 minute defaults
         tmo = timedelta(seconds=float(os.environ.get("MDNO_BENCH_INIT_TIMEOUT_S", INIT_TIMEOUT_S)))
+        kw = {}
+        if force_dist and "MASTER_PORT" not in os.environ:   # no launcher around a forced one-rank group
+            with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+                sk.bind(("127.0.0.1", 0))
+                kw["init_method"] = f"tcp://127.0.0.1:{sk.getsockname()[1]}"
+        t0 = time.perf_counter()
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo, **kw)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo, **kw)
+        t_init = time.perf_counter() - t0
 
     from molecular_dynamics_neural_operator_amd import synthetic as syn
     from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN, KernelNNNotebook
@@ -789,7 +856,9 @@ def worker(a):
     elif a.total_members is not None:
         total_members, scaling = a.total_members, "strong"
     else:
-        total_members, scaling = (1, "weak") if world == 1 else (ENSEMBLE_MEMBERS, "strong")
+        # (the default one-GPU line is configs[1], one member — not a point of either series; the N > 1 lines are the
+        # 64-member ensemble split over the ranks: fixed total work.  `scaling_note` on the line says so.)
+        total_members, scaling = (1, "strong") if world == 1 else (ENSEMBLE_MEMBERS, "strong")
     my_members = shard_members(total_members, rank, world)
     M = len(my_members)
     if M == 0:
@@ -851,12 +920,15 @@ def worker(a):
     # first produced frame of member 0 (kept for the cpu_baseline leg's parity figure)
     first_frame_gpu = eng.traj[W, 0].detach().cpu().numpy() if (a.warmup > 0 and total_members == 1) else None
     m_max = -(-total_members // world)
-    if world > 1:    # the collective of the timed region, once, untimed: communicator set-up and buffers
+    t_first_gather = None
+    if use_dist:     # the collective of the timed region, once, untimed: communicator set-up and buffers
+        t0 = time.perf_counter()
         gather_trajectories(torch.zeros((a.steps, M, N, 3), dtype=torch.float32, device=dev), total_members)
         torch.cuda.synchronize()
+        t_first_gather = time.perf_counter() - t0
 
     # ---- timed region: exactly K steps + trajectory collection
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -864,28 +936,30 @@ def worker(a):
     wait(eng)
     t_steps = time.perf_counter() - t0                                             # this rank's K steps alone
     produced = eng.traj[W + a.warmup:W + a.warmup + a.steps]                       # [K,M,N,3]
-    if world > 1:
+    if use_dist:
         full = gather_trajectories(produced, total_members)
     else:
         full = produced
     torch.cuda.synchronize()
     t_gather = time.perf_counter() - t0 - t_steps                                  # incl. waiting for the slowest rank
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     mg_timing = None
-    if world > 1:    # per-rank step time and the collective, separately (outside the timed region)
+    if use_dist:     # per-rank step time and the collective, separately (outside the timed region)
         tt = torch.tensor([t_steps, t_gather], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         allt = [torch.zeros_like(tt) for _ in range(world)]
         dist.all_gather(allt, tt)
         mg_timing = {"per_rank_steps_ms": [float(x[0]) * 1e3 for x in allt],
                      "per_rank_gather_ms": [float(x[1]) * 1e3 for x in allt],
                      "note": "gather_ms of a rank includes its wait for the slowest rank's steps; the collective "
-                             "itself is the smallest entry", "gathered_bytes_per_rank": int(produced.numel() * 4)}
+                             "itself is the smallest entry", "gathered_bytes_per_rank": int(produced.numel() * 4),
+                     "backend": backend, "world_size": world, "init_process_group_s": t_init,
+                     "first_gather_s": t_first_gather}
     eng.synchronize()   # raises on edge overflow / bad input
     assert full.shape == (a.steps, total_members, N, 3) and bool(torch.isfinite(full).all())
     eps = eng.edges_per_step[a.warmup:a.warmup + a.steps].double()
@@ -1087,6 +1161,19 @@ def worker(a):
                 note(f"{name} leg FAILED: {config_legs[name]['error']}")
             torch.cuda.empty_cache()
 
+    # ---- one rank's share of the 8-GPU run of configs[2] (8 of the 64 members), as that rank runs it: a fresh child
+    # of this file with a world-size-1 nccl group (MDNO_BENCH_FORCE_DIST=1), so that barrier, all-gather and
+    # max-over-ranks of the timed region go through RCCL on this GPU.  8 x this / the 64-member single-GPU figure =
+    # what the 8-GPU point should show if nothing but the shard size changes.
+    share_leg = None
+    if default_single and not a.skip_ensemble_leg and not a.skip_rank_share_leg:
+        if eng is not None:
+            eng.close()
+            eng = None
+        torch.cuda.empty_cache()
+        note("per-rank share leg: 8 members through a world-size-1 RCCL group (child process)")
+        share_leg = leg_rank_share(a, ensemble_leg)
+
     cpu = None
     if rank == 0 and world == 1 and not a.skip_cpu_baseline and a.variant == "intree":
         cpu = cpu_baseline(sd, a.depth, base, aa, a.threshold, a.cpu_budget_s, first_frame_gpu)
@@ -1103,6 +1190,11 @@ def worker(a):
             "metric": "rolled-out MD frames/sec", "value": value, "unit": "frames/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32",
+            "scaling_note": ("this line is BASELINE configs[1] (ONE member on one GPU), not a point of the N > 1 series; "
+                             "the series splits the 64-member ensemble of configs[2] over the ranks (fixed total work = "
+                             "strong scaling) and its 1-GPU point is `baseline_1gpu_same_workload`"
+                             if world == 1 and total_members == 1 else
+                             "fixed total work split over the ranks" if scaling == "strong" else "fixed work per rank"),
             "data": "synthetic (uniform-box frames, seeded; near-identity synthetic weights, see weights.py)",
             "config": {"workload": f"BBA all-atom stand-in N={N} r={a.threshold}A free-running autoregressive rollout, "
                                    f"{total_members}-member ensemble (BASELINE {cfg}), member m on rank m mod {world}",
@@ -1112,7 +1204,7 @@ def worker(a):
                        "mean_edges_per_member": e_mean / M,
                        "edges_first_last": [int(eps[0].item()), int(eps[-1].item())], "edge_cap": cap,
                        "parallelism": f"ensemble-sharded x{world}, no collective while stepping, one all-gather of "
-                                      f"trajectories ({backend if world > 1 else 'none'})",
+                                      f"trajectories ({(backend + (' world 1, forced' if force_dist else '')) if use_dist else 'none'})",
                        "launch": "plain" if a.no_graph else "hipGraph replay", "edge_mlp_gemm": a.gemm_mode,
                        "variant": a.variant, "conv_mode": mode, "conv_mode_requested": a.conv_mode},
             "roofline": dominant, "rooflines": roofs, "other_conv_mode": other_mode,
@@ -1122,6 +1214,8 @@ def worker(a):
             "baseline_1gpu_same_workload": ({"workload": "BASELINE configs[2]: 64-member ensemble on one GPU",
                                              "value": ensemble_leg["frames_per_s"], "unit": "frames/s"}
                                             if ensemble_leg else None),
+            "per_rank_share_8gpu": share_leg,
+            "projected_speedup_8gpu": (share_leg or {}).get("projected_speedup_8gpu"),
             "cfg2_1000_steps": config_legs.get("cfg2_1000_steps"),
             "cfg4_training": config_legs.get("cfg4_training"), "cfg5_shape_c": config_legs.get("cfg5_shape_c"),
             "shape_A": config_legs.get("shape_A"),
@@ -1130,7 +1224,7 @@ def worker(a):
         print(json.dumps(line), flush=True)
     if eng is not None:
         eng.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

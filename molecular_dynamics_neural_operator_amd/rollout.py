@@ -442,14 +442,15 @@ def gather_trajectories(local: torch.Tensor, total_members: int, group=None) -> 
     staged = local.is_cuda and dist.get_backend(group) == "gloo"     # CPU rehearsal backend: stage through host
     if staged:
         send = send.cpu()
-    recv = torch.empty((world * T, m_max, N, D), dtype=local.dtype, device=send.device)
-    dist.all_gather_into_tensor(recv, send, group=group)   # rank r's shard = rows [r*T, (r+1)*T)
+    recv = torch.empty((world, T, m_max, N, D), dtype=local.dtype, device=send.device)
+    dist.all_gather_into_tensor(recv.view(world * T, m_max, N, D), send, group=group)   # rank r's shard = recv[r]
     if staged:
         recv = recv.to(local.device)
-    recv = recv.view(world, T, m_max, N, D)
     out = torch.empty((T, total_members, N, D), dtype=local.dtype, device=local.device)
-    for r in range(world):
-        ids = shard_members(total_members, r, world)
-        if ids:
-            out[:, ids] = recv[r][:, :len(ids)]
+    if total_members == world * m_max:      # even shards: member m = j * world + r  ->  one strided copy
+        out.view(T, m_max, world, N, D).copy_(recv.permute(1, 2, 0, 3, 4))
+    else:                                   # rank r's members are r, r + world, ..: a strided slice each (no index tensors)
+        for r in range(world):
+            if counts[r]:
+                out[:, r::world] = recv[r, :, :counts[r]]
     return out

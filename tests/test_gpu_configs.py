@@ -1017,6 +1017,64 @@ def test_gather_trajectories_over_rccl_two_gpus(tmp_path):
         assert p.returncode == 0 and "ok" in out, err[-2000:]
 
 
+NCCL_WORLD1_CHILD = r"""
+import os, sys, time, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["MDNO_REPO"])
+from molecular_dynamics_neural_operator_amd.rollout import gather_trajectories
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+t0 = time.time()
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+mine = torch.arange(3 * 5 * 7 * 3, dtype=torch.float32).reshape(3, 5, 7, 3).to(dev)
+out = gather_trajectories(mine, 5)
+torch.cuda.synchronize()
+assert dist.get_backend() == "nccl" and out.is_cuda and out.data_ptr() != mine.data_ptr()
+assert torch.equal(out, mine), "gathered trajectories differ"
+t = torch.tensor([2.5], dtype=torch.float64, device=dev)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+assert float(t.item()) == 2.5
+dist.barrier()
+dist.destroy_process_group()
+print("ok world1 nccl %.1fs" % (time.time() - t0))
+"""
+
+
+def test_gather_trajectories_over_rccl_world_size_one(dev, tmp_path):
+    """RCCL executes on the one GPU a builder's box has: a fresh child process makes a world-size-1 nccl group
+    (communicator init through librccl on gfx950), runs rollout.gather_trajectories — the one collective of the
+    N > 1 path — on a [3,5,7,3] device tensor, the all_reduce(MAX) and the barrier bench.py's timed region uses,
+    and tears the group down.  (Two ranks on one card are refused by RCCL, so this is as far as one GPU goes; the
+    two-GPU test below runs where two exist.)"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    script = tmp_path / "child1.py"
+    script.write_text(NCCL_WORLD1_CHILD)
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               MDNO_REPO=str(REPO))
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ok world1 nccl" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-3000:])
+    print(r.stdout.strip())
+
+
+def test_bench_forced_world1_group_runs_the_collective_path(dev):
+    """`python bench.py --gpus 1` with MDNO_BENCH_FORCE_DIST=1: the timed region's barrier / all-gather / max over
+    ranks run through a world-size-1 nccl group; the line says so and carries the collective's timings."""
+    env = dict(os.environ, MDNO_BENCH_FORCE_DIST="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MDNO_BENCH_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--total-members", "2", "--atoms", "60", "--kernel-width", "128", "--depth", "2",
+                        "--skip-roofline", "--skip-cpu-baseline"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    mg = line["multi_gpu_timing"]
+    assert line["n_gpus"] == 1 and line["value"] > 0 and "nccl world 1, forced" in line["config"]["parallelism"]
+    assert mg["backend"] == "nccl" and mg["world_size"] == 1 and mg["init_process_group_s"] > 0
+    assert mg["gathered_bytes_per_rank"] == 3 * 2 * 60 * 3 * 4 and len(mg["per_rank_gather_ms"]) == 1
+
+
 def test_untied_conv2_kernel_is_evaluated_separately(dev, O):
     """The reference ties conv1.net and conv2.net to ONE module (graph_kernel.py:271-273) and the library
     evaluates the edge-MLP once per forward on that ground.  A state_dict whose conv2.net.* differ (loaded

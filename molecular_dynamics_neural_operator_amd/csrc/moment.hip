@@ -378,7 +378,6 @@ __global__ __launch_bounds__(256, 3) void moment_kernel(const float* __restrict_
     const int frow = 8 * (gq >> 1) + qq, fcol = 16 * (gq & 1) + 4 * pp;
     const unsigned char* hb = lds + frow * MO_HROW + (wave * 64 + fcol) * 2;                  // + cb*64 B, + plane
     const unsigned char* xb = lds + 3 * MO_HPLANE + frow * MO_XROW + fcol * 2;               // + ih*64 B, + plane
-    typedef short s16x8 __attribute__((ext_vector_type(8)));
     auto tr_frag = [&](const unsigned char* p_, int row_bytes) {
         typedef short s16x4 __attribute__((ext_vector_type(4)));
         typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -999,342 +998,6 @@ __global__ __launch_bounds__(256) void row_absmax_kernel(const float* __restrict
 }
 
 
-// ---------------------------------------------------------------- fused K1 -> K2 (EXPERIMENT: S never leaves the chip)
-// Workgroup = (tile of 16 consecutive destinations, 64 hidden units c): wave w owns destinations 2w, 2w+1 of the tile and
-// builds their S_t[64 i][64 c] in 2 x 64 accumulator registers from its own stream of H rows (two 128-B runs per edge)
-// and gathered feature rows, staged wave-privately in LDS (edge-major planes, transposing reads: K1's stage, no
-// workgroup barrier).  Then the 16 destinations' tiles are turned through LDS, a quarter (32 i x 32 c) at a time, into
-// the A operand of z[16 t][64 o] += S[t][(i, c)] . W3[(i, c)][o] on v_mfma_f32_16x16x32_f16; W3 comes pre-split and
-// pre-ordered as B fragments (w3_fragments_f16_kernel: 1 KiB per wave load), each wave takes 4 of a quarter's 32 k-steps,
-// the eight partial z are added in wave order and written as slice c/64 of the partials that finish_fused_kernel adds.
-constexpr int FU_T = 16, FU_CR = 64, FU_THREADS = 512;
-constexpr int kFusedChunk = 512;      // = kMomentChunkRows: the chunks degree_order_kernel sorts
-constexpr int FU_ROW = 64 * 2 + 64, FU_PLANE = MO_EDGES * FU_ROW;      // an edge row of a plane: 64 fp16 + 64 B of padding
-constexpr int FU_WAVE_LDS = 4 * FU_PLANE;                              // H hi, H lo, X hi, X lo: 12 KiB per wave
-constexpr int FU_AROW = 1024 * 2 + 16, FU_APLANE = FU_T * FU_AROW, FU_ABUF = 2 * FU_APLANE;
-constexpr int FU_LDS = 2 * FU_ABUF;                                    // 132,096 B (phase A: 8 x 12,288)
-static_assert(kFusedChunk == 512 && FU_LDS >= 8 * FU_WAVE_LDS && FU_LDS >= 8 * FU_T * 64 * 4, "phase B's buffers hold phase A's stages and the reduction");
-
-// W3 [64*64, k] (row i*64 + o, column c) -> two fp16 planes in B-fragment order of the fused kernel:
-// [c/64][quarter (i/32, (c/32)&1)][k-step = c & 31][o/16][plane][lane][8], lane l holding o = 16 nt + (l & 15) and
-// i = 32 ih + 8 (l >> 4) + j; column o times the power of two of w3_planes_f16_kernel (colmax_bits)
-__global__ __launch_bounds__(256) void w3_fragments_f16_kernel(const float* __restrict__ w3, int K, const int* __restrict__ colmax_bits,
-                                                               _Float16* __restrict__ w3f) {
-    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (id >= (long long)2 * 64 * K * 64) return;
-    const int j = (int)(id & 7), lane = (int)((id >> 3) & 63), p = (int)((id >> 9) & 1), nt = (int)((id >> 10) & 3);
-    const int ks = (int)((id >> 12) & 31), q = (int)((id >> 17) & 3), cr = (int)(id >> 19);
-    const int i = (q >> 1) * 32 + 8 * (lane >> 4) + j, c = cr * 64 + (q & 1) * 32 + ks, o = nt * 16 + (lane & 15);
-    const float v = w3[((size_t)i * 64 + o) * K + c] * f16_row_scale(__builtin_bit_cast(float, colmax_bits[o]));
-    const _Float16 h = (_Float16)v;
-    w3f[id] = p ? (_Float16)(v - (float)h) : h;
-}
-
-__global__ __launch_bounds__(FU_THREADS) void moment_fused_kernel(const float* __restrict__ Hm, const int* __restrict__ row_ptr,
-                                                                  const int* __restrict__ src, const int* __restrict__ order,
-                                                                  float* __restrict__ s0out, const float* __restrict__ x,
-                                                                  const float* __restrict__ xm, const uint4* __restrict__ w3f,
-                                                                  const float* __restrict__ colinv, float* __restrict__ part,
-                                                                  long long part_stride, int K, int num_rows, int cache_e,
-                                                                  int* __restrict__ range_flag, int exp_mode) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    __shared__ int es_lds[FU_T], row_lds[FU_T];
-    const int ncr = K >> 6, ntile = (num_rows + FU_T - 1) / FU_T;
-    // workgroup ids b, b+8, .. share an XCD: an XCD takes the c-ranges cr = xcd, xcd + 8, .. one after the other, all
-    // tiles of one c-range side by side — they stream the same 1 MiB of W3 fragments through that XCD's L2
-    const int xcd = blockIdx.x & 7, rr = blockIdx.x >> 3;
-    const int cr = (rr / ntile) * 8 + xcd, tile = rr % ntile;
-    if (cr >= ncr) return;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nkt = K >> 5;
-    unsigned char* wl = lds + wave * FU_WAVE_LDS;
-    // fragment addresses of the transposing reads (moment_kernel's)
-    const int gq = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
-    const int frow = 8 * (gq >> 1) + qq, fcol = 16 * (gq & 1) + 4 * pp;
-    const unsigned char* hb = wl + frow * FU_ROW + fcol * 2;
-    const unsigned char* xb = wl + 2 * FU_PLANE + frow * FU_ROW + fcol * 2;
-    auto tr_frag = [&](const unsigned char* p_) {
-        typedef short s16x4 __attribute__((ext_vector_type(4)));
-        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p_));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p_ + 4 * FU_ROW));
-        return __builtin_bit_cast(f16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-    };
-    auto max4 = [](const float4 v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); };
-    auto pre = [](const float4 v, float sc) { return make_float4(v.x * sc, v.y * sc, v.z * sc, v.w * sc); };
-    bool bad = false;      // a staged |H| out of the fp16 planes' range (EXPERIMENT: flagged, not rerun)
-
-    // ---- phase A: S_t of one destination into acc (times xsc * hsc, powers of two; returns the exponent of that factor)
-    auto moment = [&](int t, f32x16 (&acc)[2][2]) -> int {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-        if (t >= num_rows) return 0;
-        const int beg = row_ptr[t], end = row_ptr[t + 1];
-        if (end <= beg) {
-            if (cr == 0 && lane < 16) *reinterpret_cast<float4*>(s0out + (size_t)t * 64 + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);
-            return 0;
-        }
-        float m = 0.f;
-        for (int e = beg + lane; e < end; e += 64) m = fmaxf(m, xm[src[e]]);
-        m = wave_max(m);
-        const bool x_plain = !(m >= 0x1p-100f && m < 0x1p100f);
-        const float xsc = x_plain ? 1.f : f16_row_scale(m), hsc = x_plain ? 1.f : MO_F16_PRE_H;
-        float hmax = 0.f;
-        float4 rhP[4], rxP[4], rhQ[4], rxQ[4];      // TWO stages in flight per wave (16 KiB), alternating register sets
-        int sidx[4];
-        auto load_src = [&](int e0) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int e = e0 + 4 * j + (lane >> 4);
-                sidx[j] = e < end ? src[e] : 0;
-            }
-        };
-        auto load_stage = [&](float4 (&rh)[4], float4 (&rx)[4], int e0) {
-            const bool cached = e0 + MO_EDGES <= cache_e;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int e = e0 + 8 * (j >> 1) + (lane >> 3);
-                const int c = cr * FU_CR + (j & 1) * 32 + (lane & 7) * 4;
-                const float* p_ = Hm + ((size_t)(e >> 7) * nkt + (c >> 5)) * 4096 + (e & 127) * 32 + (c & 31);
-                rh[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (e < end) {
-                    if (cached) rh[j] = *reinterpret_cast<const float4*>(p_);
-                    else {
-                        const f32x4 t_ = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p_));
-                        rh[j] = make_float4(t_.x, t_.y, t_.z, t_.w);
-                    }
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int e = e0 + 4 * j + (lane >> 4);
-                rx[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (e < end) rx[j] = *reinterpret_cast<const float4*>(x + (size_t)sidx[j] * 64 + 4 * (lane & 15));
-            }
-        };
-        float4 s0a = make_float4(0.f, 0.f, 0.f, 0.f);      // (cr == 0) this lane's share of s0_t = sum_e x_src(e): features 4 (lane & 15) ..
-        auto store_stage = [&](const float4 (&rh)[4], const float4 (&rx)[4]) {
-            if (cr == 0) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { s0a.x += rx[j].x; s0a.y += rx[j].y; s0a.z += rx[j].z; s0a.w += rx[j].w; }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                hmax = fmaxf(hmax, max4(rh[j]));
-                split2_store4(pre(rh[j], hsc), wl + (8 * (j >> 1) + (lane >> 3)) * FU_ROW + ((j & 1) * 32 + (lane & 7) * 4) * 2, FU_PLANE);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                split2_store4(pre(rx[j], xsc), wl + 2 * FU_PLANE + (4 * j + (lane >> 4)) * FU_ROW + (lane & 15) * 8, FU_PLANE);
-        };
-        const int stages = exp_mode == 3 ? 1 : (end - beg + MO_EDGES - 1) / MO_EDGES;
-        // one stage: planes of the landed set to LDS, the set reloaded with the stage two ahead, fragments, products
-        auto stage = [&](float4 (&rh)[4], float4 (&rx)[4], int st) {
-            asm volatile("" ::: "memory");
-            store_stage(rh, rx);                         // (the previous stage's fragment reads were issued before: LDS is in order per wave)
-            if (st + 2 < stages) {
-                load_stage(rh, rx, beg + (st + 2) * MO_EDGES);
-                load_src(beg + (st + 3) * MO_EDGES);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            f16x8 a[2][2], b[2];
-#pragma unroll
-            for (int ih = 0; ih < 2; ++ih)
-#pragma unroll
-                for (int p = 0; p < 2; ++p) a[ih][p] = tr_frag(xb + p * FU_PLANE + ih * 64);
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-#pragma unroll
-                for (int p = 0; p < 2; ++p) b[p] = tr_frag(hb + p * FU_PLANE + cb * 64);
-                MDNO_MMA3H(a[0], b, acc[0][cb])
-                MDNO_MMA3H(a[1], b, acc[1][cb])
-            }
-        };
-        load_src(beg);
-        load_stage(rhP, rxP, beg);
-        load_src(beg + MO_EDGES);
-        load_stage(rhQ, rxQ, beg + MO_EDGES);
-        load_src(beg + 2 * MO_EDGES);
-        for (int st = 0; st < stages; st += 2) {
-            stage(rhP, rxP, st);
-            if (st + 1 < stages) stage(rhQ, rxQ, st + 1);
-        }
-        if (cr == 0) {      // the four edge classes (lane >> 4) in order: a fixed association
-            float4 v = s0a;
-#pragma unroll
-            for (int u = 1; u < 4; ++u) {
-                const int from = (lane & 15) + 16 * u;
-                const float4 o_ = make_float4(__shfl(s0a.x, from, 64), __shfl(s0a.y, from, 64), __shfl(s0a.z, from, 64), __shfl(s0a.w, from, 64));
-                v.x += o_.x; v.y += o_.y; v.z += o_.z; v.w += o_.w;
-            }
-            if (lane < 16) *reinterpret_cast<float4*>(s0out + (size_t)t * 64 + 4 * lane) = v;
-        }
-        hmax = wave_max(hmax);
-        if (x_plain || !(hmax < MO_F16_H_LIM && hmax >= MO_F16_H_MIN)) bad = true;
-        return x_plain ? 0 : f32_exponent(xsc) + MO_F16_PRE_H_EXP;
-    };
-    f32x16 accA[2][2], accB[2][2];
-    // the tile's destinations: ranks 16 tile .. + 15 of the degree-sorted order (degree_order_kernel: per 512-row chunk,
-    // decreasing degree) — the waves of a workgroup get like amounts of work (wave w: ranks w and 15 - w), heavy tiles first
-    auto dest = [&](int slot) {
-        const int r = tile * FU_T + slot;
-        return r < num_rows ? (r / kFusedChunk) * kFusedChunk + order[r] : num_rows;
-    };
-    const int slotA = wave, slotB = FU_T - 1 - wave;
-    const int tA = dest(slotA), tB = dest(slotB);
-    const int exA = moment(tA, accA);
-    const int exB = moment(tB, accB);
-    if (bad && lane == 0) atomicOr(range_flag, 1);
-
-    // ---- phase B: z[16 t][64 o] += S[t][(i, c)] . W3[(i, c)][o]
-    auto tile_max = [&](const f32x16 (&acc)[2][2]) {
-        float m = 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) m = fmaxf(m, fabsf(acc[i][j][e]));
-        return wave_max(m);
-    };
-    const float scA = f16_row_scale(tile_max(accA)), scB = f16_row_scale(tile_max(accB));
-    if (lane == 0) {
-        es_lds[slotA] = f32_exponent(scA) + exA;
-        es_lds[slotB] = f32_exponent(scB) + exB;
-        row_lds[slotA] = tA;
-        row_lds[slotB] = tB;
-    }
-    const int l31 = lane & 31, h = lane >> 5;
-    // one quarter (32 i x 32 c) of a destination's tile -> row tl of the A image: kappa'' = cl * 32 + il
-    auto put_quarter = [&](const f32x16& a, float sc, int tl, unsigned char* buf) {
-        unsigned char* d = buf + tl * FU_AROW + (l31 * 32 + 4 * h) * 2;
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            split2_store4(make_float4(a[4 * g] * sc, a[4 * g + 1] * sc, a[4 * g + 2] * sc, a[4 * g + 3] * sc), d + 8 * g * 2, FU_APLANE);
-    };
-    f32x4 zacc[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) zacc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // B fragments: [cr][q][ks][nt][plane][lane] uint4; this wave's k-steps of a quarter: 4 wave .. 4 wave + 3
-    const uint4* bw = w3f + ((size_t)cr * 4 * 32 * 4 * 2) * 64 + lane;
-    auto b_ptr = [&](int q, int kk) { return bw + ((size_t)(q * 32 + 4 * wave + kk) * 8) * 64; };
-    uint4 bP[8], bQ[8];
-    auto load_b = [&](uint4 (&r)[8], int q, int kk) {
-        const uint4* p_ = b_ptr(q, kk);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) r[u] = p_[u * 64];
-    };
-    auto mma_step = [&](const uint4 (&r)[8], const unsigned char* buf, int kk) {
-        const unsigned char* ap = buf + (lane & 15) * FU_AROW + ((4 * wave + kk) * 32 + 8 * (lane >> 4)) * 2;
-        const f16x8 a0 = *reinterpret_cast<const f16x8*>(ap), a1 = *reinterpret_cast<const f16x8*>(ap + FU_APLANE);
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const f16x8 b0 = __builtin_bit_cast(f16x8, r[2 * nt]), b1 = __builtin_bit_cast(f16x8, r[2 * nt + 1]);
-            zacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b0, zacc[nt], 0, 0, 0);
-            zacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b1, zacc[nt], 0, 0, 0);
-            zacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, zacc[nt], 0, 0, 0);
-        }
-    };
-    load_b(bP, 0, 0);
-    __syncthreads();      // every wave is through with its stage buffers: the A images may overwrite them
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        if (exp_mode == 2) break;
-        unsigned char* buf = lds + (q & 1) * FU_ABUF;
-        put_quarter(accA[q >> 1][q & 1], scA, slotA, buf);
-        put_quarter(accB[q >> 1][q & 1], scB, slotB, buf);
-        __syncthreads();
-        load_b(bQ, q, 1);
-        mma_step(bP, buf, 0);
-        load_b(bP, q, 2);
-        mma_step(bQ, buf, 1);
-        load_b(bQ, q, 3);
-        mma_step(bP, buf, 2);
-        if (q < 3) load_b(bP, q + 1, 0);
-        mma_step(bQ, buf, 3);
-    }
-    // ---- the eight waves' partial z, added in wave order; scales out; slice cr of the partials
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(lds);
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) red[(wave * FU_T + 4 * (lane >> 4) + j) * 64 + nt * 16 + (lane & 15)] = zacc[nt][j];
-    __syncthreads();
-    {
-        const int tl = tid >> 5, o = (tid & 31) * 2;
-        float z0 = 0.f, z1 = 0.f;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) {
-            const float2 v = *reinterpret_cast<const float2*>(&red[(w * FU_T + tl) * 64 + o]);
-            z0 += v.x; z1 += v.y;
-        }
-        const int row = row_lds[tl];
-        if (row < num_rows) {
-            const int er = es_lds[tl];
-            float2 out;
-            out.x = ldexpf(z0, f32_exponent(colinv[o]) - er);
-            out.y = ldexpf(z1, f32_exponent(colinv[o + 1]) - er);
-            *reinterpret_cast<float2*>(part + (size_t)cr * part_stride + (size_t)row * 64 + o) = out;
-        }
-    }
-}
-
-// K3 of the fused form: one workgroup per destination, four waves, lane = output channel o.  Wave u adds slices u, u+4, ..
-// in that order (all loads in flight), the four waves' sums are added in wave order; the b3 term s0_t . B3 (s0_t from the
-// fused kernel's c-range-0 workgroups) and the root term are split over the waves by input channel the same way.
-__global__ __launch_bounds__(256) void finish_fused_kernel(const float* __restrict__ part, long long part_stride, int nslices,
-                                                           const int* __restrict__ row_ptr, const float* __restrict__ s0,
-                                                           const float* __restrict__ x, const float* __restrict__ b3t,
-                                                           const float* __restrict__ root, const float* __restrict__ bias,
-                                                           float* __restrict__ y, int aggr, int relu, float* __restrict__ xm_out) {
-    __shared__ float red[3][4][64];
-    const int lane = threadIdx.x & 63, u = threadIdx.x >> 6;
-    const int t = blockIdx.x;
-    float zv[32];
-#pragma unroll
-    for (int j = 0; j < 32; ++j) zv[j] = u + 4 * j < nslices ? part[(size_t)(u + 4 * j) * part_stride + (size_t)t * 64 + lane] : 0.f;
-    // input channels 16 u .. 16 u + 15: lane i of this wave's copy holds s0_t[i] and x_t[i]
-    const float s0v = s0[(size_t)t * 64 + lane], xt = x[(size_t)t * 64 + lane];
-    float bv[16], rv[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int i = 16 * u + j;
-        bv[j] = b3t[(i >> 5) * 2048 + lane * 32 + (i & 31)];      // W3R's two s0 k-tiles: B3[i][o]
-        rv[j] = root != nullptr ? root[i * 64 + lane] : 0.f;
-    }
-    float z = 0.f, zb = 0.f, r = 0.f;
-#pragma unroll
-    for (int j = 0; j < 32; ++j) z += zv[j];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        zb = fmaf(__shfl(s0v, 16 * u + j, 64), bv[j], zb);
-        r = fmaf(__shfl(xt, 16 * u + j, 64), rv[j], r);
-    }
-    red[0][u][lane] = z; red[1][u][lane] = zb; red[2][u][lane] = r;
-    __syncthreads();
-    if (u != 0) return;
-    z = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
-    zb = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
-    r = red[2][0][lane] + red[2][1][lane] + red[2][2][lane] + red[2][3][lane];
-    const int deg = row_ptr[t + 1] - row_ptr[t];
-    float s = z + zb;
-    if (aggr == MDNO_AGGR_MEAN) s /= (float)(deg > 1 ? deg : 1);
-    s += r;
-    if (bias != nullptr) s += bias[lane];
-    if (relu) s = fmaxf(s, 0.f);
-    y[(size_t)t * 64 + lane] = s;
-    if (xm_out != nullptr) {
-        const float m = wave_max(fabsf(s));
-        if (lane == 0) xm_out[t] = m;
-    }
-}
-
 }  // namespace
 
 // ---------------------------------------------------------------- host side
@@ -1384,12 +1047,6 @@ MomentWs moment_carve(void* ws, int num_rows, int ker_width) {
     return f;
 }
 
-static int moment_fused_mode() {      // EXPERIMENT: 1 = fused K1 -> K2; 2 = without its projection phase, 3 = without its stage loops (timing only)
-    static const int mode = getenv("MDNO_FUSED") ? atoi(getenv("MDNO_FUSED")) : 0;
-    return mode;
-}
-static bool moment_fused_enabled() { return moment_fused_mode() != 0; }
-
 int moment_prepare_weights(const float* w3, const float* b3, int ker_width, const MomentWs& f, hipStream_t s, int gemm_mode) {
     const long long total = (long long)(64 * ker_width + 64) * 64;
     hipLaunchKernelGGL(w3_moment_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w3, b3, ker_width, f.w3r);
@@ -1398,12 +1055,6 @@ int moment_prepare_weights(const float* w3, const float* b3, int ker_width, cons
         hipLaunchKernelGGL(w3_colmax_kernel, dim3(256), dim3(256), 0, s, (const float*)f.w3r, total / 2048, f.colmax_bits);
         hipLaunchKernelGGL(w3_planes_f16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)f.w3r, total,
                            (const int*)f.colmax_bits, f.w3h, f.colinv);
-        if (moment_fused_enabled()) {      // EXPERIMENT: the same planes in the fused kernel's B-fragment order (over w3h)
-            const long long nf = (long long)2 * 64 * ker_width * 64;
-            hipLaunchKernelGGL(w3_fragments_f16_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, s, w3, ker_width,
-                               (const int*)f.colmax_bits, f.w3h);
-            MDNO_HIP(hipMemsetAsync(f.counters, 0, 64 * sizeof(int), s));
-        }
     }
     return check_launch("w3_moment_kernel");
 }
@@ -1434,24 +1085,6 @@ int moment_conv(const float* x, const float* h2, const int* row_ptr, const int* 
     if (const char* v = getenv("MDNO_EXP_CACHE_MIB")) cached_bytes = (size_t)atoi(v) << 20;
 #endif
     const int cache_e = (int)(cached_bytes / ((size_t)ker_width * sizeof(float))) & ~127;      // whole 128-edge tiles of the image
-    if (f16 && moment_fused_enabled()) {
-        static std::atomic<unsigned long long> raised{0};
-        MDNO_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(moment_fused_kernel), FU_LDS, raised));
-        const int ntile = (num_rows + FU_T - 1) / FU_T, ncr = ker_width / FU_CR;
-        {
-            TimedSection ts(KID_NNCONV, s);
-            hipLaunchKernelGGL(moment_fused_kernel, dim3((unsigned)(8 * ntile * ((ncr + 7) / 8))), dim3(FU_THREADS), FU_LDS, s, h2,
-                               row_ptr, src, (const int*)f.order, f.s, x, xm_in, reinterpret_cast<const uint4*>(f.w3h), (const float*)f.colinv,
-                               f.part, f.part_stride, ker_width, num_rows, cache_e, f.counters, moment_fused_mode());
-        }
-        {
-            TimedSection ts(KID_NNCONV_COMBINE, s);
-            hipLaunchKernelGGL(finish_fused_kernel, dim3(num_rows), dim3(256), 0, s, (const float*)f.part, f.part_stride,
-                               ncr, row_ptr, (const float*)f.s, x, (const float*)(f.w3r + (size_t)(64 * ker_width / 32) * 2048), root,
-                               bias, y, aggr, relu, xm_out);
-        }
-        return check_launch("moment_fused");
-    }
     for (int r0 = 0; r0 < num_rows; r0 += kMomentChunkRows) {
         const int cnt = num_rows - r0 < kMomentChunkRows ? num_rows - r0 : kMomentChunkRows;
         {   // K1: the chunk's destinations x the k/256 column blocks

@@ -627,7 +627,7 @@ def leg_cfg5_shape_c(dev, atoms=50000, cutoff=10.0, steps=2, slice_edges=2_000_0
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / app_s / 1e9 / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_application": alg, "ms_per_application": app_s * 1e3,
                         "traffic": profiled_traffic("moment_kernel", N, 1, "factored", "split_f16")},
-           "conv_materialized_slice": conv_slice,
+           "conv_materialized_slice": conv_slice, "fallbacks": eng.fallback_counts(),
            "launch": "plain launches (event timer attached)"}
     eng.close()
     del eng
@@ -667,7 +667,7 @@ def leg_cfg2_1000_steps(dev, a, steps=1000):
            "seconds": dt, "finite": bool(torch.isfinite(fr).all()), "conv_mode": eng.conv_mode,
            "edges_first_last": [int(e[0].item()), int(e[-1].item())], "edges_min_max": [int(e.min().item()), int(e.max().item())],
            "max_displacement_from_start_A": float((fr[-1, 0] - fr[0, 0]).abs().max().item()),
-           "launch": "plain" if a.no_graph else "hipGraph replay"}
+           "launch": "plain" if a.no_graph else "hipGraph replay", "fallbacks": eng.fallback_counts()}
     eng.close()
     if not out["finite"]:
         raise RuntimeError("cfg2 1000-step rollout produced a non-finite frame")
@@ -707,7 +707,7 @@ def leg_shape_a(dev, a):
         eng.synchronize()
         dt = min(dts)
         r = {"members": M, "steps": steps, "frames_per_s": steps * M / dt, "ms_per_step": dt / steps * 1e3, "conv_mode": eng.conv_mode,
-             "repetitions_ms_per_step": [round(t / steps * 1e3, 4) for t in dts],
+             "repetitions_ms_per_step": [round(t / steps * 1e3, 4) for t in dts], "fallbacks": eng.fallback_counts(),
              "edges_per_member": float(eng.edges_per_step[warm:warm + steps].double().mean().item()) / M}
         eng.close()
         return r
@@ -758,6 +758,7 @@ def leg_rank_share(a, ensemble_leg, members=8, timeout_s=240):
     mg = d.get("multi_gpu_timing") or {}
     out = {"members": members, "steps": d["steps"], "warmup": d["warmup"], "frames_per_s": d["value"], "ms_per_step": d["ms_per_step"],
            "member_groups": d["config"]["member_groups_this_rank"], "conv_mode": d["config"]["conv_mode"],
+           "fallbacks": {k: v for k, v in (d.get("fallbacks") or {}).items() if k != "what"},
            "collective": {"backend": mg.get("backend"), "world_size": mg.get("world_size"),
                           "init_process_group_s": mg.get("init_process_group_s"), "first_gather_s": mg.get("first_gather_s"),
                           "timed_gather_ms": (mg.get("per_rank_gather_ms") or [None])[0],
@@ -962,6 +963,9 @@ def worker(a):
                      "first_gather_s": t_first_gather}
     eng.synchronize()   # raises on edge overflow / bad input
     assert full.shape == (a.steps, total_members, N, 3) and bool(torch.isfinite(full).all())
+    # which path the split_f16 products of the TIMED steps took (device counters, zeroed per step() call): all zero = two
+    # fp16 planes everywhere, the path the headline is quoted on; anything else = pieces redone on bf16 planes
+    fallbacks = eng.fallback_counts()
     eps = eng.edges_per_step[a.warmup:a.warmup + a.steps].double()
     e_mean = float(eps.mean().item())
     frames = a.steps * total_members
@@ -1131,7 +1135,7 @@ def worker(a):
         dte = time.perf_counter() - t0
         enge.synchronize()
         note(f"ensemble leg: {me} members on this GPU, {es * me / dte:.1f} frames/s")
-        ensemble_leg = {"members": me, "steps": es, "warmup": ew, "frames_per_s": es * me / dte,
+        ensemble_leg = {"members": me, "steps": es, "warmup": ew, "frames_per_s": es * me / dte, "fallbacks": enge.fallback_counts(),
                         "ms_per_step": dte / es * 1e3, "ms_per_member_step": dte / es / me * 1e3,
                         "conv_mode": enge.conv_mode, "member_groups": len(enge.engines) if isinstance(enge, GroupedRolloutEngine) else 1,
                         "note": "BASELINE configs[2] (64-member ensemble) on ONE GPU: the 1-GPU point of the "
@@ -1207,6 +1211,9 @@ def worker(a):
                                       f"trajectories ({(backend + (' world 1, forced' if force_dist else '')) if use_dist else 'none'})",
                        "launch": "plain" if a.no_graph else "hipGraph replay", "edge_mlp_gemm": a.gemm_mode,
                        "variant": a.variant, "conv_mode": mode, "conv_mode_requested": a.conv_mode},
+            "fallbacks": dict(fallbacks, what="pieces of the timed steps that left the two-fp16-plane path (this rank): K1 "
+                              "workgroups rerun on bf16 planes, destinations with unscaled operands, edge-MLP products on "
+                              "bf16 planes; expected all zero on the benchmark's weights"),
             "roofline": dominant, "rooflines": roofs, "other_conv_mode": other_mode,
             "ensemble64_single_gpu": ensemble_leg,
             # the like-for-like 1-GPU point of the N > 1 series (same 64-member workload): divide an N-GPU

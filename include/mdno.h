@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDNO_ABI_VERSION 14
+#define MDNO_ABI_VERSION 15
 
 #define MDNO_OK            0
 #define MDNO_EINVAL       -1   /* bad argument (null pointer, non-positive size, unsupported dim) */
@@ -293,6 +293,25 @@ int mdno_rollout_plan_destroy(mdno_rollout_plan* plan);
 int mdno_rollout_plan_timer_attach(mdno_rollout_plan* plan, int max_records);
 int mdno_rollout_plan_timer_read(mdno_rollout_plan* plan, int kernel_id, double* total_ms, int64_t* count);
 int mdno_rollout_plan_timer_detach(mdno_rollout_plan* plan);
+
+/* Which path ran (ABI 15).  gemm_mode MDNO_GEMM_SPLIT_F16 takes its two-fp16-plane products where the operands' ranges
+ * allow it and redoes a piece on three bf16 planes where they do not (same result to fp32 rounding, more matrix work):
+ * the decisions are made on the device, per piece, and counted there.  The counters are zeroed by every
+ * mdno_rollout_plan_run and read here (the call synchronises `stream`, the stream the plan was run on):
+ *   counts[0]  K1 workgroups of the factored conv (one destination x 256 hidden units of one application) that ran
+ *              their stage loop again on bf16 planes (csrc/moment.hip: |H| staged by the workgroup left [2^-7, 2047),
+ *              or the destination's neighbours have no feature in [2^-100, 2^100))
+ *   counts[1]  destinations (per application) of the second kind: operands taken unscaled
+ *   counts[2]  edge-MLP products (one GEMM over one chunk of <= 262,144 edges) redone on bf16 planes
+ *              (csrc/edge_mlp_split.hip: an activation >= 65504, none >= 2^-10, or a non-finite weight)
+ *   counts[3]  reserved (0)
+ * All zero: every product of the run since the last plan_run was taken on fp16 planes.  Other GEMM modes: all zero. */
+int mdno_rollout_plan_fallback_counts(mdno_rollout_plan* plan, int64_t counts[4], void* stream);
+/* The same counters for ONE mdno_kernelnn_fwd call (which zeroes them when it starts): `workspace`, M, N, edge_cap and
+ * the params as given to that call; position_graph != 0 if it was given edge_pos and dst and no edge_attr (the
+ * workspace is laid out by the conv formulation that call resolved to).  Synchronises `stream`. */
+int mdno_kernelnn_fallback_counts(const mdno_kernelnn_params* p, int M, int N, int64_t edge_cap, int position_graph,
+                                  void* workspace, int64_t counts[4], void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Training ops (BASELINE configs[3]) — the backward of the kernel-integral block that autograd +

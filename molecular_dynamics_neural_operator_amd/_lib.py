@@ -14,7 +14,7 @@ LIB_PATH = Path(os.environ.get("MDNO_LIB", _HERE / "libmdno.so"))
 OK, EINVAL, ELAUNCH, EWORKSPACE, EUNSUPPORTED = 0, -1, -2, -3, -4
 AGGR = {"add": 0, "mean": 1, "max": 2}      # "max": mdno_nnconv_fwd only (inference)
 STATUS_EDGE_OVERFLOW, STATUS_BAD_AMINOACID = 1, 2
-ABI_VERSION = 14
+ABI_VERSION = 15
 GEMM_MODES = {"split_bf16": 0, "f32": 1, "split_f16": 2}
 CONV_MODES = {"materialized": 0, "factored": 1, "auto": 2}
 STATUS_BAD_EDGE_INDEX = 16
@@ -78,6 +78,8 @@ SIGNATURES = {
     "mdno_rollout_plan_timer_attach": (_I, [_P, _I]),
     "mdno_rollout_plan_timer_read": (_I, [_P, _I, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "mdno_rollout_plan_timer_detach": (_I, [_P]),
+    "mdno_rollout_plan_fallback_counts": (_I, [_P, _P, _P]),
+    "mdno_kernelnn_fallback_counts": (_I, [C.POINTER(KernelNNParams), _I, _I, _L, _I, _P, _P, _P]),
     "mdno_linear_fwd": (_I, [_P, _P, _P, _L, _I, _I, _I, _P, _P]),
     "mdno_linear_split_workspace_bytes": (_SZ, [_L, _I, _I]),
     "mdno_linear_split_fwd": (_I, [_P, _P, _P, _L, _I, _I, _I, _P, _P, _SZ, _P]),
@@ -170,7 +172,9 @@ def load() -> C.CDLL:
     if ver != ABI_VERSION:
         raise MdnoError(f"libmdno ABI {ver} != binding {ABI_VERSION}; rebuild the library")
     want, have = source_build_id(), lib.mdno_build_id().decode()
-    if want is not None and have != want and "MDNO_LIB" not in os.environ:
+    # (an experimental build — scripts/micro/build_exp.sh, loaded through MDNO_LIB — says so in its build id; MDNO_LIB
+    # pointing at any other library, the in-tree one included, does not switch the check off)
+    if want is not None and have != want and have != "experimental":
         raise MdnoError(f"{LIB_PATH} was built from other sources (build id {have}, the tree is {want}): run "
                         f"molecular_dynamics_neural_operator_amd/csrc/build.sh — a stale library is never used")
     _lib = lib

@@ -46,6 +46,10 @@ inline int check_launch(const char* what) {
 
 constexpr int kWave = 64;  // CDNA4 wavefront
 
+// ReLU as torch.relu has it: a NaN stays a NaN (fmaxf(NaN, 0) — v_max_f32 — returns 0: a non-finite weight or activation
+// would be turned into a finite zero at the next ReLU and never reach the output, where the reference shows it), -0 -> +0
+__device__ __forceinline__ float relu_f(float v) { return v <= 0.f ? 0.f : v; }
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: raise it once per
 // (call site, device).  `done` is that call site's device bitmask — a cache of "already raised", not
 // state a caller can observe; two threads racing on a first use both set the (idempotent) attribute.

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void edge_l0_kernel(
 #pragma unroll
             for (int f = 0; f < MAX_F; ++f) s = fmaf(attr[le][f], w[f], s);
             s += bc;
-            h[(size_t)(e - e_begin) * k + c] = fmaxf(s, 0.f);
+            h[(size_t)(e - e_begin) * k + c] = relu_f(s);
         }
     }
 }
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_mfma_kernel(GemmArgs g) {
                 const int m = bm + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (m < valid) {
                     float v = acc[i][j][r] + bv;
-                    if (RELU) v = fmaxf(v, 0.f);
+                    if (RELU) v = relu_f(v);
                     if (g.tiled_out)
                         g.C[((size_t)(m >> 7) * (g.N >> 5) + (n >> 5)) * 4096 + (m & 127) * 32 + (n & 31)] = v;
                     else
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void gemm_tn_generic_kernel(GemmArgs g) {
     }
     if (m < valid && n < g.N) {
         float v = s + (g.bias ? g.bias[n] : 0.f);
-        if (RELU) v = fmaxf(v, 0.f);
+        if (RELU) v = relu_f(v);
         g.C[(size_t)m * g.N + n] = v;
     }
 }

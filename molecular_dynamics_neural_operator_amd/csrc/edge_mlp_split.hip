@@ -62,7 +62,14 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // current forward is out of fp16 range; flags[2], flags[3]: h1 / h2 of the current forward hold at least one
 // value >= F16_ACT_MIN (split_layout.h: below that the two-plane form has only an absolute error bound).
 // `need`: which of flags[2], flags[3] (bit 0, bit 1) the product's operands depend on.  Any failure sends
-// the chunk down the bf16 path.
+// the chunk down the bf16 path.  flags[F16_FALLBACK_COUNT] counts the products (GEMM launches) that took it
+// (never reset by the library's forwards: a rollout plan zeroes it per run and reads it back, include/mdno.h).
+constexpr int F16_FALLBACK_COUNT = 8;
+// grid of a bf16 FALLBACK launch (one that exits at once unless a flag is up): a launch that is not needed then costs a
+// kernel boundary, not the dispatch of a capacity-sized grid (thousands of workgroups); when it IS needed its workgroups
+// walk the tiles with this stride
+constexpr int kFallbackGemmGrid = 512, kFallbackL0RowTiles = 32;
+
 __device__ __forceinline__ bool f16_blocked(const int* __restrict__ flags, int need) {
     bool b = (__builtin_nontemporal_load(flags) | __builtin_nontemporal_load(flags + 1)) != 0;
     if (need & 1) b |= __builtin_nontemporal_load(flags + 2) == 0;
@@ -192,65 +199,88 @@ __global__ __launch_bounds__(256) void edge_l0_split_kernel(
     unsigned char* const hph = MODE == 2 ? hp_f16 : hp;
     const int Fn = FT ? FT : F;
     const long long E = *num_edges;
+    const int u0 = blockIdx.y * UNITS, tid = threadIdx.x;
+    const int lane = tid & 63, r = (tid >> 6) * 32 + (lane >> 1), half = lane & 1;
+    const int nkt = k >> 4;
+    auto load_weights = [&]() {
+        for (int i = tid; i < UNITS * Fn; i += 256) wsh[i] = w0[(size_t)u0 * Fn + i];
+        if (tid < UNITS) bsh[tid] = b0[u0 + tid];
+    };
+    // this thread's edge of the row tile at tile0 (relative to the chunk): its attributes
+    auto gather = [&](long long tile0, float (&attr)[MAX_F], long long& le) -> bool {
+        le = tile0 + r;
+        const long long e = e_begin + le;
+        const bool valid = e < E && le < e_count;
+#pragma unroll
+        for (int f = 0; f < MAX_F; ++f) attr[f] = 0.f;
+        if (valid) {
+            if (frames != nullptr) {  // attr = [pos[src], pos[dst]]   (graph_kernel.py:372-379)
+                const float* edge_pos = frames + (size_t)(frame + (t_dev ? *t_dev : 0)) * rows_per_frame * 3;
+                const float* ps = edge_pos + (size_t)src[e] * 3;
+                const float* pd = edge_pos + (size_t)dst[e] * 3;
+                attr[0] = ps[0]; attr[1] = ps[1]; attr[2] = ps[2];
+                attr[3] = pd[0]; attr[4] = pd[1]; attr[5] = pd[2];
+            } else {
+                const long long pe = perm ? (long long)perm[e] : e;
+#pragma unroll
+                for (int f = 0; f < MAX_F; ++f)
+                    if (f < Fn) attr[f] = edge_attr[pe * Fn + f];
+            }
+        }
+        return valid;
+    };
+    bool bad = false, seen = false;
+    auto compute = [&](const float (&attr)[MAX_F], long long le) {
+#pragma unroll 2
+        for (int t = 0; t < UNITS / 16; ++t) {
+            const int c = t * 16 + half * 8;       // this thread's 8 hidden units, relative to u0
+            __bf16 o[3][8];
+            _Float16 oh[2][8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float sum = 0.f;
+#pragma unroll
+                for (int f = 0; f < MAX_F; ++f)
+                    if (f < Fn) sum = fmaf(attr[f], wsh[(c + j) * Fn + f], sum);
+                const float v = relu_f(sum + bsh[c + j]);
+                if (F16) {
+                    bad |= !(v < F16_MAX);
+                    seen |= v >= F16_ACT_MIN;
+                    split2h(v, oh[0][j], oh[1][j]);
+                }
+                if (BF16) split3(v, o[0][j], o[1][j], o[2][j]);
+            }
+            if (F16) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+                    *reinterpret_cast<uint4*>(hph + tiled_off2(le, u0 + c, nkt, p)) = *reinterpret_cast<const uint4*>(oh[p]);
+            }
+            if (BF16) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    *reinterpret_cast<uint4*>(hp + tiled_off(le, u0 + c, nkt, p)) = *reinterpret_cast<const uint4*>(o[p]);
+            }
+        }
+    };
+    float attr[MAX_F];
+    long long le;
+    if constexpr (MODE == 0) {
+        // the bf16 image alone: the launch's workgroups walk the row tiles with stride gridDim.x (a fallback launch has
+        // kFallbackL0RowTiles of them, a launch of gemm_mode SPLIT_BF16 one per tile)
+        load_weights();
+        __syncthreads();
+        for (long long tile0 = (long long)blockIdx.x * L0_ROWS; e_begin + tile0 < E && tile0 < e_count;
+             tile0 += (long long)gridDim.x * L0_ROWS)
+            if (gather(tile0, attr, le)) compute(attr, le);
+        return;
+    }
     const long long tile0 = (long long)blockIdx.x * L0_ROWS;   // first row of this tile inside the chunk
     if (e_begin + tile0 >= E || tile0 >= e_count) return;
-    const int u0 = blockIdx.y * UNITS, tid = threadIdx.x;
-    for (int i = tid; i < UNITS * Fn; i += 256) wsh[i] = w0[(size_t)u0 * Fn + i];
-    if (tid < UNITS) bsh[tid] = b0[u0 + tid];
-    const int lane = tid & 63, r = (tid >> 6) * 32 + (lane >> 1), half = lane & 1;
-    const long long le = tile0 + r, e = e_begin + le;
-    const bool valid = e < E && le < e_count;
-    float attr[MAX_F];
-#pragma unroll
-    for (int f = 0; f < MAX_F; ++f) attr[f] = 0.f;
-    if (valid) {
-        if (frames != nullptr) {  // attr = [pos[src], pos[dst]]   (graph_kernel.py:372-379)
-            const float* edge_pos = frames + (size_t)(frame + (t_dev ? *t_dev : 0)) * rows_per_frame * 3;
-            const float* ps = edge_pos + (size_t)src[e] * 3;
-            const float* pd = edge_pos + (size_t)dst[e] * 3;
-            attr[0] = ps[0]; attr[1] = ps[1]; attr[2] = ps[2];
-            attr[3] = pd[0]; attr[4] = pd[1]; attr[5] = pd[2];
-        } else {
-            const long long pe = perm ? (long long)perm[e] : e;
-#pragma unroll
-            for (int f = 0; f < MAX_F; ++f)
-                if (f < Fn) attr[f] = edge_attr[pe * Fn + f];
-        }
-    }
+    load_weights();
+    const bool valid = gather(tile0, attr, le);
     __syncthreads();
     if (!valid) return;
-    const int nkt = k >> 4;
-    bool bad = false, seen = false;
-#pragma unroll 2
-    for (int t = 0; t < UNITS / 16; ++t) {
-        const int c = t * 16 + half * 8;       // this thread's 8 hidden units, relative to u0
-        __bf16 o[3][8];
-        _Float16 oh[2][8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float sum = 0.f;
-#pragma unroll
-            for (int f = 0; f < MAX_F; ++f)
-                if (f < Fn) sum = fmaf(attr[f], wsh[(c + j) * Fn + f], sum);
-            const float v = fmaxf(sum + bsh[c + j], 0.f);
-            if (F16) {
-                bad |= !(v < F16_MAX);
-                seen |= v >= F16_ACT_MIN;
-                split2h(v, oh[0][j], oh[1][j]);
-            }
-            if (BF16) split3(v, o[0][j], o[1][j], o[2][j]);
-        }
-        if (F16) {
-#pragma unroll
-            for (int p = 0; p < 2; ++p)
-                *reinterpret_cast<uint4*>(hph + tiled_off2(le, u0 + c, nkt, p)) = *reinterpret_cast<const uint4*>(oh[p]);
-        }
-        if (BF16) {
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-                *reinterpret_cast<uint4*>(hp + tiled_off(le, u0 + c, nkt, p)) = *reinterpret_cast<const uint4*>(o[p]);
-        }
-    }
+    compute(attr, le);
     if (F16 && bad) atomicOr(f16_flags + 1, 1);
     if (F16 && seen) f16_flags[2] = 1;      // (the same value from whoever stores it: no atomic)
 }
@@ -261,7 +291,9 @@ static int launch_edge_l0_split(const float* pos_mode, int frame, const int* t_d
                                 long long e0, int cnt, int F, int k, const float* w0, const float* b0,
                                 unsigned char* hp, hipStream_t s, bool f16 = false, int* f16_flags = nullptr,
                                 int f16_need = 0, unsigned char* hp_f16 = nullptr) {
-    const dim3 grid((cnt + L0_ROWS - 1) / L0_ROWS, k / (hp_f16 ? L0_UNITS_SMALL : L0_UNITS));
+    int row_tiles = (cnt + L0_ROWS - 1) / L0_ROWS;
+    if (!f16 && f16_flags != nullptr && row_tiles > kFallbackL0RowTiles) row_tiles = kFallbackL0RowTiles;      // fallback launch
+    const dim3 grid(row_tiles, k / (hp_f16 ? L0_UNITS_SMALL : L0_UNITS));
     // hp_f16 given: both images (bf16 planes -> hp, fp16 planes -> hp_f16)
 #define MDNO_L0(FT, MODE)                                                                                             \
     hipLaunchKernelGGL((edge_l0_split_kernel<FT, MODE>), grid, dim3(256), 0, s, pos_mode, frame, t_dev, rows_per_frame, \
@@ -326,25 +358,16 @@ __device__ __forceinline__ void mma_split_stage(f32x16 (&acc)[2][2], const unsig
 // OUT: 0 = fp32 row-major (W_e), 1 = tiled bf16 planes after ReLU (next GEMM's operand),
 //      2 = fp32 k-tiled [rows/128][N/32][128][32] after ReLU (the hidden activation the factored conv streams)
 //      3 = fp32 row-major after ReLU (training: mdno_linear_split_fwd)
+// one TM x 128 tile of the product: tile `orig` of `nwg` in the XCD-aware order
 template <int TM, int OUT>
-// (second launch bound = waves per SIMD, not workgroups per CU; the LDS footprint decides the latter)
-__global__ __launch_bounds__(TM * 2, 2) void gemm_split_bf16_kernel(SplitGemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+__device__ __forceinline__ void gemm_split_bf16_tile(const SplitGemmArgs& g, unsigned char* lds, long long valid, int nwg, int orig) {
     constexpr int WAVES = TM / 32;                       // (TM/64) x 2 waves of 64x64
     constexpr int STAGE_BYTES = stage_bytes(TM);
     constexpr int PIECES = STAGE_BYTES / 1024;           // 1 KiB DMA pieces per stage: 24 or 36
     constexpr int A_PIECES = PIECES - 12;
     constexpr int PPW = (PIECES + WAVES - 1) / WAVES;    // pieces per wave: 6 or 5
-
-    if (g.f16_flags != nullptr && !f16_blocked(g.f16_flags, g.f16_need)) return;   // bf16 fallback launch, not needed
-    long long valid = g.num_edges ? (long long)(*g.num_edges) - g.row_begin : (long long)g.rows_valid;
-    if (valid > g.rows) valid = g.rows;
-    if (valid <= 0) return;
     // XCD-aware tile order over the tiles that hold valid rows: workgroups b, b+8, ... share an XCD
     // (round-robin dispatch); give each XCD a contiguous range of tiles.  Bijective for any count.
-    const int nwg = g.tiles_n * (int)((valid + TM - 1) / TM);
-    const int orig = blockIdx.x;
-    if (orig >= nwg) return;
     const int xcd = orig & 7, q = nwg >> 3, r8 = nwg & 7;
     const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
     const int tiles_mv = nwg / g.tiles_n;
@@ -440,20 +463,42 @@ __global__ __launch_bounds__(TM * 2, 2) void gemm_split_bf16_kernel(SplitGemmArg
                 if (m < valid) {
                     const float v = acc[i][j][e] + bv;
                     if (OUT == 2) {   // k-tiled fp32 image [m/128][n/32][128][32] (csrc/moment.hip K1)
-                        g.C[((size_t)(m >> 7) * (g.N >> 5) + (n >> 5)) * 4096 + (m & 127) * 32 + (n & 31)] = fmaxf(v, 0.f);
+                        g.C[((size_t)(m >> 7) * (g.N >> 5) + (n >> 5)) * 4096 + (m & 127) * 32 + (n & 31)] = relu_f(v);
                     } else if (OUT == 1) {
                         __bf16 ph, pm, pl;
-                        split3(fmaxf(v, 0.f), ph, pm, pl);
+                        split3(relu_f(v), ph, pm, pl);
                         const size_t o = tiled_off(m, n, g.N >> 4, 0);
                         *reinterpret_cast<__bf16*>(g.Cp + o) = ph;
                         *reinterpret_cast<__bf16*>(g.Cp + o + PLANE_BYTES) = pm;
                         *reinterpret_cast<__bf16*>(g.Cp + o + 2 * PLANE_BYTES) = pl;
                     } else {
-                        g.C[(size_t)m * g.N + n] = OUT == 3 ? fmaxf(v, 0.f) : v;
+                        g.C[(size_t)m * g.N + n] = OUT == 3 ? relu_f(v) : v;
                     }
                 }
             }
         }
+    }
+}
+
+// STRIDE: a FALLBACK launch of the SPLIT_F16 mode (g.f16_flags given): it exits at once unless a range flag is up, so it
+// gets a small grid (kFallbackGemmGrid) whose workgroups walk the tiles, and it counts itself (F16_FALLBACK_COUNT).
+template <int TM, int OUT, bool STRIDE = false>
+// (second launch bound = waves per SIMD, not workgroups per CU; the LDS footprint decides the latter)
+__global__ __launch_bounds__(TM * 2, 2) void gemm_split_bf16_kernel(SplitGemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    if (g.f16_flags != nullptr && !f16_blocked(g.f16_flags, g.f16_need)) return;   // bf16 fallback launch, not needed
+    if (g.f16_flags != nullptr && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(const_cast<int*>(g.f16_flags) + F16_FALLBACK_COUNT, 1);
+    long long valid = g.num_edges ? (long long)(*g.num_edges) - g.row_begin : (long long)g.rows_valid;
+    if (valid > g.rows) valid = g.rows;
+    if (valid <= 0) return;
+    const int nwg = g.tiles_n * (int)((valid + TM - 1) / TM);
+    if constexpr (STRIDE) {
+        for (int orig = blockIdx.x; orig < nwg; orig += gridDim.x) {
+            gemm_split_bf16_tile<TM, OUT>(g, lds, valid, nwg, orig);
+            __syncthreads();      // (the next tile's first DMA lands in the buffer the slowest wave may still read)
+        }
+    } else {
+        if ((int)blockIdx.x < nwg) gemm_split_bf16_tile<TM, OUT>(g, lds, valid, nwg, blockIdx.x);
     }
 }
 
@@ -688,9 +733,9 @@ __global__ __launch_bounds__(1024 / MI) void gemm_split_f16_kernel(SplitGemmArgs
                     if (ROW_SCALE) v *= ua[ROW_SCALE ? i : 0][e];
                     v += bv;
                     if (OUT == 2) {
-                        g.C[((size_t)(m >> 7) * (g.N >> 5) + (n >> 5)) * 4096 + (m & 127) * 32 + (n & 31)] = fmaxf(v, 0.f);
+                        g.C[((size_t)(m >> 7) * (g.N >> 5) + (n >> 5)) * 4096 + (m & 127) * 32 + (n & 31)] = relu_f(v);
                     } else if (OUT == 4) {
-                        const float rv = fmaxf(v, 0.f);
+                        const float rv = relu_f(v);
                         bad |= !(rv < F16_MAX);
                         seen |= rv >= F16_ACT_MIN;
                         _Float16 ph, pl;
@@ -699,7 +744,7 @@ __global__ __launch_bounds__(1024 / MI) void gemm_split_f16_kernel(SplitGemmArgs
                         *reinterpret_cast<_Float16*>(g.Cp + o) = ph;
                         *reinterpret_cast<_Float16*>(g.Cp + o + PLANE_BYTES) = pl;
                     } else {
-                        g.C[(size_t)m * g.N + n] = OUT == 3 ? fmaxf(v, 0.f) : v;
+                        g.C[(size_t)m * g.N + n] = OUT == 3 ? relu_f(v) : v;
                     }
                 }
             }
@@ -733,6 +778,7 @@ __global__ __launch_bounds__(128 * WM) void gemm_split_f16_small_kernel(SplitGem
     constexpr int A_BYTES = 4 * WM * 1024;                // A part of a stage: 4 runs (k-step, plane) of WM KiB
     const bool blocked = g.f16_flags != nullptr && f16_blocked(g.f16_flags, g.f16_need);
     if (blocked && g.Ap_b == nullptr) return;      // (the bf16 launch behind this one redoes the chunk)
+    if (blocked && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(const_cast<int*>(g.f16_flags) + F16_FALLBACK_COUNT, 1);
     long long valid = g.num_edges ? (long long)(*g.num_edges) - g.row_begin : (long long)g.rows_valid;
     if (valid > g.rows) valid = g.rows;
     if (valid <= 0) return;
@@ -870,7 +916,7 @@ __global__ __launch_bounds__(128 * WM) void gemm_split_f16_small_kernel(SplitGem
         float* patch = reinterpret_cast<float*>(lds) + wave * (32 * 40);
 #pragma unroll
         for (int e = 0; e < 16; ++e)
-            patch[((e & 3) + 8 * (e >> 2) + 4 * h) * 40 + l31] = fmaxf((acc[e] + accx[e] * F16_LO_UNSCALE) * us * ua[e] + bv, 0.f);
+            patch[((e & 3) + 8 * (e >> 2) + 4 * h) * 40 + l31] = relu_f((acc[e] + accx[e] * F16_LO_UNSCALE) * us * ua[e] + bv);
         // (LDS operations of one wave execute in order: no wait between its writes and its reads)
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
@@ -908,7 +954,7 @@ __global__ __launch_bounds__(128 * WM) void gemm_split_f16_small_kernel(SplitGem
         const int m = bm + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (m < valid) {
             const float v = (acc[e] + accx[e] * F16_LO_UNSCALE) * us * ua[e] + bv;
-            g.C[(size_t)m * g.N + n] = OUT == 3 ? fmaxf(v, 0.f) : v;
+            g.C[(size_t)m * g.N + n] = OUT == 3 ? relu_f(v) : v;
         }
     }
 }
@@ -964,6 +1010,14 @@ int launch_split_gemm_tm(SplitGemmArgs g, hipStream_t s) {
     MDNO_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(&gemm_split_bf16_kernel<TM, OUT>), lds_bytes, lds_raised));
     g.tiles_n = g.N / TN;
     g.tiles_m = g.rows / TM;
+    if (g.f16_flags != nullptr) {      // a fallback launch of SPLIT_F16: small grid, its workgroups walk the tiles
+        static std::atomic<unsigned long long> lds_raised_f{0};
+        MDNO_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(&gemm_split_bf16_kernel<TM, OUT, true>), lds_bytes, lds_raised_f));
+        const int tiles = g.tiles_n * g.tiles_m;
+        hipLaunchKernelGGL((gemm_split_bf16_kernel<TM, OUT, true>), dim3(tiles < kFallbackGemmGrid ? tiles : kFallbackGemmGrid),
+                           dim3(TM * 2), lds_bytes, s, g);
+        return check_launch("split-bf16 GEMM (fallback)");
+    }
     hipLaunchKernelGGL((gemm_split_bf16_kernel<TM, OUT>), dim3(g.tiles_n * g.tiles_m), dim3(TM * 2), lds_bytes,
                        s, g);
     return check_launch("split-bf16 GEMM");
@@ -1122,6 +1176,7 @@ size_t edge_mlp_split_workspace_bytes(int ker_width, int out_dim, long long chun
     return carve_split(nullptr, ker_width, out_dim, chunk).total;
 }
 
+// (the word behind the flags that counts the products redone on bf16 planes: activation flags + 7)
 int* edge_mlp_split_activation_flags(void* workspace, int ker_width, int out_dim, long long chunk) {
     return carve_split(workspace, ker_width, out_dim, chunk).f16_flags + 1;
 }

@@ -125,6 +125,33 @@ FwdWs carve_fwd(void* ws, const mdno_kernelnn_params* p, int M, int N, long long
     return f;
 }
 
+// device words counting the SPLIT_F16 fallbacks of a forward workspace (mdno_*_fallback_counts): the factored conv's
+// (two ints) and the edge-MLP's (one int); NULL where the configuration has none
+void fwd_counter_words(const mdno_kernelnn_params* p, const FwdWs& fw, int M, int N, long long edge_cap, int** conv, int** mlp) {
+    *conv = nullptr;
+    *mlp = nullptr;
+    if (p->gemm_mode != MDNO_GEMM_SPLIT_F16) return;
+    if (fw.factored) *conv = moment_carve(fw.fact, M * N, p->ker_width).counters;
+    int* act = edge_mlp_activation_flags(fw.mlp, p->ker_width, fw.factored ? p->ker_width : p->width * p->width, edge_cap,
+                                         p->gemm_mode);
+    if (act) *mlp = act + 7;      // (edge_mlp_split.hip: flags[F16_FALLBACK_COUNT = 8]; act = flags + 1)
+}
+
+int zero_counter_words(int* conv, int* mlp, hipStream_t s) {
+    if (conv) MDNO_HIP(hipMemsetAsync(conv, 0, 2 * sizeof(int), s));
+    if (mlp) MDNO_HIP(hipMemsetAsync(mlp, 0, sizeof(int), s));
+    return MDNO_OK;
+}
+
+int read_counter_words(const int* conv, const int* mlp, int64_t counts[4], hipStream_t s) {
+    int host[3] = {0, 0, 0};
+    if (conv) MDNO_HIP(hipMemcpyAsync(host, conv, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    if (mlp) MDNO_HIP(hipMemcpyAsync(host + 2, mlp, sizeof(int), hipMemcpyDeviceToHost, s));
+    MDNO_HIP(hipStreamSynchronize(s));
+    counts[0] = host[0]; counts[1] = host[1]; counts[2] = host[2]; counts[3] = 0;
+    return MDNO_OK;
+}
+
 // frames/t0/t_dev address the window; edge_frames/edge_frame the frame the graph was built on.
 int forward_impl(const mdno_kernelnn_params* p, const float* frames, int t0, const int* t_dev, int M, int W, int N,
                  const long long* aa, int aa_per_member, const int* row_ptr, const int* src, const int* dst,
@@ -273,9 +300,24 @@ extern "C" int mdno_kernelnn_fwd(const mdno_kernelnn_params* p, const float* fra
                          use_factored(p, M, (long long)edge_cap, edge_pos && !edge_attr && dst));
     MDNO_REQUIRE(workspace_bytes >= ws.total, MDNO_EWORKSPACE, "mdno_kernelnn_fwd: workspace %zu < %zu",
                  workspace_bytes, ws.total);
+    {   // the fallback counters of this forward (mdno_kernelnn_fallback_counts)
+        int *conv = nullptr, *mlp = nullptr;
+        fwd_counter_words(p, ws, M, N, (long long)edge_cap, &conv, &mlp);
+        MDNO_TRY(zero_counter_words(conv, mlp, static_cast<hipStream_t>(stream)));
+    }
     return forward_impl(p, frames, 0, nullptr, M, W, N, (const long long*)x_aminoacid, aa_per_member, row_ptr, src,
                         dst, num_edges, (long long)edge_cap, edge_pos, 0, edge_attr, perm, out, 0, latent, ws,
                         status, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int mdno_kernelnn_fallback_counts(const mdno_kernelnn_params* p, int M, int N, int64_t edge_cap,
+                                            int position_graph, void* workspace, int64_t counts[4], void* stream) {
+    MDNO_TRY(validate_params(p));
+    MDNO_REQUIRE(workspace && counts && M > 0 && N > 0 && edge_cap > 0, MDNO_EINVAL, "mdno_kernelnn_fallback_counts: bad arguments");
+    const FwdWs ws = carve_fwd(workspace, p, M, N, (long long)edge_cap, use_factored(p, M, (long long)edge_cap, position_graph != 0));
+    int *conv = nullptr, *mlp = nullptr;
+    fwd_counter_words(p, ws, M, N, (long long)edge_cap, &conv, &mlp);
+    return read_counter_words(conv, mlp, counts, static_cast<hipStream_t>(stream));
 }
 
 extern "C" size_t mdno_rollout_workspace_bytes(const mdno_kernelnn_params* p, int M, int N, int64_t edge_cap) {
@@ -314,6 +356,10 @@ struct mdno_rollout_plan {
     Timer* timer;
     bool weights_cached;   // weight-derived operands are rebuilt per plan_run call, not per step
 };
+
+static void plan_counter_words(const mdno_rollout_plan* pl, int** conv, int** mlp) {
+    fwd_counter_words(&pl->p, pl->fw, pl->M, pl->N, pl->edge_cap, conv, mlp);
+}
 
 // The bf16 plane images of W1 (/W2) and W3T depend on the weights only: one workspace slot each, so
 // they can be kept across steps when conv1 and conv2 share one edge-MLP (always, for KernelNN).
@@ -446,6 +492,11 @@ extern "C" int mdno_rollout_plan_run(mdno_rollout_plan* pl, int start_step, int 
     hipLaunchKernelGGL(set_step_kernel, dim3(1), dim3(256), 0, s, pl->r.t_dev, start_step, pl->r.row_done,
                        (long long)pl->M * pl->N <= 256 ? 256 : 0);
     MDNO_TRY(check_launch("set_step"));
+    {   // the fallback counters of this run
+        int *conv = nullptr, *mlp = nullptr;
+        plan_counter_words(pl, &conv, &mlp);
+        MDNO_TRY(zero_counter_words(conv, mlp, s));
+    }
     // the weights may have been updated in place since the last call: refresh their images once
     if (pl->weights_cached) MDNO_TRY(plan_prepare_weights(pl, s));
     for (int t = 0; t < steps; ++t) {
@@ -511,6 +562,13 @@ extern "C" int mdno_rollout_plan_timer_detach(mdno_rollout_plan* pl) {
     delete pl->timer;
     pl->timer = nullptr;
     return MDNO_OK;
+}
+
+extern "C" int mdno_rollout_plan_fallback_counts(mdno_rollout_plan* pl, int64_t counts[4], void* stream) {
+    MDNO_REQUIRE(pl != nullptr && counts != nullptr, MDNO_EINVAL, "mdno_rollout_plan_fallback_counts: null argument");
+    int *conv = nullptr, *mlp = nullptr;
+    plan_counter_words(pl, &conv, &mlp);
+    return read_counter_words(conv, mlp, counts, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int mdno_rollout_plan_destroy(mdno_rollout_plan* pl) {

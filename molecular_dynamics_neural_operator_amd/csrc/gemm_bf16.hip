@@ -404,7 +404,7 @@ tile_loop:      // (PERSIST: one pass per tile of this workgroup; otherwise a si
             for (int e = 0; e < 16; ++e) {
                 const int r = (e & 3) + 8 * (e >> 2) + 4 * h;
                 float v = acc[i][j][e] + bv;
-                if (RELU) v = fmaxf(v, 0.f);
+                if (RELU) v = relu_f(v);
                 unsigned char* dst = patch + r * PATCH_ROW + (j * 32 + l31) * ESZ;
                 if (OBF) *reinterpret_cast<__bf16*>(dst) = (__bf16)v;
                 else *reinterpret_cast<float*>(dst) = v;

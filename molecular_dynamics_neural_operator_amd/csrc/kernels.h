@@ -112,7 +112,7 @@ struct MomentWs {
     int* colmax_bits;
     float* rowmax;
     float* xm[2];             // every node's largest |feature|: of a conv application's input and of its output
-    int* counters;            // 64 ints
+    int* counters;            // 64 ints: [0] K1 workgroups rerun on bf16 planes, [1] destinations with unscaled operands (SPLIT_F16)
 };
 bool moment_supported(int width, int ker_width);
 size_t moment_workspace_bytes(int num_rows, int ker_width);

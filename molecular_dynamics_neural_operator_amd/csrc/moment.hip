@@ -154,9 +154,12 @@ __global__ __launch_bounds__(256) void w3_colmax_kernel(const float* __restrict_
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float4 v = row[j];
-            // (not fmaxf: a NaN must win, so that a non-finite weight reaches the output as the other paths have it)
+            // (not fmaxf: a NaN must win AND stay — once m is NaN no comparison below replaces it — so that a column with
+            // a non-finite weight gets scale 1 (f16_row_scale) and the value itself reaches the output through the planes,
+            // as in the other GEMM modes)
             const float a = fabsf(v.x), b = fabsf(v.y), c = fabsf(v.z), d = fabsf(v.w);
-            m = !(a <= m) ? a : m; m = !(b <= m) ? b : m; m = !(c <= m) ? c : m; m = !(d <= m) ? d : m;
+            m = (a > m || a != a) ? a : m; m = (b > m || b != b) ? b : m;
+            m = (c > m || c != c) ? c : m; m = (d > m || d != d) ? d : m;
         }
     }
     red[sub][o] = __builtin_bit_cast(int, m);      // non-negative floats (and NaN above Inf) order like their bits
@@ -291,6 +294,9 @@ __device__ __forceinline__ void moment_s0(const int* __restrict__ row_ptr, const
 // or none reached 2^-7 (floor 2^-30: split_layout.h's rule for activations — at most 2^-23 of the largest value), it runs
 // the loop again on the three bf16 planes (of the same scaled operands: exact scalings).  Both decisions are the
 // workgroup's own — one destination's edges —, so a destination's bits are the same alone or in any batch.
+// counters (MomentWs::counters; a rollout plan zeroes them per run and reads them back: mdno_rollout_plan_fallback_counts)
+constexpr int MOMENT_CNT_K1_RERUN = 0;      // K1 workgroups (destination x 256 hidden units) that ran their stage loop again on bf16 planes
+constexpr int MOMENT_CNT_X_PLAIN = 1;       // destinations whose neighbours have no feature in [2^-100, 2^100): unscaled operands
 constexpr int MO_F16_PRE_H_EXP = 5;      // H times 2^5: a workgroup's largest |H| may lie in [2^-7, 2047] (typical: 1 .. 10)
 constexpr float MO_F16_PRE_H = 32.f, MO_F16_H_LIM = F16_MAX / 32.f, MO_F16_H_MIN = 0.25f / 32.f;
 
@@ -299,7 +305,8 @@ __global__ __launch_bounds__(256, 3) void moment_kernel(const float* __restrict_
                                                         const int* __restrict__ row_ptr, const int* __restrict__ src,
                                                         const int* __restrict__ order, float* __restrict__ S, int K,
                                                         int row0, int cnt, const float* __restrict__ x, int cache_e,
-                                                        float* __restrict__ rowmax, const float* __restrict__ xm) {
+                                                        float* __restrict__ rowmax, const float* __restrict__ xm,
+                                                        int* __restrict__ counters) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[MO_LDS];
     __shared__ float wg_red[12];
     // workgroup ids b, b+8, b+16, .. share an XCD: a destination's k/256 column blocks (and its s0 workgroup) run there
@@ -331,7 +338,10 @@ __global__ __launch_bounds__(256, 3) void moment_kernel(const float* __restrict_
         xsc = x_plain ? 1.f : __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, f16_row_scale(m))));
         hsc = x_plain ? 1.f : MO_F16_PRE_H;
         __syncthreads();      // (wg_red is free again)
-        if (cq == 0 && tid == 0) rowmax[(size_t)tl * (nq + 1) + nq] = x_plain ? 0.f : (float)(f32_exponent(xsc) + MO_F16_PRE_H_EXP);
+        if (cq == 0 && tid == 0) {
+            rowmax[(size_t)tl * (nq + 1) + nq] = x_plain ? 0.f : (float)(f32_exponent(xsc) + MO_F16_PRE_H_EXP);
+            if (x_plain) atomicAdd(counters + MOMENT_CNT_X_PLAIN, 1);
+        }
     }
     if (cq == nq - 1) {
         moment_s0(row_ptr, src, x, S, K, t, tl, rowmax ? rowmax + (size_t)tl * (nq + 1) + cq : nullptr, xsc * hsc);
@@ -486,6 +496,7 @@ __global__ __launch_bounds__(256, 3) void moment_kernel(const float* __restrict_
         float mh, d;
         wg_max2(hmax, 0.f, mh, d);
         if (stages != 0 && (x_plain || !(mh < MO_F16_H_LIM && mh >= MO_F16_H_MIN))) {
+            if (tid == 0) atomicAdd(counters + MOMENT_CNT_K1_RERUN, 1);
             __syncthreads();      // (every wave has read wg_red; the stage buffers were free already)
             run(std::false_type{});
         }
@@ -640,10 +651,11 @@ __global__ __launch_bounds__(PJ_ROWS * 2) void project_kernel(const float* __res
     auto a_ptr = [&](int r) {
         return S + ((size_t)(NT * rg + (r >> 7)) * nkt + kt0) * 4096 + (r & 127) * 32 + scol;
     };
-    // 32-row groups past the last destination are not multiplied (wave >= live): their staging threads re-read a row
-    // of group 0 instead (always inside the image), so that every load and LDS store below is unconditional —
-    // straight-line code whose vmcnt waits the compiler can count
-    auto a_row = [&](int r) { return (r >> 5) < live ? r : (r & 31); };
+    // rows past the last destination (the tail of its 32-row group is multiplied but never stored, the groups behind it
+    // are not multiplied: wave >= live) re-read the LAST destination's row — written by K1, always inside the image — so
+    // that every load and LDS store below is unconditional (straight-line code whose vmcnt waits the compiler can count)
+    // and nothing K1 did not write goes through the matrix pipe
+    auto a_row = [&](int r) { return r < rows_here ? r : rows_here - 1; };
     const float* A0 = a_ptr(a_row(srow));
     const float* A1 = a_ptr(a_row(srow + RQ));
     const float* A2 = a_ptr(a_row(srow + 2 * RQ));
@@ -758,12 +770,11 @@ __global__ __launch_bounds__(512) void project_f16_kernel(const float* __restric
     const int first = rg * PJ_ROWS;
     const int rows_here = cnt - first < PJ_ROWS ? cnt - first : PJ_ROWS;
     const int live = (rows_here + 31) >> 5;
-    auto a_row = [&](int r) { return (r >> 5) < live ? r : (r & 31); };
+    auto a_row = [&](int r) { return r < rows_here ? r : rows_here - 1; };      // (as project_kernel: the last live row again)
     auto a_ptr = [&](int r) {
         return S + ((size_t)(NT * rg + (r >> 7)) * nkt + kt0) * 4096 + (r & 127) * 32 + scol;
     };
-    // the scale of a row: from the maxima of its nq column blocks (rows past the last destination: whatever is there —
-    // f16_row_scale returns a power of two for any bits, and nothing of those rows is stored)
+    // the scale of a row: from the maxima of its nq column blocks (rows past the last destination take the last one's)
     auto row_scale = [&](int r) {
         const float* m = rowmax + (size_t)(first + r) * (nq + 1);
         float v = 0.f;
@@ -973,7 +984,7 @@ __global__ __launch_bounds__(FN_CHAINS * 16) void finish_kernel(const float* __r
         }
         if (root != nullptr) { s.x += rs.x; s.y += rs.y; s.z += rs.z; s.w += rs.w; }
         if (bias != nullptr) { s.x += biasv.x; s.y += biasv.y; s.z += biasv.z; s.w += biasv.w; }
-        if (relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
+        if (relu) { s.x = relu_f(s.x); s.y = relu_f(s.y); s.z = relu_f(s.z); s.w = relu_f(s.w); }
         *reinterpret_cast<float4*>(y + (size_t)t * 64 + 4 * q) = s;
         if (xm_out != nullptr) {      // the row's largest |feature|: K1 on fp16 planes scales a destination's neighbours by it
             float m = fmaxf(fmaxf(fabsf(s.x), fabsf(s.y)), fmaxf(fabsf(s.z), fabsf(s.w)));
@@ -1014,37 +1025,35 @@ bool moment_supported(int width, int ker_width) { return width == 64 && ker_widt
 static int moment_nq(int ker_width) { return (ker_width + MO_CQ - 1) / MO_CQ + 1; }      // K1's column blocks + the s0 block
 static size_t s_chunk_floats(int num_rows, int ker_width) { return (size_t)(moment_chunk_rows(num_rows) / 128) * moment_nkt(ker_width) * 4096; }
 
+// ONE carve for the size and for the pointers (Carver(nullptr) only counts): the two cannot drift apart.  (Up to round 5
+// the size took xm as one run of 2 R floats while the carve took two 256-B-aligned runs of R: for R floats not a multiple
+// of 64 the second run's tail — and whatever was carved behind it — lay up to 256 B past the region.)
+static MomentWs moment_carve_impl(Carver& cv, int num_rows, int ker_width) {
+    MomentWs f{};
+    f.w3r = cv.take<float>((size_t)(64 * ker_width + 64) * 64);                       // W3R (+ the B3 rows)
+    f.s = cv.take<float>(s_chunk_floats(num_rows, ker_width));                         // S (+ s0), one chunk of destinations
+    f.part = cv.take<float>((size_t)PJ_SLICES * num_rows * 64);                        // K-slice partials of z
+    f.part_stride = (long long)num_rows * 64;
+    f.order = cv.take<int>((size_t)num_rows);                                          // destinations of each chunk by decreasing degree
+    f.w3h = cv.take<_Float16>((size_t)(64 * ker_width + 64) * 64 * 2);                 // W3R on two fp16 planes (SPLIT_F16)
+    f.colinv = cv.take<float>(64);                                                     // its columns' inverse scales
+    f.colmax_bits = cv.take<int>(64);                                                  // (their maxima, as bits)
+    f.rowmax = cv.take<float>((size_t)(moment_chunk_rows(num_rows) + 256) * (moment_nq(ker_width) + 1));   // row maxima of the S chunk (+ the rows' scale exponents)
+    f.xm[0] = cv.take<float>((size_t)num_rows);                                        // every node's largest |feature|: in,
+    f.xm[1] = cv.take<float>((size_t)num_rows);                                        // out
+    f.counters = cv.take<int>(64);                                                     // MOMENT_CNT_*
+    return f;
+}
+
 size_t moment_workspace_bytes(int num_rows, int ker_width) {
     Carver cv(nullptr);
-    cv.take<float>((size_t)(64 * ker_width + 64) * 64);                            // W3R (+ the B3 rows)
-    cv.take<float>(s_chunk_floats(num_rows, ker_width));                           // S (+ s0), one chunk of destinations
-    cv.take<float>((size_t)PJ_SLICES * num_rows * 64);                             // K-slice partials of z
-    cv.take<int>((size_t)num_rows);                                                // destinations of each chunk by decreasing degree
-    cv.take<_Float16>((size_t)(64 * ker_width + 64) * 64 * 2);                     // W3R on two fp16 planes (SPLIT_F16)
-    cv.take<float>(64);                                                            // its columns' inverse scales
-    cv.take<int>(64);                                                              // (their maxima, as bits)
-    cv.take<float>((size_t)(moment_chunk_rows(num_rows) + 256) * (moment_nq(ker_width) + 1));   // row maxima of the S chunk (+ the rows' scale exponents)
-    cv.take<float>((size_t)num_rows * 2);                                          // every node's largest |feature|: in, out
-    cv.take<int>(64);                                                              // counters
+    (void)moment_carve_impl(cv, num_rows, ker_width);
     return cv.used();
 }
 
 MomentWs moment_carve(void* ws, int num_rows, int ker_width) {
-    MomentWs f{};
     Carver cv(ws);
-    f.w3r = cv.take<float>((size_t)(64 * ker_width + 64) * 64);
-    f.s = cv.take<float>(s_chunk_floats(num_rows, ker_width));
-    f.part = cv.take<float>((size_t)PJ_SLICES * num_rows * 64);
-    f.part_stride = (long long)num_rows * 64;
-    f.order = cv.take<int>((size_t)num_rows);
-    f.w3h = cv.take<_Float16>((size_t)(64 * ker_width + 64) * 64 * 2);
-    f.colinv = cv.take<float>(64);
-    f.colmax_bits = cv.take<int>(64);
-    f.rowmax = cv.take<float>((size_t)(moment_chunk_rows(num_rows) + 256) * (moment_nq(ker_width) + 1));
-    f.xm[0] = cv.take<float>((size_t)num_rows);
-    f.xm[1] = cv.take<float>((size_t)num_rows);
-    f.counters = cv.take<int>(64);
-    return f;
+    return moment_carve_impl(cv, num_rows, ker_width);
 }
 
 int moment_prepare_weights(const float* w3, const float* b3, int ker_width, const MomentWs& f, hipStream_t s, int gemm_mode) {
@@ -1095,10 +1104,10 @@ int moment_conv(const float* x, const float* h2, const int* row_ptr, const int* 
                                    ker_width, r0, cnt, x);
             else if (f16)
                 hipLaunchKernelGGL(moment_kernel<true>, grid, dim3(256), 0, s, h2, row_ptr, src, (const int*)f.order, f.s, ker_width,
-                                   r0, cnt, x, cache_e, f.rowmax, xm_in);
+                                   r0, cnt, x, cache_e, f.rowmax, xm_in, f.counters);
             else
                 hipLaunchKernelGGL(moment_kernel<false>, grid, dim3(256), 0, s, h2, row_ptr, src, (const int*)f.order, f.s, ker_width,
-                                   r0, cnt, x, cache_e, (float*)nullptr, (const float*)nullptr);
+                                   r0, cnt, x, cache_e, (float*)nullptr, (const float*)nullptr, (int*)nullptr);
         }
         {   // K2: groups of row tiles x K slices
             TimedSection ts(KID_FACT_Y, s);

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(WAVES * 64) void nnconv64_row_kernel(
         if (aggr == MDNO_AGGR_MEAN) s = s / (float)(deg > 1 ? deg : 1);
         if (root != nullptr) s += rootred[tid];
         if (bias != nullptr) s += bias[tid];
-        if (relu) s = fmaxf(s, 0.f);
+        if (relu) s = relu_f(s);
         y[(size_t)row * 64 + tid] = s;
         if (fc.out != nullptr) {
             // the output layer on this row, as fc_out_kernel computes it (one product per lane, xor tree, bias)
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(1024 / SPLIT) void nnconv64_colsplit_kernel(
             if (aggr == MDNO_AGGR_MEAN) s = s / (float)(deg > 1 ? deg : 1);
             if (root != nullptr) s += rootred[tid];
             if (bias != nullptr) s += bias[col];
-            if (relu) s = fmaxf(s, 0.f);
+            if (relu) s = relu_f(s);
             y[(size_t)row * 64 + col] = s;
         }
         if (fc.out != nullptr) {
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void nnconv_generic_kernel(
             s += m;
         }
         if (bias != nullptr) s += bias[o];
-        if (relu) s = fmaxf(s, 0.f);
+        if (relu) s = relu_f(s);
         y[(size_t)row * Cout + o] = s;
     }
 }

@@ -114,7 +114,7 @@ __device__ __forceinline__ void node_prologue_row(const PrologueArgs& a, int r, 
         for (int e = 0; e < a.emb_dim; ++e) s = fmaf(w[e], feat[e], s);
 #pragma unroll
         for (int k = 0; k < H; ++k) s = fmaf(w[a.emb_dim + k], feat[MAX_EMB + k], s);
-        a.x0[(size_t)r * a.width + o] = fmaxf(s, 0.f);
+        a.x0[(size_t)r * a.width + o] = relu_f(s);
     }
 }
 

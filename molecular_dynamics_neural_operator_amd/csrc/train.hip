@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(const float* __rest
                 const int m = bm + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (m < rows) {
                     float v = acc[i][j][e] + bv;
-                    if (RELU) v = fmaxf(v, 0.f);
+                    if (RELU) v = relu_f(v);
                     Cm[(size_t)m * N + n] = v;
                 }
             }
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void linear_generic_kernel(const float* __rest
     float s = 0.f;
     for (int k = 0; k < K; ++k) s = fmaf(a[k], b[k], s);
     s += bias ? bias[n] : 0.f;
-    if (RELU) s = fmaxf(s, 0.f);
+    if (RELU) s = relu_f(s);
     Cm[id] = s;
 }
 

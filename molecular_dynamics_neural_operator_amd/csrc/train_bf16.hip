@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void linear_smallk_bf16_kernel(const float* __
                     for (int k = 0; k < 8; ++k)
                         if (k < K) s = fmaf(av[k], wr[k][j], s);
                     s += br[j];
-                    v[j] = RELU ? fmaxf(s, 0.f) : s;
+                    v[j] = RELU ? relu_f(s) : s;
                 }
                 const uint2 lo = pack4_bf16(v[0], v[1], v[2], v[3]), hi = pack4_bf16(v[4], v[5], v[6], v[7]);
                 C[(size_t)r * groups + g0 + grp] = make_uint4(lo.x, lo.y, hi.x, hi.y);
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const __bf16* __restr
                 const long long m = bm + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (m < rows) {
                     float v = acc[i][j][e] + bv;
-                    if (RELU) v = fmaxf(v, 0.f);
+                    if (RELU) v = relu_f(v);
                     if (OUT_BF16) static_cast<__bf16*>(Cv)[(size_t)m * N + n] = (__bf16)v;
                     else static_cast<float*>(Cv)[(size_t)m * N + n] = v;
                 }
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(WAVES * 64) void nnconv64_bf16w_kernel(const float*
         if (aggr == MDNO_AGGR_MEAN) s = s / (float)(deg > 1 ? deg : 1);
         if (root != nullptr) s += rootred[tid];
         if (bias != nullptr) s += bias[tid];
-        if (relu) s = fmaxf(s, 0.f);
+        if (relu) s = relu_f(s);
         y[(size_t)row * 64 + tid] = s;
     }
 }

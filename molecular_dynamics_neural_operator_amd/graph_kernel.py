@@ -287,6 +287,13 @@ class KernelNN(nn.Module):
         # (edge capacity >= 24,576), materialized below.  forward(data) with an explicit
         # edge_index/edge_attr follows the same rule on its counted graph.
         self.conv_mode = "auto"
+        # gemm_mode "split_f16" decides on the device, piece by piece, whether a product runs on two fp16 planes or is
+        # redone on three bf16 planes (same result, more matrix work).  With `track_fallbacks = True` an inference
+        # forward(data) reads the device counters back into `last_fallback_counts` (ops.FALLBACK_KEYS; all zero = the
+        # fast path everywhere) at the cost of one stream synchronisation; RolloutEngine.fallback_counts() is the
+        # rollout's counterpart.
+        self.track_fallbacks = False
+        self.last_fallback_counts = None
 
     def __getstate__(self):
         # the cached ParamPack holds device pointers in a ctypes struct: never copied or pickled
@@ -378,10 +385,13 @@ class KernelNN(nn.Module):
             pack = self.param_pack(x_position.device, conv_mode=self._conv_mode_for_edges(
                 x_position.device, B, n_rows // B, int(data.edge_index.shape[1])))
             graph = ops.coo_to_csr(data.edge_index.to(x_position.device), n_rows, validate=_status is None, status=_status)
+            counts = {} if getattr(self, "track_fallbacks", False) else None
             out, latent = ops.kernelnn_forward(pack, ops.f32(x_position).reshape(W, B, n_rows // B, 3),
                                                data.x_aminoacid.to(x_position.device), graph,
                                                edge_attr=data.edge_attr.to(x_position.device), return_latent=return_latent,
-                                               check_status=_status is None)
+                                               check_status=_status is None, fallback_counts=counts)
+            if counts is not None:
+                self.last_fallback_counts = counts
         return [out, latent] if return_latent else out
 
 

@@ -229,11 +229,18 @@ def node_prologue(pack: ParamPack, frames: torch.Tensor, x_aminoacid: torch.Tens
     return x0
 
 
+FALLBACK_KEYS = ("conv_k1_workgroups_rerun_bf16", "conv_destinations_unscaled", "edge_mlp_products_bf16")
+
+
 def kernelnn_forward(pack: ParamPack, frames: torch.Tensor, x_aminoacid: torch.Tensor, graph: CSRGraph,
                      edge_pos: Optional[torch.Tensor] = None, edge_attr: Optional[torch.Tensor] = None,
                      return_latent: bool = False, workspace: Optional[torch.Tensor] = None,
-                     check_status: bool = True) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+                     check_status: bool = True, fallback_counts: Optional[dict] = None
+                     ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """frames f32 [W,M,N,3] (time-major) -> out [M*N,out_width] (+ latent [M*N,width]).
+    `fallback_counts`: a dict that receives which path gemm_mode "split_f16" took in this forward (FALLBACK_KEYS:
+    all zero = every product on two fp16 planes; include/mdno.h mdno_kernelnn_fallback_counts) — reading it
+    synchronises the stream.
     The device status word (bad amino-acid id, edge overflow, bad edge index) is read back and
     raised after the call — the reference's nn.Embedding raises IndexError at that point; pass
     `check_status=False` to keep the call asynchronous and read `graph.status` yourself."""
@@ -265,6 +272,11 @@ def kernelnn_forward(pack: ParamPack, frames: torch.Tensor, x_aminoacid: torch.T
                                 ptr(ea),
                                 ptr(graph.perm) if ea is not None else None, ptr(out), ptr(latent), ptr(workspace),
                                 workspace.numel(), ptr(status), stream_ptr(dev)), "mdno_kernelnn_fwd")
+    if fallback_counts is not None:
+        cnt = (C.c_int64 * 4)()
+        check(lib.mdno_kernelnn_fallback_counts(pack.ref, M, N, graph.edge_cap, int(ep is not None and ea is None and graph.dst is not None),
+                                                ptr(workspace), cnt, stream_ptr(dev)), "mdno_kernelnn_fallback_counts")
+        fallback_counts.update({k: int(cnt[i]) for i, k in enumerate(FALLBACK_KEYS)})
     if check_status:
         raise_on_status(status.item(), "kernelnn_forward")
     return out, latent

@@ -114,9 +114,11 @@ class RolloutEngine:
         return {v: k for k, v in _lib.CONV_MODES.items()}[
             int(self.lib.mdno_conv_mode_for_graph(self.pack.ref, self.M, self.N, int(e)))]
 
-    def _apply_mode(self, want: str) -> bool:
+    def _apply_mode(self, want: str, record_at: Optional[int] = None) -> bool:
         """Switch to formulation `want` where the model's dimensions (and, for materialized, the workspace bound) allow
-        it.  Returns True if the engine changed formulation (its plan must then be rebuilt)."""
+        it.  Returns True if the engine changed formulation (its plan must then be rebuilt).  `record_at`: the step
+        from which the new formulation applies when the change happens MID-trajectory (a regrown capacity) — recorded
+        in `mode_changes`, step 0 included; None at reset() (the choice for the whole trajectory is no change)."""
         if want == self.conv_mode:
             return False
         pack = self._pack_for(want)
@@ -126,13 +128,13 @@ class RolloutEngine:
         need = self.lib.mdno_rollout_workspace_bytes(pack.ref, self.M, self.N, self.edge_cap)
         if want == "materialized" and need > AUTO_MATERIALIZED_MAX_WORKSPACE:
             return False                 # W_e at this edge capacity does not fit: stay factored
-        if self.steps_done and self.conv_mode != want:
-            self.mode_changes.append((self.steps_done, self.conv_mode, want))
+        if record_at is not None:
+            self.mode_changes.append((int(record_at), self.conv_mode, want))
         self.pack, self.conv_mode = pack, want
         return True
 
-    def _resolve_auto(self, e: int, over: bool) -> bool:
-        return self._apply_mode(self._wanted_mode(e, over))
+    def _resolve_auto(self, e: int, over: bool, record_at: Optional[int] = None) -> bool:
+        return self._apply_mode(self._wanted_mode(e, over), record_at)
 
     def _create_plan(self):
         if self.plan:
@@ -242,6 +244,20 @@ class RolloutEngine:
         check(self.lib.mdno_rollout_plan_timer_detach(self.plan), "timer_detach")
         self._timer_records = 0
 
+    FALLBACK_KEYS = ops.FALLBACK_KEYS
+
+    def fallback_counts(self) -> dict:
+        """Which path the products of gemm_mode "split_f16" took since the last `step()` call (include/mdno.h,
+        mdno_rollout_plan_fallback_counts): K1 workgroups of the factored conv rerun on bf16 planes, destinations whose
+        operands were taken unscaled, edge-MLP products (GEMM x chunk) redone on bf16 planes.  All zero = every product
+        ran on two fp16 planes (the fast path); non-zero = same results to fp32 rounding, more matrix work.
+        Synchronises the engine's stream."""
+        if not self.plan:
+            return {k: 0 for k in self.FALLBACK_KEYS}
+        out = (C.c_int64 * 4)()
+        check(self.lib.mdno_rollout_plan_fallback_counts(self.plan, out, self.stream.cuda_stream), "fallback_counts")
+        return {k: int(out[i]) for i, k in enumerate(self.FALLBACK_KEYS)}
+
     def _grow_and_rerun(self, st: int) -> int:
         """The radius graph of some step outgrew a capacity that was FITTED to the start window (no `edge_cap` given,
         N > 256): the reference keeps building the denser graph (graph_kernel.py:363-368), so the engine does too —
@@ -259,9 +275,8 @@ class RolloutEngine:
         old = self.edge_cap
         self.edge_cap = min(self.M * self.N * self.N, 4 * old)
         self.regrown.append((first, old, self.edge_cap))
-        self.steps_done = first                  # (what a formulation change below is recorded at)
         if self._auto:
-            self._resolve_auto(old, False)       # the graph now has at least `old` edges
+            self._resolve_auto(old, False, record_at=first)       # the graph now has at least `old` edges
         need = self.lib.mdno_rollout_workspace_bytes(self.pack.ref, self.M, self.N, self.edge_cap)
         self.workspace = None
         self.workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
@@ -312,7 +327,10 @@ class GroupedRolloutEngine:
     formulation when densities differ), so the frames are those of one engine holding them all: bitwise for members of
     like magnitude (the ensemble case: perturbed copies of one system), and to fp32 rounding in general — the edge-MLP
     chooses between its fp16 and bf16 plane products per launch from the magnitudes it sees (split_layout.h), and a
-    group can see other magnitudes than the whole shard.  What changes is the schedule: one group's edge-MLP (matrix-pipe-bound) and launch tails run
+    group can see other magnitudes than the whole shard.  A group whose FITTED capacity is outgrown mid-trajectory regrows
+    on its own and re-resolves "auto" on its own members (RolloutEngine._grow_and_rerun): from that step on the groups
+    may run different formulations — `conv_mode` then reads "mixed:..", every group's `mode_changes` says where — and
+    the one-engine equivalence holds to fp32 reassociation only.  What changes is the schedule: one group's edge-MLP (matrix-pipe-bound) and launch tails run
     beside another group's convs (fabric-bound) — 5 % at 8 x 504 atoms, 3 % at 64 (EXPERIMENTS.md section 0.2b).  Same
     reset / step / synchronize / run / frames interface; `traj` and `edges_per_step` are assembled on access."""
 
@@ -377,6 +395,14 @@ class GroupedRolloutEngine:
     def step(self, steps: int) -> None:
         for e in self.engines:      # asynchronous on each engine's own stream
             e.step(steps)
+
+    def fallback_counts(self) -> dict:
+        """Sum of the groups' counters (RolloutEngine.fallback_counts)."""
+        tot = {k: 0 for k in RolloutEngine.FALLBACK_KEYS}
+        for e in self.engines:
+            for k, v in e.fallback_counts().items():
+                tot[k] += v
+        return tot
 
     def wait(self) -> None:
         """Block until every group's stream has drained (no status check: `synchronize` does that)."""

@@ -345,9 +345,10 @@ def train_epoch(model, batches, optimizer, loss_fn, batch_size: Optional[int] = 
     n = len(losses)
     if n == 0:
         return 0.0, 0.0
-    # one device->host copy per value once the pass is over, added in double precision in batch order
-    tot = sum(float(v) for v in losses)
-    tot_mse = sum(float(v) for v in mses)
+    # ONE device->host copy once the pass is over (the values stacked on the device), added on the host in double
+    # precision in batch order
+    vals = torch.stack([v.reshape(()) for v in losses] + [v.detach().reshape(()) for v in mses]).double().cpu().tolist()
+    tot, tot_mse = sum(vals[:n]), sum(vals[n:])
     return tot / n, tot_mse / n
 
 
@@ -388,6 +389,6 @@ def validate_epoch(model, batches, loss_fn, batch_size: Optional[int] = None):
     n = len(losses)
     if n == 0:
         return 0.0, 0.0
-    tot = sum(float(v) for v in losses)
-    tot_mse = sum(float(v) for v in mses)
+    vals = torch.stack([v.detach().reshape(()) for v in losses] + [v.detach().reshape(()) for v in mses]).double().cpu().tolist()
+    tot, tot_mse = sum(vals[:n]), sum(vals[n:])      # (one copy; batch-order sums in double, as train_epoch)
     return tot / n, tot_mse / n

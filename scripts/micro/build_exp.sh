@@ -1,8 +1,8 @@
 #!/usr/bin/env bash
 # Build an EXPERIMENTAL copy of libmdno.so with extra -D flags, beside the real one (measurement aid only):
 #   scripts/micro/build_exp.sh out-name.so -DMDNO_EXP_SOMETHING ...
-# The result goes to scripts/micro/exp/ (git-ignored, shipped to the GPU box); run with MDNO_LIB=<path> (the loader then
-# skips the build-id check: such a library is by construction not built from the tree's sources).
+# The result goes to scripts/micro/exp/ (git-ignored, shipped to the GPU box); run with MDNO_LIB=<path> (its build id
+# reads "experimental", which is what lets the loader accept it: such a library is by construction not built from the tree's sources).
 set -euo pipefail
 root="$(cd "$(dirname "${BASH_SOURCE[0]}")/../.." && pwd)"
 src="$root/molecular_dynamics_neural_operator_amd/csrc"

@@ -51,7 +51,7 @@ def test_exports_are_c_linkage_only_mdno(lib):
 
 def test_abi_version_struct_layout_and_error_string(lib):
     from molecular_dynamics_neural_operator_amd import _lib
-    assert lib.mdno_abi_version() == _lib.ABI_VERSION == 14
+    assert lib.mdno_abi_version() == _lib.ABI_VERSION == 15
     # 12 int32 + 27 pointers, no padding surprises
     assert ctypes.sizeof(_lib.KernelNNParams) == 12 * 4 + 27 * 8
     # argument validation happens before any device work: exercise it without a GPU

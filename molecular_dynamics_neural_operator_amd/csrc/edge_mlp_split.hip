@@ -199,90 +199,154 @@ __global__ __launch_bounds__(256) void edge_l0_split_kernel(
     unsigned char* const hph = MODE == 2 ? hp_f16 : hp;
     const int Fn = FT ? FT : F;
     const long long E = *num_edges;
+    const long long tile0 = (long long)blockIdx.x * L0_ROWS;   // first row of this tile inside the chunk
+    if (e_begin + tile0 >= E || tile0 >= e_count) return;
     const int u0 = blockIdx.y * UNITS, tid = threadIdx.x;
+    // operands from which layer 0 can produce a NaN (not finite, or so large that a product overflows: |a w| <= 1e36
+    // below the bound, six of them and a bias stay finite): the fp16 image of such a chunk is not used (F16 modes)
+    bool operands_wild = false;
+    constexpr float L0_OPERAND_BOUND = 1e18f;
+    for (int i = tid; i < UNITS * Fn; i += 256) {
+        const float wv = w0[(size_t)u0 * Fn + i];
+        wsh[i] = wv;
+        if (F16) operands_wild |= !(fabsf(wv) < L0_OPERAND_BOUND);
+    }
+    if (tid < UNITS) {
+        const float bv = b0[u0 + tid];
+        bsh[tid] = bv;
+        if (F16) operands_wild |= !(fabsf(bv) < L0_OPERAND_BOUND);
+    }
+    const int lane = tid & 63, r = (tid >> 6) * 32 + (lane >> 1), half = lane & 1;
+    const long long le = tile0 + r, e = e_begin + le;
+    const bool valid = e < E && le < e_count;
+    float attr[MAX_F];
+#pragma unroll
+    for (int f = 0; f < MAX_F; ++f) attr[f] = 0.f;
+    if (valid) {
+        if (frames != nullptr) {  // attr = [pos[src], pos[dst]]   (graph_kernel.py:372-379)
+            const float* edge_pos = frames + (size_t)(frame + (t_dev ? *t_dev : 0)) * rows_per_frame * 3;
+            const float* ps = edge_pos + (size_t)src[e] * 3;
+            const float* pd = edge_pos + (size_t)dst[e] * 3;
+            attr[0] = ps[0]; attr[1] = ps[1]; attr[2] = ps[2];
+            attr[3] = pd[0]; attr[4] = pd[1]; attr[5] = pd[2];
+        } else {
+            const long long pe = perm ? (long long)perm[e] : e;
+#pragma unroll
+            for (int f = 0; f < MAX_F; ++f)
+                if (f < Fn) attr[f] = edge_attr[pe * Fn + f];
+        }
+    }
+    if (F16) {
+#pragma unroll
+        for (int f = 0; f < MAX_F; ++f) operands_wild |= !(fabsf(attr[f]) < L0_OPERAND_BOUND);
+        if (operands_wild) atomicOr(f16_flags + 1, 1);
+    }
+    __syncthreads();
+    if (!valid) return;
+    const int nkt = k >> 4;
+    bool bad = false, seen = false;
+#pragma unroll 2
+    for (int t = 0; t < UNITS / 16; ++t) {
+        const int c = t * 16 + half * 8;       // this thread's 8 hidden units, relative to u0
+        __bf16 o[3][8];
+        _Float16 oh[2][8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float sum = 0.f;
+#pragma unroll
+            for (int f = 0; f < MAX_F; ++f)
+                if (f < Fn) sum = fmaf(attr[f], wsh[(c + j) * Fn + f], sum);
+            // (v_max_f32 turns a NaN into 0 where torch's relu passes it on — and this loop is at its vector-issue rate, its
+            // schedule does not survive another instruction: 61 -> 120 registers.  A NaN can only come from operands that
+            // are not finite or large enough for a product to overflow; those raise the range flag BEFORE the loop
+            // (operands_wild below), and the chunk is then redone by the bf16 kernels, whose ReLU is relu_f.)
+            // (MODE 0, 2: the bf16 image is the one used then — relu_f's compare-and-select, written as instructions: given
+            // the expression the compiler re-vectorises the loop to 122 registers)
+            float v = sum + bsh[c + j];
+            if (MODE == 1) v = fmaxf(v, 0.f);
+            else asm("v_cmp_le_f32 vcc, %0, 0\n\tv_cndmask_b32 %0, %0, 0, vcc" : "+v"(v) : : "vcc");
+            if (F16) {
+                bad |= !(v < F16_MAX);
+                seen |= v >= F16_ACT_MIN;
+                split2h(v, oh[0][j], oh[1][j]);
+            }
+            if (BF16) split3(v, o[0][j], o[1][j], o[2][j]);
+        }
+        if (F16) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                *reinterpret_cast<uint4*>(hph + tiled_off2(le, u0 + c, nkt, p)) = *reinterpret_cast<const uint4*>(oh[p]);
+        }
+        if (BF16) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                *reinterpret_cast<uint4*>(hp + tiled_off(le, u0 + c, nkt, p)) = *reinterpret_cast<const uint4*>(o[p]);
+        }
+    }
+    if (F16 && bad) atomicOr(f16_flags + 1, 1);
+    if (F16 && seen) f16_flags[2] = 1;      // (the same value from whoever stores it: no atomic)
+}
+
+// The bf16 image of a chunk for the FALLBACK of gemm_mode SPLIT_F16 (MODE 0's arithmetic): launched behind the fp16
+// kernels with a small grid (kFallbackL0RowTiles row tiles x k/128), it exits at once unless a range flag is up — a
+// kernel boundary instead of the dispatch of a capacity-sized grid — and otherwise its workgroups walk the row tiles
+// with stride gridDim.x.
+template <int FT>
+__global__ __launch_bounds__(256) void edge_l0_split_fallback_kernel(
+    const float* __restrict__ frames, int frame, const int* __restrict__ t_dev, int rows_per_frame,
+    const int* __restrict__ src, const int* __restrict__ dst, const float* __restrict__ edge_attr,
+    const int* __restrict__ perm, const int* __restrict__ num_edges, long long e_begin, int e_count, int F, int k,
+    const float* __restrict__ w0, const float* __restrict__ b0, unsigned char* __restrict__ hp,
+    const int* __restrict__ f16_flags, int f16_need) {
+    __shared__ __attribute__((aligned(16))) float wsh[L0_UNITS * MAX_F];
+    __shared__ __attribute__((aligned(16))) float bsh[L0_UNITS];
+    if (!f16_blocked(f16_flags, f16_need)) return;
+    const int Fn = FT ? FT : F;
+    const long long E = *num_edges;
+    const int u0 = blockIdx.y * L0_UNITS, tid = threadIdx.x;
+    for (int i = tid; i < L0_UNITS * Fn; i += 256) wsh[i] = w0[(size_t)u0 * Fn + i];
+    if (tid < L0_UNITS) bsh[tid] = b0[u0 + tid];
+    __syncthreads();
     const int lane = tid & 63, r = (tid >> 6) * 32 + (lane >> 1), half = lane & 1;
     const int nkt = k >> 4;
-    auto load_weights = [&]() {
-        for (int i = tid; i < UNITS * Fn; i += 256) wsh[i] = w0[(size_t)u0 * Fn + i];
-        if (tid < UNITS) bsh[tid] = b0[u0 + tid];
-    };
-    // this thread's edge of the row tile at tile0 (relative to the chunk): its attributes
-    auto gather = [&](long long tile0, float (&attr)[MAX_F], long long& le) -> bool {
-        le = tile0 + r;
-        const long long e = e_begin + le;
-        const bool valid = e < E && le < e_count;
+    for (long long tile0 = (long long)blockIdx.x * L0_ROWS; e_begin + tile0 < E && tile0 < e_count;
+         tile0 += (long long)gridDim.x * L0_ROWS) {
+        const long long le = tile0 + r, e = e_begin + le;
+        if (!(e < E && le < e_count)) continue;
+        float attr[MAX_F];
 #pragma unroll
         for (int f = 0; f < MAX_F; ++f) attr[f] = 0.f;
-        if (valid) {
-            if (frames != nullptr) {  // attr = [pos[src], pos[dst]]   (graph_kernel.py:372-379)
-                const float* edge_pos = frames + (size_t)(frame + (t_dev ? *t_dev : 0)) * rows_per_frame * 3;
-                const float* ps = edge_pos + (size_t)src[e] * 3;
-                const float* pd = edge_pos + (size_t)dst[e] * 3;
-                attr[0] = ps[0]; attr[1] = ps[1]; attr[2] = ps[2];
-                attr[3] = pd[0]; attr[4] = pd[1]; attr[5] = pd[2];
-            } else {
-                const long long pe = perm ? (long long)perm[e] : e;
+        if (frames != nullptr) {
+            const float* edge_pos = frames + (size_t)(frame + (t_dev ? *t_dev : 0)) * rows_per_frame * 3;
+            const float* ps = edge_pos + (size_t)src[e] * 3;
+            const float* pd = edge_pos + (size_t)dst[e] * 3;
+            attr[0] = ps[0]; attr[1] = ps[1]; attr[2] = ps[2];
+            attr[3] = pd[0]; attr[4] = pd[1]; attr[5] = pd[2];
+        } else {
+            const long long pe = perm ? (long long)perm[e] : e;
 #pragma unroll
-                for (int f = 0; f < MAX_F; ++f)
-                    if (f < Fn) attr[f] = edge_attr[pe * Fn + f];
-            }
+            for (int f = 0; f < MAX_F; ++f)
+                if (f < Fn) attr[f] = edge_attr[pe * Fn + f];
         }
-        return valid;
-    };
-    bool bad = false, seen = false;
-    auto compute = [&](const float (&attr)[MAX_F], long long le) {
 #pragma unroll 2
-        for (int t = 0; t < UNITS / 16; ++t) {
-            const int c = t * 16 + half * 8;       // this thread's 8 hidden units, relative to u0
+        for (int t = 0; t < L0_UNITS / 16; ++t) {
+            const int c = t * 16 + half * 8;
             __bf16 o[3][8];
-            _Float16 oh[2][8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float sum = 0.f;
 #pragma unroll
                 for (int f = 0; f < MAX_F; ++f)
                     if (f < Fn) sum = fmaf(attr[f], wsh[(c + j) * Fn + f], sum);
-                const float v = relu_f(sum + bsh[c + j]);
-                if (F16) {
-                    bad |= !(v < F16_MAX);
-                    seen |= v >= F16_ACT_MIN;
-                    split2h(v, oh[0][j], oh[1][j]);
-                }
-                if (BF16) split3(v, o[0][j], o[1][j], o[2][j]);
+                float v = sum + bsh[c + j];
+                asm("v_cmp_le_f32 vcc, %0, 0\n\tv_cndmask_b32 %0, %0, 0, vcc" : "+v"(v) : : "vcc");      // relu_f (see edge_l0_split_kernel)
+                split3(v, o[0][j], o[1][j], o[2][j]);
             }
-            if (F16) {
 #pragma unroll
-                for (int p = 0; p < 2; ++p)
-                    *reinterpret_cast<uint4*>(hph + tiled_off2(le, u0 + c, nkt, p)) = *reinterpret_cast<const uint4*>(oh[p]);
-            }
-            if (BF16) {
-#pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    *reinterpret_cast<uint4*>(hp + tiled_off(le, u0 + c, nkt, p)) = *reinterpret_cast<const uint4*>(o[p]);
-            }
+            for (int p = 0; p < 3; ++p)
+                *reinterpret_cast<uint4*>(hp + tiled_off(le, u0 + c, nkt, p)) = *reinterpret_cast<const uint4*>(o[p]);
         }
-    };
-    float attr[MAX_F];
-    long long le;
-    if constexpr (MODE == 0) {
-        // the bf16 image alone: the launch's workgroups walk the row tiles with stride gridDim.x (a fallback launch has
-        // kFallbackL0RowTiles of them, a launch of gemm_mode SPLIT_BF16 one per tile)
-        load_weights();
-        __syncthreads();
-        for (long long tile0 = (long long)blockIdx.x * L0_ROWS; e_begin + tile0 < E && tile0 < e_count;
-             tile0 += (long long)gridDim.x * L0_ROWS)
-            if (gather(tile0, attr, le)) compute(attr, le);
-        return;
     }
-    const long long tile0 = (long long)blockIdx.x * L0_ROWS;   // first row of this tile inside the chunk
-    if (e_begin + tile0 >= E || tile0 >= e_count) return;
-    load_weights();
-    const bool valid = gather(tile0, attr, le);
-    __syncthreads();
-    if (!valid) return;
-    compute(attr, le);
-    if (F16 && bad) atomicOr(f16_flags + 1, 1);
-    if (F16 && seen) f16_flags[2] = 1;      // (the same value from whoever stores it: no atomic)
 }
 
 // f16 = true: fp16 planes + range flag; f16 = false with flags: the bf16 fallback (runs if a flag is up)
@@ -291,8 +355,17 @@ static int launch_edge_l0_split(const float* pos_mode, int frame, const int* t_d
                                 long long e0, int cnt, int F, int k, const float* w0, const float* b0,
                                 unsigned char* hp, hipStream_t s, bool f16 = false, int* f16_flags = nullptr,
                                 int f16_need = 0, unsigned char* hp_f16 = nullptr) {
-    int row_tiles = (cnt + L0_ROWS - 1) / L0_ROWS;
-    if (!f16 && f16_flags != nullptr && row_tiles > kFallbackL0RowTiles) row_tiles = kFallbackL0RowTiles;      // fallback launch
+    const int row_tiles = (cnt + L0_ROWS - 1) / L0_ROWS;
+    if (!f16 && f16_flags != nullptr && hp_f16 == nullptr) {      // the fallback launch behind the fp16 kernels
+        const dim3 fgrid(row_tiles < kFallbackL0RowTiles ? row_tiles : kFallbackL0RowTiles, k / L0_UNITS);
+        if (F == 6)
+            hipLaunchKernelGGL((edge_l0_split_fallback_kernel<6>), fgrid, dim3(256), 0, s, pos_mode, frame, t_dev, rows_per_frame,
+                               src, dst, edge_attr, perm, num_edges, e0, cnt, F, k, w0, b0, hp, (const int*)f16_flags, f16_need);
+        else
+            hipLaunchKernelGGL((edge_l0_split_fallback_kernel<0>), fgrid, dim3(256), 0, s, pos_mode, frame, t_dev, rows_per_frame,
+                               src, dst, edge_attr, perm, num_edges, e0, cnt, F, k, w0, b0, hp, (const int*)f16_flags, f16_need);
+        return check_launch("edge_l0_split_fallback_kernel");
+    }
     const dim3 grid(row_tiles, k / (hp_f16 ? L0_UNITS_SMALL : L0_UNITS));
     // hp_f16 given: both images (bf16 planes -> hp, fp16 planes -> hp_f16)
 #define MDNO_L0(FT, MODE)                                                                                             \

@@ -896,6 +896,23 @@ def test_factored_conv_non_finite_last_layer_weight_reaches_the_output(dev, bad)
             out, lat = ops.kernelnn_forward(model.param_pack(dev, conv_mode=conv), win.unsqueeze(1), aa, g, edge_pos=win[-1],
                                             return_latent=True)
             assert not bool(torch.isfinite(lat).all()) and not bool(torch.isfinite(out).all()), (conv, gemm)
+    # the same for a non-finite EDGE ATTRIBUTE (it enters at the edge-MLP's first layer: relu(W0 a + b0)) with the weights
+    # finite again: explicit edge list, one attribute replaced
+    model.load_state_dict(near_identity_state_dict(64, 128, seed=7, kernel_gain=2e-2, feature_gain=0.2, kernel_to_coords=1.0))
+    ei = g.to_edge_index()
+    pos = win[-1]
+    ea = torch.cat([pos[ei[0]], pos[ei[1]]], dim=1).contiguous()
+    ea[11, 2] = bad
+    csr = ops.coo_to_csr(ei, N)
+    for conv in ("factored", "materialized"):
+        for gemm in ("split_f16", "split_bf16", "f32"):
+            model.gemm_mode = gemm
+            counts = {}
+            out, _ = ops.kernelnn_forward(model.param_pack(dev, conv_mode=conv), win.unsqueeze(1), aa, csr, edge_attr=ea,
+                                          fallback_counts=counts)
+            assert not bool(torch.isfinite(out).all()), (conv, gemm, "edge attribute")
+            if gemm == "split_f16":      # the fp16 image of that chunk is not used: the products ran on the bf16 planes
+                assert counts["edge_mlp_products_bf16"] >= 1, counts
 
 
 def test_edge_cases_single_atom_window1_zero_steps_and_c_rollout(dev, O):

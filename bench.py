@@ -922,9 +922,11 @@ def worker(a):
     first_frame_gpu = eng.traj[W, 0].detach().cpu().numpy() if (a.warmup > 0 and total_members == 1) else None
     m_max = -(-total_members // world)
     t_first_gather = None
-    if use_dist:     # the collective of the timed region, once, untimed: communicator set-up and buffers
+    if use_dist:     # the collective of the timed region, once, untimed, on the same path (the groups' frames concatenated,
+        # gathered, re-ordered): communicator set-up, buffers, and the first-use load of every kernel involved — a first
+        # torch.cat alone is ~10 ms
         t0 = time.perf_counter()
-        gather_trajectories(torch.zeros((a.steps, M, N, 3), dtype=torch.float32, device=dev), total_members)
+        gather_trajectories(eng.produced(0, a.steps), total_members)
         torch.cuda.synchronize()
         t_first_gather = time.perf_counter() - t0
 
@@ -936,7 +938,7 @@ def worker(a):
     eng.step(a.steps)
     wait(eng)
     t_steps = time.perf_counter() - t0                                             # this rank's K steps alone
-    produced = eng.traj[W + a.warmup:W + a.warmup + a.steps]                       # [K,M,N,3]
+    produced = eng.produced(a.warmup, a.steps)                                     # [K,M,N,3]
     if use_dist:
         full = gather_trajectories(produced, total_members)
     else:

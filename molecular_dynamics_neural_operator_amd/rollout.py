@@ -307,6 +307,10 @@ class RolloutEngine:
     def frames(self) -> torch.Tensor:
         return self.traj[self.W:self.W + self.steps_done]
 
+    def produced(self, first_step: int, steps: int) -> torch.Tensor:
+        """Frames of steps first_step .. first_step + steps - 1: f32 [steps, M, N, 3] (a view of the trajectory buffer)."""
+        return self.traj[self.W + first_step:self.W + first_step + steps]
+
     def close(self) -> None:
         if self.plan:
             self.stream.synchronize()
@@ -425,6 +429,11 @@ class GroupedRolloutEngine:
 
     def frames(self) -> torch.Tensor:
         return torch.cat([e.frames() for e in self.engines], dim=1)
+
+    def produced(self, first_step: int, steps: int) -> torch.Tensor:
+        """Frames of steps first_step .. first_step + steps - 1 of every group, members in order: [steps, M, N, 3] (only
+        these frames are copied — `traj` concatenates the groups' whole buffers)."""
+        return torch.cat([e.produced(first_step, steps) for e in self.engines], dim=1)
 
     @property
     def edges_per_step(self) -> torch.Tensor:

@@ -400,7 +400,7 @@ def leg_cfg4_training(dev, frames=10000, batch=128, kernel_width=1024, depth=6, 
     from molecular_dynamics_neural_operator_amd import ops, synthetic as syn
     from molecular_dynamics_neural_operator_amd.dataset import ContactMapDataset, write_trajectory_npz
     from molecular_dynamics_neural_operator_amd.graph_kernel import KernelNN, LpLoss
-    from molecular_dynamics_neural_operator_amd.training import DeviceTrajectory, train_epoch
+    from molecular_dynamics_neural_operator_amd.training import Adam, DeviceTrajectory, train_epoch
     N, W = 28, 10
     traj = syn.ou_trajectory(syn.chain_frame(N, seed=0), frames, sigma=0.3, theta=0.1, seed=2)
     cms = [syn.contact_map(f, 8.0) for f in traj]
@@ -413,7 +413,7 @@ def leg_cfg4_training(dev, frames=10000, batch=128, kernel_width=1024, depth=6, 
     idx = [list(range(s, s + batch)) for s in range(0, n_train - batch + 1, batch)]      # drop_last
     out = {"frames": frames, "atoms": N, "window": W, "batch_size": batch, "train_batches": len(idx),
            "kernel_width": kernel_width, "depth": depth, "collate": "device (mdno_collate_samples)",
-           "optimizer": "torch.optim.Adam(lr=1e-4, weight_decay=5e-4)"}
+           "optimizer": "training.Adam(lr=1e-4, weight_decay=5e-4): torch.optim.Adam's update, one libmdno launch (mdno_adam_step)"}
     E0 = None
     for precision in ("bf16", "fp32"):
         torch.manual_seed(0)
@@ -423,10 +423,7 @@ def leg_cfg4_training(dev, frames=10000, batch=128, kernel_width=1024, depth=6, 
                 p_.mul_(0.05)
         model.to(dev)
         model.train_precision = precision
-        try:      # torch's single-kernel Adam where the build has it (same update rule)
-            opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=5e-4, fused=True)
-        except (RuntimeError, TypeError):
-            opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=5e-4)
+        opt = Adam(model.parameters(), lr=1e-4, weight_decay=5e-4)      # torch.optim.Adam's update as one libmdno launch
         loss_fn = LpLoss(size_average=False)
         train_epoch(model, (dtraj.batch(i) for i in idx[:2]), opt, loss_fn)              # warm-up
         torch.cuda.synchronize()
@@ -525,7 +522,7 @@ def leg_cfg4_training(dev, frames=10000, batch=128, kernel_width=1024, depth=6, 
             m_.load_state_dict(sd0)
             m_.to(dev)
             m_.train_precision = precision
-            o_ = torch.optim.Adam(m_.parameters(), lr=1e-4, weight_decay=5e-4)
+            o_ = Adam(m_.parameters(), lr=1e-4, weight_decay=5e-4)
             ep[f"hip_{precision}"], _ = train_epoch(m_, (dtraj.batch(i) for i in ep_idx), o_, LpLoss(size_average=False))
             del m_, o_
         t0 = time.perf_counter()

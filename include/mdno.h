@@ -314,6 +314,23 @@ int mdno_kernelnn_fallback_counts(const mdno_kernelnn_params* p, int M, int N, i
                                   void* workspace, int64_t counts[4], void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The optimiser step of train() (graph_kernel.py:467 on torch.optim.Adam(lr, weight_decay), :541-543) for all parameter
+ * tensors in ONE launch (ABI 15): g' = g + weight_decay p;  m += (g' - m)(1 - beta1);  v = beta2 v + (1 - beta2) g'^2;
+ * p -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps) — torch.optim.Adam's arithmetic (L2 weight
+ * decay, no amsgrad), fp32, in place.  `tensors`: HOST array of `count` entries (device pointers, element counts);
+ * step >= 1 is the number of this update.  Asynchronous on `stream`.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct mdno_adam_tensor {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    int64_t numel;
+} mdno_adam_tensor;
+int mdno_adam_step(int count, const mdno_adam_tensor* tensors, double lr, double beta1, double beta2, double eps,
+                   double weight_decay, int64_t step, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Training ops (BASELINE configs[3]) — the backward of the kernel-integral block that autograd +
  * torch_geometric provide to train() (graph_kernel.py:445-474) for the path :299-302 / :194-209 /
  * :239-242.  All fp32; row/edge reductions use fixed-order partial sums (bitwise reproducible).

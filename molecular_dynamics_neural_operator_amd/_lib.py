@@ -80,6 +80,7 @@ SIGNATURES = {
     "mdno_rollout_plan_timer_detach": (_I, [_P]),
     "mdno_rollout_plan_fallback_counts": (_I, [_P, _P, _P]),
     "mdno_kernelnn_fallback_counts": (_I, [C.POINTER(KernelNNParams), _I, _I, _L, _I, _P, _P, _P]),
+    "mdno_adam_step": (_I, [_I, _P, _D, _D, _D, _D, _D, _L, _P]),
     "mdno_linear_fwd": (_I, [_P, _P, _P, _L, _I, _I, _I, _P, _P]),
     "mdno_linear_split_workspace_bytes": (_SZ, [_L, _I, _I]),
     "mdno_linear_split_fwd": (_I, [_P, _P, _P, _L, _I, _I, _I, _P, _P, _SZ, _P]),

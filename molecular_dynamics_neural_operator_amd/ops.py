@@ -282,6 +282,30 @@ def kernelnn_forward(pack: ParamPack, frames: torch.Tensor, x_aminoacid: torch.T
     return out, latent
 
 
+class AdamTensor(C.Structure):
+    """include/mdno.h mdno_adam_tensor"""
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("numel", C.c_int64)]
+
+
+def adam_step(params, grads, exp_avgs, exp_avg_sqs, lr: float, beta1: float, beta2: float, eps: float,
+              weight_decay: float, step: int) -> None:
+    """torch.optim.Adam's update (L2 weight decay, no amsgrad) of all the given fp32 tensors in ONE launch
+    (include/mdno.h mdno_adam_step), in place, on the current stream."""
+    n = len(params)
+    if n == 0:
+        return
+    arr = (AdamTensor * n)()
+    for i, (p, g, m, v) in enumerate(zip(params, grads, exp_avgs, exp_avg_sqs)):
+        if not (p.dtype == g.dtype == m.dtype == v.dtype == torch.float32):
+            raise MdnoError("adam_step: fp32 tensors only")
+        if not (p.numel() == g.numel() == m.numel() == v.numel()):
+            raise MdnoError("adam_step: parameter, gradient and moments must have the same number of elements")
+        arr[i] = AdamTensor(ptr(p), ptr(g), ptr(m), ptr(v), p.numel())
+    check(_lib.load().mdno_adam_step(n, arr, float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
+                                     stream_ptr(params[0].device)), "mdno_adam_step")
+
+
 # ------------------------------------------------------------------------------------------------
 # Training ops (include/mdno.h "Training ops"): thin wrappers, torch only allocates the outputs.
 def _ws(nbytes: int, dev) -> torch.Tensor:

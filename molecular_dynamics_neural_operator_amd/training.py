@@ -314,6 +314,47 @@ def check_train_status(model) -> None:
     raise_on_status(word, "training forward")
 
 
+class Adam(torch.optim.Optimizer):
+    """`torch.optim.Adam(params, lr, betas, eps, weight_decay)` — the optimiser of the reference's main()
+    (graph_kernel.py:541-543) — with its step as ONE libmdno launch over all parameter tensors (`mdno_adam_step`: the same
+    arithmetic in the same order; torch's fused form walks tensor lists through multi_tensor_apply).  A
+    `torch.optim.Optimizer`: lr schedulers (StepLR, :544-546) drive `param_groups[i]["lr"]`, and `state_dict()` has
+    torch.optim.Adam's layout (`step`, `exp_avg`, `exp_avg_sq` per parameter), so a checkpoint written with either
+    (graph_kernel.py:633-639) loads into the other.  fp32 parameters on the GPU; no amsgrad / maximize."""
+
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
+        if lr < 0 or eps < 0 or weight_decay < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
+            raise ValueError("Adam: invalid hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            by_step = {}      # parameters of one group normally share their step count: one launch per distinct count
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if p.grad.is_sparse:
+                    raise RuntimeError("Adam does not support sparse gradients")
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.zeros((), dtype=torch.float32)                     # (host tensor, as torch.optim.Adam keeps it)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                by_step.setdefault(int(st["step"]), []).append((p, g, st["exp_avg"], st["exp_avg_sq"]))
+            b1, b2 = group["betas"]
+            for t, items in by_step.items():
+                ops.adam_step([i[0] for i in items], [i[1] for i in items], [i[2] for i in items], [i[3] for i in items],
+                              group["lr"], b1, b2, group["eps"], group["weight_decay"], t)
+        return loss
+
+
 def train_epoch(model, batches, optimizer, loss_fn, batch_size: Optional[int] = None):
     """One pass over `batches` — an iterable of lists of PairData (as the reference's DataListLoader yields)
     or of collated batches (`DeviceTrajectory.batch`): returns (avg relative-L2 loss, avg MSE) like train()

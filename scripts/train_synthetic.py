@@ -36,6 +36,7 @@ ap.add_argument("--cpu-batches", type=int, default=0)
 ap.add_argument("--precision", choices=["fp32", "bf16"], default="bf16",
                 help="bf16 (BASELINE configs[3]): h1, h2, W_e, dW_e stored in bf16, single-product bf16 GEMMs with "
                      "fp32 accumulation, fp32 master weights; fp32: split-bf16 GEMMs at fp32-level accuracy")
+ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam(fused=True) instead of training.Adam (mdno_adam_step)")
 ap.add_argument("--host-collate", action="store_true",
                 help="collate every batch on the host from ContactMapDataset samples (what the reference's "
                      "DataListLoader does) instead of on the device from the resident trajectory")
@@ -89,10 +90,14 @@ with torch.no_grad():     # the reference's init makes activations explode throu
 cpu_model = copy.deepcopy(model)
 model.to(dev)
 model.train_precision = a.precision
-try:      # torch's single-kernel Adam where the build has it (same update rule; graph_kernel.py:541-543)
-    opt = torch.optim.Adam(model.parameters(), lr=a.lr, weight_decay=5e-4, fused=True)
-except (RuntimeError, TypeError):
-    opt = torch.optim.Adam(model.parameters(), lr=a.lr, weight_decay=5e-4)
+from molecular_dynamics_neural_operator_amd.training import Adam  # noqa: E402
+if a.torch_adam:      # torch's own (its single-kernel form where the build has it): the same update rule (graph_kernel.py:541-543)
+    try:
+        opt = torch.optim.Adam(model.parameters(), lr=a.lr, weight_decay=5e-4, fused=True)
+    except (RuntimeError, TypeError):
+        opt = torch.optim.Adam(model.parameters(), lr=a.lr, weight_decay=5e-4)
+else:                 # training.Adam: torch.optim.Adam's arithmetic and state as ONE libmdno launch over the 27 tensors
+    opt = Adam(model.parameters(), lr=a.lr, weight_decay=5e-4)
 sched = torch.optim.lr_scheduler.StepLR(opt, step_size=50, gamma=0.8)
 loss_fn = LpLoss(size_average=False)
 

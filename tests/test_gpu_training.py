@@ -784,7 +784,8 @@ def _oracle_adam_trajectory(step_fn, sd0, batches, depth, lr, weight_decay, step
 
 @pytest.mark.parametrize("precision,lr,tol_loss,tol_param", [("fp32", 3e-4, 1e-5, 1e-4), ("fp32", 1e-2, 1e-3, 1e-2),
                                                              ("bf16", 3e-4, 1e-3, 2e-2)])
-def test_adam_trajectory_vs_oracle(dev, O, tmp_path, precision, lr, tol_loss, tol_param):
+@pytest.mark.parametrize("optimizer", ["torch", "mdno"])
+def test_adam_trajectory_vs_oracle(dev, O, tmp_path, precision, lr, tol_loss, tol_param, optimizer):
     """SURVEY.md §8(d) cfg4, "loss ... vs the CPU restatement" over a multi-step optimiser trajectory: six epochs
     of one batch of 4 dataset samples through training.train_epoch with the reference's optimiser set-up —
     Adam(lr, weight_decay 5e-4) + StepLR(step_size 2, gamma 0.8), scheduler.step() after every epoch
@@ -814,7 +815,10 @@ def test_adam_trajectory_vs_oracle(dev, O, tmp_path, precision, lr, tol_loss, to
     sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
     model.to(dev)
     model.gemm_mode, model.train_precision = "split_f16", precision
-    opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=wd)
+    # torch.optim.Adam as the reference sets it up (graph_kernel.py:541-543), or training.Adam: the same update as one
+    # libmdno launch over all parameter tensors
+    from molecular_dynamics_neural_operator_amd.training import Adam as MdnoAdam
+    opt = (MdnoAdam if optimizer == "mdno" else torch.optim.Adam)(model.parameters(), lr=lr, weight_decay=wd)
     sched = torch.optim.lr_scheduler.StepLR(opt, step_size=step_size, gamma=gamma)
     got, got_lr = [], []
     for e in range(epochs):
@@ -838,6 +842,53 @@ def test_adam_trajectory_vs_oracle(dev, O, tmp_path, precision, lr, tol_loss, to
     errs = {k: rel_err(now[k], final[k]) for k in final}
     print(precision, "final parameters, rel. L2 vs the oracle:", {k: f"{v:.1e}" for k, v in errs.items()})
     assert max(errs.values()) < tol_param, errs
+
+
+def test_mdno_adam_matches_torch_adam(dev):
+    """training.Adam (mdno_adam_step: every parameter tensor of a group in ONE launch) against torch.optim.Adam on the
+    host in fp64 and on the device in fp32, step by step: tensors of awkward sizes (1, 3, 108 floats cut into unaligned
+    slices like the LSTM gradients, 4,097, 1.05 M elements), weight decay, a learning rate a scheduler changes between
+    steps, a parameter that gets no gradient in one step; state_dicts interchange with torch.optim.Adam both ways."""
+    from molecular_dynamics_neural_operator_amd.training import Adam as MdnoAdam
+    gen = torch.Generator().manual_seed(5)
+    shapes = [(1,), (3,), (12, 3), (4097,), (1024, 1025), (20, 4)]
+    init = [torch.randn(*sh, generator=gen) for sh in shapes]
+    buf = torch.randn(108, generator=gen)                       # gradients handed out as slices of one buffer
+    def make(dtype, device):
+        return [torch.nn.Parameter(t.detach().clone().to(device=device, dtype=dtype)) for t in init]
+    ours, theirs, exact = make(torch.float32, dev), make(torch.float32, dev), make(torch.float64, "cpu")
+    kw = dict(lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4)
+    o1, o2, o3 = MdnoAdam(ours, **kw), torch.optim.Adam(theirs, **kw), torch.optim.Adam(exact, **kw)
+    scheds = [torch.optim.lr_scheduler.StepLR(o, step_size=2, gamma=0.5) for o in (o1, o2, o3)]
+    for step in range(6):
+        grads = [torch.randn(*sh, generator=gen) * (10.0 ** (step - 3)) for sh in shapes]
+        grads[2] = buf[5:41].reshape(12, 3) * (step + 1)        # an unaligned contiguous slice
+        for plist, dt, dv in ((ours, torch.float32, dev), (theirs, torch.float32, dev), (exact, torch.float64, "cpu")):
+            for i, (p_, g_) in enumerate(zip(plist, grads)):
+                p_.grad = None if (i == 1 and step == 2) else g_.to(device=dv, dtype=dt)
+        for o, sc in zip((o1, o2, o3), scheds):
+            o.step()
+            sc.step()
+        for a_, b_, c_ in zip(ours, theirs, exact):
+            ref = c_.detach()
+            err = float((a_.detach().cpu().double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+            err_t = float((b_.detach().cpu().double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+            assert err < 3e-6 and err <= 4 * err_t + 1e-7, (step, tuple(a_.shape), err, err_t)
+    assert o1.param_groups[0]["lr"] == pytest.approx(3e-3 * 0.5 ** 3)
+    # state_dict layout == torch.optim.Adam's: each loads the other's and carries on identically to fp32 rounding
+    sd1, sd2 = o1.state_dict(), o2.state_dict()
+    assert sd1["state"].keys() == sd2["state"].keys() and set(sd1["state"][0]) == set(sd2["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+    assert float(sd1["state"][0]["step"]) == float(sd2["state"][0]["step"]) == 6.0 and float(sd1["state"][1]["step"]) == 5.0
+    n1, n2 = MdnoAdam(make(torch.float32, dev), **kw), torch.optim.Adam(make(torch.float32, dev), **kw)
+    n1.load_state_dict(sd2)
+    n2.load_state_dict(sd1)
+    for o in (n1, n2):
+        for p_, src_ in zip(o.param_groups[0]["params"], ours):
+            p_.data.copy_(src_.data)
+            p_.grad = torch.ones_like(p_) * 0.25
+        o.step()
+    for a_, b_ in zip(n1.param_groups[0]["params"], n2.param_groups[0]["params"]):
+        torch.testing.assert_close(a_.detach(), b_.detach(), rtol=2e-6, atol=1e-7)
 
 
 @pytest.mark.parametrize("B,D,size_average", [(1, 84, False), (4, 84, True), (128, 84, False), (37, 1512, False), (300, 3, True)])
